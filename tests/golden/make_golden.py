@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REAL REFERENCE.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference is a
+Python repo, so it is imported (never copied): four stub modules stand in for packages the
+image lacks (torchvision, easydict, basicsr.utils / registry / arch_util — SURVEY.md
+Appendix C).  Parameters come from ``oodgan.synth`` (numpy PCG64 keyed by state-dict key), so
+the tests rebuild the same weights without the reference; only inputs that are small and all
+expected outputs are stored.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, 'ood-gan-inversion_amd'))
+sys.path.insert(0, '/root/reference')
+
+from oodgan import synth  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    tv = _stub('torchvision')
+    tv.ops = _stub('torchvision.ops', deform_conv2d=None)
+    tv.transforms = _stub('torchvision.transforms')
+
+    class EasyDict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    _stub('easydict', EasyDict=EasyDict)
+
+    class Registry:
+        def __init__(self, n):
+            self._d = {}
+
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self._d.setdefault(o.__name__, o)
+            self._d[obj.__name__] = obj
+            return obj
+
+        def get(self, k):
+            return self._d[k]
+
+    _stub('basicsr')
+    _stub('basicsr.utils', scandir=lambda *a, **k: iter(()))
+    _stub('basicsr.utils.registry',
+          **{f'{n}_REGISTRY': Registry(n) for n in ('ARCH', 'LOSS', 'METRIC', 'MODEL', 'DATASET')})
+    _stub('basicsr.archs')
+    _stub('basicsr.archs.arch_util', trunc_normal_=torch.nn.init.trunc_normal_)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, keys={len(out)}')
+
+
+def gold_ops():
+    """Per-op vectors: upfirdn2d, fused_leaky_relu, EqualLinear, ModulatedConv2d x3,
+    StyledConv, ToRGB."""
+    from src.ops.op import upfirdn2d, fused_leaky_relu
+    from src.ops.StyleGAN.model import (EqualLinear, ModulatedConv2d, StyledConv, ToRGB, make_kernel)
+    g = {}
+    k4 = make_kernel([1, 3, 3, 1])
+    x = synth.normal('ops.x', (2, 3, 9, 11), 11)
+    g['ufd_x'] = x
+    # the three parameterisations on the forward path + the two adjoints
+    for tag, kern, up, down, pad in [
+        ('blur11', k4 * 4, 1, 1, (1, 1)), ('up2', k4 * 4, 2, 1, (2, 1)), ('blur21', k4, 1, 1, (2, 1)),
+        ('down2', k4 * 4, 1, 2, (1, 2)), ('blur22', k4 * 4, 1, 1, (2, 2)), ('crop', k4, 1, 1, (-1, 3)),
+    ]:
+        g[f'ufd_{tag}'] = upfirdn2d(x, kern, up=up, down=down, pad=pad)
+    b = synth.normal('ops.b', (3,), 11)
+    g['flr_b'] = b
+    g['flr_y'] = fused_leaky_relu(x, b)
+    g['flr_y2'] = fused_leaky_relu(x, b, negative_slope=0.1, scale=1.5)
+    xl = synth.normal('ops.xl', (4, 32), 11)
+    g['lin_x'] = xl
+    for act in (None, 'fused_lrelu'):
+        lin = EqualLinear(32, 24, bias_init=0.0, lr_mul=0.01, activation=act)
+        lin.weight.data = synth.normal('ops.lin.w', (24, 32), 11, 100.0)
+        lin.bias.data = synth.normal('ops.lin.b', (24,), 11)
+        g['lin_w'], g['lin_b'] = lin.weight.data, lin.bias.data
+        g['lin_y_act' if act else 'lin_y'] = lin(xl)
+    # modulated convs, small channel counts
+    B, Ci, Co, H, S = 2, 16, 8, 12, 64
+    xm = synth.normal('ops.mc.x', (B, Ci, H, H), 12)
+    wl = synth.normal('ops.mc.wlat', (B, S), 12)
+    g['mc_x'], g['mc_wlat'] = xm, wl
+    for tag, k, demod, ups in [('plain', 3, True, False), ('up', 3, True, True), ('rgb', 1, False, False)]:
+        cout = 3 if tag == 'rgb' else Co
+        mc = ModulatedConv2d(Ci, cout, k, S, demodulate=demod, upsample=ups)
+        mc.weight.data = synth.normal(f'ops.mc.{tag}.w', (1, cout, Ci, k, k), 12)
+        mc.modulation.weight.data = synth.normal(f'ops.mc.{tag}.mw', (Ci, S), 12)
+        mc.modulation.bias.data = synth.normal(f'ops.mc.{tag}.mb', (Ci,), 12, 0.1, 1.0)
+        g[f'mc_{tag}_w'], g[f'mc_{tag}_mw'], g[f'mc_{tag}_mb'] = mc.weight.data, mc.modulation.weight.data, mc.modulation.bias.data
+        g[f'mc_{tag}_y'] = mc(xm, wl)
+    # StyledConv (noise + bias + act) plain and upsample, ToRGB with skip
+    for tag, ups in [('sc', False), ('scup', True)]:
+        sc = StyledConv(Ci, Co, 3, S, upsample=ups)
+        sd = {}
+        synth._styled_conv(sd, 'q', Ci, Co, S, 13, ups, 0.1)
+        sc.load_state_dict({k_[2:]: v for k_, v in sd.items()})
+        r = 2 * H if ups else H
+        nz = synth.normal(f'ops.{tag}.noise', (B, 1, r, r), 13)
+        g[f'{tag}_noise'] = nz
+        g[f'{tag}_y'] = sc(xm, wl, noise=nz)
+    rgb = ToRGB(Ci, S)
+    sd = {}
+    synth._to_rgb(sd, 'q', Ci, S, 13, True)
+    rgb.load_state_dict({k_[2:]: v for k_, v in sd.items()})
+    skip = synth.normal('ops.rgb.skip', (B, 3, H // 2, H // 2), 13)
+    g['rgb_skip'] = skip
+    g['rgb_y'] = rgb(xm, wl, skip)
+    g['rgb_y_noskip'] = rgb(xm, wl, None)
+    save('ops.npz', **g)
+
+
+def gold_generator(size=32):
+    from src.ops.StyleGAN.model import Generator
+    torch.manual_seed(0)
+    G = Generator(size, 512, 8).eval()
+    sd = synth.generator_state(size, seed=5)
+    missing = G.load_state_dict(sd, strict=True)
+    print('generator load:', missing)
+    B = 2
+    lat = synth.make_latents(size, B, seed=6)
+    noises = synth.make_noises(size, B, seed=7)
+    g = {}
+    with torch.no_grad():
+        img, feat = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True)
+        g['image'] = img
+        g['last_feature_sub'] = feat[:, ::16]
+        # stored noise buffers + mapping network path ([z] -> style MLP -> broadcast latent)
+        z = synth.normal('gen.z', (B, 512), 8)
+        img2, lat2 = G([z], randomize_noise=False, return_latents=True)
+        g['z'] = z
+        g['image_from_z'] = img2
+        g['latent_from_z'] = lat2
+        # truncation path
+        mean_lat = synth.normal('gen.mean_lat', (1, 512), 8, 0.3)
+        img3, _ = G([z], randomize_noise=False, truncation=0.7, truncation_latent=mean_lat)
+        g['mean_lat'] = mean_lat
+        g['image_trunc'] = img3
+    save(f'generator_s{size}.npz', **g)
+    return G, sd, lat, noises
+
+
+def gold_wplus(size=32, steps=5):
+    """W+ Adam trajectory through the REFERENCE Generator autograd (SURVEY §8 A9 anchors)."""
+    from src.ops.StyleGAN.model import Generator
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(synth.generator_state(size, seed=5), strict=True)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    B = 2
+    target = synth.make_images(size, B, seed=9)
+    noises = synth.make_noises(size, B, seed=7)
+    w = synth.make_latents(size, B, seed=6).clone().requires_grad_(True)
+    opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    losses, traj, grads = [], [], []
+    for _ in range(steps):
+        opt.zero_grad()
+        img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=noises)
+        per = ((img - target) ** 2).mean(dim=(1, 2, 3))
+        per.sum().backward()
+        losses.append(per.detach().clone())
+        grads.append(w.grad.detach().clone())
+        opt.step()
+        traj.append(w.detach().clone())
+    save(f'wplus_s{size}.npz', losses=torch.stack(losses), traj=torch.stack(traj), grads=torch.stack(grads))
+
+
+def gold_samm():
+    """AlignNet / SPM_Warp (2 cycles, with and without a coarser field) at C=8, H=16."""
+    from src.ops.SAMM.helpers import SPM_Warp, new_PRM
+    C, H, B = 8, 16, 2
+    warp = SPM_Warp(C, scale=0.08, cycle_align=2, diff_fAndg=True).eval()
+    sd = synth.samm_state(C, 'm', seed=21)
+    sub = {k[len('m.alignment.'):]: v for k, v in sd.items() if k.startswith('m.alignment.')}
+    print('samm load:', warp.load_state_dict(sub, strict=True))
+    src = synth.normal('samm.src', (B, C, H, H), 22)
+    tgt = synth.normal('samm.tgt', (B, C, H, H), 22)
+    prev = torch.cat([synth.normal('samm.prev.d', (B, 2, H // 2, H // 2), 22, 0.04),
+                      synth.uniform('samm.prev.a', (B, 1, H // 2, H // 2), 22)], dim=1)
+    g = dict(src=src, tgt=tgt, prev=prev)
+    with torch.no_grad():
+        g['alignnet'] = warp.body(tgt, src)
+        y0, f0 = warp(src, tgt, None, None)
+        y1, f1 = warp(src, tgt, None, prev)
+        g['warp_out'], g['warp_field'] = y0, f0
+        g['warp_out_prev'], g['warp_field_prev'] = y1, f1
+        g['prm_up'] = new_PRM(prev[:, 2:], f0[:, 2:])
+        g['prm_same'] = new_PRM(f0[:, 2:], f1[:, 2:])
+        warp1 = SPM_Warp(C, scale=0.08, cycle_align=1, diff_fAndg=True).eval()
+        warp1.load_state_dict(sub, strict=True)
+        y2, f2 = warp1(src, tgt, None, prev)
+        g['warp1_out_prev'], g['warp1_field_prev'] = y2, f2
+    save('samm.npz', **g)
+
+
+class _NoiseFeed:
+    """Make every NoiseInjection of the reference draw a PRESET noise map instead of a fresh
+    RNG sample (the OOD path never exposes ``noise=`` — passing it would bypass the SAMM
+    callback, model.py:284-290 — and its RNG stream cannot travel).
+    ``Tensor.normal_`` is swapped for the duration of each NoiseInjection.forward only, so
+    the reference code itself runs unmodified."""
+
+    def __init__(self, noises):
+        self.noises = list(noises)
+        self.calls = 0
+
+    def install(self):
+        from src.ops.StyleGAN import model as M
+        orig = M.NoiseInjection.forward
+        feed = self
+
+        def fwd(self_, image, noise=None, **kw):
+            if noise is not None:
+                return orig(self_, image, noise=noise, **kw)
+            preset = feed.noises[feed.calls]
+            feed.calls += 1
+            real_normal = torch.Tensor.normal_
+
+            def fake_normal(t, *a, **k):
+                assert tuple(t.shape) == tuple(preset.shape), (t.shape, preset.shape)
+                return t.copy_(preset)
+
+            torch.Tensor.normal_ = fake_normal
+            try:
+                return orig(self_, image, noise=None, **kw)
+            finally:
+                torch.Tensor.normal_ = real_normal
+
+        M.NoiseInjection.forward = fwd
+        self._restore = lambda: setattr(M.NoiseInjection, 'forward', orig)
+
+    def remove(self):
+        self._restore()
+
+
+def gold_ood(B=1):
+    """Full 1024² OOD forward after the encoder.  The e4e encoder is replaced
+    by a stand-in that returns recipe tensors; everything downstream is the reference."""
+    from src.archs.OOD_faceGAN_e4e_arch import ood_faceGAN_e4e
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True,
+                        warp_scale=0.08, cycle_align=2, blend_with_gen=True, ModSize=256).eval()
+    sd = synth.ood_state(1024, seed=31)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith('encoder.') for k in res.missing_keys), [k for k in res.missing_keys if not k.startswith('encoder.')][:5]
+    enc_lats = synth.make_latents(1024, B, seed=32, std=0.3)
+    enc_feats = synth.make_encoder_feats(B, seed=33)
+
+    class FakeEncoder(torch.nn.Module):
+        channels = [64, 64, 128, 256, 512]
+
+        def forward(self, x, return_feats=False):
+            return enc_lats.clone(), [f.clone() for f in enc_feats] + [None]
+
+    fe = FakeEncoder()
+    fe.progressive_stage = m.encoder.progressive_stage
+    m.encoder = fe
+    x = synth.make_images(1024, B, seed=34)
+    noises = synth.make_noises(1024, B, seed=35)
+    feed = _NoiseFeed(noises)
+    feed.install()
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        out, lats = m(x)
+    feed.remove()
+    assert feed.calls == 17, feed.calls
+    g = dict(out_sub=out[:, :, ::16, ::16], out_crop=out[:, :, 480:544, 480:544], lats=lats,
+             out_mean=out.mean(dim=(2, 3)), out_std=out.std(dim=(2, 3)), out_absmax=out.abs().amax())
+    for k in (1, 2, 3, 4):
+        a = m.aligns[k]
+        step = max(1, a.shape[-1] // 32)
+        g[f'align{k}_sub'] = a[:, :, ::step, ::step]
+        g[f'align{k}_mean'] = a.mean(dim=(2, 3))
+    g['align1024_sub'] = m.aligns[1024][:, :, ::16, ::16]
+    g['align1024_crop'] = m.aligns[1024][:, :1, 480:544, 480:544]
+    # mask strip of run_ood_faceGAN_inversion.py:74-87 (nearest upsample) — integer index work
+    sys.argv = ['x']
+    masks = []
+    for key, val in m.aligns.items():
+        masks.append(torch.nn.functional.interpolate(val[:, 2:], size=1024))
+    strip = torch.cat(masks, dim=-1)
+    g['mask_strip_sub'] = strip[:, :, ::16, ::16]
+    g['mask_strip_rows'] = strip[:, :, 500:502, :]
+    save('ood_1024.npz', **g)
+    return m, x, enc_lats, enc_feats, noises, out
+
+
+def main():
+    install_stubs()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['ops', 'gen', 'wplus', 'samm', 'ood']
+    if 'ops' in which:
+        gold_ops()
+    if 'gen' in which:
+        gold_generator(32)
+    if 'wplus' in which:
+        gold_wplus(32, 5)
+    if 'samm' in which:
+        gold_samm()
+    if 'ood' in which:
+        gold_ood(1)
+
+
+if __name__ == '__main__':
+    main()
