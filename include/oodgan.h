@@ -1,0 +1,233 @@
+/*
+ * oodgan.h — C ABI of liboodgan_hip.so: the MI355X (gfx950) implementation of the hot path of
+ * AbnerVictor/OOD-GAN-inversion (StyleGAN2 generator forward, SAMM/SAIM feature decomposition,
+ * and the W+ latent-optimisation loop).  SURVEY.md §8(b) is the contract this header follows.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 where stated) owned by the caller; the
+ *     library never allocates, frees or retains caller memory (engine objects own only their
+ *     private scratch, sized at creation);
+ *   - tensors are dense NCHW unless a pitch is stated;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously, no sync;
+ *   - return value: OODGAN_OK (0) or a negative OODGAN_E_* code; no C++ exception crosses the
+ *     boundary; oodgan_last_error() returns a thread-local message for the last failure;
+ *   - a NULL optional pointer means "term absent" (the reference encodes that as an empty tensor,
+ *     fused_bias_act_kernel.cu:62-63).
+ *
+ * Each entry names the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef OODGAN_H
+#define OODGAN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OODGAN_OK 0
+#define OODGAN_E_ARG (-1)      /* bad shape / null pointer / unsupported parameter */
+#define OODGAN_E_LAUNCH (-2)   /* hipGetLastError() after a launch */
+#define OODGAN_E_STATE (-3)    /* engine used in the wrong order */
+#define OODGAN_E_NODEV (-4)    /* no HIP device */
+
+int oodgan_version(void);
+const char* oodgan_last_error(void);
+/* number of HIP devices visible (0 on a CPU-only box); never throws */
+int oodgan_device_count(void);
+
+/* ------------------------------------------------------------------ L1 custom ops ---------- */
+
+/* y = scale * leaky_relu(x + noise_w[0]*noise[b,0,p] + bias[c], slope)
+ * replaces: fused_bias_act(input,bias,refer,act=3,grad=0,alpha,scale) (src/ops/op/fused_bias_act.cpp:11-17)
+ * and NoiseInjection.forward + FusedLeakyReLU (src/ops/StyleGAN/model.py:283-292,343-350).
+ * x,y (B,C,HW); bias (C) or NULL; noise (noise_batch,1,HW) or NULL with noise_batch in {1,B};
+ * noise_w device scalar (NULL = 1). */
+int oodgan_bias_act_fwd(const float* x, const float* bias, const float* noise, const float* noise_w,
+                        float* y, int B, int C, long HW, int noise_batch, float slope, float scale,
+                        void* stream);
+
+/* gx = gy * (y > 0 ? scale : slope*scale) — fused_bias_act(..., act=3, grad=1) with refer = out
+ * (src/ops/op/fused_bias_act_kernel.cu:36-45, fused_act.py:25-58).  gbias (C) optional:
+ * gbias[c] = sum_{b,p} gx (fused_act.py:36-41). */
+int oodgan_bias_act_bwd(const float* gy, const float* y, float* gx, float* gbias, int B, int C, long HW,
+                        float slope, float scale, void* stream);
+
+/* upfirdn2d(input.reshape(-1,in_h,in_w,1), kernel, up_x,up_y,down_x,down_y,pad_x0,pad_x1,pad_y0,pad_y1)
+ * replaces: upfirdn2d_op.upfirdn2d (src/ops/op/upfirdn2d.cpp:12-19) == upfirdn2d_native
+ * (src/ops/op/upfirdn2d.py:160-193).  x (planes,in_h,in_w) row pitch in_pitch (elements; 0 = in_w);
+ * y (planes,out_h,out_w) row pitch out_pitch; kernel (kh,kw) un-flipped (the op flips it).
+ * Backward = same call with up/down swapped, flipped kernel and g_pad (upfirdn2d.py:115-120). */
+int oodgan_upfirdn2d(const float* x, const float* kernel, float* y, int planes, int in_h, int in_w,
+                     int in_pitch, int out_pitch, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* Blur(pad) of the up-sampling StyledConv fused with its tail: y = act(upfirdn2d(x,k,pad=(pad0,pad1)) +
+ * noise_w*noise + bias)   (src/ops/StyleGAN/model.py:255-258,343-350).  x (B,C,in_h,in_w) row pitch in_pitch. */
+int oodgan_blur_bias_act(const float* x, const float* kernel, float* y, int B, int C, int in_h, int in_w,
+                         int in_pitch, int kh, int kw, int pad0, int pad1, const float* bias, const float* noise,
+                         int noise_batch, const float* noise_w, int act, void* stream);
+
+/* ------------------------------------------------------------------ A1 style affine -------- */
+
+/* Batched EqualLinear(512->Ci, bias_init=1) for any number of modulation layers at once:
+ * s[b,r] = scale * sum_k wcat[r,k]*latent[b,row_lat[r],k] + bcat[r]*lr_mul
+ * replaces: ModulatedConv2d.modulation(style) (src/ops/StyleGAN/model.py:148-158,223,236), 26 calls
+ * per generator forward.  latent (B,L,S); wcat (R,S); bcat (R) or NULL; row_lat int32 (R) or NULL (all 0). */
+int oodgan_style_affine_fwd(const float* latent, const float* wcat, const float* bcat, const int* row_lat,
+                            float* s, int B, int L, int S, int R, float scale, float lr_mul, void* stream);
+/* The MFMA path (R%16==0 and S%16==0) requires every aligned group of 16 rows to share one latent
+ * index (row_lat[r] == row_lat[r & ~15]); the generator's channel counts guarantee it.
+ * glat[b,l,k] = scale * sum_{r in [lat_start[l], lat_start[l+1])} gs[b,r]*wcat[r,k]  (overwrites glat);
+ * rows must be grouped by latent index; lat_start int32 (L+1). */
+int oodgan_style_affine_bwd(const float* gs, const float* wcat, const int* lat_start, float* glat,
+                            int B, int L, int S, int R, float scale, void* stream);
+/* EqualLinear with fused_lrelu (mapping network layer, model.py:148-151): y = sqrt2*lrelu(scale*x@W^T + b*lr_mul) */
+int oodgan_equal_linear(const float* x, const float* w, const float* b, float* y, int B, int in_dim, int out_dim,
+                        float scale, float lr_mul, int activate, void* stream);
+/* PixelNorm (model.py:11-16): y = x * rsqrt(mean_k x^2 + 1e-8) */
+int oodgan_pixel_norm(const float* x, float* y, int B, int S, void* stream);
+
+/* ------------------------------------------------------------------ A2/A3 modulated conv --- */
+
+/* wsq[co,ci] = sum_k w[co,ci,k]^2   (weight preparation for the demodulation coefficients) */
+int oodgan_weight_sqsum(const float* w, float* wsq, int Co, int Ci, int KK, void* stream);
+/* d[b,co] = rsqrt(scale^2 * sum_ci s[b,ci]^2 * wsq[co,ci] + 1e-8)  — model.py:239-241 factorised
+ * (SURVEY.md Appendix A).  s row stride s_stride, d row stride d_stride (elements). */
+int oodgan_demod_fwd(const float* s, int s_stride, const float* wsq, float* d, int d_stride,
+                     int B, int Ci, int Co, float scale, void* stream);
+/* gs[b,ci] += s[b,ci]*(-scale^2) * sum_co r[b,co]*d[b,co]^2*wsq[co,ci],  r = sum_p gy*y (y demodulated) */
+int oodgan_demod_bwd(const float* s, int s_stride, const float* wsq, const float* d, int d_stride,
+                     const float* r, float* gs, int gs_stride, int B, int Ci, int Co, float scale, void* stream);
+
+/* Pack a (Co,Ci,3,3) conv weight (optionally scaled) into the K-major layout the MFMA kernels
+ * stream: wpk[k][tap][Mp], Mp = round_up(M,64), zero padded.
+ *   transpose=0: k=ci, m=co (forward);  transpose=1: k=co, m=ci (input-gradient);
+ *   flip=1: tap -> 8-tap (adjoint of a stride-1 correlation). */
+int oodgan_pack_conv3x3(const float* w, float* wpk, int Co, int Ci, float scale, int transpose, int flip,
+                        void* stream);
+
+#define OODGAN_CONV_S1 0   /* 3x3, stride 1, zero pad 1:            (B,K,H,W)       -> (B,M,H,W)       */
+#define OODGAN_CONV_T2 1   /* 3x3 transposed, stride 2, pad 0:       (B,K,H,W)       -> (B,M,2H+1,2W+1) */
+#define OODGAN_CONV_S2 2   /* 3x3, stride 2, no pad:                 (B,K,2H+1,2W+1) -> (B,M,H,W)       */
+
+#define OODGAN_ACT_NONE 0
+#define OODGAN_ACT_LRELU 1   /* sqrt2 * leaky_relu(.,0.2) */
+#define OODGAN_ACT_PRELU 2   /* per-channel slope */
+
+typedef struct oodgan_conv_args {
+    const float* x;          /* (B,K,Hin,Win), row pitch in_pitch */
+    const float* wpk;        /* packed by oodgan_pack_conv3x3 */
+    const float* in_scale;   /* (B,K) stride in_scale_stride, or NULL: staged value = x*in_scale+in_shift */
+    const float* in_shift;   /* (B,K) same stride, or NULL (applied to in-bounds samples only) */
+    const float* out_scale;  /* (B,M) stride out_scale_stride, or NULL */
+    const float* bias;       /* (M) or NULL */
+    const float* noise;      /* (noise_batch,1,Hout,Wout) or NULL */
+    const float* noise_w;    /* device scalar or NULL (=1) */
+    const float* slope;      /* (M) PReLU slopes for OODGAN_ACT_PRELU */
+    const float* dotx;       /* (B,M,Hout,Wout) or NULL: dot_part = sum_p acc*dotx BEFORE out_scale */
+    float* dot_part;         /* (B,M,dot_nparts) partial sums; reduce with oodgan_reduce_parts */
+    float* y;                /* (B,M,Hout,Wout), row pitch out_pitch */
+    int B, K, M, Hin, Win;   /* Hin/Win: logical input size */
+    int in_pitch, out_pitch; /* elements; 0 = dense */
+    int in_scale_stride, out_scale_stride;
+    int noise_batch;
+    int mode, act;
+    int dot_nparts;          /* out: must equal oodgan_conv3x3_nparts(...) */
+} oodgan_conv_args;
+
+/* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * replaces: the grouped F.conv2d / F.conv_transpose2d of ModulatedConv2d.forward
+ * (src/ops/StyleGAN/model.py:247-272) — with input-side modulation (in_scale = style) and
+ * output-side demodulation (out_scale) instead of B materialised weight copies — and the dense
+ * Conv2d 3x3 of bottleneck_IR (src/ops/e4e/encoders/helpers.py:439-444). */
+int oodgan_conv3x3(const oodgan_conv_args* args, void* stream);
+int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
+/* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
+int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ A5 ToRGB -------------- */
+
+/* y[b,c,p] = sum_ci scale*w[c,ci]*s[b,ci]*x[b,ci,p] + bias[c] + upfirdn2d(skip, k4*4, up=2, pad=(2,1))[b,c,p]
+ * replaces: ToRGB.forward (src/ops/StyleGAN/model.py:363-372) incl. Upsample (:30-48).
+ * x (B,Ci,H,W); w (3,Ci); s (B,Ci) stride s_stride; skip (B,3,H/2,W/2) or NULL; kernel (4,4) already x4. */
+int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                     const float* skip, const float* kernel, float* y, int B, int Ci, int H, int W,
+                     float scale, void* stream);
+
+/* Backward through (bias + noise + lrelu*sqrt2) of one StyledConv, merged with the ToRGB branch that
+ * reads the same feature (build-defined W+ loop):
+ *   t[b,c,p]   = rgb_scale * sum_k w_rgb[k,c]*g_rgb[b,k,p]                (0 if g_rgb NULL)
+ *   g          = g_feat[b,c,p] (0 if NULL) + s_rgb[b,c]*t
+ *   g_pre      = g * (out>0 ? sqrt2 : 0.2*sqrt2)
+ *   y_cv       = (out>0 ? out/sqrt2 : out/(0.2*sqrt2)) - noise_w*noise[b,p] - bias[c]
+ *   part_r[b,c,j]   = partial sum_p g_pre*y_cv    (demodulation gradient)
+ *   part_rgb[b,c,j] = partial sum_p out*t         (ToRGB style gradient)
+ * nparts = oodgan_act_bwd_nparts(HW). */
+int oodgan_act_bwd_fused(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                         const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
+                         const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre,
+                         float* part_r, float* part_rgb, int B, int C, long HW, void* stream);
+int oodgan_act_bwd_nparts(long HW);
+
+/* ------------------------------------------------------------------ A9 loss / optimiser ---- */
+
+/* loss[b] = mean_{c,p} (img-target)^2 (per image, deterministic), gimg = 2*(img-target)/(C*HW).
+ * anchors: basicsr MSELoss (BasicSR/basicsr/losses/losses.py:58-83). part: (B,nparts) scratch. */
+int oodgan_mse_fwd_bwd(const float* img, const float* target, float* gimg, float* part, float* loss,
+                       int B, long CHW, void* stream);
+int oodgan_mse_nparts(long CHW);
+/* torch.optim.Adam step (no weight decay, no amsgrad), step index t>=1 given by the host:
+ * anchors: get_optimizer (src/models/OOD_faceGAN_model.py:398-400). */
+int oodgan_adam_step(float* w, const float* g, float* m, float* v, long n, float lr, float beta1,
+                     float beta2, float eps, int t, void* stream);
+
+/* ------------------------------------------------------------------ A7/A10 SAMM / SAIM ----- */
+
+/* per-(b,c) mean and rstd (biased variance, eps) of x (B,C,HW): nn.InstanceNorm2d statistics
+ * (src/ops/SAMM/helpers.py:88, e4e/encoders/helpers.py:93-95). stats (B,C,2) = {mean, rstd}. */
+int oodgan_instnorm_stats(const float* x, float* stats, int B, int C, long HW, float eps, void* stream);
+/* scale/shift so that IN_affine(x) = x*sc + sh: sc = rstd*gamma, sh = beta - mean*rstd*gamma (gamma/beta NULL = 1/0) */
+int oodgan_instnorm_coeffs(const float* stats, const float* gamma, const float* beta, float* sc, float* sh,
+                           int B, int C, void* stream);
+/* y = x*sc[b,c] + sh[b,c] (+ res) */
+int oodgan_affine_apply(const float* x, const float* sc, const float* sh, const float* res, float* y,
+                        int B, int C, long HW, void* stream);
+/* AlignNet input (diff_fAndg=True, src/ops/SAMM/helpers.py:97-100):
+ * out[:, :C] = IN(gen) - IN(enc), out[:, C:] = IN(enc); stats from oodgan_instnorm_stats */
+int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc,
+                       float* out, int B, int C, long HW, void* stream);
+/* dense 1x1 conv with optional bias: y[b,m,p] = sum_k w[m,k]*x[b,k,p] + bias[m]
+ * replaces feats_conv (OOD_faceGAN_e4e_arch.py:70-75) and the AlignNet shortcut (helpers.py:431-434) */
+int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,
+                   void* stream);
+/* small direct 3x3 conv (K,M <= 8), pad 1, with optional in scale/shift (B,K) and PReLU */
+int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, const float* in_sh,
+                         const float* slope, float* y, int B, int K, int M, int H, int W, void* stream);
+/* AlignNet head (helpers.py:104-107): ch0,1 -> tanh*scale ; ch2 -> sigmoid */
+int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream);
+/* SPM_Warp.add / upsample_add (helpers.py:129-147) with new_PRM (:62-77):
+ * mode 0 (add):          dx,dy = clip(acc+cur, +-scale); a = clip(cur_a*acc_a + acc_a*(1-acc_a),0,1)
+ * mode 1 (upsample_add): dx,dy = cur; pa = bicubic_ac(prev_a -> HxW); a = clip(cur_a*pa + pa*(1-pa),0,1)
+ * acc/cur/out (B,3,H,W); prev (B,3,Hp,Wp). */
+int oodgan_field_compose(const float* acc, const float* cur, const float* prev, float* out, int B, int H, int W,
+                         int Hp, int Wp, float scale, int mode, void* stream);
+/* grid_sample(target, identity+field[:, :2]) (bilinear, zeros, align_corners=False) then
+ * lerp with field[:,2]: y = warped*a + target*(1-a)   (helpers.py:168-177) */
+int oodgan_warp_blend(const float* target, const float* field, float* y, int B, int C, int H, int W, void* stream);
+/* y = cond + noise_w*noise ; then bias + lrelu — the conditioned-layer epilogue
+ * (OOD_faceGAN_e4e_arch.py:239-242 + model.py:292,348) is oodgan_bias_act_fwd on cond. */
+/* blending_mask + blend (OOD_faceGAN_e4e_arch.py:315-347): alpha = compose(bilinear-upsampled alpha
+ * channels of up to 4 fields, coarse->fine), clip; out = alpha*x + gen*(1-alpha).
+ * fields: HOST array of nfields (<=4) device pointers, fields[i] (B,3,sizes[i],sizes[i]); sizes: HOST array;
+ * alpha_out (B,1,S,S) ; out (B,3,S,S). gen/x/out may be NULL (mask only). */
+int oodgan_mask_blend(const float* const* fields, const int* sizes, int nfields, const float* x, const float* gen,
+                      float* alpha_out, float* out, int B, int S, void* stream);
+/* F.interpolate(x, size, mode='nearest') (run_ood_faceGAN_inversion.py:80-83): src = floor(dst*in/out) */
+int oodgan_resize_nearest(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout,
+                          int out_pitch, int out_xoff, void* stream);
+/* F.interpolate(x, size, mode='bilinear', align_corners=False) */
+int oodgan_resize_bilinear(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OODGAN_H */

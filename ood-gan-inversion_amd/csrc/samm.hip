@@ -1,0 +1,447 @@
+// SAMM / SAIM (spatial alignment + invertibility mask) feature-decomposition ops and the final
+// mask-compose + blend.  reference: src/ops/SAMM/helpers.py:62-179, OOD_faceGAN_e4e_arch.py:315-347.
+// Index math (nearest / bilinear / bicubic source indices, linspace grid) restates ATen's float
+// formulas so that masks match the reference bit-for-bit where they are pure indexing.
+#include "common.hpp"
+
+using namespace oodgan;
+
+namespace {
+
+// ---------------------------------------------------------------- InstanceNorm statistics
+// one block per (b,c) plane; two passes (mean, then centred second moment) — the plane (<=256 KB)
+// is served from L2 on the second pass.
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, long HW,
+                                                             float eps) {
+    __shared__ float red[4];
+    __shared__ float mean_s;
+    const float* p = x + (long)blockIdx.x * HW;
+    float s = 0.f;
+    if ((HW & 3) == 0) {
+        for (long i = threadIdx.x; i < (HW >> 2); i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) mean_s = s / (float)HW;
+    __syncthreads();
+    const float mean = mean_s;
+    float q = 0.f;
+    if ((HW & 3) == 0) {
+        for (long i = threadIdx.x; i < (HW >> 2); i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) { const float a = p[i] - mean; q += a * a; }
+    }
+    q = block_sum_256(q, red);
+    if (threadIdx.x == 0) {
+        stats[2 * (long)blockIdx.x] = mean;
+        stats[2 * (long)blockIdx.x + 1] = rsqrtf(q / (float)HW + eps);
+    }
+}
+
+__global__ void instnorm_coeffs_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ sc, float* __restrict__ sh, int B,
+                                       int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int c = i % C;
+    const float mean = stats[2 * i], rstd = stats[2 * i + 1];
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    sc[i] = rstd * g;
+    sh[i] = bt - mean * rstd * g;
+}
+
+// grid (chunks, B*C)
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, const float* __restrict__ res,
+                                                           float* __restrict__ y, long HW) {
+    const long base = (long)blockIdx.y * HW;
+    const float a = sc[blockIdx.y], b = sh[blockIdx.y];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256)
+        y[base + i] = x[base + i] * a + b + (res ? res[base + i] : 0.f);
+}
+
+// grid (chunks, B*C): out[b, c] = IN(gen)-IN(enc), out[b, C+c] = IN(enc)
+__global__ __launch_bounds__(256) void align_input_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
+                                                          const float* __restrict__ sg, const float* __restrict__ se,
+                                                          float* __restrict__ out, int C, long HW) {
+    const int bc = blockIdx.y, b = bc / C, c = bc % C;
+    const float mg = sg[2 * bc], rg = sg[2 * bc + 1], me = se[2 * bc], re = se[2 * bc + 1];
+    const float* gp = gen + (long)bc * HW;
+    const float* ep = enc + (long)bc * HW;
+    float* o0 = out + ((long)b * 2 * C + c) * HW;
+    float* o1 = out + ((long)b * 2 * C + C + c) * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+        const float a = (gp[i] - mg) * rg, e = (ep[i] - me) * re;
+        o0[i] = a - e;
+        o1[i] = e;
+    }
+}
+
+// ---------------------------------------------------------------- dense 1x1 conv
+// block: 256 pixels x 16 output channels; weights for the 16 rows staged in LDS per K chunk of 64.
+constexpr int C1_MT = 16, C1_KC = 64;
+__global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int K, int M,
+                                                      long HW) {
+    __shared__ float ws[C1_MT * C1_KC];
+    const int b = blockIdx.z, m0 = blockIdx.y * C1_MT;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const float* xp = x + (long)b * K * HW + p;
+    float acc[C1_MT];
+#pragma unroll
+    for (int j = 0; j < C1_MT; ++j) acc[j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += C1_KC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < C1_MT * C1_KC; e += 256) {
+            const int j = e / C1_KC, kk = e % C1_KC;
+            ws[e] = (m0 + j < M && k0 + kk < K) ? w[(long)(m0 + j) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        if (p < HW) {
+            const int kn = (K - k0) < C1_KC ? (K - k0) : C1_KC;
+            for (int kk = 0; kk < kn; ++kk) {
+                const float v = xp[(long)(k0 + kk) * HW];
+#pragma unroll
+                for (int j = 0; j < C1_MT; ++j) acc[j] += ws[j * C1_KC + kk] * v;
+            }
+        }
+    }
+    if (p < HW) {
+#pragma unroll
+        for (int j = 0; j < C1_MT; ++j)
+            if (m0 + j < M) y[((long)b * M + m0 + j) * HW + p] = acc[j] + (bias ? bias[m0 + j] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------- small direct 3x3 (K,M <= 8)
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ in_sc, const float* __restrict__ in_sh,
+                                                            const float* __restrict__ slope, float* __restrict__ y, int K, int M,
+                                                            int H, int W) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int py = (int)(p / W), px = (int)(p % W);
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float sc = in_sc ? in_sc[b * K + k] : 1.f, sh = in_sh ? in_sh[b * K + k] : 0.f;
+        const float* xp = x + ((long)b * K + k) * HW;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = py + ky - 1, ix = px + kx - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float v = xp[(long)iy * W + ix] * sc + sh;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (m < M) acc[m] += w[((m * K + k) * 3 + ky) * 3 + kx] * v;
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        if (m < M) {
+            float v = acc[m];
+            if (slope) v = v > 0.f ? v : slope[m] * v;
+            y[((long)b * M + m) * HW + p] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void align_head_kernel(const float* __restrict__ x, float* __restrict__ y, long HW, long total,
+                                                         float scale) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)((e / HW) % 3);
+        const float v = x[e];
+        y[e] = c < 2 ? tanhf(v) * scale : 1.f / (1.f + expf(-v));
+    }
+}
+
+// ---------------------------------------------------------------- resampling helpers (ATen float formulas)
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// bicubic, align_corners=True, A=-0.75, border-clamped taps (F.interpolate(mode='bicubic', align_corners=True))
+__device__ float bicubic_ac(const float* __restrict__ src, int Hs, int Ws, int oy, int ox, int Ho, int Wo) {
+    const float A = -0.75f;
+    const float sy = Ho > 1 ? (float)(Hs - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(Ws - 1) / (float)(Wo - 1) : 0.f;
+    const float ry = sy * oy, rx = sx * ox;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    const float ty = ry - iy, tx = rx - ix;
+    float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+    float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int yy = iy - 1 + i;
+        yy = yy < 0 ? 0 : (yy > Hs - 1 ? Hs - 1 : yy);
+        float row = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int xx = ix - 1 + j;
+            xx = xx < 0 ? 0 : (xx > Ws - 1 ? Ws - 1 : xx);
+            row += wx[j] * src[(long)yy * Ws + xx];
+        }
+        acc += wy[i] * row;
+    }
+    return acc;
+}
+
+// bilinear, align_corners=False (F.interpolate(mode='bilinear'))
+__device__ float bilinear_nc(const float* __restrict__ src, int Hs, int Ws, int oy, int ox, int Ho, int Wo) {
+    const float sy = (float)Hs / (float)Ho, sx = (float)Ws / (float)Wo;
+    float ry = sy * (oy + 0.5f) - 0.5f, rx = sx * (ox + 0.5f) - 0.5f;
+    ry = ry < 0.f ? 0.f : ry;
+    rx = rx < 0.f ? 0.f : rx;
+    const int y0 = (int)ry, x0 = (int)rx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = ry - y0, lx = rx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * src[(long)y0 * Ws + x0] + lx * src[(long)y0 * Ws + x1]) +
+           ly * (hx * src[(long)y1 * Ws + x0] + lx * src[(long)y1 * Ws + x1]);
+}
+
+__device__ __forceinline__ float clipf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// SPM_Warp.add / upsample_add
+__global__ __launch_bounds__(256) void field_compose_kernel(const float* __restrict__ acc, const float* __restrict__ cur,
+                                                            const float* __restrict__ prev, float* __restrict__ out, int B, int H,
+                                                            int W, int Hp, int Wp, float scale, int mode) {
+    const long HW = (long)H * W;
+    const long total = (long)B * HW;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int b = (int)(e / HW);
+        const long p = e % HW;
+        const float* c = cur + (long)b * 3 * HW;
+        float* o = out + (long)b * 3 * HW;
+        float dx, dy, xa;   // xa: the "x" argument of new_PRM (coarser / accumulated alpha)
+        if (mode == 0) {
+            const float* a = acc + (long)b * 3 * HW;
+            dx = clipf(a[p] + c[p], -scale, scale);
+            dy = clipf(a[HW + p] + c[HW + p], -scale, scale);
+            xa = a[2 * HW + p];
+        } else {
+            dx = c[p];
+            dy = c[HW + p];
+            const float* pa = prev + ((long)b * 3 + 2) * Hp * Wp;
+            xa = (Hp == H && Wp == W) ? pa[p] : bicubic_ac(pa, Hp, Wp, (int)(p / W), (int)(p % W), H, W);
+        }
+        const float ya = c[2 * HW + p];
+        o[p] = dx;
+        o[HW + p] = dy;
+        o[2 * HW + p] = clipf(ya * xa + xa * (1.f - xa), 0.f, 1.f);
+    }
+}
+
+// torch.linspace(-1, 1, n)[i] in float (symmetric evaluation of ATen's kernel)
+__device__ __forceinline__ float linspace_pm1(int i, int n) {
+    if (n == 1) return -1.f;
+    const float step = 2.f / (float)(n - 1);
+    return i < n / 2 ? -1.f + step * i : 1.f - step * (n - 1 - i);
+}
+
+// grid (chunks of pixels, B); each thread one pixel, loops over channels (coalesced per plane)
+__global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict__ target, const float* __restrict__ field,
+                                                         float* __restrict__ y, int C, int H, int W) {
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int py = (int)(p / W), px = (int)(p % W);
+    const float* f = field + (long)b * 3 * HW;
+    const float gx = linspace_pm1(px, W) + f[p];
+    const float gy = linspace_pm1(py, H) + f[HW + p];
+    const float alpha = f[2 * HW + p];
+    // grid_sampler_unnormalize, align_corners=False
+    const float ix = ((gx + 1.f) * W - 1.f) / 2.f, iy = ((gy + 1.f) * H - 1.f) / 2.f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;   // nw, ne, sw, se
+    const float* tb = target + (long)b * C * HW;
+    float* yb = y + (long)b * C * HW;
+    for (int c = 0; c < C; ++c) {
+        const float* t = tb + (long)c * HW;
+        float v = 0.f;
+        if (vy0 && vx0) v += t[(long)y0 * W + x0] * w00;
+        if (vy0 && vx1) v += t[(long)y0 * W + x1] * w01;
+        if (vy1 && vx0) v += t[(long)y1 * W + x0] * w10;
+        if (vy1 && vx1) v += t[(long)y1 * W + x1] * w11;
+        const float tv = t[p];
+        yb[(long)c * HW + p] = v * alpha + tv * (1.f - alpha);
+    }
+}
+
+struct MaskArgs {
+    const float* fields[4];
+    int sizes[4];
+    int nfields;
+};
+
+// grid (chunks, B)
+__global__ __launch_bounds__(256) void mask_blend_kernel(const MaskArgs m, const float* __restrict__ x, const float* __restrict__ gen,
+                                                         float* __restrict__ alpha_out, float* __restrict__ out, int S) {
+    const int b = blockIdx.y;
+    const long SS = (long)S * S;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < SS; p += (long)gridDim.x * 256) {
+        const int oy = (int)(p / S), ox = (int)(p % S);
+        float a = 0.f;
+        for (int k = 0; k < m.nfields; ++k) {
+            const int s = m.sizes[k];
+            const float* src = m.fields[k] + ((long)b * 3 + 2) * s * s;
+            const float ak = (s == S) ? src[p] : bilinear_nc(src, s, s, oy, ox, S, S);
+            a = (k == 0) ? ak : ak * a + a * (1.f - a);
+        }
+        a = clipf(a, 0.f, 1.f);
+        if (alpha_out) alpha_out[(long)b * SS + p] = a;
+        if (out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const long q = ((long)b * 3 + c) * SS + p;
+                out[q] = a * x[q] + gen[q] * (1.f - a);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Hin,
+                                                             int Win, int Hout, int Wout, int out_pitch, int out_xoff) {
+    const long total = (long)planes * Hout * Wout;
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+        const long pl = e / ((long)Wout * Hout);
+        int iy = (int)floorf(oy * sy), ix = (int)floorf(ox * sx);
+        iy = iy < Hin - 1 ? iy : Hin - 1;
+        ix = ix < Win - 1 ? ix : Win - 1;
+        y[(pl * Hout + oy) * (long)out_pitch + out_xoff + ox] = x[(pl * Hin + iy) * (long)Win + ix];
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Hin,
+                                                              int Win, int Hout, int Wout) {
+    const long total = (long)planes * Hout * Wout;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+        const long pl = e / ((long)Wout * Hout);
+        y[e] = bilinear_nc(x + pl * Hin * Win, Hin, Win, oy, ox, Hout, Wout);
+    }
+}
+
+}  // namespace
+
+extern "C" int oodgan_instnorm_stats(const float* x, float* stats, int B, int C, long HW, float eps, void* stream) {
+    OODGAN_REQUIRE(x && stats && B > 0 && C > 0 && HW > 0, "instnorm_stats: bad args");
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(B * C), dim3(256), 0, as_stream(stream), x, stats, HW, eps);
+    return check_launch("instnorm_stats");
+}
+
+extern "C" int oodgan_instnorm_coeffs(const float* stats, const float* gamma, const float* beta, float* sc, float* sh, int B,
+                                      int C, void* stream) {
+    OODGAN_REQUIRE(stats && sc && sh && B > 0 && C > 0, "instnorm_coeffs: bad args");
+    hipLaunchKernelGGL(instnorm_coeffs_kernel, dim3((B * C + 255) / 256), dim3(256), 0, as_stream(stream), stats, gamma, beta, sc,
+                       sh, B, C);
+    return check_launch("instnorm_coeffs");
+}
+
+extern "C" int oodgan_affine_apply(const float* x, const float* sc, const float* sh, const float* res, float* y, int B, int C,
+                                   long HW, void* stream) {
+    OODGAN_REQUIRE(x && sc && sh && y && B > 0 && C > 0 && HW > 0 && (long)B * C <= 65535, "affine_apply: bad args");
+    int gx = (int)((HW + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(affine_apply_kernel, dim3(gx, B * C), dim3(256), 0, as_stream(stream), x, sc, sh, res, y, HW);
+    return check_launch("affine_apply");
+}
+
+extern "C" int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, int B,
+                                  int C, long HW, void* stream) {
+    OODGAN_REQUIRE(gen && enc && st_gen && st_enc && out && B > 0 && C > 0 && HW > 0 && (long)B * C <= 65535,
+                   "align_input: bad args");
+    int gx = (int)((HW + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(align_input_kernel, dim3(gx, B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, C, HW);
+    return check_launch("align_input");
+}
+
+extern "C" int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,
+                              void* stream) {
+    OODGAN_REQUIRE(x && w && y && B > 0 && K > 0 && M > 0 && HW > 0, "conv1x1: bad args");
+    dim3 grid((unsigned)((HW + 255) / 256), (M + C1_MT - 1) / C1_MT, B);
+    hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, as_stream(stream), x, w, bias, y, K, M, HW);
+    return check_launch("conv1x1");
+}
+
+extern "C" int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, const float* in_sh, const float* slope,
+                                    float* y, int B, int K, int M, int H, int W, void* stream) {
+    OODGAN_REQUIRE(x && w && y && B > 0 && K > 0 && K <= 8 && M > 0 && M <= 8 && H > 0 && W > 0, "conv3x3_small: bad args");
+    dim3 grid((unsigned)(((long)H * W + 255) / 256), B);
+    hipLaunchKernelGGL(conv3x3_small_kernel, grid, dim3(256), 0, as_stream(stream), x, w, in_sc, in_sh, slope, y, K, M, H, W);
+    return check_launch("conv3x3_small");
+}
+
+extern "C" int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream) {
+    OODGAN_REQUIRE(x && y && B > 0 && HW > 0, "align_head: bad args");
+    const long total = (long)B * 3 * HW;
+    hipLaunchKernelGGL(align_head_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, y, HW, total, scale);
+    return check_launch("align_head");
+}
+
+extern "C" int oodgan_field_compose(const float* acc, const float* cur, const float* prev, float* out, int B, int H, int W, int Hp,
+                                    int Wp, float scale, int mode, void* stream) {
+    OODGAN_REQUIRE(cur && out && B > 0 && H > 0 && W > 0, "field_compose: bad args");
+    OODGAN_REQUIRE((mode == 0 && acc) || (mode == 1 && prev && Hp > 0 && Wp > 0), "field_compose: mode %d operands", mode);
+    hipLaunchKernelGGL(field_compose_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, as_stream(stream), acc, cur,
+                       prev, out, B, H, W, Hp, Wp, scale, mode);
+    return check_launch("field_compose");
+}
+
+extern "C" int oodgan_warp_blend(const float* target, const float* field, float* y, int B, int C, int H, int W, void* stream) {
+    OODGAN_REQUIRE(target && field && y && B > 0 && C > 0 && H > 0 && W > 0, "warp_blend: bad args");
+    dim3 grid((unsigned)(((long)H * W + 255) / 256), B);
+    hipLaunchKernelGGL(warp_blend_kernel, grid, dim3(256), 0, as_stream(stream), target, field, y, C, H, W);
+    return check_launch("warp_blend");
+}
+
+extern "C" int oodgan_mask_blend(const float* const* fields, const int* sizes, int nfields, const float* x, const float* gen,
+                                 float* alpha_out, float* out, int B, int S, void* stream) {
+    OODGAN_REQUIRE(fields && sizes && nfields >= 1 && nfields <= 4 && B > 0 && S > 0, "mask_blend: bad args");
+    OODGAN_REQUIRE(!out || (x && gen), "mask_blend: out needs x and gen");
+    MaskArgs m{};
+    m.nfields = nfields;
+    for (int i = 0; i < nfields; ++i) {
+        OODGAN_REQUIRE(fields[i] && sizes[i] > 0, "mask_blend: field %d", i);
+        m.fields[i] = fields[i];
+        m.sizes[i] = sizes[i];
+    }
+    long chunks = ((long)S * S + 255) / 256;
+    if (chunks > 1024) chunks = 1024;
+    hipLaunchKernelGGL(mask_blend_kernel, dim3((unsigned)chunks, B), dim3(256), 0, as_stream(stream), m, x, gen, alpha_out, out, S);
+    return check_launch("mask_blend");
+}
+
+extern "C" int oodgan_resize_nearest(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, int out_pitch,
+                                     int out_xoff, void* stream) {
+    OODGAN_REQUIRE(x && y && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "resize_nearest: bad args");
+    if (out_pitch == 0) out_pitch = Wout;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(stream_grid((long)planes * Hout * Wout, 256)), dim3(256), 0, as_stream(stream),
+                       x, y, planes, Hin, Win, Hout, Wout, out_pitch, out_xoff);
+    return check_launch("resize_nearest");
+}
+
+extern "C" int oodgan_resize_bilinear(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream) {
+    OODGAN_REQUIRE(x && y && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "resize_bilinear: bad args");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(stream_grid((long)planes * Hout * Wout, 256)), dim3(256), 0, as_stream(stream),
+                       x, y, planes, Hin, Win, Hout, Wout);
+    return check_launch("resize_bilinear");
+}

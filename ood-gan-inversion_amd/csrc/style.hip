@@ -1,0 +1,223 @@
+// Style path: the 26 style affines of a generator forward as ONE dense contraction on the fp32 matrix
+// cores, demodulation coefficients by wavefront reduction, the mapping network layers.
+//   reference: EqualLinear (src/ops/StyleGAN/model.py:129-158), ModulatedConv2d.forward :236-241.
+#include "common.hpp"
+
+using namespace oodgan;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// s[b, r] = scale * sum_k W[r,k] * lat[b, row_lat[r], k] + bias[r]*lr_mul
+// MFMA path: one wave per 16-row tile x 16 batch columns; v_mfma_f32_16x16x4_f32:
+//   A[i=l&15][k=l>>4] = W[r0+i][k], B[k=l>>4][j=l&15] = lat[b0+j][.][k]; each lane loads 16 B of both
+//   operands per 16-deep K step and issues 4 MFMAs (k order inside a step is irrelevant for a sum as long
+//   as A and B agree).  Requires all 16 rows of a tile to read the same latent row.
+__global__ __launch_bounds__(256) void style_affine_mfma_kernel(const float* __restrict__ lat, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const int* __restrict__ row_lat,
+                                                                float* __restrict__ s, int B, int L, int S, int R, float scale,
+                                                                float lr_mul) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = tile * 16;
+    if (r0 >= R) return;
+    const int b0 = blockIdx.y * 16;
+    const int i = lane & 15, kq = lane >> 4;
+    const int li = row_lat ? row_lat[r0] : 0;
+    const int bj = b0 + i;
+    const float* wp = w + (long)(r0 + i) * S + 4 * kq;
+    const float* lp = lat + ((long)(bj < B ? bj : 0) * L + li) * S + 4 * kq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < S; k0 += 16) {
+        const float4 av = *reinterpret_cast<const float4*>(wp + k0);
+        float4 bv = *reinterpret_cast<const float4*>(lp + k0);
+        if (bj >= B) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    // C/D: col = lane&15 (batch), row = (lane>>4)*4 + reg
+    if (bj < B) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + kq * 4 + q;
+            s[(long)bj * R + r] = acc[q] * scale + (bias ? bias[r] * lr_mul : 0.f);
+        }
+    }
+}
+
+// generic path (any R, per-row latent index): one wave per row
+__global__ __launch_bounds__(256) void style_affine_wave_kernel(const float* __restrict__ lat, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const int* __restrict__ row_lat,
+                                                                float* __restrict__ s, int B, int L, int S, int R, float scale,
+                                                                float lr_mul) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int li = row_lat ? row_lat[r] : 0;
+    const float bv = bias ? bias[r] * lr_mul : 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* lp = lat + ((long)b * L + li) * S;
+        float acc = 0.f;
+        for (int k = lane; k < S; k += 64) acc += w[r * S + k] * lp[k];
+        acc = wave_sum(acc);
+        if (lane == 0) s[(long)b * R + r] = acc * scale + bv;
+    }
+}
+
+// glat[b,l,k] = scale * sum_{r in [lat_start[l], lat_start[l+1])} gs[b,r] * W[r,k]
+// grid (ceil(S/256), L, ceil(B/8)); thread = one k, 8 batch accumulators, W row reads coalesced over k.
+__global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ w,
+                                                               const int* __restrict__ lat_start, float* __restrict__ glat,
+                                                               int B, int L, int S, int R, float scale) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    const int b0 = blockIdx.z * 8;
+    const int ra = lat_start[l], rb = lat_start[l + 1];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (k < S) {
+        for (int r = ra; r < rb; ++r) {
+            const float wv = w[(long)r * S + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = b0 + j;
+                if (b < B) acc[j] += gs[(long)b * R + r] * wv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j;
+            if (b < B) glat[((long)b * L + l) * S + k] = acc[j] * scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void equal_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                           int in_dim, int out_dim, float scale, float lr_mul, int activate) {
+    const int lane = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (long)B * out_dim) return;
+    const int b = (int)(idx / out_dim), o = (int)(idx % out_dim);
+    float acc = 0.f;
+    for (int k = lane; k < in_dim; k += 64) acc += x[(long)b * in_dim + k] * (w[(long)o * in_dim + k] * scale);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[o] * lr_mul : 0.f);
+        if (activate) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
+        y[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void pixel_norm_kernel(const float* __restrict__ x, float* __restrict__ y, int S) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int k = lane; k < S; k += 64) { const float v = x[(long)b * S + k]; acc += v * v; }
+    acc = wave_sum(acc);
+    const float r = rsqrtf(acc / (float)S + 1e-8f);
+    for (int k = lane; k < S; k += 64) y[(long)b * S + k] = x[(long)b * S + k] * r;
+}
+
+__global__ __launch_bounds__(256) void weight_sqsum_kernel(const float* __restrict__ w, float* __restrict__ wsq, long n, int KK) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int k = 0; k < KK; ++k) { const float v = w[i * KK + k]; acc += v * v; }
+    wsq[i] = acc;
+}
+
+// one wave per (b,co): d = rsqrt(scale^2 * sum_ci s^2 * wsq + 1e-8)   (literal 1e-8: model.py:240)
+__global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict__ s, int s_stride, const float* __restrict__ wsq,
+                                                        float* __restrict__ d, int d_stride, int B, int Ci, int Co, float scale2) {
+    const int lane = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (long)B * Co) return;
+    const int b = (int)(idx / Co), co = (int)(idx % Co);
+    float acc = 0.f;
+    for (int ci = lane; ci < Ci; ci += 64) { const float sv = s[(long)b * s_stride + ci]; acc += sv * sv * wsq[(long)co * Ci + ci]; }
+    acc = wave_sum(acc);
+    if (lane == 0) d[(long)b * d_stride + co] = rsqrtf(acc * scale2 + 1e-8f);
+}
+
+// gs[b,ci] += -scale^2 * s[b,ci] * sum_co r[b,co]*d[b,co]^2*wsq[co,ci]
+__global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict__ s, int s_stride, const float* __restrict__ wsq,
+                                                        const float* __restrict__ d, int d_stride, const float* __restrict__ r,
+                                                        float* __restrict__ gs, int gs_stride, int B, int Ci, int Co, float scale2) {
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (ci >= Ci) return;
+    float acc = 0.f;
+    for (int co = 0; co < Co; ++co) {
+        const float dv = d[(long)b * d_stride + co];
+        acc += r[(long)b * Co + co] * dv * dv * wsq[(long)co * Ci + ci];
+    }
+    gs[(long)b * gs_stride + ci] += -scale2 * s[(long)b * s_stride + ci] * acc;
+}
+
+}  // namespace
+
+extern "C" int oodgan_style_affine_fwd(const float* latent, const float* wcat, const float* bcat, const int* row_lat, float* s,
+                                       int B, int L, int S, int R, float scale, float lr_mul, void* stream) {
+    OODGAN_REQUIRE(latent && wcat && s && B > 0 && L > 0 && S > 0 && R > 0, "style_affine_fwd: bad args");
+    // negative S selects the generic path explicitly (per-row latent index not tile-uniform)
+    hipStream_t st = as_stream(stream);
+    const bool mfma = (R % 16 == 0) && (S % 16 == 0);
+    if (mfma)
+        hipLaunchKernelGGL(style_affine_mfma_kernel, dim3((R / 16 + 3) / 4, (B + 15) / 16), dim3(256), 0, st, latent, wcat, bcat,
+                           row_lat, s, B, L, S, R, scale, lr_mul);
+    else
+        hipLaunchKernelGGL(style_affine_wave_kernel, dim3((R + 3) / 4), dim3(256), 0, st, latent, wcat, bcat, row_lat, s, B, L,
+                           S, R, scale, lr_mul);
+    return check_launch("style_affine_fwd");
+}
+
+extern "C" int oodgan_style_affine_bwd(const float* gs, const float* wcat, const int* lat_start, float* glat, int B, int L,
+                                       int S, int R, float scale, void* stream) {
+    OODGAN_REQUIRE(gs && wcat && lat_start && glat && B > 0 && L > 0 && S > 0 && R > 0, "style_affine_bwd: bad args");
+    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3((S + 255) / 256, L, (B + 7) / 8), dim3(256), 0, as_stream(stream), gs,
+                       wcat, lat_start, glat, B, L, S, R, scale);
+    return check_launch("style_affine_bwd");
+}
+
+extern "C" int oodgan_equal_linear(const float* x, const float* w, const float* b, float* y, int B, int in_dim, int out_dim,
+                                   float scale, float lr_mul, int activate, void* stream) {
+    OODGAN_REQUIRE(x && w && y && B > 0 && in_dim > 0 && out_dim > 0, "equal_linear: bad args");
+    const long n = (long)B * out_dim;
+    hipLaunchKernelGGL(equal_linear_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), x, w, b, y, B, in_dim,
+                       out_dim, scale, lr_mul, activate);
+    return check_launch("equal_linear");
+}
+
+extern "C" int oodgan_pixel_norm(const float* x, float* y, int B, int S, void* stream) {
+    OODGAN_REQUIRE(x && y && B > 0 && S > 0, "pixel_norm: bad args");
+    hipLaunchKernelGGL(pixel_norm_kernel, dim3(B), dim3(64), 0, as_stream(stream), x, y, S);
+    return check_launch("pixel_norm");
+}
+
+extern "C" int oodgan_weight_sqsum(const float* w, float* wsq, int Co, int Ci, int KK, void* stream) {
+    OODGAN_REQUIRE(w && wsq && Co > 0 && Ci > 0 && KK > 0, "weight_sqsum: bad args");
+    const long n = (long)Co * Ci;
+    hipLaunchKernelGGL(weight_sqsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, wsq, n, KK);
+    return check_launch("weight_sqsum");
+}
+
+extern "C" int oodgan_demod_fwd(const float* s, int s_stride, const float* wsq, float* d, int d_stride, int B, int Ci, int Co,
+                                float scale, void* stream) {
+    OODGAN_REQUIRE(s && wsq && d && B > 0 && Ci > 0 && Co > 0, "demod_fwd: bad args");
+    const long n = (long)B * Co;
+    hipLaunchKernelGGL(demod_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), s, s_stride, wsq, d,
+                       d_stride, B, Ci, Co, scale * scale);
+    return check_launch("demod_fwd");
+}
+
+extern "C" int oodgan_demod_bwd(const float* s, int s_stride, const float* wsq, const float* d, int d_stride, const float* r,
+                                float* gs, int gs_stride, int B, int Ci, int Co, float scale, void* stream) {
+    OODGAN_REQUIRE(s && wsq && d && r && gs && B > 0 && Ci > 0 && Co > 0, "demod_bwd: bad args");
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Ci + 255) / 256, B), dim3(256), 0, as_stream(stream), s, s_stride, wsq, d,
+                       d_stride, r, gs, gs_stride, B, Ci, Co, scale * scale);
+    return check_launch("demod_bwd");
+}

@@ -1,0 +1,98 @@
+// ToRGB: 1x1 modulated conv Ci->3 without demodulation + bias + 2x FIR-upsampled skip, one pass.
+// reference: ToRGB.forward / Upsample (src/ops/StyleGAN/model.py:353-372, 30-48).
+// HBM-bound (AI ~1.4 flop/B): every feature element is read exactly once with 16-B loads; the three
+// modulated weight rows live in LDS; the skip (3 channels at half resolution) is gathered from L2.
+#include "common.hpp"
+
+using namespace oodgan;
+
+namespace {
+
+constexpr int kMaxCi = 1024;
+
+// grid (ceil(HW/1024), B); thread = 4 consecutive pixels
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ s, int s_stride, const float* __restrict__ bias,
+                                                        const float* __restrict__ skip, const float* __restrict__ kern,
+                                                        float* __restrict__ y, int Ci, int H, int W, float scale) {
+    __shared__ float ws[3 * kMaxCi];
+    __shared__ float kf[16];
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    for (int e = threadIdx.x; e < 3 * Ci; e += 256) {
+        const int c = e / Ci, ci = e % Ci;
+        ws[e] = scale * w[c * Ci + ci] * s[(long)b * s_stride + ci];
+    }
+    if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
+    __syncthreads();
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const float* xp = x + (long)b * Ci * HW + p;
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const bool vec = (HW & 3) == 0;
+    if (vec) {
+#pragma unroll 8
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + (long)ci * HW);
+            const float w0 = ws[ci], w1 = ws[Ci + ci], w2 = ws[2 * Ci + ci];
+            a0[0] += w0 * v.x; a0[1] += w0 * v.y; a0[2] += w0 * v.z; a0[3] += w0 * v.w;
+            a1[0] += w1 * v.x; a1[1] += w1 * v.y; a1[2] += w1 * v.z; a1[3] += w1 * v.w;
+            a2[0] += w2 * v.x; a2[1] += w2 * v.y; a2[2] += w2 * v.z; a2[3] += w2 * v.w;
+        }
+    } else {
+        for (int ci = 0; ci < Ci; ++ci) {
+            const float w0 = ws[ci], w1 = ws[Ci + ci], w2 = ws[2 * Ci + ci];
+            for (int j = 0; j < 4; ++j)
+                if (p + j < HW) {
+                    const float v = xp[(long)ci * HW + j];
+                    a0[j] += w0 * v; a1[j] += w1 * v; a2[j] += w2 * v;
+                }
+        }
+    }
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    const int h2 = H >> 1, w2_ = W >> 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (p + j >= HW) break;
+        float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
+        if (skip) {
+            const int Y = (int)((p + j) / W), X = (int)((p + j) % W);
+            const float* sp = skip + (long)b * 3 * h2 * w2_;
+            // upfirdn2d(skip, k, up=2, pad=(2,1)): taps with (Y+ky-2) even
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ky = (Y & 1) + 2 * t;
+                const int iy = (Y + ky - 2) >> 1;
+                if (Y + ky - 2 < 0 || iy >= h2) continue;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kx = (X & 1) + 2 * u;
+                    const int ix = (X + kx - 2) >> 1;
+                    if (X + kx - 2 < 0 || ix >= w2_) continue;
+                    const float kv = kf[ky * 4 + kx];
+                    const long q = (long)iy * w2_ + ix;
+                    o0 += kv * sp[q];
+                    o1 += kv * sp[(long)h2 * w2_ + q];
+                    o2 += kv * sp[2L * h2 * w2_ + q];
+                }
+            }
+        }
+        float* yp = y + (long)b * 3 * HW + p + j;
+        yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
+    }
+}
+
+}  // namespace
+
+extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                                const float* skip, const float* kernel, float* y, int B, int Ci, int H, int W, float scale,
+                                void* stream) {
+    OODGAN_REQUIRE(x && w && s && y && B > 0 && Ci > 0 && H > 0 && W > 0, "torgb_fwd: bad args");
+    OODGAN_REQUIRE(Ci <= kMaxCi, "torgb_fwd: Ci %d > %d", Ci, kMaxCi);
+    OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "torgb_fwd: skip needs kernel and even H,W");
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 1023) / 1024), B);
+    hipLaunchKernelGGL(torgb_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y, Ci, H,
+                       W, scale);
+    return check_launch("torgb_fwd");
+}

@@ -1,0 +1,94 @@
+"""ctypes binding of liboodgan_hip.so (the C ABI declared in include/oodgan.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the reference's pybind ops raise RuntimeError from TORCH_CHECK the same
+way, src/ops/op/fused_bias_act.cpp:7,13-14)."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liboodgan_hip.so')
+
+CONV_S1, CONV_T2, CONV_S2 = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
+
+P = c_void_p  # device pointers travel as integers
+
+
+class ConvArgs(Structure):
+    _fields_ = [
+        ('x', P), ('wpk', P), ('in_scale', P), ('in_shift', P), ('out_scale', P), ('bias', P), ('noise', P),
+        ('noise_w', P), ('slope', P), ('dotx', P), ('dot_part', P), ('y', P),
+        ('B', c_int), ('K', c_int), ('M', c_int), ('Hin', c_int), ('Win', c_int),
+        ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
+        ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int),
+    ]
+
+
+_SIGS = {
+    'oodgan_version': (c_int, []),
+    'oodgan_last_error': (c_char_p, []),
+    'oodgan_device_count': (c_int, []),
+    'oodgan_bias_act_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_int, c_float, c_float, P]),
+    'oodgan_bias_act_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, c_float, c_float, P]),
+    'oodgan_upfirdn2d': (c_int, [P, P, P] + [c_int] * 15 + [P]),
+    'oodgan_blur_bias_act': (c_int, [P, P, P] + [c_int] * 9 + [P, P, c_int, P, c_int, P]),
+    'oodgan_style_affine_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    'oodgan_style_affine_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_equal_linear': (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    'oodgan_pixel_norm': (c_int, [P, P, c_int, c_int, P]),
+    'oodgan_weight_sqsum': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'oodgan_demod_fwd': (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_demod_bwd': (c_int, [P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_pack_conv3x3': (c_int, [P, P, c_int, c_int, c_float, c_int, c_int, P]),
+    'oodgan_conv3x3': (c_int, [POINTER(ConvArgs), P]),
+    'oodgan_conv3x3_nparts': (c_int, [c_int, c_int, c_int]),
+    'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
+    'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_act_bwd_nparts': (c_int, [c_long]),
+    'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, P]),
+    'oodgan_mse_nparts': (c_int, [c_long]),
+    'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); '
+                'there is no CPU or PyTorch fallback for the hot path')
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name, None)
+            if fn is None:
+                continue  # optional groups are bound lazily by bind_extra()
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def bind_extra(sigs):
+    h = lib()
+    for name, (res, args) in sigs.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    _SIGS.update(sigs)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().oodgan_last_error()
+        raise RuntimeError(f'liboodgan_hip {what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def exported_symbols():
+    return sorted(_SIGS)

@@ -1,0 +1,254 @@
+"""``ood_faceGAN_e4e`` — the drop-in top level of the path (reference
+src/archs/OOD_faceGAN_e4e_arch.py:28-347): same constructor surface (the ``network_g`` block of
+options/test/E4E_Face_test.yml), ``forward(x, **kw) -> (out, lats)``, side channels ``.aligns``,
+``.delta_latent``, ``.avg_latent``, ``.generator.size``, ``random_gen``; plus the build-defined W+
+refinement (``invert``) that the north star adds in front of the OOD forward.
+
+The e4e encoder (the step *before* the path) is pluggable: ``self.encoder`` is any
+callable ``encoder(x256, return_feats=True) -> (lats (B,18,512), feats[>=4])``; alternatively the
+encoder outputs can be passed to ``forward`` as ``enc_lats=`` / ``enc_feats=``."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, samm
+from .engine import WPlusInverter
+from .modules import Generator
+from .synth import generator_channels
+
+
+class Registry:
+    """name -> class registry, the plugin mechanism of BasicSR (basicsr/utils/registry.py:30-66)."""
+
+    def __init__(self, name):
+        self._name, self._obj_map = name, {}
+
+    def register(self, obj=None):
+        def deco(o):
+            assert o.__name__ not in self._obj_map, f'{o.__name__} already registered in {self._name}'
+            self._obj_map[o.__name__] = o
+            return o
+        return deco if obj is None else deco(obj)
+
+    def get(self, name):
+        if name not in self._obj_map:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        return self._obj_map[name]
+
+    def __contains__(self, name):
+        return name in self._obj_map
+
+    def keys(self):
+        return self._obj_map.keys()
+
+
+ARCH_REGISTRY = Registry('arch')
+
+
+def build_network(opt):
+    """basicsr.archs.build_network (BasicSR/basicsr/archs/__init__.py:19-25): pops ``type``."""
+    opt = dict(opt)
+    return ARCH_REGISTRY.get(opt.pop('type'))(**opt)
+
+
+class _MissingEncoder(nn.Module):
+    channels = [64, 64, 128, 256, 512]
+    progressive_stage = None
+
+    def forward(self, x, return_feats=False):
+        raise RuntimeError('no e4e encoder attached: pass enc_lats=/enc_feats= to forward(), or assign a callable '
+                           'to model.encoder (the encoder is the step before the accelerated path, SURVEY.md §8f N1)')
+
+
+@ARCH_REGISTRY.register()
+class ood_faceGAN_e4e(nn.Module):
+    def __init__(self,
+                 out_size=1024, style_dim=512, n_mlp=8, channel_multiplier=2, narrow=1, merge='',
+                 StyleGAN_pth=None, StyleGAN_pth_key='params_ema',
+                 aug_alignment=False, aug_inputcolor=False,
+                 stage='Inference', encoder='E4E', E4E_pth=None, avg_latent_pth=None,
+                 optim_delta_latent=False, delta_latent_pth=None,
+                 enable_modulation=True, modulation_type='NOISE', warp_scale=0.02,
+                 blend_with_gen=True, ModSize=None,
+                 progressiveModSize=[16, 32, 64, 128, 256], progressiveStart=20000,
+                 progressiveStep=2000, progressiveStageSteps=[999999999], eval_path_length=None,
+                 **kwargs):
+        super().__init__()
+        if aug_alignment or aug_inputcolor:
+            # the reference reads undefined names for these options (OOD_faceGAN_e4e_arch.py:88-97 -> NameError)
+            raise NotImplementedError('aug_alignment / aug_inputcolor are unusable in the reference as well')
+        if encoder != 'E4E':
+            raise NotImplementedError("only encoder='E4E' is on the accelerated path")
+        if modulation_type != 'NOISE':
+            raise NotImplementedError("only modulation_type='NOISE' (every shipped YAML)")
+        if narrow != 1:
+            raise NotImplementedError('narrow != 1')
+        self.encoder_type = encoder
+        log_outsize = int(math.log(out_size, 2))
+        self.style_cnt = log_outsize * 2 - 2
+        self.style_dim = style_dim
+        self.channels = generator_channels(channel_multiplier, narrow)
+        self.encoder = _MissingEncoder()
+        self.aligns = {}
+        self.log_outsize = int(math.log(256, 2))
+        self.stage = stage
+        if enable_modulation:
+            self.feats_conv = nn.ModuleList()
+            featsize = 256
+            for i in range(4):
+                self.feats_conv.append(nn.Conv2d(_MissingEncoder.channels[i], self.channels[featsize], 1, 1, 0))
+                featsize //= 2
+            self.modulation = nn.ModuleList()
+            self.progressiveModSize = list(progressiveModSize)
+            self.modulation_type = modulation_type
+            self.blend_with_gen = blend_with_gen
+            self.blend_cnt = kwargs.get('blend_cnt', 1)
+            self.skip_SA = kwargs.get('skip_SA', False)
+            self.randomTransform = None
+            self.colorTransform = None
+            self.ModSize = self.progressiveModSize.pop(0) if ModSize is None else ModSize
+            self.warp_scale = warp_scale
+            self.cycle_align = kwargs.get('cycle_align', 1)
+            for i in range(self.log_outsize, 4, -1):
+                chn = self.channels[2 ** i]
+                self.modulation.append(samm.StyledscaleNshfitBlock(chn, chn, style_dim, scale=warp_scale,
+                                                                   btn=kwargs.get('mod_btn', None),
+                                                                   cycle_align=self.cycle_align,
+                                                                   diff_fAndg=kwargs.get('diff_fAndg', True)))
+        else:
+            self.modulation = None
+            self.ModSize = 0
+        self.generator = Generator(size=out_size, n_mlp=n_mlp, style_dim=style_dim, channel_multiplier=channel_multiplier)
+        self.avg_latent = nn.Parameter(torch.zeros((1, style_dim)), requires_grad=False)
+        if optim_delta_latent:
+            self.delta_latent = nn.Parameter(torch.randn((1, self.style_cnt, style_dim)) * 0.1, requires_grad=True)
+        else:
+            self.delta_latent = nn.Parameter(torch.zeros((1, self.style_cnt, style_dim)), requires_grad=False)
+        self.progressiveStageSteps = progressiveStageSteps
+        if self.progressiveStageSteps is None:
+            self.progressiveStageSteps = [progressiveStart + progressiveStep * i for i in range(self.style_cnt)]
+        if StyleGAN_pth is not None:
+            from .io import load_generator_checkpoint
+            load_generator_checkpoint(self.generator, StyleGAN_pth, StyleGAN_pth_key)
+        if E4E_pth is not None:
+            raise NotImplementedError('loading e4e_ffhq_encode.pt needs the e4e encoder (SURVEY.md §8f N1)')
+        if avg_latent_pth is not None:
+            self.avg_latent.data = torch.load(avg_latent_pth, map_location='cpu')
+        if delta_latent_pth is not None:
+            self.delta_latent.data = torch.load(delta_latent_pth, map_location='cpu')
+        self.eval_path_length = bool(eval_path_length) if eval_path_length is not None else False
+
+    # ---------------------------------------------------------------- reference helpers
+    def get_style_mlp(self, x):
+        return self.generator.style(x)
+
+    def random_gen(self, batch_size=1, gen=True):
+        style = torch.randn((batch_size, self.style_dim), device=self.avg_latent.device)
+        lats = self.get_style_mlp(style).unsqueeze(1).repeat(1, self.style_cnt, 1)
+        out = self.generator(lats, input_is_tensor=True, input_is_latent=True)[0] if gen else None
+        return out, lats
+
+    def random_gen_center(self, scale=0.1, gen=True):
+        lats = self.avg_latent + (torch.randn_like(self.avg_latent) * scale)
+        lats = lats.unsqueeze(1).repeat(1, self.style_cnt, 1)
+        out = self.generator(lats, input_is_tensor=True, input_is_latent=True)[0] if gen else None
+        return out, lats
+
+    def feats2condition(self, feats, **kwargs):
+        conditions = []
+        if self.ModSize > 0:
+            max_size = int(np.floor(math.log(self.ModSize, 2)))
+            min_size = int(np.floor(math.log(feats[-1].shape[-1], 2)))
+            cond_len = min(max((1 + max_size - min_size), 0), len(feats))
+            conditions = [[None, None] for _ in range(cond_len)]
+        return conditions
+
+    def _cond_hook(self, k, raw, style, noise, noise_weight):
+        """feats2condition_callback (OOD_faceGAN_e4e_arch.py:224-242) in its algebraically reduced
+        form: the layer becomes aligned_target + w*noise (model.py:292), so the aligned feature
+        itself is returned and the engine adds noise/bias/activation."""
+        ind = k + 1
+        feat = self.feats[-ind]
+        mod = self.modulation[-ind]
+        aligned = self.aligns[ind - 1] if ind > 1 else None
+        cond, align = mod(feat, style, image=raw, aligned=aligned)
+        self.aligns[ind] = align
+        return cond
+
+    def encode(self, x, **kwargs):
+        """Step 1-2 of forward (:256-267): encoder at 256², + avg_latent + delta_latent (+ truncation)."""
+        enc_lats, enc_feats = kwargs.get('enc_lats', None), kwargs.get('enc_feats', None)
+        if enc_lats is None or (self.modulation is not None and enc_feats is None):
+            x256 = samm.resize_bilinear(x, 256)
+            enc_lats, enc_feats = self.encoder(x256, return_feats=True)
+        lats = enc_lats + self.avg_latent.reshape(1, 1, -1) + self.delta_latent
+        truncation = kwargs.get('truncation', 1.0)
+        if truncation < 1.0:
+            lats = self.avg_latent.reshape(1, 1, -1) * (1. - truncation) + (lats * truncation)
+        return lats.contiguous(), enc_feats
+
+    def forward(self, x, **kwargs):
+        if kwargs.get('random_gen', False):
+            return self.random_gen(batch_size=kwargs.get('batch_size', 1), gen=kwargs.get('gen', True))
+        lats, enc_feats = self.encode(x, **kwargs)
+        if 'lats' in kwargs and kwargs['lats'] is not None:      # W+ refined latents replace the encoder's
+            lats = kwargs['lats']
+        self.ori_lats = lats
+        noise = kwargs.get('noise', None)
+        if self.modulation is None:
+            out, _ = self.generator(lats, input_is_tensor=True, input_is_latent=True, noise=noise)
+            return out, lats
+        self.feats = [samm.conv1x1(enc_feats[i], self.feats_conv[i].weight, self.feats_conv[i].bias) for i in range(4)]
+        self.lats = lats
+        self.aligns = {}
+        conditions = self.feats2condition(self.feats)
+        cond_ind = [(2 * (k + 2)) + 1 for k in range(len(conditions))]
+        out, _ = self.generator(lats, input_is_tensor=True, input_is_latent=True, conditions=conditions,
+                                cond_layers=cond_ind, cond_type=self.modulation_type, cond_hook=self._cond_hook,
+                                noise=noise)
+        if self.blend_with_gen:
+            if self.skip_SA:
+                out, _ = self.generator(lats, input_is_tensor=True, input_is_latent=True, noise=noise)
+            for _ in range(self.blend_cnt):
+                out = self.blend(x, out, alpha_scale=None)
+        return out, lats
+
+    def blending_mask(self):
+        """:315-339 — compose the up-sampled alpha channels (coarse -> fine), clip; stores aligns[size]."""
+        self.aligns.pop(self.generator.size, None)
+        keys = sorted(self.aligns.keys())
+        if not keys:
+            return None
+        alpha, _ = samm.mask_blend([self.aligns[k] for k in keys], size=self.generator.size)
+        self.aligns[self.generator.size] = alpha.repeat(1, 3, 1, 1)
+        return alpha
+
+    def blend(self, target, output, detach=True, alpha_scale=None):
+        """:341-347; with alpha_scale=None the mask is composed and applied in one fused kernel."""
+        if alpha_scale is not None:
+            return alpha_scale * target + output * (1 - alpha_scale)
+        self.aligns.pop(self.generator.size, None)
+        keys = sorted(self.aligns.keys())
+        if not keys:
+            return None
+        alpha, out = samm.mask_blend([self.aligns[k] for k in keys], target, output, size=self.generator.size)
+        self.aligns[self.generator.size] = alpha.repeat(1, 3, 1, 1)
+        return out
+
+    # ---------------------------------------------------------------- build-defined: W+ refinement
+    def invert(self, x, steps=100, lr=0.01, noise=None, **kwargs):
+        """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
+        Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
+        latents (masks + blend).  Returns (out, lats, losses[steps,B])."""
+        lats0, enc_feats = self.encode(x, **kwargs)
+        B = x.shape[0]
+        if noise is None:
+            noise = [n.expand(B, -1, -1, -1).contiguous() for n in self.generator.make_noise()]
+        inv = WPlusInverter(self.generator.engine(), lr=lr)
+        w, losses = inv.invert(x, lats0, noise, steps=steps)
+        kw = dict(kwargs)
+        kw.update({'enc_lats': lats0, 'enc_feats': enc_feats, 'lats': w, 'noise': noise})
+        out, lats = self.forward(x, **kw)
+        return out, lats, losses

@@ -1,0 +1,240 @@
+"""Generator schedule on the HIP ops: forward (with optional SAMM hooks), backward w.r.t. the W+
+latents, and the W+ Adam inversion loop.
+
+``GeneratorEngine`` owns the *prepared* form of the frozen generator weights:
+  * every 3x3 weight packed K-major for the MFMA implicit-GEMM kernels (forward and input-gradient
+    layouts), scaled by 1/sqrt(fan_in) once;
+  * per-(co,ci) squared tap sums for the factorised demodulation;
+  * all 26 modulation matrices concatenated (rows grouped by latent index) so that the style affine
+    of a whole forward is one MFMA contraction and its backward one kernel.
+Layer order / latent indexing follow reference src/ops/StyleGAN/model.py:548-576."""
+import math
+
+import torch
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE, CONV_S1, CONV_S2, CONV_T2
+from .synth import generator_channels, make_kernel
+
+
+_Cols = ops.Cols
+
+
+class _Layer:
+    __slots__ = ('name', 'kind', 'cin', 'cout', 'res', 'lat', 'row', 'drow', 'wpk', 'wpk_bwd', 'wsq', 'w_rgb',
+                 'bias', 'noise_w', 'scale', 'noise_idx', 'src')
+
+
+class GeneratorEngine:
+    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True):
+        self.size, self.style_dim = size, style_dim
+        self.log_size = int(math.log2(size))
+        self.n_latent = self.log_size * 2 - 2
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        ch = generator_channels(channel_multiplier)
+        g = lambda k: state[prefix + k].detach().float().contiguous()
+        dev = g('input.input').device
+        if dev.type != 'cuda':
+            raise RuntimeError('GeneratorEngine needs its parameters on a ROCm device (no CPU fallback)')
+        self.device = dev
+        self.const_input = g('input.input')
+        self.k4x4 = (make_kernel() * 4.0).to(dev)          # Blur(upsample_factor=2) / Upsample kernel
+        self.k4x4_flip = torch.flip(self.k4x4, [0, 1]).contiguous()
+        layers = []
+
+        def styled(name, cin, cout, res, lat, up, nidx):
+            L = _Layer()
+            L.name, L.kind, L.cin, L.cout, L.res, L.lat, L.noise_idx = name, ('up' if up else 'conv'), cin, cout, res, lat, nidx
+            w = g(f'{name}.conv.weight')[0]                 # (Co,Ci,3,3)
+            L.scale = 1.0 / math.sqrt(cin * 9)
+            L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False)
+            L.wpk_bwd = ops.pack_conv3x3(w, L.scale, transpose=True, flip=not up) if with_backward else None
+            L.wsq = ops.weight_sqsum(w)
+            L.bias = g(f'{name}.activate.bias')
+            L.noise_w = g(f'{name}.noise.weight')
+            layers.append(L)
+            return L
+
+        def rgb(name, cin, res, lat):
+            L = _Layer()
+            L.name, L.kind, L.cin, L.cout, L.res, L.lat = name, 'rgb', cin, 3, res, lat
+            L.w_rgb = g(f'{name}.conv.weight').reshape(3, cin).contiguous()
+            L.bias = g(f'{name}.bias').reshape(3).contiguous()
+            L.scale = 1.0 / math.sqrt(cin)
+            layers.append(L)
+            return L
+
+        styled('conv1', ch[4], ch[4], 4, 0, False, 0)
+        rgb('to_rgb1', ch[4], 4, 1)
+        cin, i = ch[4], 1
+        for j in range(self.log_size - 2):
+            res = 2 ** (j + 3)
+            cout = ch[res]
+            styled(f'convs.{2 * j}', cin, cout, res, i, True, 2 * j + 1)
+            styled(f'convs.{2 * j + 1}', cout, cout, res, i + 1, False, 2 * j + 2)
+            rgb(f'to_rgbs.{j}', cout, res, i + 2)
+            cin, i = cout, i + 2
+        self.layers = layers
+        src = 'input'
+        for L in layers:            # producer of every layer's input feature
+            L.src = src
+            if L.kind != 'rgb':
+                src = L.name
+        # concatenated modulation matrix, rows grouped by latent index (execution order already is)
+        rows, drows, wl, bl, rl = 0, 0, [], [], []
+        lat_start = [0] * (self.n_latent + 1)
+        for L in layers:
+            L.row = rows
+            wl.append(g(f'{L.name}.conv.modulation.weight'))
+            bl.append(g(f'{L.name}.conv.modulation.bias'))
+            rl += [L.lat] * L.cin
+            rows += L.cin
+            lat_start[L.lat + 1] = rows
+            if L.kind != 'rgb':
+                L.drow = drows
+                drows += L.cout
+        for l in range(1, self.n_latent + 1):
+            lat_start[l] = max(lat_start[l], lat_start[l - 1])
+        self.R, self.DR = rows, drows
+        self.wcat = torch.cat(wl, 0).contiguous()
+        self.bcat = torch.cat(bl, 0).contiguous()
+        self.row_lat = torch.tensor(rl, dtype=torch.int32, device=dev)
+        self.lat_start = torch.tensor(lat_start, dtype=torch.int32, device=dev)
+        self.stored_noises = [g(f'noises.noise_{k}') for k in range(self.num_layers)] if (prefix + 'noises.noise_0') in state else None
+        self.saved = None
+
+    # ------------------------------------------------------------------ forward
+    def styles(self, latent):
+        """(B, n_latent, S) -> all style vectors (B, R) in one contraction."""
+        return ops.style_affine(latent, self.wcat, self.bcat, self.row_lat)
+
+    def forward(self, latent, noises, save=False, cond_hook=None, cond_layers=None, return_features=False):
+        """latent (B,n_latent,S); noises list[num_layers] of (B|1,1,r,r).
+        cond_hook(k, raw, latent_i, noise, noise_w) -> cond tensor replacing the raw up-conv output
+        (the algebra of OOD_faceGAN_e4e_arch.py:239-242 + model.py:292: layer = cond + w*noise)."""
+        B = latent.shape[0]
+        s_all = self.styles(latent)
+        d_all = torch.empty(B, self.DR, device=self.device, dtype=torch.float32)
+        for L in self.layers:
+            if L.kind != 'rgb':
+                self._demod(L, s_all, d_all)
+        acts = {}
+        x = self.const_input.expand(B, -1, -1, -1).contiguous()
+        acts['input'] = x
+        skip, out = None, x
+        i = 1
+        for L in self.layers:
+            s = _Cols(s_all, L.row, L.cin)
+            if L.kind == 'rgb':
+                skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None)
+                continue
+            d = _Cols(d_all, L.drow, L.cout)
+            nz = noises[L.noise_idx]
+            if L.kind == 'conv':
+                out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
+                                  noise_weight=L.noise_w, act=ACT_LRELU)
+            else:
+                z = ops.conv3x3(out, L.wpk, L.cout, CONV_T2, in_scale=s, out_scale=d)
+                H2 = 2 * out.shape[2] + 1
+                lat_idx = L.lat
+                if cond_hook is not None and cond_layers is not None and lat_idx in cond_layers:
+                    raw = ops.blur_bias_act(z, self.k4x4, (1, 1), act=False, in_hw=(H2, H2), in_pitch=z.shape[3])
+                    cond = cond_hook(cond_layers.index(lat_idx), raw, latent[:, lat_idx], nz, L.noise_w)
+                    out = ops.bias_noise_act(cond, L.bias, nz, L.noise_w)
+                else:
+                    out = ops.blur_bias_act(z, self.k4x4, (1, 1), L.bias, nz, L.noise_w, act=True, in_hw=(H2, H2),
+                                            in_pitch=z.shape[3])
+                del z
+            acts[L.name] = out
+        if save:
+            self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B)
+        if return_features:
+            return skip, out
+        return skip
+
+    def _demod(self, L, s_all, d_all):
+        from ._lib import lib, check
+        import ctypes
+        B = s_all.shape[0]
+        check(lib().oodgan_demod_fwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
+                                     ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, B, L.cin, L.cout, L.scale,
+                                     ops._stream()), 'demod_fwd')
+
+    # ------------------------------------------------------------------ backward (w.r.t. latents only)
+    def backward(self, gimg):
+        """gimg (B,3,size,size) -> dL/dlatent (B,n_latent,S).  Needs forward(..., save=True)."""
+        from ._lib import lib, check
+        import ctypes
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError('backward() without forward(save=True)')
+        acts, s_all, d_all, noises, B = sv['acts'], sv['s_all'], sv['d_all'], sv['noises'], sv['B']
+        gs_all = torch.zeros(B, self.R, device=self.device, dtype=torch.float32)
+        # gradient of the skip chain: gskip[res] for every ToRGB level
+        gskip = {self.size: gimg.contiguous()}
+        r = self.size
+        while r > 4:
+            gskip[r // 2] = ops.upfirdn2d(gskip[r], self.k4x4_flip, up=1, down=2, pad=(1, 1))
+            r //= 2
+        g_feat = None
+        prev_rgb = None
+        for L in reversed(self.layers):
+            if L.kind == 'rgb':          # fused into the backward of the styled conv that feeds it
+                prev_rgb = L
+                continue
+            out, x_in, nz = acts[L.name], acts[L.src], noises[L.noise_idx]
+            if prev_rgb is not None:
+                Rg = prev_rgb
+                g_pre, rsum, tsum = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
+                                                      _Cols(s_all, Rg.row, Rg.cin))
+                gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
+                prev_rgb = None
+            else:
+                g_pre, rsum, _ = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias)
+            # demodulation gradient
+            check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
+                                         ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
+                                         ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
+                                         ops._stream()), 'demod_bwd')
+            s = _Cols(s_all, L.row, L.cin)
+            d = _Cols(d_all, L.drow, L.cout)
+            if L.kind == 'conv':
+                dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in)
+            else:
+                H2 = 2 * x_in.shape[2] + 1
+                g2 = ops.upfirdn2d(g_pre, self.k4x4_flip, pad=(2, 2), out_pitch=H2 + 1)
+                dx, dot = ops.conv3x3(g2, L.wpk_bwd, L.cin, CONV_S2, in_scale=d, out_scale=s, dotx=x_in, in_hw=(H2, H2),
+                                      in_pitch=H2 + 1)
+                del g2
+            gs_all[:, L.row:L.row + L.cin] += dot
+            g_feat = dx
+            del g_pre
+        return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent)
+
+
+class WPlusInverter:
+    """Build-defined W+ optimisation loop: ``steps`` x {G(w) with fixed noise,
+    per-image MSE, backward to w, Adam(lr, betas, eps)} — anchors: reference Generator.forward with
+    ``noise=<list>`` (model.py:483-585), torch.optim.Adam as built by get_optimizer
+    (src/models/OOD_faceGAN_model.py:398-400), basicsr MSELoss (losses.py:58-83)."""
+
+    def __init__(self, engine, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+        self.engine, self.lr, self.betas, self.eps = engine, lr, betas, eps
+
+    def invert(self, target, w0, noises, steps=100, return_trajectory=False):
+        w = w0.detach().clone().contiguous()
+        m = torch.zeros_like(w)
+        v = torch.zeros_like(w)
+        losses, traj = [], []
+        for t in range(1, steps + 1):
+            img = self.engine.forward(w, noises, save=True)
+            loss, gimg = ops.mse_loss_grad(img, target)
+            g = self.engine.backward(gimg)
+            ops.adam_step(w, g, m, v, t, self.lr, self.betas, self.eps)
+            losses.append(loss)
+            if return_trajectory:
+                traj.append(w.clone())
+        self.engine.saved = None
+        if return_trajectory:
+            return w, torch.stack(losses), traj
+        return w, torch.stack(losses)

@@ -1,0 +1,312 @@
+"""Thin functional wrappers: torch ROCm tensors in (used purely as device buffers), HIP kernels
+through the C ABI, torch tensors out.  Names/arguments mirror the reference's op layer
+(src/ops/op/upfirdn2d.py:149, src/ops/op/fused_act.py:92) where one exists."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_PRELU, CONV_S1, CONV_S2, CONV_T2, ConvArgs, check
+
+SQRT2 = 2 ** 0.5
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Cols:
+    """A column block [off, off+n) of a dense (B, R) matrix, passed by pointer + row stride (no copy)."""
+
+    def __init__(self, base, off, n):
+        self.base, self.off, self.n = base, off, n
+        self.shape = (base.shape[0], base.shape[1])   # shape[1] is the ROW STRIDE seen by the kernels
+        self.is_cuda, self.dtype = base.is_cuda, base.dtype
+
+    def data_ptr(self):
+        return self.base.data_ptr() + 4 * self.off
+
+    def dense(self):
+        return self.base[:, self.off:self.off + self.n]
+
+
+def _dev(t, name='input'):
+    if isinstance(t, Cols):
+        return t
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f'{name} must be a ROCm (cuda) tensor: the HIP path has no CPU fallback')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{name} must be float32, got {t.dtype}')
+    return t.contiguous()
+
+
+def _opt(t, name):
+    return None if t is None else _dev(t, name)
+
+
+# ----------------------------------------------------------------------------- L1 ops
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), device='hip', out_pitch=0):
+    """reference signature: upfirdn2d(input, kernel, up=1, down=1, pad=(0,0), device='cpu')
+    (src/ops/op/upfirdn2d.py:149-157).  ``device`` is accepted and ignored: this always runs the HIP
+    kernel on the tensor's GPU."""
+    x = _dev(input)
+    k = _dev(kernel, 'kernel')
+    B, C, H, W = x.shape
+    kh, kw = k.shape
+    p0, p1 = int(pad[0]), int(pad[1])
+    oh = (H * up + p0 + p1 - kh) // down + 1
+    ow = (W * up + p0 + p1 - kw) // down + 1
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError(f'upfirdn2d: empty output {oh}x{ow}')
+    y = torch.empty(B, C, oh, out_pitch if out_pitch else ow, device=x.device, dtype=torch.float32)
+    if B * C == 0:
+        return y
+    check(_lib.lib().oodgan_upfirdn2d(_p(x), _p(k), _p(y), B * C, H, W, 0, out_pitch, kh, kw, up, up, down, down, p0, p1, p0,
+                                      p1, _stream()), 'upfirdn2d')
+    return y
+
+
+def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=SQRT2, device='hip'):
+    """reference: fused_leaky_relu(input, bias, negative_slope=0.2, scale=2**0.5, device='cpu')
+    (src/ops/op/fused_act.py:92-96).  Bias indexes dim 1."""
+    x = _dev(input)
+    shp = x.shape
+    B, C = shp[0], shp[1] if x.ndim > 1 else 1
+    HW = x.numel() // max(B * C, 1)
+    y = torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    b = _opt(bias, 'bias')
+    check(_lib.lib().oodgan_bias_act_fwd(_p(x), _p(b), None, None, _p(y), B, C, HW, 1, float(negative_slope), float(scale),
+                                         _stream()), 'bias_act_fwd')
+    return y
+
+
+def fused_leaky_relu_backward(grad_output, out, negative_slope=0.2, scale=SQRT2, need_bias_grad=False):
+    """FusedLeakyReLUFunctionBackward (src/ops/op/fused_act.py:25-58): returns (grad_input, grad_bias)."""
+    g = _dev(grad_output, 'grad_output')
+    o = _dev(out, 'out')
+    B, C = g.shape[0], g.shape[1]
+    HW = g.numel() // (B * C)
+    gx = torch.empty_like(g)
+    gb = torch.empty(C, device=g.device, dtype=torch.float32) if need_bias_grad else None
+    check(_lib.lib().oodgan_bias_act_bwd(_p(g), _p(o), _p(gx), _p(gb), B, C, HW, float(negative_slope), float(scale),
+                                         _stream()), 'bias_act_bwd')
+    return gx, gb
+
+
+def bias_noise_act(x, bias=None, noise=None, noise_weight=None, negative_slope=0.2, scale=SQRT2):
+    """NoiseInjection + FusedLeakyReLU in one pass (src/ops/StyleGAN/model.py:283-292,343-350)."""
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    nz = _opt(noise, 'noise')
+    nb = 1 if nz is None else nz.shape[0]
+    check(_lib.lib().oodgan_bias_act_fwd(_p(x), _p(_opt(bias, 'bias')), _p(nz), _p(_opt(noise_weight, 'noise_weight')), _p(y),
+                                         B, C, HW, nb, float(negative_slope), float(scale), _stream()), 'bias_act_fwd')
+    return y
+
+
+def blur_bias_act(x, kernel, pad, bias=None, noise=None, noise_weight=None, act=True, in_hw=None, in_pitch=0):
+    """Blur(pad) + noise + bias + lrelu*sqrt2 (src/ops/StyleGAN/model.py:255-258,343-350).  ``x`` may
+    be a pitched buffer (B,C,in_h,in_pitch) with logical width in_hw[1]."""
+    x = _dev(x)
+    k = _dev(kernel, 'kernel')
+    B, C = x.shape[0], x.shape[1]
+    H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
+    kh, kw = k.shape
+    oh, ow = H + pad[0] + pad[1] - kh + 1, W + pad[0] + pad[1] - kw + 1
+    y = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
+    nz = _opt(noise, 'noise')
+    nb = 1 if nz is None else nz.shape[0]
+    check(_lib.lib().oodgan_blur_bias_act(_p(x), _p(k), _p(y), B, C, H, W, in_pitch, kh, kw, int(pad[0]), int(pad[1]),
+                                          _p(_opt(bias, 'bias')), _p(nz), nb, _p(_opt(noise_weight, 'nw')),
+                                          ACT_LRELU if act else ACT_NONE, _stream()), 'blur_bias_act')
+    return y
+
+
+# ----------------------------------------------------------------------------- style path
+def style_affine(latent, wcat, bcat=None, row_lat=None, lr_mul=1.0):
+    """s[b,r] = (1/sqrt(S)) * lr_mul * W[r]·latent[b,row_lat[r]] + bias[r]*lr_mul  (EqualLinear, model.py:129-158)."""
+    lat = _dev(latent, 'latent')
+    if lat.ndim == 2:
+        lat = lat.unsqueeze(1)
+    B, L, S = lat.shape
+    w = _dev(wcat, 'wcat')
+    R = w.shape[0]
+    s = torch.empty(B, R, device=lat.device, dtype=torch.float32)
+    scale = (1.0 / math.sqrt(S)) * lr_mul
+    check(_lib.lib().oodgan_style_affine_fwd(_p(lat.contiguous()), _p(w), _p(_opt(bcat, 'bcat')), _p(row_lat), _p(s), B, L, S, R,
+                                             scale, float(lr_mul), _stream()), 'style_affine_fwd')
+    return s
+
+
+def style_affine_backward(gs, wcat, lat_start, L, lr_mul=1.0):
+    g = _dev(gs, 'gs')
+    w = _dev(wcat, 'wcat')
+    B, R = g.shape
+    S = w.shape[1]
+    glat = torch.empty(B, L, S, device=g.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_style_affine_bwd(_p(g), _p(w), _p(lat_start), _p(glat), B, L, S, R, (1.0 / math.sqrt(S)) * lr_mul,
+                                             _stream()), 'style_affine_bwd')
+    return glat
+
+
+def equal_linear(x, weight, bias=None, lr_mul=1.0, activation=False):
+    x = _dev(x)
+    w = _dev(weight, 'weight')
+    B, I = x.shape
+    O = w.shape[0]
+    y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_equal_linear(_p(x), _p(w), _p(_opt(bias, 'bias')), _p(y), B, I, O, (1.0 / math.sqrt(I)) * lr_mul,
+                                         float(lr_mul), 1 if activation else 0, _stream()), 'equal_linear')
+    return y
+
+
+def pixel_norm(x):
+    x = _dev(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().oodgan_pixel_norm(_p(x), _p(y), x.shape[0], x.shape[1], _stream()), 'pixel_norm')
+    return y
+
+
+def weight_sqsum(weight):
+    """(Co,Ci,k,k) -> (Co,Ci) sum of squares over the taps."""
+    w = _dev(weight, 'weight')
+    Co, Ci = w.shape[0], w.shape[1]
+    out = torch.empty(Co, Ci, device=w.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_weight_sqsum(_p(w), _p(out), Co, Ci, w.shape[2] * w.shape[3], _stream()), 'weight_sqsum')
+    return out
+
+
+def demod(s, wsq, scale):
+    s = _dev(s, 's')
+    B, Ci = s.shape
+    Co = wsq.shape[0]
+    d = torch.empty(B, Co, device=s.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_demod_fwd(_p(s), Ci, _p(wsq), _p(d), Co, B, Ci, Co, float(scale), _stream()), 'demod_fwd')
+    return d
+
+
+def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False):
+    """(Co,Ci,3,3) -> wpk (K,9,Mp): the K-major layout streamed by the MFMA conv kernels."""
+    w = _dev(weight, 'weight')
+    Co, Ci = w.shape[0], w.shape[1]
+    M, K = (Ci, Co) if transpose else (Co, Ci)
+    Mp = (M + 63) // 64 * 64
+    out = torch.empty(K, 9, Mp, device=w.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_pack_conv3x3(_p(w), _p(out), Co, Ci, float(scale), int(transpose), int(flip), _stream()), 'pack')
+    return out
+
+
+def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
+            noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0):
+    """Implicit-GEMM 3x3 conv on the fp32 matrix cores.  Returns y, or (y, dot[B,M]) when ``dotx`` is given."""
+    x = _dev(x)
+    B, K = x.shape[0], x.shape[1]
+    H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
+    if mode == CONV_S1:
+        oh, ow = H, W
+    elif mode == CONV_T2:
+        oh, ow = 2 * H + 1, 2 * W + 1
+        if out_pitch == 0:
+            out_pitch = ow + 1
+    else:
+        oh, ow = (H - 1) // 2, (W - 1) // 2
+    pitch = out_pitch if out_pitch else ow
+    if out is None:
+        out = torch.empty(B, M, oh, pitch, device=x.device, dtype=torch.float32)
+    a = ConvArgs()
+    a.x, a.wpk, a.y = _p(x), _p(wpk), _p(out)
+    a.in_scale, a.in_shift, a.out_scale = _p(_opt(in_scale, 'in_scale')), _p(_opt(in_shift, 'in_shift')), _p(_opt(out_scale, 'out_scale'))
+    a.bias, a.noise, a.noise_w, a.slope = _p(_opt(bias, 'bias')), _p(_opt(noise, 'noise')), _p(_opt(noise_weight, 'nw')), _p(_opt(slope, 'slope'))
+    a.B, a.K, a.M, a.Hin, a.Win = B, K, M, H, W
+    a.in_pitch, a.out_pitch = in_pitch, out_pitch
+    a.in_scale_stride = in_scale.shape[1] if in_scale is not None else 0
+    a.out_scale_stride = out_scale.shape[1] if out_scale is not None else 0
+    a.noise_batch = noise.shape[0] if noise is not None else 1
+    a.mode, a.act = mode, act
+    part = None
+    if dotx is not None:
+        dx_ = _dev(dotx, 'dotx')
+        npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
+        part = torch.empty(B, M, npart, device=x.device, dtype=torch.float32)
+        a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
+    check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
+    if dotx is not None:
+        dot = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
+        return out, dot
+    return out
+
+
+def torgb(x, weight, s, bias=None, skip=None, kernel=None):
+    """ToRGB.forward (src/ops/StyleGAN/model.py:363-372): weight (3,Ci), s (B,Ci) style, skip (B,3,H/2,W/2)."""
+    x = _dev(x)
+    B, Ci, H, W = x.shape
+    y = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
+    w = _dev(weight, 'weight').reshape(3, Ci)
+    check(_lib.lib().oodgan_torgb_fwd(_p(x), _p(w), _p(_dev(s, 's')), s.shape[1], _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')),
+                                      _p(_opt(kernel, 'kernel')), _p(y), B, Ci, H, W, 1.0 / math.sqrt(Ci), _stream()), 'torgb_fwd')
+    return y
+
+
+def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_rgb=None, w_rgb=None, s_rgb=None):
+    """Backward through bias+noise+lrelu*sqrt2 merged with the ToRGB branch; returns
+    (g_pre, r[B,C] = sum g_pre*y_cv, t[B,C] = sum out*t or None)."""
+    o = _dev(out, 'out')
+    B, C = o.shape[0], o.shape[1]
+    HW = o.numel() // (B * C)
+    L = _lib.lib()
+    npart = L.oodgan_act_bwd_nparts(HW)
+    g_pre = torch.empty_like(o)
+    part_r = torch.empty(B, C, npart, device=o.device, dtype=torch.float32)
+    part_t = torch.empty(B, C, npart, device=o.device, dtype=torch.float32) if g_rgb is not None else None
+    nz = _opt(noise, 'noise')
+    check(L.oodgan_act_bwd_fused(_p(_opt(g_feat, 'g_feat')), _p(o), _p(nz), 1 if nz is None else nz.shape[0],
+                                 _p(_opt(noise_weight, 'nw')), _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')),
+                                 _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)), _p(_opt(s_rgb, 's_rgb')),
+                                 0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(g_pre), _p(part_r), _p(part_t),
+                                 B, C, HW, _stream()), 'act_bwd_fused')
+    r = torch.empty(B, C, device=o.device, dtype=torch.float32)
+    check(L.oodgan_reduce_parts(_p(part_r), _p(r), B * C, npart, 0, _stream()), 'reduce')
+    t = None
+    if part_t is not None:
+        t = torch.empty(B, C, device=o.device, dtype=torch.float32)
+        check(L.oodgan_reduce_parts(_p(part_t), _p(t), B * C, npart, 0, _stream()), 'reduce')
+    return g_pre, r, t
+
+
+def demod_backward(s, wsq, d, r, gs, scale):
+    """gs += d(demod)/d(style) contribution (in place)."""
+    B, Ci = s.shape
+    Co = wsq.shape[0]
+    check(_lib.lib().oodgan_demod_bwd(_p(_dev(s)), Ci, _p(wsq), _p(_dev(d)), Co, _p(_dev(r)), _p(gs), gs.shape[1], B, Ci, Co,
+                                      float(scale), _stream()), 'demod_bwd')
+    return gs
+
+
+def mse_loss_grad(img, target):
+    """Per-image MSE and its gradient: (loss[B], gimg)."""
+    a, t = _dev(img, 'img'), _dev(target, 'target')
+    B = a.shape[0]
+    CHW = a.numel() // B
+    L = _lib.lib()
+    npart = L.oodgan_mse_nparts(CHW)
+    part = torch.empty(B, npart, device=a.device, dtype=torch.float32)
+    loss = torch.empty(B, device=a.device, dtype=torch.float32)
+    g = torch.empty_like(a)
+    check(L.oodgan_mse_fwd_bwd(_p(a), _p(t), _p(g), _p(part), _p(loss), B, CHW, _stream()), 'mse')
+    return loss, g
+
+
+def adam_step(w, g, m, v, step, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+    check(_lib.lib().oodgan_adam_step(_p(w), _p(_dev(g)), _p(m), _p(v), w.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                      float(eps), int(step), _stream()), 'adam')
+    return w

@@ -1,0 +1,302 @@
+"""SAMM / SAIM — spatial alignment + invertibility mask — on the HIP ops.
+
+Mirrors reference src/ops/SAMM/helpers.py (AlignNet :85-109, SPM_Warp :111-179,
+StyledscaleNshfitBlock :182-216, new_PRM :62-77) and bottleneck_IR
+(src/ops/e4e/encoders/helpers.py:426-448).  torch.nn containers are used only to hold parameters
+under the reference's state-dict keys; every forward runs HIP kernels."""
+import ctypes
+from ctypes import POINTER, c_float, c_int, c_long, c_void_p
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import ACT_NONE, ACT_PRELU, CONV_S1, check
+from .ops import _dev, _opt, _p, _stream
+from .synth import make_kernel
+
+P = c_void_p
+_lib.bind_extra({
+    'oodgan_instnorm_stats': (c_int, [P, P, c_int, c_int, c_long, c_float, P]),
+    'oodgan_instnorm_coeffs': (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    'oodgan_affine_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
+    'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_align_head': (c_int, [P, P, c_int, c_long, c_float, P]),
+    'oodgan_field_compose': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'oodgan_warp_blend': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_mask_blend': (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, P, P, P, P, c_int, c_int, P]),
+    'oodgan_resize_nearest': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_resize_bilinear': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+})
+
+
+# ----------------------------------------------------------------------------- functional layer
+def instnorm_stats(x, eps=1e-5):
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    st = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_instnorm_stats(_p(x), _p(st), B, C, x.numel() // (B * C), eps, _stream()), 'instnorm_stats')
+    return st
+
+
+def instnorm_coeffs(stats, gamma=None, beta=None):
+    B, C = stats.shape[0], stats.shape[1]
+    sc = torch.empty(B, C, device=stats.device, dtype=torch.float32)
+    sh = torch.empty_like(sc)
+    check(_lib.lib().oodgan_instnorm_coeffs(_p(stats), _p(_opt(gamma, 'gamma')), _p(_opt(beta, 'beta')), _p(sc), _p(sh), B, C,
+                                            _stream()), 'instnorm_coeffs')
+    return sc, sh
+
+
+def affine_apply(x, sc, sh, res=None):
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    check(_lib.lib().oodgan_affine_apply(_p(x), _p(sc), _p(sh), _p(_opt(res, 'res')), _p(y), B, C, x.numel() // (B * C),
+                                         _stream()), 'affine_apply')
+    return y
+
+
+def instance_norm(x, gamma=None, beta=None, eps=1e-5, res=None):
+    sc, sh = instnorm_coeffs(instnorm_stats(x, eps), gamma, beta)
+    return affine_apply(x, sc, sh, res)
+
+
+def align_input(gen, enc, st_gen, st_enc):
+    gen, enc = _dev(gen), _dev(enc)
+    B, C, H, W = gen.shape
+    out = torch.empty(B, 2 * C, H, W, device=gen.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_align_input(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), B, C, H * W, _stream()), 'align_input')
+    return out
+
+
+def conv1x1(x, weight, bias=None):
+    x = _dev(x)
+    B, K, H, W = x.shape
+    w = _dev(weight).reshape(weight.shape[0], K)
+    M = w.shape[0]
+    y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_conv1x1(_p(x), _p(w), _p(_opt(bias, 'bias')), _p(y), B, K, M, H * W, _stream()), 'conv1x1')
+    return y
+
+
+def conv3x3_small(x, weight, in_sc=None, in_sh=None, slope=None):
+    x = _dev(x)
+    B, K, H, W = x.shape
+    w = _dev(weight)
+    M = w.shape[0]
+    y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_conv3x3_small(_p(x), _p(w), _p(in_sc), _p(in_sh), _p(_opt(slope, 'slope')), _p(y), B, K, M, H, W,
+                                          _stream()), 'conv3x3_small')
+    return y
+
+
+def align_head(x, scale):
+    x = _dev(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().oodgan_align_head(_p(x), _p(y), x.shape[0], x.shape[2] * x.shape[3], float(scale), _stream()), 'align_head')
+    return y
+
+
+def field_add(acc, cur, scale):
+    """SPM_Warp.add (helpers.py:129-137)."""
+    acc, cur = _dev(acc), _dev(cur)
+    B, _, H, W = cur.shape
+    out = torch.empty_like(cur)
+    check(_lib.lib().oodgan_field_compose(_p(acc), _p(cur), None, _p(out), B, H, W, 0, 0, float(scale), 0, _stream()), 'field_add')
+    return out
+
+
+def field_upsample_add(prev, cur, scale=0.0):
+    """SPM_Warp.upsample_add (helpers.py:139-147): alpha of the coarser level is bicubic(align_corners) upsampled."""
+    prev, cur = _dev(prev), _dev(cur)
+    B, _, H, W = cur.shape
+    out = torch.empty_like(cur)
+    check(_lib.lib().oodgan_field_compose(None, _p(cur), _p(prev), _p(out), B, H, W, prev.shape[2], prev.shape[3], float(scale), 1,
+                                          _stream()), 'field_upsample_add')
+    return out
+
+
+def warp_blend(target, field):
+    target, field = _dev(target), _dev(field)
+    B, C, H, W = target.shape
+    y = torch.empty_like(target)
+    check(_lib.lib().oodgan_warp_blend(_p(target), _p(field), _p(y), B, C, H, W, _stream()), 'warp_blend')
+    return y
+
+
+def mask_blend(fields, x=None, gen=None, size=1024):
+    """blending_mask + blend (OOD_faceGAN_e4e_arch.py:315-347).  fields: list of (B,3,s,s) coarse->fine.
+    Returns (alpha (B,1,S,S), out or None)."""
+    fields = [_dev(f) for f in fields]
+    B = fields[0].shape[0]
+    n = len(fields)
+    ptrs = (c_void_p * n)(*[f.data_ptr() for f in fields])
+    sizes = (c_int * n)(*[f.shape[-1] for f in fields])
+    alpha = torch.empty(B, 1, size, size, device=fields[0].device, dtype=torch.float32)
+    out = torch.empty(B, 3, size, size, device=alpha.device, dtype=torch.float32) if gen is not None else None
+    check(_lib.lib().oodgan_mask_blend(ptrs, sizes, n, _p(_opt(x, 'x')), _p(_opt(gen, 'gen')), _p(alpha), _p(out), B, size,
+                                       _stream()), 'mask_blend')
+    return alpha, out
+
+
+def resize_nearest(x, size, out=None, xoff=0):
+    x = _dev(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (size, size) if isinstance(size, int) else size
+    if out is None:
+        out = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_resize_nearest(_p(x), _p(out), B * C, H, W, Ho, Wo, out.shape[-1], xoff, _stream()), 'resize_nearest')
+    return out
+
+
+def resize_bilinear(x, size):
+    x = _dev(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (size, size) if isinstance(size, int) else size
+    y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_resize_bilinear(_p(x), _p(y), B * C, H, W, Ho, Wo, _stream()), 'resize_bilinear')
+    return y
+
+
+def extract_masks(aligns):
+    """run_ood_faceGAN_inversion.py:74-87: alpha channel of every level, nearest to 1024, side by side."""
+    keys = sorted(aligns)
+    B = aligns[keys[0]].shape[0]
+    dev = aligns[keys[0]].device
+    strip = torch.empty(B, 1, 1024, 1024 * len(keys), device=dev, dtype=torch.float32)
+    for i, k in enumerate(keys):
+        a = aligns[k][:, 2:3].contiguous()
+        resize_nearest(a, 1024, out=strip, xoff=1024 * i)
+    return strip
+
+
+# ----------------------------------------------------------------------------- parameter containers
+def BN(depth, bn=True):
+    if bn == 'InstanceNorm':
+        return nn.InstanceNorm2d(depth, affine=True)
+    if bn == 'BatchNorm' or bn is True:
+        raise NotImplementedError('BatchNorm bottlenecks belong to the e4e encoder (SURVEY.md §8f N1)')
+    return nn.Identity()
+
+
+class bottleneck_IR(nn.Module):
+    """bottleneck_IR(in_channel, depth, stride=1, bn='InstanceNorm', bias=False)."""
+
+    def __init__(self, in_channel, depth, stride=1, bn='InstanceNorm', bias=False):
+        super().__init__()
+        if stride != 1 or bias or bn != 'InstanceNorm':
+            raise NotImplementedError('SAMM uses stride-1, bias-free, InstanceNorm bottlenecks only')
+        self.in_channel, self.depth = in_channel, depth
+        if in_channel == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = nn.Sequential(nn.Conv2d(in_channel, depth, (1, 1), stride, bias=False), BN(depth, bn))
+        self.res_layer = nn.Sequential(BN(in_channel, bn), nn.Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+                                       nn.PReLU(depth), nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False), BN(depth, bn))
+        self._key, self._prep = None, None
+
+    def _prepared(self):
+        w1, w2 = self.res_layer[1].weight, self.res_layer[3].weight
+        key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version)
+        if key != self._key:
+            prep = {'w1': ops.pack_conv3x3(w1.detach())}
+            if self.depth > 8:
+                prep['w2'] = ops.pack_conv3x3(w2.detach())
+            self._key, self._prep = key, prep
+        return self._prep
+
+    def forward(self, x):
+        prep = self._prepared()
+        rl = self.res_layer
+        sc, sh = instnorm_coeffs(instnorm_stats(x), rl[0].weight, rl[0].bias)
+        r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)
+        if self.depth > 8:
+            r = ops.conv3x3(r, prep['w2'], self.depth, CONV_S1)
+        else:
+            r = conv3x3_small(r, rl[3].weight)
+        if self.in_channel == self.depth:
+            shortcut = x
+        else:
+            s = conv1x1(x, self.shortcut_layer[0].weight)
+            shortcut = instance_norm(s, self.shortcut_layer[1].weight, self.shortcut_layer[1].bias)
+        return instance_norm(r, rl[4].weight, rl[4].bias, res=shortcut)
+
+
+def scaleNshiftBlock(in_chn, out_chn, norm_type=False, bias=False):
+    return nn.Sequential(bottleneck_IR(in_chn, in_chn, 1, norm_type, bias), bottleneck_IR(in_chn, out_chn, 1, norm_type, bias))
+
+
+class AlignNet(nn.Module):
+    def __init__(self, in_chn, out_chn=3, scale=1., blur_kernel=[1, 3, 3, 1], **kwargs):
+        super().__init__()
+        self.norm = nn.InstanceNorm2d(in_chn)
+        self.body = scaleNshiftBlock(in_chn * 2, out_chn, 'InstanceNorm', kwargs.get('bias', False))
+        self.scale = scale
+        self.diff_fAndg = kwargs.get('diff_fAndg', True)
+        if not self.diff_fAndg:
+            raise NotImplementedError('diff_fAndg=False is not used by any shipped config')
+
+    def forward(self, source, target, st_target=None, **kwargs):
+        st_s = instnorm_stats(source)
+        st_t = st_target if st_target is not None else instnorm_stats(target)
+        a = align_input(source, target, st_s, st_t)
+        a = self.body[1](self.body[0](a))
+        return align_head(a, self.scale)
+
+
+class SPM_Warp(nn.Module):
+    def __init__(self, in_chn, scale=0.1, style_dim=512, blur_kernel=[1, 3, 3, 1], cycle_align=1, **kwargs):
+        super().__init__()
+        self.body = AlignNet(in_chn, 3, scale=scale, style_dim=style_dim, blur_kernel=blur_kernel, **kwargs)
+        for m in self.modules():                        # reference init: helpers.py:117-127
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+        self.scale, self.cycle_align = scale, cycle_align
+        self.blur = _BlurBuf(blur_kernel)
+
+    def forward(self, source, target, style=None, aligned=None):
+        """source = encoder feature, target = generator feature; returns (aligned_target, field)."""
+        cur, acc = target, None
+        st_src = instnorm_stats(source)
+        for k in range(self.cycle_align):
+            a = ops.upfirdn2d(self.body(cur, source, st_target=st_src), self.blur.kernel, pad=(2, 1))
+            acc = a if acc is None else field_add(acc, a, self.scale)
+            if k == self.cycle_align - 1 and aligned is not None:
+                acc = field_upsample_add(aligned, acc)
+            cur = warp_blend(target, acc)
+        return cur, acc
+
+
+class _BlurBuf(nn.Module):
+    def __init__(self, blur_kernel):
+        super().__init__()
+        self.register_buffer('kernel', make_kernel(blur_kernel))
+        self.pad = (2, 1)
+
+
+class _NoiseInj(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class StyledscaleNshfitBlock(nn.Module):
+    """btn=None (identity feature extractor: every shipped YAML)."""
+
+    def __init__(self, in_chn, out_chn, style_dim, alignment=True, btn=None, **kwargs):
+        super().__init__()
+        if btn is not None:
+            raise NotImplementedError("mod_btn is never set by the shipped option files; only btn=None is implemented")
+        if not alignment:
+            raise NotImplementedError('alignment=False')
+        self.alignment = SPM_Warp(in_chn, **kwargs)
+        self.weight = nn.Parameter(torch.ones(1), requires_grad=False)
+        self.noiseInj = _NoiseInj()
+
+    def forward(self, x, styles, **kwargs):
+        gen_feat = kwargs.get('image', None)
+        assert gen_feat is not None
+        return self.alignment(x, gen_feat, styles, kwargs.get('aligned', None))

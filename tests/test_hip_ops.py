@@ -1,0 +1,226 @@
+"""GPU parity: every HIP kernel (through the C ABI) against the CPU oracle on the same seeded inputs
+and against the committed golden vectors.  Tolerance: |diff| <= 1e-3 absolute in fp32 (north star),
+in practice ~1e-5; integer/index work is exact."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oodgan import synth  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f'max abs err {err:.3e} (ref max {ref:.3e})'
+
+
+def test_upfirdn2d_golden_and_oracle(dev, golden):
+    from oodgan import ops
+    g = golden('ops.npz')
+    k4 = R.make_kernel([1, 3, 3, 1])
+    x = g['ufd_x']
+    for tag, kern, up, down, pad in [
+        ('blur11', k4 * 4, 1, 1, (1, 1)), ('up2', k4 * 4, 2, 1, (2, 1)), ('blur21', k4, 1, 1, (2, 1)),
+        ('down2', k4 * 4, 1, 2, (1, 2)), ('blur22', k4 * 4, 1, 1, (2, 2)), ('crop', k4, 1, 1, (-1, 3)),
+    ]:
+        close(ops.upfirdn2d(x.to(dev), kern.to(dev), up, down, pad), g[f'ufd_{tag}'])
+    # tiled path (>= 64x64 outputs), ragged sizes, asymmetric kernel (checks the flip)
+    ka = synth.normal('t.k', (4, 4), 1)
+    for shape, pad in [((2, 3, 70, 131), (2, 1)), ((1, 2, 129, 65), (1, 1)), ((1, 1, 64, 64), (2, 2)), ((1, 2, 97, 200), (0, 3))]:
+        xx = synth.normal('t.x', shape, 2)
+        close(ops.upfirdn2d(xx.to(dev), ka.to(dev), 1, 1, pad), R.upfirdn2d(xx, ka, 1, 1, pad))
+    k3 = synth.normal('t.k3', (3, 2), 1)
+    xx = synth.normal('t.x2', (2, 2, 33, 47), 3)
+    for up, down, pad in [(1, 1, (1, 1)), (2, 1, (1, 2)), (1, 2, (2, 0)), (3, 2, (2, 2))]:
+        close(ops.upfirdn2d(xx.to(dev), k3.to(dev), up, down, pad), R.upfirdn2d(xx, k3, up, down, pad))
+
+
+def test_upfirdn2d_empty_batch(dev):
+    from oodgan import ops
+    y = ops.upfirdn2d(torch.zeros(0, 3, 8, 8, device=dev), torch.ones(4, 4, device=dev), pad=(2, 1))
+    assert y.shape == (0, 3, 8, 8)
+
+
+def test_fused_leaky_relu(dev, golden):
+    from oodgan import ops
+    g = golden('ops.npz')
+    close(ops.fused_leaky_relu(g['ufd_x'].to(dev), g['flr_b'].to(dev)), g['flr_y'])
+    close(ops.fused_leaky_relu(g['ufd_x'].to(dev), g['flr_b'].to(dev), 0.1, 1.5), g['flr_y2'])
+    # 2-D input (mapping network) and backward (case 31 of the reference kernel)
+    x = synth.normal('f.x', (5, 24), 1)
+    b = synth.normal('f.b', (24,), 1)
+    close(ops.fused_leaky_relu(x.to(dev), b.to(dev)), R.fused_leaky_relu(x, b))
+    x4 = synth.normal('f.x4', (2, 6, 9, 13), 1).requires_grad_(True)
+    b4 = synth.normal('f.b4', (6,), 1).requires_grad_(True)
+    y = R.fused_leaky_relu(x4, b4)
+    gy = synth.normal('f.gy', tuple(y.shape), 1)
+    y.backward(gy)
+    gx, gb = ops.fused_leaky_relu_backward(gy.to(dev), y.detach().to(dev), need_bias_grad=True)
+    close(gx, x4.grad)
+    close(gb, b4.grad)
+
+
+def test_equal_linear_and_mapping(dev, golden):
+    from oodgan import ops
+    g = golden('ops.npz')
+    close(ops.equal_linear(g['lin_x'].to(dev), g['lin_w'].to(dev), g['lin_b'].to(dev), 0.01, False), g['lin_y'])
+    close(ops.equal_linear(g['lin_x'].to(dev), g['lin_w'].to(dev), g['lin_b'].to(dev), 0.01, True), g['lin_y_act'])
+    z = synth.normal('pn', (3, 512), 1)
+    close(ops.pixel_norm(z.to(dev)), z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8))
+
+
+def test_style_affine_mfma_and_generic(dev):
+    from oodgan import ops
+    B, L, S = 5, 3, 64
+    lat = synth.normal('sa.lat', (B, L, S), 1)
+    for R_, rl in [(48, [0] * 16 + [2] * 32), (20, [1] * 7 + [0] * 13)]:
+        w = synth.normal('sa.w', (R_, S), 2)
+        b = synth.normal('sa.b', (R_,), 2)
+        row_lat = torch.tensor(rl, dtype=torch.int32)
+        ref = torch.stack([R.equal_linear(lat[:, rl[r]], w[r:r + 1], b[r:r + 1])[:, 0] for r in range(R_)], dim=1)
+        close(ops.style_affine(lat.to(dev), w.to(dev), b.to(dev), row_lat.to(dev)), ref)
+    # backward: rows grouped by latent
+    R_, rl = 48, [0] * 16 + [2] * 32
+    w = synth.normal('sa.w', (R_, S), 2)
+    gs = synth.normal('sa.gs', (B, R_), 3)
+    lat_start = torch.tensor([0, 16, 16, 48], dtype=torch.int32)
+    ref = torch.zeros(B, L, S)
+    for r in range(R_):
+        ref[:, rl[r]] += gs[:, r:r + 1] * w[r] / math.sqrt(S)
+    close(ops.style_affine_backward(gs.to(dev), w.to(dev), lat_start.to(dev), L), ref)
+
+
+def _mc_ref(g, tag, demod, ups):
+    return R.modulated_conv2d(g['mc_x'], g['mc_wlat'], g[f'mc_{tag}_w'], g[f'mc_{tag}_mw'], g[f'mc_{tag}_mb'], demod, ups)
+
+
+def test_modulated_conv_modules_vs_golden(dev, golden):
+    from oodgan.modules import ModulatedConv2d, StyledConv, ToRGB
+    g = golden('ops.npz')
+    B, Ci, Co, H, S = 2, 16, 8, 12, 64
+    x, wl = g['mc_x'].to(dev), g['mc_wlat'].to(dev)
+    for tag, k, demod, ups in [('plain', 3, True, False), ('up', 3, True, True), ('rgb', 1, False, False)]:
+        cout = 3 if tag == 'rgb' else Co
+        mc = ModulatedConv2d(Ci, cout, k, S, demodulate=demod, upsample=ups)
+        mc.weight.data = g[f'mc_{tag}_w']
+        mc.modulation.weight.data = g[f'mc_{tag}_mw']
+        mc.modulation.bias.data = g[f'mc_{tag}_mb']
+        mc = mc.to(dev)
+        close(mc(x, wl), g[f'mc_{tag}_y'])
+    for tag, ups in [('sc', False), ('scup', True)]:
+        sc = StyledConv(Ci, Co, 3, S, upsample=ups)
+        sd = {}
+        synth._styled_conv(sd, 'q', Ci, Co, S, 13, ups, 0.1)
+        sc.load_state_dict({k_[2:]: v for k_, v in sd.items()})
+        sc = sc.to(dev)
+        close(sc(x, wl, noise=g[f'{tag}_noise'].to(dev)), g[f'{tag}_y'])
+    rgb = ToRGB(Ci, S)
+    sd = {}
+    synth._to_rgb(sd, 'q', Ci, S, 13, True)
+    rgb.load_state_dict({k_[2:]: v for k_, v in sd.items()})
+    rgb = rgb.to(dev)
+    close(rgb(x, wl, g['rgb_skip'].to(dev)), g['rgb_y'])
+    close(rgb(x, wl, None), g['rgb_y_noskip'])
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(1, 8, 32, 4, 4), (2, 24, 40, 9, 37), (1, 64, 64, 16, 16), (2, 32, 96, 33, 65),
+                                          (1, 512, 64, 8, 8)])
+def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W):
+    """Raw implicit-GEMM kernels (ragged sizes, channel counts that are not multiples of the tile)
+    against F.conv2d / conv_transpose2d with in/out scales and the dot epilogue."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    x = synth.normal('cv.x', (B, Ci, H, W), 1)
+    w = synth.normal('cv.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('cv.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('cv.d', (B, Co), 4, 0.3, 1.0)
+    xs = x * s[:, :, None, None]
+    # S1 forward with scales
+    ref = F.conv2d(xs, w, padding=1) * d[:, :, None, None]
+    wpk = ops.pack_conv3x3(w.to(dev))
+    close(ops.conv3x3(x.to(dev), wpk, Co, ops.CONV_S1, in_scale=s.to(dev), out_scale=d.to(dev)), ref)
+    # S1 with fused noise + bias + lrelu
+    nz = synth.normal('cv.nz', (B, 1, H, W), 5)
+    nw = torch.tensor([0.37])
+    bias = synth.normal('cv.b', (Co,), 6)
+    ref2 = R.fused_leaky_relu(ref + nw * nz, bias)
+    close(ops.conv3x3(x.to(dev), wpk, Co, ops.CONV_S1, in_scale=s.to(dev), out_scale=d.to(dev), bias=bias.to(dev),
+                      noise=nz.to(dev), noise_weight=nw.to(dev), act=ops.ACT_LRELU), ref2)
+    # T2 (transposed, stride 2): pitched output (B,Co,2H+1,2W+2)
+    reft = F.conv_transpose2d(xs, w.transpose(0, 1), stride=2) * d[:, :, None, None]
+    z = ops.conv3x3(x.to(dev), wpk, Co, ops.CONV_T2, in_scale=s.to(dev), out_scale=d.to(dev))
+    assert z.shape == (B, Co, 2 * H + 1, 2 * W + 2)
+    close(z[..., :2 * W + 1], reft)
+    # input gradient of S1 (= S1 with transposed+flipped weights) with the style-gradient dot epilogue
+    gy = synth.normal('cv.gy', (B, Co, H, W), 7)
+    xs_ = xs.clone().requires_grad_(True)
+    (F.conv2d(xs_, w, padding=1) * d[:, :, None, None] * gy).sum().backward()
+    wpk_b = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=True)
+    dx, dot = ops.conv3x3(gy.to(dev), wpk_b, Ci, ops.CONV_S1, in_scale=d.to(dev), out_scale=s.to(dev), dotx=x.to(dev))
+    close(dx, xs_.grad * s[:, :, None, None], 2e-4)
+    close(dot, (xs_.grad * x).sum(dim=(2, 3)), 2e-4)
+    # S2 = input gradient of T2
+    gz = synth.normal('cv.gz', (B, Co, 2 * H + 1, 2 * W + 1), 8)
+    xs_ = xs.clone().requires_grad_(True)
+    (F.conv_transpose2d(xs_, w.transpose(0, 1), stride=2) * d[:, :, None, None] * gz).sum().backward()
+    wpk_t = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=False)
+    gzp = torch.zeros(B, Co, 2 * H + 1, 2 * W + 2)
+    gzp[..., :2 * W + 1] = gz
+    dx, dot = ops.conv3x3(gzp.to(dev), wpk_t, Ci, ops.CONV_S2, in_scale=d.to(dev), out_scale=s.to(dev), dotx=x.to(dev),
+                          in_hw=(2 * H + 1, 2 * W + 1), in_pitch=2 * W + 2)
+    close(dx, xs_.grad * s[:, :, None, None], 2e-4)
+    close(dot, (xs_.grad * x).sum(dim=(2, 3)), 2e-4)
+
+
+def test_torgb_and_blur_bias_act(dev):
+    from oodgan import ops
+    B, Ci, H = 2, 40, 18
+    x = synth.normal('tr.x', (B, Ci, H, H), 1)
+    w = synth.normal('tr.w', (3, Ci), 2)
+    s = synth.normal('tr.s', (B, Ci), 3, 0.3, 1.0)
+    bias = synth.normal('tr.b', (3,), 4)
+    skip = synth.normal('tr.skip', (B, 3, H // 2, H // 2), 5)
+    k = R.make_kernel([1, 3, 3, 1]) * 4
+    ref = torch.einsum('kc,bc,bchw->bkhw', w, s, x) / math.sqrt(Ci) + bias.view(1, 3, 1, 1) + R.upfirdn2d(skip, k, up=2, pad=(2, 1))
+    close(ops.torgb(x.to(dev), w.to(dev), s.to(dev), bias.to(dev), skip.to(dev), k.to(dev)), ref)
+    z = synth.normal('bb.z', (B, 6, 67, 67), 6)
+    nz = synth.normal('bb.nz', (B, 1, 66, 66), 7)
+    nw = torch.tensor([0.2])
+    b6 = synth.normal('bb.b', (6,), 8)
+    ref = R.fused_leaky_relu(R.upfirdn2d(z, k, pad=(1, 1)) + nw * nz, b6)
+    close(ops.blur_bias_act(z.to(dev), k.to(dev), (1, 1), b6.to(dev), nz.to(dev), nw.to(dev)), ref)
+
+
+def test_mse_and_adam(dev):
+    from oodgan import ops
+    a = synth.normal('m.a', (3, 3, 20, 20), 1).requires_grad_(True)
+    t = synth.normal('m.t', (3, 3, 20, 20), 2)
+    per = ((a - t) ** 2).mean(dim=(1, 2, 3))
+    per.sum().backward()
+    loss, g = ops.mse_loss_grad(a.detach().to(dev), t.to(dev))
+    close(loss, per.detach(), 1e-5)
+    close(g, a.grad, 1e-5)
+    w = synth.normal('ad.w', (2, 18, 512), 3).requires_grad_(True)
+    opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    wd = w.detach().clone().to(dev)
+    m, v = torch.zeros_like(wd), torch.zeros_like(wd)
+    for step in range(1, 4):
+        gr = synth.normal(f'ad.g{step}', (2, 18, 512), 4) * (10.0 ** (-step))
+        w.grad = gr.clone()
+        opt.step()
+        ops.adam_step(wd, gr.to(dev), m, v, step)
+        close(wd, w.detach(), 1e-6)

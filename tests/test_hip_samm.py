@@ -1,0 +1,133 @@
+"""GPU parity of the SAMM/SAIM ops and the full OOD forward (post-encoder) at 1024²."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oodgan import synth  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def close(a, b, tol=1e-4):
+    a = a.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f'max abs err {err:.3e} (ref max {ref:.3e})'
+
+
+def test_instance_norm_and_small_convs(dev):
+    from oodgan import samm
+    x = synth.normal('in.x', (2, 5, 13, 17), 1, 2.0, 0.7)
+    g, b = synth.normal('in.g', (5,), 2, 0.1, 1.0), synth.normal('in.b', (5,), 3, 0.1)
+    close(samm.instance_norm(x.to(dev), g.to(dev), b.to(dev)), R.instance_norm(x, g, b))
+    close(samm.instance_norm(x.to(dev)), R.instance_norm(x))
+    w = synth.normal('c1.w', (7, 5, 1, 1), 4)
+    bb = synth.normal('c1.b', (7,), 5)
+    close(samm.conv1x1(x.to(dev), w.to(dev), bb.to(dev)), F.conv2d(x, w, bb))
+    x2 = synth.normal('c1.x2', (1, 130, 9, 9), 6)
+    w2 = synth.normal('c1.w2', (35, 130, 1, 1), 7, 0.1)
+    close(samm.conv1x1(x2.to(dev), w2.to(dev)), F.conv2d(x2, w2))
+    w3 = synth.normal('c3.w', (3, 5, 3, 3), 8, 0.3)
+    sl = synth.normal('c3.s', (3,), 9, 0.05, 0.25)
+    close(samm.conv3x3_small(x.to(dev), w3.to(dev), slope=sl.to(dev)), F.prelu(F.conv2d(x, w3, padding=1), sl))
+
+
+def test_resize_index_math_exact(dev):
+    """nearest / bilinear source-index math must match ATen bit for bit (mask indexing)."""
+    from oodgan import samm
+    for s in (32, 64, 128, 256, 37):
+        x = synth.uniform('rs.x', (2, 1, s, s), s)
+        yn = samm.resize_nearest(x.to(dev), 1024).cpu()
+        assert torch.equal(yn, F.interpolate(x, size=1024)), f'nearest {s}->1024 not exact'
+        yb = samm.resize_bilinear(x.to(dev), 1024).cpu()
+        assert (yb - F.interpolate(x, size=(1024, 1024), mode='bilinear')).abs().max() < 2e-6
+    x = synth.uniform('rs.y', (1, 3, 1024, 1024), 5)
+    close(samm.resize_bilinear(x.to(dev), 256), F.interpolate(x, (256, 256), mode='bilinear'), 1e-5)
+
+
+def test_field_ops_and_warp(dev, golden):
+    from oodgan import samm
+    g = golden('samm.npz')
+    close(samm.field_add(g['warp_field'].to(dev), g['warp_field_prev'].to(dev), 0.08),
+          R.spm_add(g['warp_field'], g['warp_field_prev'], 0.08), 1e-5)
+    close(samm.field_upsample_add(g['prev'].to(dev), g['warp_field'].to(dev)),
+          R.spm_upsample_add(g['prev'], g['warp_field']), 1e-5)
+    close(samm.warp_blend(g['tgt'].to(dev), g['warp_field'].to(dev)), R.warp_blend(g['tgt'], g['warp_field']), 1e-5)
+    # larger, non-square, displacement beyond the border (zeros padding)
+    t = synth.normal('wb.t', (2, 6, 40, 56), 1)
+    f = torch.cat([synth.normal('wb.f', (2, 2, 40, 56), 2, 0.3), synth.uniform('wb.a', (2, 1, 40, 56), 3)], 1)
+    close(samm.warp_blend(t.to(dev), f.to(dev)), R.warp_blend(t, f), 1e-5)
+    # bicubic(align_corners=True) up-sampling inside upsample_add at the real level ratios
+    for hp, h in [(32, 64), (64, 128), (8, 16)]:
+        prev = torch.cat([synth.normal('ua.d', (1, 2, hp, hp), 4, 0.05), synth.uniform('ua.a', (1, 1, hp, hp), 5)], 1)
+        cur = torch.cat([synth.normal('ua.d2', (1, 2, h, h), 6, 0.05), synth.uniform('ua.a2', (1, 1, h, h), 7)], 1)
+        close(samm.field_upsample_add(prev.to(dev), cur.to(dev)), R.spm_upsample_add(prev, cur), 1e-5)
+
+
+def test_alignnet_and_spm_warp_vs_golden(dev, golden):
+    from oodgan import samm
+    g = golden('samm.npz')
+    sd = synth.samm_state(8, 'm', seed=21)
+    blk = samm.StyledscaleNshfitBlock(8, 8, 512, scale=0.08, cycle_align=2, diff_fAndg=True)
+    res = blk.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    blk = blk.to(dev)
+    src, tgt, prev = g['src'].to(dev), g['tgt'].to(dev), g['prev'].to(dev)
+    close(blk.alignment.body(tgt, src), g['alignnet'], 2e-4)
+    y, f = blk(src, None, image=tgt, aligned=None)
+    close(y, g['warp_out'], 3e-4)
+    close(f, g['warp_field'], 3e-4)
+    y, f = blk(src, None, image=tgt, aligned=prev)
+    close(y, g['warp_out_prev'], 3e-4)
+    close(f, g['warp_field_prev'], 3e-4)
+
+
+def test_mask_blend_vs_oracle(dev):
+    from oodgan import samm
+    B = 2
+    aligns = {k + 1: torch.cat([synth.normal(f'mb.d{k}', (B, 2, s, s), 1, 0.05), synth.uniform(f'mb.a{k}', (B, 1, s, s), 2)], 1)
+              for k, s in enumerate((32, 64, 128, 256))}
+    x = synth.make_images(1024, B, seed=3)
+    gen = synth.normal('mb.gen', (B, 3, 1024, 1024), 4)
+    alpha_ref = R.blending_mask(aligns, 1024)
+    out_ref = alpha_ref * x + gen * (1 - alpha_ref)
+    alpha, out = samm.mask_blend([aligns[k].to(dev) for k in sorted(aligns)], x.to(dev), gen.to(dev), 1024)
+    close(alpha, alpha_ref, 1e-5)
+    close(out, out_ref, 1e-5)
+    strip = samm.extract_masks({k: v.to(dev) for k, v in aligns.items()})
+    assert torch.equal(strip.cpu(), R.extract_masks(aligns))
+
+
+def test_ood_forward_1024_vs_golden(dev, golden):
+    """The whole path after the encoder at 1024², B=1, against vectors produced by the reference."""
+    from oodgan.arch import ood_faceGAN_e4e
+    g = golden('ood_1024.npz')
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
+                        cycle_align=2, blend_with_gen=True, ModSize=256)
+    res = m.load_state_dict(synth.ood_state(1024, seed=31), strict=True)
+    m = m.to(dev).eval()
+    enc_lats = synth.make_latents(1024, 1, seed=32, std=0.3).to(dev)
+    enc_feats = [f.to(dev) for f in synth.make_encoder_feats(1, seed=33)]
+    x = synth.make_images(1024, 1, seed=34).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(1024, 1, seed=35)]
+    out, lats = m(x, enc_lats=enc_lats, enc_feats=enc_feats, noise=noises)
+    tol = 1e-3
+    close(lats, g['lats'], 1e-6)
+    close(out[:, :, ::16, ::16], g['out_sub'], tol)
+    close(out[:, :, 480:544, 480:544], g['out_crop'], tol)
+    for k in (1, 2, 3, 4):
+        a = m.aligns[k]
+        step = max(1, a.shape[-1] // 32)
+        close(a[:, :, ::step, ::step], g[f'align{k}_sub'], tol)
+    close(m.aligns[1024][:, :, ::16, ::16], g['align1024_sub'], tol)
+    from oodgan import samm
+    strip = samm.extract_masks(m.aligns)
+    close(strip[:, :, ::16, ::16], g['mask_strip_sub'], tol)
+    close(strip[:, :, 500:502, :], g['mask_strip_rows'], tol)
