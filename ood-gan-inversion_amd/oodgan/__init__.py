@@ -11,6 +11,8 @@ __version__ = '0.1.0'
 def __getattr__(name):
     # heavy modules are imported lazily so that `import oodgan` works on a box without the .so
     import importlib
+    if name in ('modules', 'ops', 'engine', 'samm', 'arch', 'io'):
+        return importlib.import_module(f'.{name}', __name__)
     for mod in ('modules', 'ops', 'engine'):
         m = importlib.import_module(f'.{mod}', __name__)
         if hasattr(m, name):

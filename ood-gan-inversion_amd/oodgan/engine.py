@@ -209,6 +209,7 @@ class GeneratorEngine:
             gs_all[:, L.row:L.row + L.cin] += dot
             g_feat = dx
             del g_pre
+        self.last_gs = gs_all
         return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent)
 
 

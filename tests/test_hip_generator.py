@@ -56,23 +56,30 @@ def test_stylegan2generator_basicsr_keys(dev, golden):
 
 @pytest.mark.parametrize('size,B', [(16, 2), (64, 1)])
 def test_generator_backward_vs_oracle_autograd(dev, size, B):
+    """dL/dW+ from the HIP backward kernels vs torch autograd through the oracle evaluated in
+    float64.  (The fp32 CPU autograd of the same graph is itself ~1e-2 off on the 4x4 conv1 layer —
+    oneDNN grouped-conv backward — so fp64 is the ground truth; the fp32 run is only required to agree
+    to that looser level.)"""
     from oodgan.engine import GeneratorEngine
     from oodgan import ops
     P = synth.generator_state(size, seed=5)
     lat = synth.make_latents(size, B, seed=6)
     noises = synth.make_noises(size, B, seed=7)
     target = synth.make_images(size, B, seed=9)
-    w = lat.clone().requires_grad_(True)
-    img_ref = R.generator_forward(P, w, noises, size)
-    R.wplus_loss(img_ref, target).backward()
+    w = lat.double().requires_grad_(True)
+    img_ref = R.generator_forward({k: v.double() for k, v in P.items()}, w, [n.double() for n in noises], size)
+    R.wplus_loss(img_ref, target.double()).backward()
     eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
     img = eng.forward(lat.to(dev), [n.to(dev) for n in noises], save=True)
-    assert maxdiff(img, img_ref.detach()) < 1e-3
+    assert maxdiff(img, img_ref.detach().float()) < 1e-3
     loss, gimg = ops.mse_loss_grad(img, target.to(dev))
     glat = eng.backward(gimg)
     gref = w.grad
-    rel = maxdiff(glat, gref) / gref.abs().max().item()
-    assert rel < 2e-3, rel
+    rel = (glat.detach().cpu().double() - gref).abs().max().item() / gref.abs().max().item()
+    assert rel < 1e-4, rel
+    w32 = lat.clone().requires_grad_(True)
+    R.wplus_loss(R.generator_forward(P, w32, noises, size), target).backward()
+    assert maxdiff(glat, w32.grad) / gref.abs().max().item() < 2e-2
 
 
 def test_wplus_trajectory_vs_golden(dev, golden):
