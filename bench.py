@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1024² face inversions/sec (100 W+ Adam steps + final OOD/SAIM forward).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1 directly
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: B=8 images per GPU (BASELINE.json configs[2]:
+"Full OOD inversion loop (100 W+ Adam steps + SAIM mask) 1024² batch=8, 1xMI355X"), i.e. 100 x
+{generator forward, per-image MSE, backward to W+, Adam} followed by one full OOD forward (SAMM
+alignment + invertibility masks + blend) with the refined latents.  Inputs (weights, target
+images, encoder latents/features, noise maps) are synthetic (oodgan.synth) and resident in HBM
+before the timed region.  Multi-GPU = batch sharding (weak scaling): every rank inverts its own 8
+images, the only collective is one all_gather of the finished latents (RCCL over xGMI).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events on
+the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'ood-gan-inversion_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector peak
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--wsteps', type=int, default=100, help='W+ Adam steps per inversion (metric is quoted at 100)')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline-events', action='store_true')
+    return ap.parse_args()
+
+
+class ConvProbe:
+    """HIP-event timing of every launch of the dominant kernel (plain 3x3 implicit-GEMM conv,
+    template instance conv_mfma_kernel<S1, MT=2>: M > 32 output channels) inside the timed region.
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.recs, self.on = ops, ops.conv3x3, [], False
+
+    def install(self):
+        probe = self
+
+        def conv3x3(x, wpk, M, mode=0, **kw):
+            if not (probe.on and mode == probe.ops.CONV_S1 and M > 32):
+                return probe.orig(x, wpk, M, mode, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = probe.orig(x, wpk, M, mode, **kw)
+            e1.record()
+            B, K, H, W = x.shape
+            probe.recs.append((e0, e1, 2.0 * B * K * M * 9 * H * W, 4.0 * (B * K * H * W + B * M * H * W + K * M * 9)))
+            return r
+
+        self.ops.conv3x3 = conv3x3
+        import oodgan.engine as eng
+        eng.ops.conv3x3 = conv3x3
+
+    def summary(self):
+        if not self.recs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in self.recs)
+        flops = sum(f for _, _, f, _ in self.recs)
+        n = len(self.recs)
+        return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n)
+
+
+def cpu_baseline(size):
+    """Reported baseline: the CPU oracle (same ATen graph as the reference's PyTorch path) doing ONE W+ step
+    (forward + backward + Adam) for one image at the bench resolution, extrapolated to 100 steps."""
+    from oracle import ref_cpu as R
+    from oodgan import synth
+    n = torch.get_num_threads()
+    P = synth.generator_state(size, seed=0)
+    lat = synth.make_latents(size, 1, seed=3)
+    noises = synth.make_noises(size, 1, seed=2)
+    target = synth.make_images(size, 1, seed=1)
+    t0 = time.time()
+    R.wplus_invert(P, target, lat, noises, size, steps=1)
+    dt = time.time() - t0
+    return dict(value=1.0 / (100.0 * dt), unit='images/s', cores=n, kind='port',
+                sample=f'1 W+ step (fwd+bwd+Adam) of 1 image at {size}x{size} in {dt:.1f}s on {n} threads, x100; '
+                       'final OOD forward not included')
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist_on = world > 1
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the hot path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from oodgan import ops, synth
+    from oodgan.arch import ood_faceGAN_e4e
+    from oodgan.parallel import shard_slice, gather_latents
+
+    size, B = a.size, a.batch
+    model = ood_faceGAN_e4e(out_size=size, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
+                            cycle_align=2, blend_with_gen=True, ModSize=256)
+    model.load_state_dict(synth.ood_state(size, seed=0), strict=True)
+    model = model.to(dev).eval()
+    # per-rank shard of the global synthetic batch (global batch = B*world, contiguous slices by rank)
+    gB = B * world
+    sl = shard_slice(gB, rank, world)
+    x = synth.make_images(size, gB, seed=1)[sl].to(dev)
+    enc_lats = synth.make_latents(size, gB, seed=3, std=0.3)[sl].to(dev)
+    enc_feats = [f[sl].to(dev) for f in synth.make_encoder_feats(gB, seed=4)]
+    noises = [n[sl].to(dev) for n in synth.make_noises(size, gB, seed=2)]
+    torch.cuda.synchronize()
+
+    probe = ConvProbe(ops)
+    if not a.no_roofline_events:
+        probe.install()
+
+    def one_step():
+        out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, enc_lats=enc_lats, enc_feats=enc_feats)
+        return gather_latents(lats) if dist_on else lats, losses
+
+    for _ in range(a.warmup):
+        one_step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    probe.on = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        all_lats, losses = one_step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    probe.on = False
+    if dist_on:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    if rank == 0:
+        ps = probe.summary()
+        roof = None
+        if ps:
+            roof = dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(ps['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                        kernel='conv_mfma_kernel<S1,MT=2> (plain 3x3 implicit GEMM, fwd + input-gradient, M>32)',
+                        launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
+                        alg_flops_per_launch=ps['flops_per_launch'])
+        line = {
+            'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
+                                   f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
+                       'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}',
+                       'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
+            'roofline': roof,
+            'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(size),
+        }
+        print(json.dumps(line, ensure_ascii=False))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
