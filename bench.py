@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, 'ood-gan-inversion_amd')):
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (spec, MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -41,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
+    ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
     return ap.parse_args()
 
 
@@ -111,6 +113,7 @@ def main():
         dist.init_process_group(backend='nccl', device_id=dev)
 
     from oodgan import ops, synth
+    ops.PRECISION = a.precision
     from oodgan.arch import ood_faceGAN_e4e
     from oodgan.parallel import shard_slice, gather_latents
 
@@ -159,15 +162,22 @@ def main():
         ps = probe.summary()
         roof = None
         if ps:
-            roof = dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(ps['tflops'] / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
-                        kernel='conv_mfma_kernel<S1,MT=2> (plain 3x3 implicit GEMM, fwd + input-gradient, M>32)',
+            f16s = a.precision == 'f16s'
+            peak = MFMA_F16_PEAK_TFLOPS if f16s else MFMA_F32_PEAK_TFLOPS
+            roof = dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
+                        frac=round(ps['tflops'] / peak, 4), traffic=None,
+                        kernel=('conv_f16s_kernel<S1,MT=2>' if f16s else 'conv_mfma_kernel<S1,MT=2>') +
+                               ' (plain 3x3 implicit GEMM, fwd + input-gradient, M>32)',
+                        note=('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product, so its own ceiling is '
+                              'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
                         launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
                         alg_flops_per_launch=ps['flops_per_launch'])
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16-split (hi+lo f16 operands, 3 MFMA/product, f32 accumulate; fp32-equivalent)' if a.precision == 'f16s' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
                                    f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
                        'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}',

@@ -140,6 +140,16 @@ typedef struct oodgan_conv_args {
  * output-side demodulation (out_scale) instead of B materialised weight copies — and the dense
  * Conv2d 3x3 of bottleneck_IR (src/ops/e4e/encoders/helpers.py:439-444). */
 int oodgan_conv3x3(const oodgan_conv_args* args, void* stream);
+
+/* Split-f16 variant (default of the engine): every operand is split v = hi + lo in f16 and each product
+ * costs three v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate): fp32-equivalent accuracy
+ * (~1e-6 relative) at up to 16/3 the fp32 matrix rate.  Same arguments and epilogues as
+ * oodgan_conv3x3; args->wpk must come from oodgan_pack_conv3x3_f16s, which also writes unscale2[2] =
+ * {2^-e, 2^e}: the weights are stored times 2^e (max |w| in [512,1024)) and the kernel multiplies by 2^-e. */
+long oodgan_pack_conv3x3_f16s_bytes(int Co, int Ci, int transpose);
+int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int Co, int Ci, float scale, int transpose,
+                             int flip, void* stream);
+int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
 /* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
 int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);
@@ -170,10 +180,12 @@ int oodgan_act_bwd_nparts(long HW);
 
 /* ------------------------------------------------------------------ A9 loss / optimiser ---- */
 
-/* loss[b] = mean_{c,p} (img-target)^2 (per image, deterministic), gimg = 2*(img-target)/(C*HW).
+/* loss[b] = mean_{c,p} (img-target)^2 (per image, deterministic), gimg = grad_mul*2*(img-target)/(C*HW).
+ * grad_mul is the (power-of-two) loss scale that keeps the back-propagated values O(1) for the split-f16
+ * kernels; the caller divides the final latent gradient by it (exact).
  * anchors: basicsr MSELoss (BasicSR/basicsr/losses/losses.py:58-83). part: (B,nparts) scratch. */
 int oodgan_mse_fwd_bwd(const float* img, const float* target, float* gimg, float* part, float* loss,
-                       int B, long CHW, void* stream);
+                       int B, long CHW, float grad_mul, void* stream);
 int oodgan_mse_nparts(long CHW);
 /* torch.optim.Adam step (no weight decay, no amsgrad), step index t>=1 given by the host:
  * anchors: get_optimizer (src/models/OOD_faceGAN_model.py:398-400). */

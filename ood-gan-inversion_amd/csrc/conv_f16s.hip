@@ -1,0 +1,364 @@
+// Split-f16 implicit-GEMM 3x3 convolutions: fp32-equivalent accuracy at up to 16/3 x the fp32 MFMA rate.
+//
+// Every fp32 operand v is split v = hi + lo with hi = f16(v), lo = f16(v - hi) (22 significant bits; f16
+// subnormals are kept by v_mfma_f32_32x32x16_f16 — probed on gfx950).  A product needs three
+// MFMAs, hi·hi + hi·lo + lo·hi (the lo·lo term is 2^-22 relative and dropped), every f16 x f16 product is
+// exact in fp32 and accumulation is fp32, so the result differs from the exact-fp32 kernel (conv_mfma.hip) by
+// ~1e-6 relative — measured 1.4e-6 at K = 4608 against a float64 dot, better than an fp32 fmaf chain.
+// Weights are pre-scaled by a power of two (max |w| in [512,1024)) when packed so that their lo parts stay
+// normal; the scale is undone exactly in the epilogue (KArgs::w_unscale).  Gradients are kept O(1) by the
+// caller's loss scaling (engine: power-of-two loss scale, exact).
+//
+// MFMA operand layout (v_mfma_f32_32x32x16_f16): lane (r = l&31, h = l>>5) holds A[m=r][k=8h+j], B[k=8h+j][n=r],
+// j = 0..7.  One MFMA therefore contracts 16 input channels of ONE filter tap for 32 channels x 32 pixels.
+// LDS images (K chunk = 16 channels):
+//   x: one 80-byte record per tile position: [hi: 16 ch f16][lo: 16 ch f16][16 B pad]; a B fragment is one
+//      ds_read_b128 at pos*80 + 16h (+32 for lo); stride 80 B = 5 x 16 B makes the 16 lanes of a read group hit
+//      16 distinct 16-byte slots (conflict-free).
+//   w: [tap][hi|lo][h][MB channels][8 ch f16]: an A fragment is one ds_read_b128, consecutive lanes consecutive
+//      16-byte slots; the global packing has the same order so staging is a straight 16-byte copy.
+#include "conv_common.hpp"
+
+using namespace oodgan;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CK = 16;         // input channels per K chunk
+constexpr int REC = 80;        // bytes per x-tile position record
+
+template <int MODE> struct GeoH;
+template <> struct GeoH<OODGAN_CONV_S1> { static constexpr int TR = 8, NT = 2, IN_R = 10, IN_C = 34; };
+template <> struct GeoH<OODGAN_CONV_T2> { static constexpr int TR = 4, NT = 1, IN_R = 5, IN_C = 33; };
+template <> struct GeoH<OODGAN_CONV_S2> { static constexpr int TR = 8, NT = 2, IN_R = 17, IN_C = 66; };
+
+template <int MODE, int MT>
+__global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uint4* __restrict__ wpk16) {
+    using G = GeoH<MODE>;
+    constexpr int NT = G::NT, TR = G::TR, IN_R = G::IN_R, IN_C = G::IN_C;
+    constexpr int NPOS = IN_R * IN_C;
+    constexpr int MB = 32 * MT;
+    constexpr int XBYTES = NPOS * REC;
+    constexpr int WROWS = 9 * 2 * 2;                 // (tap, hi|lo, h)
+    constexpr int WBYTES = WROWS * MB * 16;
+    constexpr int XITEMS = NPOS * 4;                 // (position, quad of 4 channels)
+    constexpr int XPT = (XITEMS + 255) / 256;
+    constexpr int WE = WROWS * MB;                   // 16-byte units
+    constexpr int WPT = (WE + 255) / 256;
+    constexpr int NACC = (MODE == OODGAN_CONV_T2) ? 4 : NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lx = smem;
+    unsigned char* lw = smem + XBYTES;
+
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const BlockCtx ctx = decode_block<TR, MB>(p);
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+
+    const float* xb = a.x + (long)b * a.K * p.in_plane;
+    const float* isc = a.in_scale ? a.in_scale + (long)b * a.in_scale_stride : nullptr;
+    const float* ish = a.in_shift ? a.in_shift + (long)b * a.in_scale_stride : nullptr;
+
+    // per-thread staging descriptors
+    int xoff[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int e = tid + i * 256;
+        const int pos = e % NPOS;
+        const int r = pos / IN_C, col = pos % IN_C;
+        int gy, gx;
+        if (MODE == OODGAN_CONV_S2) {
+            const int par = col / 33, idx = col % 33;
+            gy = 2 * r0 + r;
+            gx = 2 * (c0 + idx) + par;
+        } else {
+            gy = r0 - 1 + r;
+            gx = c0 - 1 + col;
+        }
+        const bool ok = (e < XITEMS) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        xoff[i] = ok ? gy * a.in_pitch + gx : -1;
+    }
+
+    float xr[XPT][4];
+    uint4 wr[WPT];
+    const int nchunk = (a.K + CK - 1) / CK;
+    const long wchunk = (long)WROWS * p.Mp;          // 16-byte units per K chunk in the packed weights
+
+    auto load_chunk = [&](int t) {
+        const int k0 = t * CK;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            const int q = e / NPOS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 4 * q + j;
+                float v = 0.f;
+                if (xoff[i] >= 0 && k < a.K) {
+                    v = xb[(long)k * p.in_plane + xoff[i]];
+                    if (isc) v *= isc[k];
+                    if (ish) v += ish[k];
+                }
+                xr[i][j] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * 256;
+            const int row = e / MB, j = e % MB;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (e < WE) v = wpk16[(long)t * wchunk + (long)row * p.Mp + m0 + j];
+            wr[i] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int e = tid + i * 256;
+            if (e >= XITEMS) continue;
+            const int q = e / NPOS, pos = e % NPOS;
+            half4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = xr[i][j];
+                const _Float16 h = (_Float16)v;
+                hi[j] = h;
+                lo[j] = (_Float16)(v - (float)h);
+            }
+            *reinterpret_cast<half4*>(lx + pos * REC + q * 8) = hi;
+            *reinterpret_cast<half4*>(lx + pos * REC + 32 + q * 8) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < WE) reinterpret_cast<uint4*>(lw)[e] = wr[i];
+        }
+    };
+
+    f32x16 acc[MT][NACC];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+
+    // lane bases
+    const unsigned char* lwh = lw + (half * MB + l31) * 16;
+    int pbase;
+    if (MODE == OODGAN_CONV_S1) pbase = (wave * NT) * IN_C + l31;
+    else if (MODE == OODGAN_CONV_T2) pbase = wave * IN_C + l31;
+    else pbase = (wave * NT) * 2 * IN_C + l31;
+    const unsigned char* lxh = lx + pbase * REC + half * 16;
+
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
+#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
+#define MFMA3(accv, ah, al, bh, bl)                                              \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+
+    load_chunk(0);
+    for (int t = 0; t < nchunk; ++t) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (t + 1 < nchunk) load_chunk(t + 1);
+
+        if constexpr (MODE == OODGAN_CONV_T2) {
+            half8 bh[2][2], bl[2][2];
+#pragma unroll
+            for (int da = 0; da < 2; ++da)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    bh[da][db] = XFRAG((1 - da) * IN_C + (1 - db), 0);
+                    bl[da][db] = XFRAG((1 - da) * IN_C + (1 - db), 1);
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int ky = tp / 3, kx = tp % 3;
+                    const int ph = (ky & 1) * 2 + (kx & 1);
+                    const int da = ky >> 1, db = kx >> 1;      // x[i' - ky/2, j' - kx/2] for even taps, 0 shift for odd
+                    const half8 ah = WFRAG(tp, 0, mt), al = WFRAG(tp, 1, mt);
+                    MFMA3(acc[mt][ph], ah, al, bh[(ky & 1) ? 0 : da][(kx & 1) ? 0 : db], bl[(ky & 1) ? 0 : da][(kx & 1) ? 0 : db]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { ah[mt] = WFRAG(ky * 3 + kx, 0, mt); al[mt] = WFRAG(ky * 3 + kx, 1, mt); }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        int po;
+                        if constexpr (MODE == OODGAN_CONV_S1) po = (nt + ky) * IN_C + kx;
+                        else po = (2 * nt + ky) * IN_C + (kx == 1 ? 33 : (kx == 2 ? 1 : 0));
+                        bh[nt] = XFRAG(po, 0);
+                        bl[nt] = XFRAG(po, 1);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) { MFMA3(acc[mt][nt], ah[mt], al[mt], bh[nt], bl[nt]); }
+                }
+        }
+    }
+#undef XFRAG
+#undef WFRAG
+#undef MFMA3
+    conv_epilogue<MODE, MT, NT, NACC>(p, acc, ctx, wave, l31, half);
+}
+
+template <int MODE, int MT>
+constexpr int smem_bytes() {
+    using G = GeoH<MODE>;
+    return G::IN_R * G::IN_C * REC + 9 * 2 * 2 * 32 * MT * 16;
+}
+
+template <int MODE>
+int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st) {
+    using G = GeoH<MODE>;
+    KArgs p;
+    p.a = a;
+    p.w_unscale = unscale;
+    if (MODE == OODGAN_CONV_S1) { p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win; }
+    else if (MODE == OODGAN_CONV_T2) { p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1; }
+    else { p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn; }
+    if (p.a.in_pitch == 0) p.a.in_pitch = a.Win;
+    if (p.a.out_pitch == 0) p.a.out_pitch = p.Wout;
+    p.in_plane = (long)a.Hin * p.a.in_pitch;
+    p.out_plane = (long)p.Hout * p.a.out_pitch;
+    if (MODE == OODGAN_CONV_T2) {
+        OODGAN_REQUIRE((p.a.out_pitch & 1) == 0, "conv3x3 T2: out_pitch must be even (got %d)", p.a.out_pitch);
+        OODGAN_REQUIRE(a.dotx == nullptr && a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE,
+                       "conv3x3 T2: only out_scale is supported in the epilogue");
+    }
+    p.tiles_y = (p.Hn + G::TR - 1) / G::TR;
+    p.tiles_x = (p.Wn + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    const bool mt2 = a.M > 32;
+    const int MB = mt2 ? 64 : 32;
+    p.mblocks = (a.M + MB - 1) / MB;
+    if (a.dotx) {
+        OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
+        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y * 4, "conv3x3: dot_nparts %d != %d", a.dot_nparts,
+                       p.tiles_x * p.tiles_y * 4);
+    }
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    dim3 grid((unsigned)total), block(256);
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    if (mt2) {
+        constexpr int sm = smem_bytes<MODE, 2>();
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MODE, 2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
+        (void)once;
+        hipLaunchKernelGGL((conv_f16s_kernel<MODE, 2>), grid, block, sm, st, p, w16);
+    } else {
+        constexpr int sm = smem_bytes<MODE, 1>();
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MODE, 1>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
+        (void)once;
+        hipLaunchKernelGGL((conv_f16s_kernel<MODE, 1>), grid, block, sm, st, p, w16);
+    }
+    return check_launch("conv3x3_f16s");
+}
+
+// ------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, long n, float scale, float* __restrict__ out2) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i] * scale));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // power of two s.t. max|w|*2^e in [512, 1024)
+        int e = 0;
+        if (m > 0.f && isfinite(m)) e = 9 - (int)floorf(log2f(m));
+        e = e < -60 ? -60 : (e > 60 ? 60 : e);
+        out2[0] = ldexpf(1.f, -e);    // unscale
+        out2[1] = ldexpf(1.f, e);     // scale
+    }
+}
+
+// wpk16[kchunk][tap][hi|lo][h][Mp][8] f16
+__global__ __launch_bounds__(256) void pack_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Co, int Ci,
+                                                        int Mp, float scale, int transpose, int flip,
+                                                        const float* __restrict__ sc2) {
+    const int K = transpose ? Co : Ci, M = transpose ? Ci : Co;
+    const int nchunk = (K + CK - 1) / CK;
+    const long total = (long)nchunk * 9 * 2 * Mp * 8;           // one thread per (chunk,tap,h,m,j): writes hi and lo
+    const float s2 = sc2[1] * scale;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int j = (int)(e & 7);
+        long r = e >> 3;
+        const int m = (int)(r % Mp); r /= Mp;
+        const int h = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9);
+        const int t = (int)(r / 9);
+        const int k = t * CK + 8 * h + j;
+        float v = 0.f;
+        if (m < M && k < K) {
+            const int co = transpose ? k : m, ci = transpose ? m : k;
+            v = w[((long)co * Ci + ci) * 9 + (flip ? 8 - tap : tap)] * s2;
+        }
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const long base = (((long)t * 9 + tap) * 2) * 2;        // index of (tap, hl=0, h=0) row
+        out[((base + 0 * 2 + h) * Mp + m) * 8 + j] = hi;
+        out[((base + 1 * 2 + h) * Mp + m) * 8 + j] = lo;
+    }
+}
+
+}  // namespace
+
+extern "C" long oodgan_pack_conv3x3_f16s_bytes(int Co, int Ci, int transpose) {
+    const int M = transpose ? Ci : Co, K = transpose ? Co : Ci;
+    const long Mp = (M + 63) / 64 * 64;
+    return (long)((K + CK - 1) / CK) * 9 * 2 * 2 * Mp * 16;
+}
+
+extern "C" int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int Co, int Ci, float scale, int transpose,
+                                        int flip, void* stream) {
+    OODGAN_REQUIRE(w && wpk16 && unscale2 && Co > 0 && Ci > 0, "pack_conv3x3_f16s: bad args");
+    const int M = transpose ? Ci : Co, K = transpose ? Co : Ci;
+    const int Mp = (M + 63) / 64 * 64;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, st, w, (long)Co * Ci * 9, scale, unscale2);
+    const long total = (long)((K + CK - 1) / CK) * 9 * 2 * Mp * 8;
+    hipLaunchKernelGGL(pack_f16s_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, w, reinterpret_cast<_Float16*>(wpk16),
+                       Co, Ci, Mp, scale, transpose, flip, unscale2);
+    return check_launch("pack_conv3x3_f16s");
+}
+
+extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream) {
+    OODGAN_REQUIRE(args != nullptr, "conv3x3_f16s: null args");
+    const oodgan_conv_args& a = *args;
+    OODGAN_REQUIRE(a.x && a.wpk && a.y && unscale2, "conv3x3_f16s: null tensor");
+    OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
+    OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
+    OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
+    hipStream_t st = as_stream(stream);
+    switch (a.mode) {
+        case OODGAN_CONV_S1: return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
+        case OODGAN_CONV_T2: return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
+        case OODGAN_CONV_S2:
+            OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
+            return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);
+        default: break;
+    }
+    set_error("conv3x3_f16s: unknown mode %d", a.mode);
+    return OODGAN_E_ARG;
+}

@@ -20,11 +20,9 @@
 //   w tile  [CK][9][MB]        (MB = 32*MT output channels, channel fastest) — same property
 // Global->register loads of chunk t+1 are issued before the MFMA loop of chunk t (register
 // double-buffering, one LDS buffer, two barriers per chunk); 2+ blocks per CU hide the rest.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 using namespace oodgan;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -32,23 +30,6 @@ template <int MODE> struct Geo;
 template <> struct Geo<OODGAN_CONV_S1> { static constexpr int TR = 8, NT = 2, IN_R = 10, IN_C = 34, CK = 8, NPH = 1; };
 template <> struct Geo<OODGAN_CONV_T2> { static constexpr int TR = 4, NT = 1, IN_R = 5, IN_C = 33, CK = 8, NPH = 4; };
 template <> struct Geo<OODGAN_CONV_S2> { static constexpr int TR = 8, NT = 2, IN_R = 17, IN_C = 66, CK = 4, NPH = 1; };
-
-struct KArgs {
-    oodgan_conv_args a;
-    int Hn, Wn;          // N-space size
-    int Hout, Wout;      // output size
-    int tiles_x, tiles_y;
-    int mblocks, Mp;     // Mp = padded M of the packed weights
-    long in_plane, out_plane;
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int total) {
-    // contiguous chunk of the work list per XCD (blocks b and b+8 share an XCD): neighbouring
-    // work items (same weight block, adjacent tiles) hit the same L2.  Bijective for any total.
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int q = total >> 3, r = total & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 template <int MODE, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs p) {
@@ -71,15 +52,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
 
-    int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = p.tiles_x * p.tiles_y;
-    const int tile = w % ntile;
-    w /= ntile;
-    const int b = w % a.B;
-    const int mblk = w / a.B;
-    const int ty = tile / p.tiles_x, tx = tile % p.tiles_x;
-    const int r0 = ty * TR, c0 = tx * 32;
-    const int m0 = mblk * MB;
+    const BlockCtx ctx = decode_block<TR, MB>(p);
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
 
     const float* xb = a.x + (long)b * a.K * p.in_plane;
     const float* isc = a.in_scale ? a.in_scale + (long)b * a.in_scale_stride : nullptr;
@@ -218,73 +192,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const KArgs p) {
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
-    const float* osc = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : nullptr;
-    float* yb = a.y + (long)b * a.M * p.out_plane;
-    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
-
-    if constexpr (MODE == OODGAN_CONV_T2) {
-        const int ip = r0 + wave;          // i'
-        const int jp = c0 + l31;           // j'
-        const int zx = 2 * jp;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= a.M || zx >= p.Wout) continue;
-                const float sc = osc ? osc[m] : 1.f;
-#pragma unroll
-                for (int py = 0; py < 2; ++py) {
-                    const int zy = 2 * ip + py;
-                    if (zy >= p.Hout) continue;
-                    float2 v = make_float2(acc[mt][py * 2 + 0][r] * sc, acc[mt][py * 2 + 1][r] * sc);
-                    // out_pitch is even and out_plane is even for T2 (host guarantees) -> 8-byte aligned
-                    *reinterpret_cast<float2*>(yb + (long)m * p.out_plane + (long)zy * a.out_pitch + zx) = v;
-                }
-            }
-    } else {
-    const int px = c0 + l31;
-    const float* db = a.dotx ? a.dotx + (long)b * a.M * ((long)p.Hout * p.Wout) : nullptr;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float dsum[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dsum[r] = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int py = r0 + wave * NT + nt;
-            const bool pix_ok = (py < p.Hout) && (px < p.Wout);
-            float nz = 0.f;
-            if (a.noise && pix_ok)
-                nz = nw * a.noise[(long)(a.noise_batch > 1 ? b : 0) * p.Hout * p.Wout + (long)py * p.Wout + px];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (!pix_ok || m >= a.M) continue;
-                float v = acc[mt][nt][r];
-                if (db) dsum[r] += v * db[(long)m * p.Hout * p.Wout + (long)py * p.Wout + px];
-                if (osc) v *= osc[m];
-                v += nz;
-                if (a.bias) v += a.bias[m];
-                if (a.act == OODGAN_ACT_LRELU) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
-                else if (a.act == OODGAN_ACT_PRELU) v = v > 0.f ? v : a.slope[m] * v;
-                yb[(long)m * p.out_plane + (long)py * a.out_pitch + px] = v;
-            }
-        }
-        if (db) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = dsum[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (l31 == 0 && m < a.M)
-                    a.dot_part[((long)b * a.M + m) * a.dot_nparts + tile * 4 + wave] = s;
-            }
-        }
-    }
-    }
+    conv_epilogue<MODE, MT, NT, NACC>(p, acc, ctx, wave, l31, half);
 }
 
 template <int MODE>
@@ -292,6 +200,7 @@ int launch_mode(const oodgan_conv_args& a, hipStream_t st) {
     using G = Geo<MODE>;
     KArgs p;
     p.a = a;
+    p.w_unscale = nullptr;
     if (MODE == OODGAN_CONV_S1) { p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == OODGAN_CONV_T2) { p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1; }
     else { p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn; }

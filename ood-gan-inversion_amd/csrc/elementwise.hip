@@ -265,11 +265,11 @@ extern "C" int oodgan_reduce_parts(const float* part, float* out, long rows, int
 extern "C" int oodgan_mse_nparts(long CHW) { return (int)((CHW + kMseChunk - 1) / kMseChunk); }
 
 extern "C" int oodgan_mse_fwd_bwd(const float* img, const float* target, float* gimg, float* part, float* loss, int B,
-                                  long CHW, void* stream) {
+                                  long CHW, float grad_mul, void* stream) {
     OODGAN_REQUIRE(img && target && part && loss && B > 0 && CHW > 0, "mse: bad args");
     const int nparts = oodgan_mse_nparts(CHW);
     hipLaunchKernelGGL(mse_kernel, dim3(nparts, B), dim3(256), 0, as_stream(stream), img, target, gimg, part, CHW, nparts,
-                       2.0f / (float)CHW);
+                       grad_mul * 2.0f / (float)CHW);
     int rc = check_launch("mse");
     if (rc != OODGAN_OK) return rc;
     hipLaunchKernelGGL(mse_finish_kernel, dim3(B), dim3(64), 0, as_stream(stream), part, loss, nparts, 1.0f / (float)CHW);

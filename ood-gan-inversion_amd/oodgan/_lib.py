@@ -44,11 +44,14 @@ _SIGS = {
     'oodgan_pack_conv3x3': (c_int, [P, P, c_int, c_int, c_float, c_int, c_int, P]),
     'oodgan_conv3x3': (c_int, [POINTER(ConvArgs), P]),
     'oodgan_conv3x3_nparts': (c_int, [c_int, c_int, c_int]),
+    'oodgan_pack_conv3x3_f16s_bytes': (c_long, [c_int, c_int, c_int]),
+    'oodgan_pack_conv3x3_f16s': (c_int, [P, P, P, c_int, c_int, c_float, c_int, c_int, P]),
+    'oodgan_conv3x3_f16s': (c_int, [POINTER(ConvArgs), P, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),
-    'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, P]),
+    'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_nparts': (c_int, [c_long]),
     'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),
 }

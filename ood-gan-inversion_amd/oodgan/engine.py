@@ -26,8 +26,9 @@ class _Layer:
 
 
 class GeneratorEngine:
-    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True):
+    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None):
         self.size, self.style_dim = size, style_dim
+        self.precision = precision or ops.PRECISION
         self.log_size = int(math.log2(size))
         self.n_latent = self.log_size * 2 - 2
         self.num_layers = (self.log_size - 2) * 2 + 1
@@ -47,8 +48,8 @@ class GeneratorEngine:
             L.name, L.kind, L.cin, L.cout, L.res, L.lat, L.noise_idx = name, ('up' if up else 'conv'), cin, cout, res, lat, nidx
             w = g(f'{name}.conv.weight')[0]                 # (Co,Ci,3,3)
             L.scale = 1.0 / math.sqrt(cin * 9)
-            L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False)
-            L.wpk_bwd = ops.pack_conv3x3(w, L.scale, transpose=True, flip=not up) if with_backward else None
+            L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False, precision=self.precision)
+            L.wpk_bwd = ops.pack_conv3x3(w, L.scale, transpose=True, flip=not up, precision=self.precision) if with_backward else None
             L.wsq = ops.weight_sqsum(w)
             L.bias = g(f'{name}.activate.bias')
             L.noise_w = g(f'{name}.noise.weight')
@@ -161,8 +162,10 @@ class GeneratorEngine:
                                      ops._stream()), 'demod_fwd')
 
     # ------------------------------------------------------------------ backward (w.r.t. latents only)
-    def backward(self, gimg):
-        """gimg (B,3,size,size) -> dL/dlatent (B,n_latent,S).  Needs forward(..., save=True)."""
+    def backward(self, gimg, grad_scale=1.0):
+        """gimg (B,3,size,size), already multiplied by ``grad_scale`` -> dL/dlatent (B,n_latent,S).
+        Needs forward(..., save=True).  Every step is linear in the gradient, so a power-of-two
+        grad_scale is undone exactly at the end."""
         from ._lib import lib, check
         import ctypes
         sv = self.saved
@@ -210,7 +213,7 @@ class GeneratorEngine:
             g_feat = dx
             del g_pre
         self.last_gs = gs_all
-        return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent)
+        return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent, grad_div=grad_scale)
 
 
 class WPlusInverter:
@@ -227,10 +230,11 @@ class WPlusInverter:
         m = torch.zeros_like(w)
         v = torch.zeros_like(w)
         losses, traj = [], []
+        gmul = ops.loss_scale_for(target.numel() // target.shape[0])
         for t in range(1, steps + 1):
             img = self.engine.forward(w, noises, save=True)
-            loss, gimg = ops.mse_loss_grad(img, target)
-            g = self.engine.backward(gimg)
+            loss, gimg = ops.mse_loss_grad(img, target, gmul)
+            g = self.engine.backward(gimg, gmul)
             ops.adam_step(w, g, m, v, t, self.lr, self.betas, self.eps)
             losses.append(loss)
             if return_trajectory:

@@ -147,14 +147,14 @@ def style_affine(latent, wcat, bcat=None, row_lat=None, lr_mul=1.0):
     return s
 
 
-def style_affine_backward(gs, wcat, lat_start, L, lr_mul=1.0):
+def style_affine_backward(gs, wcat, lat_start, L, lr_mul=1.0, grad_div=1.0):
     g = _dev(gs, 'gs')
     w = _dev(wcat, 'wcat')
     B, R = g.shape
     S = w.shape[1]
     glat = torch.empty(B, L, S, device=g.device, dtype=torch.float32)
-    check(_lib.lib().oodgan_style_affine_bwd(_p(g), _p(w), _p(lat_start), _p(glat), B, L, S, R, (1.0 / math.sqrt(S)) * lr_mul,
-                                             _stream()), 'style_affine_bwd')
+    check(_lib.lib().oodgan_style_affine_bwd(_p(g), _p(w), _p(lat_start), _p(glat), B, L, S, R,
+                                             (1.0 / math.sqrt(S)) * lr_mul / grad_div, _stream()), 'style_affine_bwd')
     return glat
 
 
@@ -194,15 +194,38 @@ def demod(s, wsq, scale):
     return d
 
 
-def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False):
-    """(Co,Ci,3,3) -> wpk (K,9,Mp): the K-major layout streamed by the MFMA conv kernels."""
+PRECISION = 'f16s'   # default conv arithmetic: 'f16s' (split-f16, 3 MFMAs per product) or 'f32' (exact fp32 MFMA)
+
+
+class PackedConv:
+    """Packed 3x3 weights for one of the two MFMA conv kernels."""
+    __slots__ = ('data', 'unscale', 'precision', 'M')
+
+    def __init__(self, data, unscale, precision, M):
+        self.data, self.unscale, self.precision, self.M = data, unscale, precision, M
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+
+def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None):
+    """(Co,Ci,3,3) -> K-major packed weights for the MFMA conv kernels (fp32: wpk[K][9][Mp]; split-f16:
+    [K/16][9][hi|lo][2][Mp][8] f16 + power-of-two unscale)."""
+    precision = precision or PRECISION
     w = _dev(weight, 'weight')
     Co, Ci = w.shape[0], w.shape[1]
     M, K = (Ci, Co) if transpose else (Co, Ci)
-    Mp = (M + 63) // 64 * 64
-    out = torch.empty(K, 9, Mp, device=w.device, dtype=torch.float32)
-    check(_lib.lib().oodgan_pack_conv3x3(_p(w), _p(out), Co, Ci, float(scale), int(transpose), int(flip), _stream()), 'pack')
-    return out
+    if precision == 'f32':
+        Mp = (M + 63) // 64 * 64
+        out = torch.empty(K, 9, Mp, device=w.device, dtype=torch.float32)
+        check(_lib.lib().oodgan_pack_conv3x3(_p(w), _p(out), Co, Ci, float(scale), int(transpose), int(flip), _stream()), 'pack')
+        return PackedConv(out, None, 'f32', M)
+    nbytes = _lib.lib().oodgan_pack_conv3x3_f16s_bytes(Co, Ci, int(transpose))
+    out = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    unscale = torch.empty(2, device=w.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_pack_conv3x3_f16s(_p(w), _p(out), _p(unscale), Co, Ci, float(scale), int(transpose), int(flip),
+                                              _stream()), 'pack_f16s')
+    return PackedConv(out, unscale, 'f16s', M)
 
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
@@ -238,7 +261,10 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
         part = torch.empty(B, M, npart, device=x.device, dtype=torch.float32)
         a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
-    check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
+    if wpk.precision == 'f16s':
+        check(_lib.lib().oodgan_conv3x3_f16s(ctypes.byref(a), _p(wpk.unscale), _stream()), 'conv3x3_f16s')
+    else:
+        check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
     if dotx is not None:
         dot = torch.empty(B, M, device=x.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
@@ -292,8 +318,13 @@ def demod_backward(s, wsq, d, r, gs, scale):
     return gs
 
 
-def mse_loss_grad(img, target):
-    """Per-image MSE and its gradient: (loss[B], gimg)."""
+def loss_scale_for(chw):
+    """Power of two ~ CHW/2 so that grad_mul*2*(img-target)/CHW is O(img-target)."""
+    return float(2 ** max(0, int(math.floor(math.log2(max(chw, 2) / 2.0)))))
+
+
+def mse_loss_grad(img, target, grad_mul=1.0):
+    """Per-image MSE and its gradient (times grad_mul): (loss[B], gimg)."""
     a, t = _dev(img, 'img'), _dev(target, 'target')
     B = a.shape[0]
     CHW = a.numel() // B
@@ -302,7 +333,7 @@ def mse_loss_grad(img, target):
     part = torch.empty(B, npart, device=a.device, dtype=torch.float32)
     loss = torch.empty(B, device=a.device, dtype=torch.float32)
     g = torch.empty_like(a)
-    check(L.oodgan_mse_fwd_bwd(_p(a), _p(t), _p(g), _p(part), _p(loss), B, CHW, _stream()), 'mse')
+    check(L.oodgan_mse_fwd_bwd(_p(a), _p(t), _p(g), _p(part), _p(loss), B, CHW, float(grad_mul), _stream()), 'mse')
     return loss, g
 
 

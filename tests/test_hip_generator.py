@@ -54,8 +54,9 @@ def test_stylegan2generator_basicsr_keys(dev, golden):
     assert set(G.state_dict().keys()) == set(bsd.keys())
 
 
+@pytest.mark.parametrize('prec', ['f16s', 'f32'])
 @pytest.mark.parametrize('size,B', [(16, 2), (64, 1)])
-def test_generator_backward_vs_oracle_autograd(dev, size, B):
+def test_generator_backward_vs_oracle_autograd(dev, size, B, prec):
     """dL/dW+ from the HIP backward kernels vs torch autograd through the oracle evaluated in
     float64.  The latent seed is chosen so that no pre-activation of the low-resolution layers lies
     within fp32 rounding of the LeakyReLU kink (seed 6 has one at 7e-8 in conv1: its sign — and with it
@@ -69,11 +70,12 @@ def test_generator_backward_vs_oracle_autograd(dev, size, B):
     w = lat.double().requires_grad_(True)
     img_ref = R.generator_forward({k: v.double() for k, v in P.items()}, w, [n.double() for n in noises], size)
     R.wplus_loss(img_ref, target.double()).backward()
-    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size, precision=prec)
     img = eng.forward(lat.to(dev), [n.to(dev) for n in noises], save=True)
     assert maxdiff(img, img_ref.detach().float()) < 1e-3
-    loss, gimg = ops.mse_loss_grad(img, target.to(dev))
-    glat = eng.backward(gimg)
+    gmul = ops.loss_scale_for(3 * size * size)
+    loss, gimg = ops.mse_loss_grad(img, target.to(dev), gmul)
+    glat = eng.backward(gimg, gmul)
     gref = w.grad
     rel = (glat.detach().cpu().double() - gref).abs().max().item() / gref.abs().max().item()
     assert rel < 1e-4, rel

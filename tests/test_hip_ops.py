@@ -137,11 +137,13 @@ def test_modulated_conv_modules_vs_golden(dev, golden):
     close(rgb(x, wl, None), g['rgb_y_noskip'])
 
 
+@pytest.mark.parametrize('prec', ['f32', 'f16s'])
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(1, 8, 32, 4, 4), (2, 24, 40, 9, 37), (1, 64, 64, 16, 16), (2, 32, 96, 33, 65),
                                           (1, 512, 64, 8, 8)])
-def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W):
+def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W, prec):
     """Raw implicit-GEMM kernels (ragged sizes, channel counts that are not multiples of the tile)
-    against F.conv2d / conv_transpose2d with in/out scales and the dot epilogue."""
+    against F.conv2d / conv_transpose2d with in/out scales and the dot epilogue, for both arithmetic
+    variants: exact fp32 MFMA and split-f16 (3 MFMAs per product, fp32-equivalent)."""
     import torch.nn.functional as F
     from oodgan import ops
     x = synth.normal('cv.x', (B, Ci, H, W), 1)
@@ -151,7 +153,7 @@ def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W):
     xs = x * s[:, :, None, None]
     # S1 forward with scales
     ref = F.conv2d(xs, w, padding=1) * d[:, :, None, None]
-    wpk = ops.pack_conv3x3(w.to(dev))
+    wpk = ops.pack_conv3x3(w.to(dev), precision=prec)
     close(ops.conv3x3(x.to(dev), wpk, Co, ops.CONV_S1, in_scale=s.to(dev), out_scale=d.to(dev)), ref)
     # S1 with fused noise + bias + lrelu
     nz = synth.normal('cv.nz', (B, 1, H, W), 5)
@@ -169,7 +171,7 @@ def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W):
     gy = synth.normal('cv.gy', (B, Co, H, W), 7)
     xs_ = xs.clone().requires_grad_(True)
     (F.conv2d(xs_, w, padding=1) * d[:, :, None, None] * gy).sum().backward()
-    wpk_b = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=True)
+    wpk_b = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=True, precision=prec)
     dx, dot = ops.conv3x3(gy.to(dev), wpk_b, Ci, ops.CONV_S1, in_scale=d.to(dev), out_scale=s.to(dev), dotx=x.to(dev))
     close(dx, xs_.grad * s[:, :, None, None], 2e-4)
     close(dot, (xs_.grad * x).sum(dim=(2, 3)), 2e-4)
@@ -177,7 +179,7 @@ def test_conv3x3_modes_vs_oracle(dev, B, Ci, Co, H, W):
     gz = synth.normal('cv.gz', (B, Co, 2 * H + 1, 2 * W + 1), 8)
     xs_ = xs.clone().requires_grad_(True)
     (F.conv_transpose2d(xs_, w.transpose(0, 1), stride=2) * d[:, :, None, None] * gz).sum().backward()
-    wpk_t = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=False)
+    wpk_t = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=False, precision=prec)
     gzp = torch.zeros(B, Co, 2 * H + 1, 2 * W + 2)
     gzp[..., :2 * W + 1] = gz
     dx, dot = ops.conv3x3(gzp.to(dev), wpk_t, Ci, ops.CONV_S2, in_scale=d.to(dev), out_scale=s.to(dev), dotx=x.to(dev),
