@@ -132,6 +132,9 @@ typedef struct oodgan_conv_args {
     int noise_batch;
     int mode, act;
     int dot_nparts;          /* out: must equal oodgan_conv3x3_nparts(...) */
+    const float* in_mul2;    /* device {unscale, scale} pair or NULL: the staged input is multiplied by scale and the
+                                accumulators by unscale (power-of-two range control of the split-f16 kernels,
+                                produced by oodgan_absmax_scale; ignored by the exact-fp32 kernel) */
 } oodgan_conv_args;
 
 /* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -177,6 +180,14 @@ int oodgan_act_bwd_fused(const float* g_feat, const float* out, const float* noi
                          const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre,
                          float* part_r, float* part_rgb, int B, int C, long HW, void* stream);
 int oodgan_act_bwd_nparts(long HW);
+/* same, additionally part_max[b,c,j] = partial max |g_pre| (feeds oodgan_absmax_scale) */
+int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                             const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
+                             const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre,
+                             float* part_r, float* part_rgb, float* part_max, int B, int C, long HW, void* stream);
+/* out2 = {2^-e, 2^e} with e chosen so that max_i |part[i]| * 2^e lies in [512,1024) (e = 0 for an all-zero or
+ * non-finite input): the power-of-two scale that keeps a tensor inside the f16 range of the split-f16 kernels. */
+int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream);
 
 /* ------------------------------------------------------------------ A9 loss / optimiser ---- */
 

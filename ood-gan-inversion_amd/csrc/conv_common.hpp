@@ -16,6 +16,7 @@ struct KArgs {
     int mblocks, Mp;     // Mp = padded M of the packed weights
     long in_plane, out_plane;
     const float* w_unscale;   // device scalar multiplying every accumulator (split-f16 weights are pre-scaled); NULL = 1
+    int ablate;               // debug: bit0 skip MFMA, bit1 skip x loads, bit2 skip w loads, bit3 skip LDS stores, bit4 skip epilogue
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& p, f32x16 (&acc)[MT][
     const float* osc = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : nullptr;
     float* yb = a.y + (long)b * a.M * p.out_plane;
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
-    const float us = p.w_unscale ? p.w_unscale[0] : 1.f;
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * ((p.w_unscale && a.in_mul2) ? a.in_mul2[0] : 1.f);
     if constexpr (MODE == OODGAN_CONV_T2) {
         const int ip = r0 + wave;          // i'
         const int jp = c0 + l31;           // j'

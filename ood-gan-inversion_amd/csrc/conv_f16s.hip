@@ -18,6 +18,8 @@
 //   w: [tap][hi|lo][h][MB channels][8 ch f16]: an A fragment is one ds_read_b128, consecutive lanes consecutive
 //      16-byte slots; the global packing has the same order so staging is a straight 16-byte copy.
 #include "conv_common.hpp"
+#include <cstdlib>
+#include <cstdint>
 
 using namespace oodgan;
 
@@ -30,11 +32,15 @@ constexpr int CK = 16;         // input channels per K chunk
 constexpr int REC = 80;        // bytes per x-tile position record
 
 template <int MODE> struct GeoH;
-template <> struct GeoH<OODGAN_CONV_S1> { static constexpr int TR = 8, NT = 2, IN_R = 10, IN_C = 34; };
-template <> struct GeoH<OODGAN_CONV_T2> { static constexpr int TR = 4, NT = 1, IN_R = 5, IN_C = 33; };
-template <> struct GeoH<OODGAN_CONV_S2> { static constexpr int TR = 8, NT = 2, IN_R = 17, IN_C = 66; };
+// IN_C: tile columns held in LDS.  S1/T2: global column c0-4 .. (16-byte aligned so that the halo'd rows can be
+// fetched with float4 loads); S2: 2*c0 .. 2*c0+67, de-interleaved into an even and an odd plane of 34.
+template <> struct GeoH<OODGAN_CONV_S1> { static constexpr int TR = 8, NT = 2, IN_R = 10, IN_C = 40; };
+template <> struct GeoH<OODGAN_CONV_T2> { static constexpr int TR = 4, NT = 1, IN_R = 5, IN_C = 36; };
+template <> struct GeoH<OODGAN_CONV_S2> { static constexpr int TR = 8, NT = 2, IN_R = 17, IN_C = 68; };
 
-template <int MODE, int MT>
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int MODE, int MT, bool VEC>
 __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uint4* __restrict__ wpk16) {
     using G = GeoH<MODE>;
     constexpr int NT = G::NT, TR = G::TR, IN_R = G::IN_R, IN_C = G::IN_C;
@@ -42,11 +48,11 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     constexpr int MB = 32 * MT;
     constexpr int XBYTES = NPOS * REC;
     constexpr int WROWS = 9 * 2 * 2;                 // (tap, hi|lo, h)
-    constexpr int WBYTES = WROWS * MB * 16;
-    constexpr int XITEMS = NPOS * 4;                 // (position, quad of 4 channels)
+    constexpr int WPIECES = WROWS * MB * 16 / 1024;  // 1-KiB LDS-DMA pieces (one wave-instruction each)
+    constexpr int NF4 = IN_R * (IN_C / 4);           // float4 units of the x tile (per channel)
+    constexpr int XITEMS = VEC ? NF4 * 4 : NPOS * 4; // (unit, quad of 4 channels)
     constexpr int XPT = (XITEMS + 255) / 256;
-    constexpr int WE = WROWS * MB;                   // 16-byte units
-    constexpr int WPT = (WE + 255) / 256;
+    constexpr int XV = VEC ? 16 : 4;                 // floats held per item
     constexpr int NACC = (MODE == OODGAN_CONV_T2) ? 4 : NT;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -62,80 +68,100 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     const float* xb = a.x + (long)b * a.K * p.in_plane;
     const float* isc = a.in_scale ? a.in_scale + (long)b * a.in_scale_stride : nullptr;
     const float* ish = a.in_shift ? a.in_shift + (long)b * a.in_scale_stride : nullptr;
+    const float in_mul = a.in_mul2 ? a.in_mul2[1] : 1.f;
+    const int row_org = (MODE == OODGAN_CONV_S2) ? 2 * r0 : r0 - 1;
+    const int col_org = (MODE == OODGAN_CONV_S2) ? 2 * c0 : c0 - 4;
 
-    // per-thread staging descriptors
-    int xoff[XPT];
+    // ---- per-thread staging descriptors: item e -> (channel quad q = e&3, unit u = e>>2)
+    int xoff[XPT];     // offset inside a channel plane of the unit's first element, -1 = nothing to load
+    int xgx[XPT];      // global column of the unit's first element (for per-element masking)
+    int xpos[XPT];     // LDS position of the unit's first element
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int e = tid + i * 256;
-        const int pos = e % NPOS;
-        const int r = pos / IN_C, col = pos % IN_C;
-        int gy, gx;
-        if (MODE == OODGAN_CONV_S2) {
-            const int par = col / 33, idx = col % 33;
-            gy = 2 * r0 + r;
-            gx = 2 * (c0 + idx) + par;
-        } else {
-            gy = r0 - 1 + r;
-            gx = c0 - 1 + col;
-        }
-        const bool ok = (e < XITEMS) && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        const int u = e >> 2;
+        int r, c;
+        if (VEC) { r = u / (IN_C / 4); c = 4 * (u % (IN_C / 4)); }
+        else { r = u / IN_C; c = u % IN_C; }
+        const int gy = row_org + r, gx = col_org + c;
+        bool ok = (e < XITEMS) && gy >= 0 && gy < a.Hin && gx >= 0;
+        if (VEC) ok = ok && (gx + 3 < a.in_pitch) && (gx < a.Win);
+        else ok = ok && (gx < a.Win);
         xoff[i] = ok ? gy * a.in_pitch + gx : -1;
+        xgx[i] = gx;
+        if (MODE == OODGAN_CONV_S2) xpos[i] = r * IN_C + (c & 1) * 34 + (c >> 1);
+        else xpos[i] = r * IN_C + c;
     }
 
-    float xr[XPT][4];
-    uint4 wr[WPT];
+    float xr[XPT][XV];
     const int nchunk = (a.K + CK - 1) / CK;
     const long wchunk = (long)WROWS * p.Mp;          // 16-byte units per K chunk in the packed weights
 
-    auto load_chunk = [&](int t) {
-        const int k0 = t * CK;
+    auto load_x = [&](int t) {
+        const int k0 = t * CK + 4 * (tid & 3);
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const int e = tid + i * 256;
-            const int q = e / NPOS;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 4 * q + j;
-                float v = 0.f;
-                if (xoff[i] >= 0 && k < a.K) {
-                    v = xb[(long)k * p.in_plane + xoff[i]];
-                    if (isc) v *= isc[k];
-                    if (ish) v += ish[k];
+                const int k = k0 + j;
+                const bool ld = xoff[i] >= 0 && k < a.K && !(p.ablate & 2);
+                const float sc = ((ld && isc) ? isc[k] : 1.f) * in_mul;
+                const float sh = ((ld && ish) ? ish[k] : 0.f) * in_mul;
+                if (VEC) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ld) {
+                        v = *reinterpret_cast<const float4*>(xb + (long)k * p.in_plane + xoff[i]);
+                        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                        // elements beyond the logical width (pitch padding / S2 odd width) are zero
+                        if (xgx[i] + 1 >= a.Win) v.y = 0.f;
+                        if (xgx[i] + 2 >= a.Win) v.z = 0.f;
+                        if (xgx[i] + 3 >= a.Win) v.w = 0.f;
+                    }
+                    xr[i][j * 4 + 0] = v.x; xr[i][j * 4 + 1] = v.y; xr[i][j * 4 + 2] = v.z; xr[i][j * 4 + 3] = v.w;
+                } else {
+                    float v = 0.f;
+                    if (ld) v = xb[(long)k * p.in_plane + xoff[i]] * sc + sh;
+                    xr[i][j] = v;
                 }
-                xr[i][j] = v;
             }
         }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * 256;
-            const int row = e / MB, j = e % MB;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (e < WE) v = wpk16[(long)t * wchunk + (long)row * p.Mp + m0 + j];
-            wr[i] = v;
-        }
     };
-    auto store_chunk = [&]() {
+    auto store_x = [&]() {
+        const int q = tid & 3;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
             if (e >= XITEMS) continue;
-            const int q = e / NPOS, pos = e % NPOS;
-            half4 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = xr[i][j];
-                const _Float16 h = (_Float16)v;
-                hi[j] = h;
-                lo[j] = (_Float16)(v - (float)h);
+            for (int px = 0; px < (VEC ? 4 : 1); ++px) {
+                half4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = VEC ? xr[i][j * 4 + px] : xr[i][j];
+                    const _Float16 h = (_Float16)v;
+                    hi[j] = h;
+                    lo[j] = (_Float16)(v - (float)h);
+                }
+                int pos = xpos[i];
+                if (VEC) pos += (MODE == OODGAN_CONV_S2) ? ((px & 1) * 34 + (px >> 1)) : px;
+                *reinterpret_cast<half4*>(lx + pos * REC + q * 8) = hi;
+                *reinterpret_cast<half4*>(lx + pos * REC + 32 + q * 8) = lo;
             }
-            *reinterpret_cast<half4*>(lx + pos * REC + q * 8) = hi;
-            *reinterpret_cast<half4*>(lx + pos * REC + 32 + q * 8) = lo;
         }
+    };
+    // weights: straight 16-byte-per-lane LDS-DMA copies, one 1-KiB piece per wave-instruction
+    auto dma_w = [&](int t) {
+        if (p.ablate & 4) return;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * 256;
-            if (e < WE) reinterpret_cast<uint4*>(lw)[e] = wr[i];
+        for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+            const int pc = wave + i * 4;
+            if (pc < WPIECES) {
+                const int u = pc * 64 + lane;
+                const int row = u / MB, j = u % MB;
+                const uint4* src = wpk16 + (long)t * wchunk + (long)row * p.Mp + m0 + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (lds_void*)(lw + pc * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -150,8 +176,8 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     // lane bases
     const unsigned char* lwh = lw + (half * MB + l31) * 16;
     int pbase;
-    if (MODE == OODGAN_CONV_S1) pbase = (wave * NT) * IN_C + l31;
-    else if (MODE == OODGAN_CONV_T2) pbase = wave * IN_C + l31;
+    if (MODE == OODGAN_CONV_S1) pbase = (wave * NT) * IN_C + l31 + 3;      // tile col 0 = global col c0-4
+    else if (MODE == OODGAN_CONV_T2) pbase = wave * IN_C + l31 + 3;
     else pbase = (wave * NT) * 2 * IN_C + l31;
     const unsigned char* lxh = lx + pbase * REC + half * 16;
 
@@ -162,12 +188,14 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
 
-    load_chunk(0);
+    load_x(0);
     for (int t = 0; t < nchunk; ++t) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (t + 1 < nchunk) load_chunk(t + 1);
+        __syncthreads();                       // previous chunk fully consumed
+        dma_w(t);                              // async global->LDS, lands while x is converted
+        if (!(p.ablate & 8)) store_x();
+        __syncthreads();                       // (hipcc drains vmcnt before the barrier: DMA complete)
+        if (t + 1 < nchunk) load_x(t + 1);     // in flight during the MFMA loop
+        if (p.ablate & 1) continue;
 
         if constexpr (MODE == OODGAN_CONV_T2) {
             half8 bh[2][2], bl[2][2];
@@ -201,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
                     for (int nt = 0; nt < NT; ++nt) {
                         int po;
                         if constexpr (MODE == OODGAN_CONV_S1) po = (nt + ky) * IN_C + kx;
-                        else po = (2 * nt + ky) * IN_C + (kx == 1 ? 33 : (kx == 2 ? 1 : 0));
+                        else po = (2 * nt + ky) * IN_C + (kx == 1 ? 34 : (kx == 2 ? 1 : 0));
                         bh[nt] = XFRAG(po, 0);
                         bl[nt] = XFRAG(po, 1);
                     }
@@ -215,6 +243,7 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
 #undef XFRAG
 #undef WFRAG
 #undef MFMA3
+    if (p.ablate & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 1.f; return; }
     conv_epilogue<MODE, MT, NT, NACC>(p, acc, ctx, wave, l31, half);
 }
 
@@ -230,6 +259,7 @@ int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     KArgs p;
     p.a = a;
     p.w_unscale = unscale;
+    { static int abl = getenv("OODGAN_ABLATE") ? atoi(getenv("OODGAN_ABLATE")) : 0; p.ablate = abl; }
     if (MODE == OODGAN_CONV_S1) { p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == OODGAN_CONV_T2) { p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1; }
     else { p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn; }
@@ -257,19 +287,20 @@ int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     dim3 grid((unsigned)total), block(256);
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (mt2) {
-        constexpr int sm = smem_bytes<MODE, 2>();
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MODE, 2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
-        (void)once;
-        hipLaunchKernelGGL((conv_f16s_kernel<MODE, 2>), grid, block, sm, st, p, w16);
-    } else {
-        constexpr int sm = smem_bytes<MODE, 1>();
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MODE, 1>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
-        (void)once;
-        hipLaunchKernelGGL((conv_f16s_kernel<MODE, 1>), grid, block, sm, st, p, w16);
+    // float4 staging needs 16-byte aligned rows: pitch % 4 == 0, aligned base, and (S1/T2) width % 4 == 0
+    const bool vec = (p.a.in_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+                     (MODE == OODGAN_CONV_S2 || a.Win % 4 == 0);
+#define OODGAN_LAUNCH(MT_, VEC_)                                                                                   \
+    {                                                                                                              \
+        constexpr int sm = smem_bytes<MODE, MT_>();                                                                \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<MODE, MT_, VEC_>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);      \
+        (void)once;                                                                                                \
+        hipLaunchKernelGGL((conv_f16s_kernel<MODE, MT_, VEC_>), grid, block, sm, st, p, w16);                      \
     }
+    if (mt2) { if (vec) OODGAN_LAUNCH(2, true) else OODGAN_LAUNCH(2, false) }
+    else { if (vec) OODGAN_LAUNCH(1, true) else OODGAN_LAUNCH(1, false) }
+#undef OODGAN_LAUNCH
     return check_launch("conv3x3_f16s");
 }
 

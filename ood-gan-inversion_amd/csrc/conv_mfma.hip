@@ -201,6 +201,7 @@ int launch_mode(const oodgan_conv_args& a, hipStream_t st) {
     KArgs p;
     p.a = a;
     p.w_unscale = nullptr;
+    p.ablate = 0;
     if (MODE == OODGAN_CONV_S1) { p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == OODGAN_CONV_T2) { p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1; }
     else { p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn; }

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
     const float* __restrict__ g_feat, const float* __restrict__ out, const float* __restrict__ noise, int noise_batch,
     const float* __restrict__ noise_w, const float* __restrict__ bias, const float* __restrict__ g_rgb,
     const float* __restrict__ w_rgb, const float* __restrict__ s_rgb, int s_rgb_stride, float rgb_scale,
-    float* __restrict__ g_pre, float* __restrict__ part_r, float* __restrict__ part_rgb, int C, long HW, int nparts) {
+    float* __restrict__ g_pre, float* __restrict__ part_r, float* __restrict__ part_rgb, float* __restrict__ part_max, int C,
+    long HW, int nparts) {
     __shared__ float red[4];
     const int bc = blockIdx.y, b = bc / C, c = bc % C;
     const long base = (long)bc * HW;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
         gr = g_rgb + (long)b * 3 * HW;
     }
     const float inv_pos = 1.f / kSqrt2, inv_neg = 1.f / (0.2f * kSqrt2);
-    float acc_r = 0.f, acc_t = 0.f;
+    float acc_r = 0.f, acc_t = 0.f, amax = 0.f;
     auto one = [&](float gf, float o, float nz, float r0, float r1, float r2) -> float {
         const float t = w0 * r0 + w1 * r1 + w2 * r2;
         const float g = gf + sr * t;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
         const float ycv = (o > 0.f ? o * inv_pos : o * inv_neg) - nw * nz - bv;
         acc_r += gp * ycv;
         acc_t += o * t;
+        amax = fmaxf(amax, fabsf(gp));
         return gp;
     };
     if ((HW & 3) == 0) {
@@ -137,6 +139,32 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
     if (part_rgb) {
         const float st_ = block_sum_256(acc_t, red);
         if (threadIdx.x == 0) part_rgb[(long)bc * nparts + blockIdx.x] = st_;
+    }
+    if (part_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) part_max[(long)bc * nparts + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ part, long n, float* __restrict__ out2) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(part[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = 0;
+        if (m > 0.f && isfinite(m)) e = 9 - (int)floorf(log2f(m));
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        out2[0] = ldexpf(1.f, -e);
+        out2[1] = ldexpf(1.f, e);
     }
 }
 
@@ -239,20 +267,35 @@ extern "C" int oodgan_bias_act_bwd(const float* gy, const float* y, float* gx, f
 
 extern "C" int oodgan_act_bwd_nparts(long HW) { return (int)((HW + kActChunk - 1) / kActChunk); }
 
-extern "C" int oodgan_act_bwd_fused(const float* g_feat, const float* out, const float* noise, int noise_batch,
-                                    const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
-                                    const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre, float* part_r,
-                                    float* part_rgb, int B, int C, long HW, void* stream) {
+extern "C" int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                                        const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
+                                        const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre, float* part_r,
+                                        float* part_rgb, float* part_max, int B, int C, long HW, void* stream) {
     OODGAN_REQUIRE(out && g_pre && B > 0 && C > 0 && HW > 0, "act_bwd_fused: bad args");
     OODGAN_REQUIRE(g_feat || g_rgb, "act_bwd_fused: no incoming gradient");
     OODGAN_REQUIRE(!g_rgb || (w_rgb && s_rgb), "act_bwd_fused: rgb branch needs w_rgb and s_rgb");
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "act_bwd_fused: noise_batch");
+    OODGAN_REQUIRE((long)B * C <= 65535, "act_bwd_fused: B*C too large");
     const int nparts = oodgan_act_bwd_nparts(HW);
     dim3 grid(nparts, B * C);
     hipLaunchKernelGGL(act_bwd_fused_kernel, grid, dim3(256), 0, as_stream(stream), g_feat, out, noise, noise_batch, noise_w,
-                       bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, g_pre, part_r, g_rgb ? part_rgb : nullptr, C, HW,
-                       nparts);
+                       bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, g_pre, part_r, g_rgb ? part_rgb : nullptr, part_max,
+                       C, HW, nparts);
     return check_launch("act_bwd_fused");
+}
+
+extern "C" int oodgan_act_bwd_fused(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                                    const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
+                                    const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre, float* part_r,
+                                    float* part_rgb, int B, int C, long HW, void* stream) {
+    return oodgan_act_bwd_fused_max(g_feat, out, noise, noise_batch, noise_w, bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale,
+                                    g_pre, part_r, part_rgb, nullptr, B, C, HW, stream);
+}
+
+extern "C" int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream) {
+    OODGAN_REQUIRE(part && out2 && n > 0, "absmax_scale: bad args");
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), part, n, out2);
+    return check_launch("absmax_scale");
 }
 
 extern "C" int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream) {

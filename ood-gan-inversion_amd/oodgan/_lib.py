@@ -22,7 +22,7 @@ class ConvArgs(Structure):
         ('noise_w', P), ('slope', P), ('dotx', P), ('dot_part', P), ('y', P),
         ('B', c_int), ('K', c_int), ('M', c_int), ('Hin', c_int), ('Win', c_int),
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
-        ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int),
+        ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
     ]
 
 
@@ -51,6 +51,8 @@ _SIGS = {
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),
+    'oodgan_act_bwd_fused_max': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_absmax_scale': (c_int, [P, c_long, P, P]),
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_nparts': (c_int, [c_long]),
     'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),

@@ -188,12 +188,12 @@ class GeneratorEngine:
             out, x_in, nz = acts[L.name], acts[L.src], noises[L.noise_idx]
             if prev_rgb is not None:
                 Rg = prev_rgb
-                g_pre, rsum, tsum = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
-                                                      _Cols(s_all, Rg.row, Rg.cin))
+                g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
+                                                            _Cols(s_all, Rg.row, Rg.cin), want_scale=True)
                 gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
                 prev_rgb = None
             else:
-                g_pre, rsum, _ = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias)
+                g_pre, rsum, _, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, want_scale=True)
             # demodulation gradient
             check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
                                          ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
@@ -202,12 +202,13 @@ class GeneratorEngine:
             s = _Cols(s_all, L.row, L.cin)
             d = _Cols(d_all, L.drow, L.cout)
             if L.kind == 'conv':
-                dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in)
+                dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in, in_mul2=mul2)
             else:
                 H2 = 2 * x_in.shape[2] + 1
-                g2 = ops.upfirdn2d(g_pre, self.k4x4_flip, pad=(2, 2), out_pitch=H2 + 1)
+                P2 = (H2 + 3) // 4 * 4
+                g2 = ops.upfirdn2d(g_pre, self.k4x4_flip, pad=(2, 2), out_pitch=P2)
                 dx, dot = ops.conv3x3(g2, L.wpk_bwd, L.cin, CONV_S2, in_scale=d, out_scale=s, dotx=x_in, in_hw=(H2, H2),
-                                      in_pitch=H2 + 1)
+                                      in_pitch=P2, in_mul2=mul2)
                 del g2
             gs_all[:, L.row:L.row + L.cin] += dot
             g_feat = dx

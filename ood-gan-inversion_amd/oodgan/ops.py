@@ -229,7 +229,8 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
-            noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0):
+            noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
+            in_mul2=None):
     """Implicit-GEMM 3x3 conv on the fp32 matrix cores.  Returns y, or (y, dot[B,M]) when ``dotx`` is given."""
     x = _dev(x)
     B, K = x.shape[0], x.shape[1]
@@ -239,7 +240,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     elif mode == CONV_T2:
         oh, ow = 2 * H + 1, 2 * W + 1
         if out_pitch == 0:
-            out_pitch = ow + 1
+            out_pitch = (ow + 3) // 4 * 4        # 16-byte aligned rows (float4 staging of the consumer), even for float2 stores
     else:
         oh, ow = (H - 1) // 2, (W - 1) // 2
     pitch = out_pitch if out_pitch else ow
@@ -255,6 +256,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.out_scale_stride = out_scale.shape[1] if out_scale is not None else 0
     a.noise_batch = noise.shape[0] if noise is not None else 1
     a.mode, a.act = mode, act
+    a.in_mul2 = _p(in_mul2)
     part = None
     if dotx is not None:
         dx_ = _dev(dotx, 'dotx')
@@ -283,9 +285,11 @@ def torgb(x, weight, s, bias=None, skip=None, kernel=None):
     return y
 
 
-def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_rgb=None, w_rgb=None, s_rgb=None):
+def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_rgb=None, w_rgb=None, s_rgb=None,
+                  want_scale=False):
     """Backward through bias+noise+lrelu*sqrt2 merged with the ToRGB branch; returns
-    (g_pre, r[B,C] = sum g_pre*y_cv, t[B,C] = sum out*t or None)."""
+    (g_pre, r[B,C] = sum g_pre*y_cv, t[B,C] = sum out*t or None[, mul2]) where mul2 = device {2^-e, 2^e} with
+    max|g_pre|*2^e in [512,1024) (range control for the split-f16 convs)."""
     o = _dev(out, 'out')
     B, C = o.shape[0], o.shape[1]
     HW = o.numel() // (B * C)
@@ -295,17 +299,22 @@ def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_
     part_r = torch.empty(B, C, npart, device=o.device, dtype=torch.float32)
     part_t = torch.empty(B, C, npart, device=o.device, dtype=torch.float32) if g_rgb is not None else None
     nz = _opt(noise, 'noise')
-    check(L.oodgan_act_bwd_fused(_p(_opt(g_feat, 'g_feat')), _p(o), _p(nz), 1 if nz is None else nz.shape[0],
-                                 _p(_opt(noise_weight, 'nw')), _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')),
-                                 _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)), _p(_opt(s_rgb, 's_rgb')),
-                                 0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(g_pre), _p(part_r), _p(part_t),
-                                 B, C, HW, _stream()), 'act_bwd_fused')
+    part_m = torch.empty(B, C, npart, device=o.device, dtype=torch.float32) if want_scale else None
+    check(L.oodgan_act_bwd_fused_max(_p(_opt(g_feat, 'g_feat')), _p(o), _p(nz), 1 if nz is None else nz.shape[0],
+                                     _p(_opt(noise_weight, 'nw')), _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')),
+                                     _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)), _p(_opt(s_rgb, 's_rgb')),
+                                     0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(g_pre), _p(part_r),
+                                     _p(part_t), _p(part_m), B, C, HW, _stream()), 'act_bwd_fused')
     r = torch.empty(B, C, device=o.device, dtype=torch.float32)
     check(L.oodgan_reduce_parts(_p(part_r), _p(r), B * C, npart, 0, _stream()), 'reduce')
     t = None
     if part_t is not None:
         t = torch.empty(B, C, device=o.device, dtype=torch.float32)
         check(L.oodgan_reduce_parts(_p(part_t), _p(t), B * C, npart, 0, _stream()), 'reduce')
+    if want_scale:
+        mul2 = torch.empty(2, device=o.device, dtype=torch.float32)
+        check(L.oodgan_absmax_scale(_p(part_m), part_m.numel(), _p(mul2), _stream()), 'absmax_scale')
+        return g_pre, r, t, mul2
     return g_pre, r, t
 
 

@@ -79,6 +79,14 @@ def test_generator_backward_vs_oracle_autograd(dev, size, B, prec):
     gref = w.grad
     rel = (glat.detach().cpu().double() - gref).abs().max().item() / gref.abs().max().item()
     assert rel < 1e-4, rel
+    # range control: a 2^24 x larger (or smaller) loss scale must give the same gradient (the split-f16 convs
+    # rescale every gradient tensor by a power of two derived from its max)
+    for k in (2.0 ** 24, 2.0 ** -20):
+        loss2, gimg2 = ops.mse_loss_grad(img, target.to(dev), gmul * k)
+        glat2 = eng.backward(gimg2, gmul * k)
+        assert torch.isfinite(glat2).all()
+        rel2 = (glat2 - glat).abs().max().item() / gref.abs().max().item()
+        assert rel2 < 1e-4, (k, rel2)
 
 
 def test_wplus_trajectory_vs_golden(dev, golden):
