@@ -153,6 +153,7 @@ long oodgan_pack_conv3x3_f16s_bytes(int Co, int Ci, int transpose);
 int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int Co, int Ci, float scale, int transpose,
                              int flip, void* stream);
 int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream);
+int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expected by oodgan_conv3x3_f16s */
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
 /* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
 int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);

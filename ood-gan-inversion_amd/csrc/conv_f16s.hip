@@ -23,6 +23,8 @@
 
 using namespace oodgan;
 
+namespace oodgan { int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st); }
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
@@ -355,6 +357,12 @@ __global__ __launch_bounds__(256) void pack_f16s_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win) {
+    if (mode == OODGAN_CONV_S1) return ((Hin + 7) / 8) * ((Win + 31) / 32) * (getenv("OODGAN_S1_LEGACY") ? 4 : 1);
+    if (mode == OODGAN_CONV_S2) return (((Hin - 1) / 2 + 7) / 8) * (((Win - 1) / 2 + 31) / 32) * 4;
+    return 0;
+}
+
 extern "C" long oodgan_pack_conv3x3_f16s_bytes(int Co, int Ci, int transpose) {
     const int M = transpose ? Ci : Co, K = transpose ? Co : Ci;
     const long Mp = (M + 63) / 64 * 64;
@@ -382,8 +390,11 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
     hipStream_t st = as_stream(stream);
+    static const bool legacy_s1 = getenv("OODGAN_S1_LEGACY") != nullptr;   // A/B switch: single-pipeline S1 kernel
     switch (a.mode) {
-        case OODGAN_CONV_S1: return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
+        case OODGAN_CONV_S1:
+            if (legacy_s1) return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
+            return launch_s1pp(a, a.wpk, unscale2, st);
         case OODGAN_CONV_T2: return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");

@@ -68,11 +68,14 @@ __global__ __launch_bounds__(256) void style_affine_wave_kernel(const float* __r
 }
 
 // glat[b,l,k] = scale * sum_{r in [lat_start[l], lat_start[l+1])} gs[b,r] * W[r,k]
-// grid (ceil(S/256), L, ceil(B/8)); thread = one k, 8 batch accumulators, W row reads coalesced over k.
+// grid (ceil(S/64), L, ceil(B/8)); block = 64 k-columns x 4 row groups (rows of the latent split 4 ways, reduced
+// through LDS); W row reads are 256-B coalesced, the 8 batch accumulators share every W element.
 __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ w,
                                                                const int* __restrict__ lat_start, float* __restrict__ glat,
                                                                int B, int L, int S, int R, float scale) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][8][64];
+    const int kl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     const int l = blockIdx.y;
     const int b0 = blockIdx.z * 8;
     const int ra = lat_start[l], rb = lat_start[l + 1];
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (k < S) {
-        for (int r = ra; r < rb; ++r) {
+#pragma unroll 4
+        for (int r = ra + rg; r < rb; r += 4) {
             const float wv = w[(long)r * S + k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -88,10 +92,15 @@ __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __re
                 if (b < B) acc[j] += gs[(long)b * R + r] * wv;
             }
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rg][j][kl] = acc[j];
+    __syncthreads();
+    if (rg == 0 && k < S) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int b = b0 + j;
-            if (b < B) glat[((long)b * L + l) * S + k] = acc[j] * scale;
+            if (b < B) glat[((long)b * L + l) * S + k] = (red[0][j][kl] + red[1][j][kl] + red[2][j][kl] + red[3][j][kl]) * scale;
         }
     }
 }
@@ -144,18 +153,33 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict_
 }
 
 // gs[b,ci] += -scale^2 * s[b,ci] * sum_co r[b,co]*d[b,co]^2*wsq[co,ci]
+// grid (ceil(Ci/64), B); block = 64 ci x 4 co-groups; r*d^2 staged in LDS, wsq rows read 256-B coalesced.
 __global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict__ s, int s_stride, const float* __restrict__ wsq,
                                                         const float* __restrict__ d, int d_stride, const float* __restrict__ r,
                                                         float* __restrict__ gs, int gs_stride, int B, int Ci, int Co, float scale2) {
-    const int ci = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float rd2[1024];
+    __shared__ float red[4][64];
     const int b = blockIdx.y;
-    if (ci >= Ci) return;
+    const int cil = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int ci = blockIdx.x * 64 + cil;
     float acc = 0.f;
-    for (int co = 0; co < Co; ++co) {
-        const float dv = d[(long)b * d_stride + co];
-        acc += r[(long)b * Co + co] * dv * dv * wsq[(long)co * Ci + ci];
+    for (int c0 = 0; c0 < Co; c0 += 1024) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 1024 && c0 + e < Co; e += 256) {
+            const float dv = d[(long)b * d_stride + c0 + e];
+            rd2[e] = r[(long)b * Co + c0 + e] * dv * dv;
+        }
+        __syncthreads();
+        const int cn = (Co - c0) < 1024 ? (Co - c0) : 1024;
+        if (ci < Ci) {
+#pragma unroll 8
+            for (int co = cg; co < cn; co += 4) acc += rd2[co] * wsq[(long)(c0 + co) * Ci + ci];
+        }
     }
-    gs[(long)b * gs_stride + ci] += -scale2 * s[(long)b * s_stride + ci] * acc;
+    red[cg][cil] = acc;
+    __syncthreads();
+    if (cg == 0 && ci < Ci)
+        gs[(long)b * gs_stride + ci] += -scale2 * s[(long)b * s_stride + ci] * (red[0][cil] + red[1][cil] + red[2][cil] + red[3][cil]);
 }
 
 }  // namespace
@@ -178,7 +202,7 @@ extern "C" int oodgan_style_affine_fwd(const float* latent, const float* wcat, c
 extern "C" int oodgan_style_affine_bwd(const float* gs, const float* wcat, const int* lat_start, float* glat, int B, int L,
                                        int S, int R, float scale, void* stream) {
     OODGAN_REQUIRE(gs && wcat && lat_start && glat && B > 0 && L > 0 && S > 0 && R > 0, "style_affine_bwd: bad args");
-    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3((S + 255) / 256, L, (B + 7) / 8), dim3(256), 0, as_stream(stream), gs,
+    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3((S + 63) / 64, L, (B + 7) / 8), dim3(256), 0, as_stream(stream), gs,
                        wcat, lat_start, glat, B, L, S, R, scale);
     return check_launch("style_affine_bwd");
 }
@@ -217,7 +241,7 @@ extern "C" int oodgan_demod_fwd(const float* s, int s_stride, const float* wsq, 
 extern "C" int oodgan_demod_bwd(const float* s, int s_stride, const float* wsq, const float* d, int d_stride, const float* r,
                                 float* gs, int gs_stride, int B, int Ci, int Co, float scale, void* stream) {
     OODGAN_REQUIRE(s && wsq && d && r && gs && B > 0 && Ci > 0 && Co > 0, "demod_bwd: bad args");
-    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Ci + 255) / 256, B), dim3(256), 0, as_stream(stream), s, s_stride, wsq, d,
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Ci + 63) / 64, B), dim3(256), 0, as_stream(stream), s, s_stride, wsq, d,
                        d_stride, r, gs, gs_stride, B, Ci, Co, scale * scale);
     return check_launch("demod_bwd");
 }

@@ -47,6 +47,7 @@ _SIGS = {
     'oodgan_pack_conv3x3_f16s_bytes': (c_long, [c_int, c_int, c_int]),
     'oodgan_pack_conv3x3_f16s': (c_int, [P, P, P, c_int, c_int, c_float, c_int, c_int, P]),
     'oodgan_conv3x3_f16s': (c_int, [POINTER(ConvArgs), P, P]),
+    'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),

@@ -260,7 +260,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     part = None
     if dotx is not None:
         dx_ = _dev(dotx, 'dotx')
-        npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
+        npart = (_lib.lib().oodgan_conv3x3_f16s_nparts if wpk.precision == 'f16s' else _lib.lib().oodgan_conv3x3_nparts)(mode, H, W)
         part = torch.empty(B, M, npart, device=x.device, dtype=torch.float32)
         a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
     if wpk.precision == 'f16s':
