@@ -135,6 +135,11 @@ typedef struct oodgan_conv_args {
     const float* in_mul2;    /* device {unscale, scale} pair or NULL: the staged input is multiplied by scale and the
                                 accumulators by unscale (power-of-two range control of the split-f16 kernels,
                                 produced by oodgan_absmax_scale; ignored by the exact-fp32 kernel) */
+    int x_sform;             /* 1: x is an S-form buffer (oodgan_to_sform / a producer's `ys`): already scaled and split,
+                                in_scale/in_shift must be NULL (split-f16 kernels only) */
+    void* ys;                /* optional S-form output of (activated y) * ys_scale[b,m] for the next conv, or NULL */
+    const float* ys_scale;   /* (B,M) stride ys_scale_stride, or NULL */
+    int ys_scale_stride;
 } oodgan_conv_args;
 
 /* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -154,6 +159,14 @@ int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int C
                              int flip, void* stream);
 int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream);
 int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expected by oodgan_conv3x3_f16s */
+
+/* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
+ * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
+ * fetch their halo'd tiles as contiguous runs by LDS-DMA.  Buffers must be zero-initialised once (border).
+ * oodgan_to_sform converts an fp32 NCHW tensor: value = x*scale[b,c]*mul2[1]. */
+long oodgan_sform_bytes(int B, int C, int H, int W);
+int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
+                    int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
 /* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
 int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);

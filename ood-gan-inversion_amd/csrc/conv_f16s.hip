@@ -23,7 +23,10 @@
 
 using namespace oodgan;
 
-namespace oodgan { int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st); }
+namespace oodgan {
+int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -385,7 +388,8 @@ extern "C" int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unsc
 extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream) {
     OODGAN_REQUIRE(args != nullptr, "conv3x3_f16s: null args");
     const oodgan_conv_args& a = *args;
-    OODGAN_REQUIRE(a.x && a.wpk && a.y && unscale2, "conv3x3_f16s: null tensor");
+    OODGAN_REQUIRE(a.x && a.wpk && unscale2 && (a.y || a.x_sform), "conv3x3_f16s: null tensor");
+    OODGAN_REQUIRE(!a.x_sform || a.mode == OODGAN_CONV_S1, "conv3x3_f16s: S-form input is implemented for mode S1");
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
@@ -393,6 +397,8 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     static const bool legacy_s1 = getenv("OODGAN_S1_LEGACY") != nullptr;   // A/B switch: single-pipeline S1 kernel
     switch (a.mode) {
         case OODGAN_CONV_S1:
+            if (a.x_sform) return launch_s1v2(a, a.wpk, unscale2, st);
+            OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");
             if (legacy_s1) return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
             return launch_s1pp(a, a.wpk, unscale2, st);
         case OODGAN_CONV_T2: return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);

@@ -1,0 +1,389 @@
+// Split-f16 3x3 stride-1 conv reading its input in S-form (sform.hpp): the x tile arrives by LDS-DMA exactly
+// like the weights — no staging registers, no conversion VALU, contiguous 2176-byte runs.  Same ping-pong
+// schedule, MFMA loop and LDS-staged epilogue as conv_f16s_pp.hip; additionally the epilogue can emit the
+// S-form of (activated output x next layer's style) so that the next conv finds its input ready.
+#include "conv_common.hpp"
+#include "sform.hpp"
+#include <cstdint>
+#include <cstdlib>
+
+using namespace oodgan;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int CK = 16, REC = 80;
+constexpr int TR = 8, NT = 2, IN_R = 10, IN_C = 34, NPOS = IN_R * IN_C;   // 340 positions
+constexpr int XSLOTS = NPOS * 5;                                          // 16-byte LDS slots incl. the pad slot
+constexpr int XPIECES = (XSLOTS + 63) / 64;                               // 27 one-KiB DMA pieces
+constexpr int XBYTES = XPIECES * 1024;                                    // 27648
+constexpr int OP = 260;
+
+template <int MT>
+constexpr int group_bytes() {
+    constexpr int stage = XBYTES + 36 * 32 * MT * 16;
+    constexpr int epi = 32 * MT * OP * 4;
+    return (stage > epi ? stage : epi);
+}
+
+struct SConv {
+    const uint4* xs;        // S-form input
+    SDims xd;
+    uint4* ys;              // S-form output or null
+    SDims yd;
+    const float* ys_scale;  // (B,M) scale applied to the S-form output (next layer's style), stride ys_scale_stride
+    int ys_scale_stride;
+};
+
+template <int MT, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
+                                                             const SConv sc) {
+    constexpr int MB = 32 * MT;
+    constexpr int WROWS = 36;
+    constexpr int WPIECES = WROWS * MB * 16 / 1024;
+    constexpr int GB = group_bytes<MT>();
+    constexpr int XPW = (XPIECES + 3) / 4;          // x pieces per wave
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int grp = threadIdx.x >> 8;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    unsigned char* lx = smem + grp * GB;
+    unsigned char* lw = lx + XBYTES;
+
+    const int wi = NG * xcd_remap(blockIdx.x, gridDim.x) + grp;
+    const bool active = wi < total_items;
+    BlockCtx ctx;
+    {
+        int w = active ? wi : 0;
+        const int ntile = p.tiles_x * p.tiles_y;
+        ctx.mblk = w % p.mblocks;
+        w /= p.mblocks;
+        ctx.tile = w % ntile;
+        ctx.b = w / ntile;
+        ctx.r0 = (ctx.tile / p.tiles_x) * TR;
+        ctx.c0 = (ctx.tile % p.tiles_x) * 32;
+        ctx.m0 = ctx.mblk * MB;
+    }
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+
+    // per-lane DMA source offsets (16-byte units inside one (b,kc) plane) of this wave's x pieces
+    long xsrc[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int pc = wave + 4 * i;
+        int P = pc * 64 + lane;                 // physical LDS slot
+        if (P >= XSLOTS) P = XSLOTS - 1;        // tail of the last piece: harmless duplicate
+        const int pos = P / 5;
+        int s = P % 5;
+        if (s == 4) s = 0;                      // pad slot: any valid address
+        const int r = pos / IN_C, c = pos % IN_C;
+        // tile origin = image (r0-1, c0-1) = padded (r0, c0)
+        xsrc[i] = ((long)(r0 + r) * sc.xd.Wp + (c0 + c)) * 4 + s;
+    }
+    const uint4* xplane0 = sc.xs + (long)b * sc.xd.KC * sc.xd.plane;
+    const int nchunk = (a.K + CK - 1) / CK;
+    const long wchunk = (long)WROWS * p.Mp;
+
+    auto dma_x = [&](int t) {
+        const uint4* base = xplane0 + (long)t * sc.xd.plane;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int pc = wave + 4 * i;
+            if (pc < XPIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
+                                                 (lds_void*)(lx + pc * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_w = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+            const int pc = wave + i * 4;
+            if (pc < WPIECES) {
+                const int u = pc * 64 + lane;
+                const int row = u / MB, j = u % MB;
+                const uint4* src = wpk16 + (long)t * wchunk + (long)row * p.Mp + m0 + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (lds_void*)(lw + pc * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+
+    const unsigned char* lwh = lw + (half * MB + l31) * 16;
+    const unsigned char* lxh = lx + ((wave * NT) * IN_C + l31) * REC + half * 16;
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
+#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
+#define MFMA3(accv, ah, al, bh, bl)                                              \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+
+    const int nsteps = 2 * nchunk + 1;
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();
+        const int s = step - grp;
+        if (!active || s < 0 || s >= 2 * nchunk) continue;
+        const int t = s >> 1;
+        if ((s & 1) == 0) {
+            // stage segment: both operands by LDS-DMA; drained explicitly (a bare s_barrier does not wait for it)
+            dma_x(t);
+            dma_w(t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#define LOADF(buf, tp_)                                                                               \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
+            ah[buf][mt] = WFRAG(tp_, 0, mt);                                                          \
+            al[buf][mt] = WFRAG(tp_, 1, mt);                                                          \
+        }                                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+            bh[buf][nt] = XFRAG((nt + (tp_) / 3) * IN_C + (tp_) % 3, 0);                              \
+            bl[buf][nt] = XFRAG((nt + (tp_) / 3) * IN_C + (tp_) % 3, 1);                              \
+        }                                                                                             \
+    }
+            LOADF(0, 0)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int cur = tp & 1;
+                if (tp + 1 < 9) LOADF(cur ^ 1, tp + 1)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { MFMA3(acc[mt][nt], ah[cur][mt], al[cur][mt], bh[cur][nt], bl[cur][nt]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef LOADF
+        }
+    }
+#undef XFRAG
+#undef WFRAG
+#undef MFMA3
+    __syncthreads();
+
+    // ---------------------------------------------------------------- epilogue through LDS
+    float* lo = reinterpret_cast<float*>(lx);
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    lo[m * OP + (wave * NT + nt) * 32 + l31] = acc[mt][nt][r] * us;
+                }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float* osc = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : nullptr;
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const long HWo = (long)p.Hout * p.Wout;
+    const float* nzp = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : nullptr;
+    const float* db = a.dotx ? a.dotx + (long)b * a.M * HWo : nullptr;
+    float* yb = a.y ? a.y + (long)b * a.M * p.out_plane : nullptr;
+    const bool vec = (p.Wout % 4 == 0) && (a.out_pitch % 4 == 0);
+    {
+        const int c4 = tid & 63;
+        const int prow = c4 >> 3, pcol = (c4 & 7) * 4;
+        const int py = r0 + prow, px = c0 + pcol;
+        const bool row_ok = py < p.Hout;
+#pragma unroll 4
+        for (int i = 0; i < MB / 4; ++i) {
+            const int ml = (tid >> 6) + 4 * i;
+            const int m = m0 + ml;
+            float4 v = *reinterpret_cast<const float4*>(lo + ml * OP + c4 * 4);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            float dsum = 0.f;
+            const bool m_ok = m < a.M;
+            if (m_ok && row_ok && (yb || db)) {
+                const long pix = (long)py * p.Wout + px;
+                const float scl = osc ? osc[m] : 1.f;
+                const float bv = a.bias ? a.bias[m] : 0.f;
+                const float sl = (a.act == OODGAN_ACT_PRELU) ? a.slope[m] : 0.f;
+                float* yp = yb ? yb + (long)m * p.out_plane + (long)py * a.out_pitch + px : nullptr;
+                if (vec && px + 3 < p.Wout) {
+                    if (db) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(db + (long)m * HWo + pix);
+                        dsum = vv[0] * d4.x + vv[1] * d4.y + vv[2] * d4.z + vv[3] * d4.w;
+                    }
+                    if (yp) {
+                        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (nzp) n4 = *reinterpret_cast<const float4*>(nzp + pix);
+                        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float o = vv[j] * scl + nw * nn[j] + bv;
+                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                            vv[j] = o;
+                        }
+                        *reinterpret_cast<float4*>(yp) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (px + j >= p.Wout) continue;
+                        if (db) dsum += vv[j] * db[(long)m * HWo + pix + j];
+                        if (yp) {
+                            float o = vv[j] * scl + (nzp ? nw * nzp[pix + j] : 0.f) + bv;
+                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                            yp[j] = o;
+                        }
+                    }
+                }
+            }
+            if (db) {
+                dsum = wave_sum(dsum);
+                if (lane == 0 && m_ok) a.dot_part[((long)b * a.M + m) * a.dot_nparts + ctx.tile] = dsum;
+            }
+        }
+    }
+    // ---- optional S-form output: (activated output) * ys_scale[b,m], split hi/lo, 16 channels per 64-byte record
+    if (sc.ys) {
+        const float* ysc = sc.ys_scale ? sc.ys_scale + (long)b * sc.ys_scale_stride : nullptr;
+        // unit = (pixel of the 8x32 tile, 16-channel block): the thread activates 16 channels once and writes the
+        // whole 64-byte record (4 x 16 B, consecutive lanes -> consecutive records: 4 KB contiguous per wave)
+        for (int u = tid; u < 256 * (MB / 16); u += 256) {
+            const int pxl = u & 255, g16 = u >> 8;
+            const int py = r0 + (pxl >> 5), px = c0 + (pxl & 31);
+            if (py >= p.Hout || px >= p.Wout) continue;
+            const float nz = nzp ? nw * nzp[(long)py * p.Wout + px] : 0.f;
+            half8 hv[2], lv[2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ml = g16 * 16 + j, m = m0 + ml;
+                float o = 0.f;
+                if (m < a.M) {
+                    o = lo[ml * OP + pxl] * (osc ? osc[m] : 1.f) + nz + (a.bias ? a.bias[m] : 0.f);
+                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : a.slope[m] * o;
+                    if (ysc) o *= ysc[m];
+                }
+                const _Float16 h = (_Float16)o;
+                hv[j >> 3][j & 7] = h;
+                lv[j >> 3][j & 7] = (_Float16)(o - (float)h);
+            }
+            half8* rec = reinterpret_cast<half8*>(sc.ys + sform_unit(sc.yd, b, (m0 >> 4) + g16, py, px, 0));
+            rec[0] = hv[0]; rec[1] = hv[1]; rec[2] = lv[0]; rec[3] = lv[1];
+        }
+    }
+}
+
+// F-form (B,C,H,W) fp32 -> S-form, value = x*scale[b,c]*mul2[1]; one thread per (b,kc,y,x) record
+__global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       int scale_stride, const float* __restrict__ mul2, uint4* __restrict__ out,
+                                                       int B, SDims d, int in_pitch) {
+    const long total = (long)B * d.KC * d.H * d.W;
+    const float gm = mul2 ? mul2[1] : 1.f;
+    const long in_plane = (long)d.H * in_pitch;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int xx = (int)(e % d.W);
+        const int yy = (int)((e / d.W) % d.H);
+        const int kc = (int)((e / ((long)d.W * d.H)) % d.KC);
+        const int b = (int)(e / ((long)d.W * d.H * d.KC));
+        half8 h0, h1, l0, l1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = kc * 16 + j;
+            float v = 0.f;
+            if (c < d.C) v = x[((long)b * d.C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) * gm;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            if (j < 8) { h0[j] = h; l0[j] = l; } else { h1[j - 8] = h; l1[j - 8] = l; }
+        }
+        const long u = sform_unit(d, b, kc, yy, xx, 0);
+        half8* o = reinterpret_cast<half8*>(out + u);
+        o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
+    }
+}
+
+}  // namespace
+
+extern "C" long oodgan_sform_bytes(int B, int C, int H, int W) {
+    const SDims d = sform_dims(C, H, W);
+    return (long)B * d.KC * d.plane * 16;
+}
+
+extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
+                               int H, int W, int in_pitch, void* stream) {
+    OODGAN_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "to_sform: bad args");
+    const SDims d = sform_dims(C, H, W);
+    if (in_pitch == 0) in_pitch = W;
+    const long total = (long)B * d.KC * H * W;
+    hipLaunchKernelGGL(to_sform_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale, scale_stride,
+                       mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch);
+    return check_launch("to_sform");
+}
+
+namespace oodgan {
+
+int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st) {
+    KArgs p;
+    p.a = a;
+    p.w_unscale = unscale;
+    p.ablate = 0;
+    p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win;
+    OODGAN_REQUIRE(a.in_scale == nullptr && a.in_shift == nullptr, "conv3x3 S-form input: scales are applied by the producer");
+    if (p.a.out_pitch == 0) p.a.out_pitch = p.Wout;
+    p.in_plane = 0;
+    p.out_plane = (long)p.Hout * p.a.out_pitch;
+    p.tiles_y = (p.Hn + TR - 1) / TR;
+    p.tiles_x = (p.Wn + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    const bool mt2 = a.M > 32;
+    const int MB = mt2 ? 64 : 32;
+    p.mblocks = (a.M + MB - 1) / MB;
+    if (a.dotx) {
+        OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
+        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 f16s S1: dot_nparts %d != %d", a.dot_nparts,
+                       p.tiles_x * p.tiles_y);
+        OODGAN_REQUIRE((reinterpret_cast<uintptr_t>(a.dotx) & 15) == 0 || (a.Win % 4), "conv3x3: unaligned dotx");
+    }
+    OODGAN_REQUIRE(a.y || a.ys || a.dotx, "conv3x3: no output requested");
+    SConv sc;
+    sc.xs = reinterpret_cast<const uint4*>(a.x);
+    sc.xd = sform_dims(a.K, a.Hin, a.Win);
+    sc.ys = reinterpret_cast<uint4*>(a.ys);
+    sc.yd = sform_dims(a.M, p.Hout, p.Wout);
+    sc.ys_scale = a.ys_scale;
+    sc.ys_scale_stride = a.ys_scale_stride;
+    OODGAN_REQUIRE(!a.ys || (a.M % 16 == 0), "conv3x3: S-form output needs M %% 16 == 0");
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    const int items = (int)total;
+    // NG = 2: two anti-phase pipelines per 512-thread workgroup (1 workgroup per CU); NG = 1: independent 256-thread
+    // workgroups, 2-3 per CU — better when K is small and the epilogue dominates (it then overlaps other blocks)
+    static const int force_ng = getenv("OODGAN_V2_GROUPS") ? atoi(getenv("OODGAN_V2_GROUPS")) : 0;
+    const int ng = force_ng ? force_ng : (a.K >= 128 ? 2 : 1);
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+#define OODGAN_LAUNCH(MT_, NG_)                                                                                          \
+    {                                                                                                                    \
+        constexpr int sm = NG_ * group_bytes<MT_>();                                                                     \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1v2_kernel<MT_, NG_>),   \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);            \
+        (void)once;                                                                                                      \
+        dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                                \
+        hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_>), grid, block, sm, st, p, w16, items, sc);                   \
+    }
+    if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(2, 1) }
+    else { if (ng == 2) OODGAN_LAUNCH(1, 2) else OODGAN_LAUNCH(1, 1) }
+#undef OODGAN_LAUNCH
+    return check_launch("conv3x3_f16s_s1v2");
+}
+
+}  // namespace oodgan

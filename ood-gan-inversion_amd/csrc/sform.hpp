@@ -1,0 +1,37 @@
+// "S-form" activations: the layout the split-f16 conv kernels consume with zero conversion work.
+//
+//   S[b][kc = ceil(C/16)][Hp][Wp][slot 0..3][8 x f16]        64 bytes per pixel and 16-channel block
+//     slot 0 = hi(ch 0-7)  slot 1 = hi(ch 8-15)  slot 2 = lo(ch 0-7)  slot 3 = lo(ch 8-15)
+//   v = hi + lo (f16 split of the fp32 value, already multiplied by the consumer's per-(b,channel) scale:
+//   style for the forward, demodulation x power-of-two range scale for the backward).
+//   Pixel (y,x) of the image lives at [y+1][x+1]: a one-pixel ZERO border plus zero padding up to the conv
+//   tile grid (Hp = roundup(H+1, 8) + 2, Wp = roundup(W+1, 32) + 2) so that a halo'd tile row is ONE
+//   contiguous run (34 positions = 2176 B, ~95 % cache-line use; the NCHW fp32 tile rows were 160-B runs at
+//   >=256-B stride, ~40 %) that the kernels fetch with LDS-DMA — no registers, no VALU, no bounds checks.
+//   Producers write the interior only; the border is zeroed once at allocation and never touched.
+#pragma once
+#include "common.hpp"
+
+namespace oodgan {
+
+struct SDims {
+    int C, H, W, KC, Hp, Wp;
+    long plane;      // 16-byte units per (b,kc) plane
+};
+
+__host__ __device__ inline SDims sform_dims(int C, int H, int W) {
+    SDims d;
+    d.C = C; d.H = H; d.W = W;
+    d.KC = (C + 15) / 16;
+    d.Hp = (H + 1 + 7) / 8 * 8 + 2;
+    d.Wp = (W + 1 + 31) / 32 * 32 + 2;
+    d.plane = (long)d.Hp * d.Wp * 4;
+    return d;
+}
+
+// index (16-byte units) of slot `s` of image pixel (y,x), channel block kc, batch b
+__host__ __device__ inline long sform_unit(const SDims& d, int b, int kc, int y, int x, int s) {
+    return (((long)b * d.KC + kc) * d.Hp + (y + 1)) * (long)d.Wp * 4 + (long)(x + 1) * 4 + s;
+}
+
+}  // namespace oodgan

@@ -23,6 +23,7 @@ class ConvArgs(Structure):
         ('B', c_int), ('K', c_int), ('M', c_int), ('Hin', c_int), ('Win', c_int),
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
+        ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
     ]
 
 
@@ -48,6 +49,8 @@ _SIGS = {
     'oodgan_pack_conv3x3_f16s': (c_int, [P, P, P, c_int, c_int, c_float, c_int, c_int, P]),
     'oodgan_conv3x3_f16s': (c_int, [POINTER(ConvArgs), P, P]),
     'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
+    'oodgan_sform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
+    'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),

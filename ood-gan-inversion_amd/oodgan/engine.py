@@ -29,6 +29,7 @@ class GeneratorEngine:
     def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None):
         self.size, self.style_dim = size, style_dim
         self.precision = precision or ops.PRECISION
+        self.sform = (self.precision == 'f16s') and ops.USE_SFORM
         self.log_size = int(math.log2(size))
         self.n_latent = self.log_size * 2 - 2
         self.num_layers = (self.log_size - 2) * 2 + 1
@@ -132,8 +133,15 @@ class GeneratorEngine:
             d = _Cols(d_all, L.drow, L.cout)
             nz = noises[L.noise_idx]
             if L.kind == 'conv':
-                out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
-                                  noise_weight=L.noise_w, act=ACT_LRELU)
+                if self.sform:
+                    # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA
+                    xs = ops.to_sform(out, s)
+                    out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
+                                      noise_weight=L.noise_w, act=ACT_LRELU)
+                    del xs
+                else:
+                    out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
+                                      noise_weight=L.noise_w, act=ACT_LRELU)
             else:
                 z = ops.conv3x3(out, L.wpk, L.cout, CONV_T2, in_scale=s, out_scale=d)
                 H2 = 2 * out.shape[2] + 1
@@ -202,7 +210,12 @@ class GeneratorEngine:
             s = _Cols(s_all, L.row, L.cin)
             d = _Cols(d_all, L.drow, L.cout)
             if L.kind == 'conv':
-                dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in, in_mul2=mul2)
+                if self.sform:
+                    gs_ = ops.to_sform(g_pre, d, mul2)
+                    dx, dot = ops.conv3x3(gs_, L.wpk_bwd, L.cin, CONV_S1, out_scale=s, dotx=x_in, in_mul2=mul2)
+                    del gs_
+                else:
+                    dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in, in_mul2=mul2)
             else:
                 H2 = 2 * x_in.shape[2] + 1
                 P2 = (H2 + 3) // 4 * 4

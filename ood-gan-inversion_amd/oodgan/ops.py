@@ -194,6 +194,37 @@ def demod(s, wsq, scale):
     return d
 
 
+class SForm:
+    """S-form activation buffer (csrc/sform.hpp): (B, C, H, W) logical, 64-byte {hi,lo} f16 records per pixel and
+    16-channel block, zero border + tile padding.  ``data`` must stay zero outside the interior."""
+    __slots__ = ('data', 'B', 'C', 'H', 'W')
+
+    def __init__(self, B, C, H, W, device):
+        n = _lib.lib().oodgan_sform_bytes(B, C, H, W)
+        self.data = torch.zeros(n // 2, device=device, dtype=torch.float16)
+        self.B, self.C, self.H, self.W = B, C, H, W
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    @property
+    def shape(self):
+        return (self.B, self.C, self.H, self.W)
+
+
+def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
+    """fp32 NCHW -> S-form of x*scale[b,c]*mul2[1]."""
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
+    if out is None:
+        out = SForm(B, C, H, W, x.device)
+    check(_lib.lib().oodgan_to_sform(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2), _p(out),
+                                     B, C, H, W, in_pitch, _stream()), 'to_sform')
+    return out
+
+
+USE_SFORM = True     # S1 convs of the generator engine take their input through an S-form conversion + LDS-DMA kernel
 PRECISION = 'f16s'   # default conv arithmetic: 'f16s' (split-f16, 3 MFMAs per product) or 'f32' (exact fp32 MFMA)
 
 
@@ -230,9 +261,13 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None):
-    """Implicit-GEMM 3x3 conv on the fp32 matrix cores.  Returns y, or (y, dot[B,M]) when ``dotx`` is given."""
-    x = _dev(x)
+            in_mul2=None, ys=None, ys_scale=None, want_y=True):
+    """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
+    mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
+    act(y)*ys_scale in S-form for the next conv."""
+    sform_in = isinstance(x, SForm)
+    if not sform_in:
+        x = _dev(x)
     B, K = x.shape[0], x.shape[1]
     H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
     if mode == CONV_S1:
@@ -244,8 +279,8 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     else:
         oh, ow = (H - 1) // 2, (W - 1) // 2
     pitch = out_pitch if out_pitch else ow
-    if out is None:
-        out = torch.empty(B, M, oh, pitch, device=x.device, dtype=torch.float32)
+    if out is None and want_y:
+        out = torch.empty(B, M, oh, pitch, device=x.data.device if sform_in else x.device, dtype=torch.float32)
     a = ConvArgs()
     a.x, a.wpk, a.y = _p(x), _p(wpk), _p(out)
     a.in_scale, a.in_shift, a.out_scale = _p(_opt(in_scale, 'in_scale')), _p(_opt(in_shift, 'in_shift')), _p(_opt(out_scale, 'out_scale'))
@@ -257,18 +292,21 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.noise_batch = noise.shape[0] if noise is not None else 1
     a.mode, a.act = mode, act
     a.in_mul2 = _p(in_mul2)
+    a.x_sform = 1 if sform_in else 0
+    a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
+    a.ys_scale_stride = ys_scale.shape[1] if ys_scale is not None else 0
     part = None
     if dotx is not None:
         dx_ = _dev(dotx, 'dotx')
         npart = (_lib.lib().oodgan_conv3x3_f16s_nparts if wpk.precision == 'f16s' else _lib.lib().oodgan_conv3x3_nparts)(mode, H, W)
-        part = torch.empty(B, M, npart, device=x.device, dtype=torch.float32)
+        part = torch.empty(B, M, npart, device=dx_.device, dtype=torch.float32)
         a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
     if wpk.precision == 'f16s':
         check(_lib.lib().oodgan_conv3x3_f16s(ctypes.byref(a), _p(wpk.unscale), _stream()), 'conv3x3_f16s')
     else:
         check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
     if dotx is not None:
-        dot = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        dot = torch.empty(B, M, device=dx_.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
         return out, dot
     return out

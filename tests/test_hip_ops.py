@@ -226,3 +226,36 @@ def test_mse_and_adam(dev):
         opt.step()
         ops.adam_step(wd, gr.to(dev), m, v, step)
         close(wd, w.detach(), 1e-6)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(1, 16, 32, 4, 4), (2, 24, 40, 9, 37), (2, 64, 64, 16, 16), (1, 32, 96, 33, 64)])
+def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
+    """S-form path: F->S conversion (style folded in), S1 conv by LDS-DMA, fused epilogue, dot epilogue, and the
+    S-form output consumed by a second conv (the conv->conv hand-off of the generator)."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    x = synth.normal('sf.x', (B, Ci, H, W), 1)
+    w = synth.normal('sf.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('sf.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('sf.d', (B, Co), 4, 0.3, 1.0)
+    nz = synth.normal('sf.nz', (B, 1, H, W), 5)
+    nw = torch.tensor([0.37])
+    bias = synth.normal('sf.b', (Co,), 6)
+    xs = ops.to_sform(x.to(dev), s.to(dev))
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    ref = R.fused_leaky_relu(F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None] + nw * nz, bias)
+    s2 = synth.normal('sf.s2', (B, Co), 7, 0.3, 1.0)
+    ys = ops.SForm(B, Co, H, W, dev) if Co % 16 == 0 else None
+    y = ops.conv3x3(xs, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), bias=bias.to(dev), noise=nz.to(dev), noise_weight=nw.to(dev),
+                    act=ops.ACT_LRELU, ys=ys, ys_scale=None if ys is None else s2.to(dev))
+    close(y, ref)
+    dotx = synth.normal('sf.dx', (B, Co, H, W), 8)
+    y2, dot = ops.conv3x3(xs, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev))
+    raw = F.conv2d(x * s[:, :, None, None], w, padding=1)
+    close(y2, raw * d[:, :, None, None])
+    close(dot, (raw * dotx).sum(dim=(2, 3)), 2e-4)
+    if ys is not None:
+        w2 = synth.normal('sf.w2', (Co, Co, 3, 3), 9, 1.0 / math.sqrt(Co * 9))
+        wpk2 = ops.pack_conv3x3(w2.to(dev), precision='f16s')
+        z = ops.conv3x3(ys, wpk2, Co, ops.CONV_S1)
+        close(z, F.conv2d(ref * s2[:, :, None, None], w2, padding=1), 2e-4)
