@@ -284,6 +284,121 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed 3x3 stride-2 conv (the up-sampling ModulatedConv2d before its blur) with S-form input: block = 4 waves,
+// N tile = 4 rows x 32 positions (i',j') of the (H+1)x(W+1) position grid, 4 output phases per position.
+// x tile = rows r0-1..r0+3, cols c0-1..c0+31 of the S-form image (165 records, 13 one-KiB DMA pieces).
+constexpr int T2_R = 5, T2_C = 33, T2_NPOS = T2_R * T2_C;
+constexpr int T2_XPIECES = (T2_NPOS * 5 + 63) / 64;          // 13
+constexpr int T2_XBYTES = T2_XPIECES * 1024;
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv_f16s_t2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, const SConv sc) {
+    constexpr int MB = 32 * MT;
+    constexpr int WROWS = 36;
+    constexpr int WPIECES = WROWS * MB * 16 / 1024;
+    constexpr int XPW = (T2_XPIECES + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lx = smem;
+    unsigned char* lw = smem + T2_XBYTES;
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    BlockCtx ctx;
+    {
+        int w = xcd_remap(blockIdx.x, gridDim.x);
+        const int ntile = p.tiles_x * p.tiles_y;
+        ctx.mblk = w % p.mblocks;
+        w /= p.mblocks;
+        ctx.tile = w % ntile;
+        ctx.b = w / ntile;
+        ctx.r0 = (ctx.tile / p.tiles_x) * 4;
+        ctx.c0 = (ctx.tile % p.tiles_x) * 32;
+        ctx.m0 = ctx.mblk * MB;
+    }
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+    long xsrc[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int pc = wave + 4 * i;
+        int P = pc * 64 + lane;
+        if (P >= T2_NPOS * 5) P = T2_NPOS * 5 - 1;
+        const int pos = P / 5;
+        int s = P % 5;
+        if (s == 4) s = 0;
+        const int r = pos / T2_C, c = pos % T2_C;
+        xsrc[i] = ((long)(r0 + r) * sc.xd.Wp + (c0 + c)) * 4 + s;      // tile origin (r0-1,c0-1) = padded (r0,c0)
+    }
+    const uint4* xplane0 = sc.xs + (long)b * sc.xd.KC * sc.xd.plane;
+    const int nchunk = (a.K + CK - 1) / CK;
+    const long wchunk = (long)WROWS * p.Mp;
+
+    f32x16 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+    const unsigned char* lwh = lw + (half * MB + l31) * 16;
+    const unsigned char* lxh = lx + (wave * T2_C + l31) * REC + half * 16;
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
+#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
+#define MFMA3(accv, ah, al, bh, bl)                                              \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+    for (int t = 0; t < nchunk; ++t) {
+        __syncthreads();
+        {
+            const uint4* base = xplane0 + (long)t * sc.xd.plane;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) {
+                const int pc = wave + 4 * i;
+                if (pc < T2_XPIECES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
+                                                     (lds_void*)(lx + pc * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
+                const int pc = wave + i * 4;
+                if (pc < WPIECES) {
+                    const int u = pc * 64 + lane;
+                    const int row = u / MB, j = u % MB;
+                    const uint4* src = wpk16 + (long)t * wchunk + (long)row * p.Mp + m0 + j;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (lds_void*)(lw + pc * 1024), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        half8 bh[2][2], bl[2][2];
+#pragma unroll
+        for (int da = 0; da < 2; ++da)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                bh[da][db] = XFRAG((1 - da) * T2_C + (1 - db), 0);
+                bl[da][db] = XFRAG((1 - da) * T2_C + (1 - db), 1);
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ky = tp / 3, kx = tp % 3;
+                const int ph = (ky & 1) * 2 + (kx & 1);
+                const half8 ah = WFRAG(tp, 0, mt), al = WFRAG(tp, 1, mt);
+                MFMA3(acc[mt][ph], ah, al, bh[ky >> 1][kx >> 1], bl[ky >> 1][kx >> 1]);
+            }
+        }
+    }
+#undef XFRAG
+#undef WFRAG
+#undef MFMA3
+    conv_epilogue<OODGAN_CONV_T2, MT, 1, 4>(p, acc, ctx, wave, l31, half);
+}
+
 // F-form (B,C,H,W) fp32 -> S-form, value = x*scale[b,c]*mul2[1]; one thread per (b,kc,y,x) record
 __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        int scale_stride, const float* __restrict__ mul2, uint4* __restrict__ out,
@@ -384,6 +499,43 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     else { if (ng == 2) OODGAN_LAUNCH(1, 2) else OODGAN_LAUNCH(1, 1) }
 #undef OODGAN_LAUNCH
     return check_launch("conv3x3_f16s_s1v2");
+}
+
+int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st) {
+    KArgs p;
+    p.a = a;
+    p.w_unscale = unscale;
+    p.ablate = 0;
+    p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1;
+    OODGAN_REQUIRE(a.in_scale == nullptr && a.in_shift == nullptr, "conv3x3 S-form input: scales are applied by the producer");
+    if (p.a.out_pitch == 0) p.a.out_pitch = p.Wout;
+    OODGAN_REQUIRE((p.a.out_pitch & 1) == 0, "conv3x3 T2: out_pitch must be even (got %d)", p.a.out_pitch);
+    OODGAN_REQUIRE(a.dotx == nullptr && a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && a.ys == nullptr,
+                   "conv3x3 T2: only out_scale is supported in the epilogue");
+    p.in_plane = 0;
+    p.out_plane = (long)p.Hout * p.a.out_pitch;
+    p.tiles_y = (p.Hn + 3) / 4;
+    p.tiles_x = (p.Wn + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    const bool mt2 = a.M > 32;
+    const int MB = mt2 ? 64 : 32;
+    p.mblocks = (a.M + MB - 1) / MB;
+    SConv sc;
+    sc.xs = reinterpret_cast<const uint4*>(a.x);
+    sc.xd = sform_dims(a.K, a.Hin, a.Win);
+    sc.ys = nullptr; sc.yd = sc.xd; sc.ys_scale = nullptr; sc.ys_scale_stride = 0;
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    dim3 grid((unsigned)total), block(256);
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    if (mt2) {
+        constexpr int sm = T2_XBYTES + 36 * 64 * 16;
+        hipLaunchKernelGGL((conv_f16s_t2v2_kernel<2>), grid, block, sm, st, p, w16, sc);
+    } else {
+        constexpr int sm = T2_XBYTES + 36 * 32 * 16;
+        hipLaunchKernelGGL((conv_f16s_t2v2_kernel<1>), grid, block, sm, st, p, w16, sc);
+    }
+    return check_launch("conv3x3_f16s_t2v2");
 }
 
 }  // namespace oodgan

@@ -135,7 +135,7 @@ class GeneratorEngine:
             if L.kind == 'conv':
                 if self.sform:
                     # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA
-                    xs = ops.to_sform(out, s)
+                    xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
                     out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                       noise_weight=L.noise_w, act=ACT_LRELU)
                     del xs
@@ -143,7 +143,12 @@ class GeneratorEngine:
                     out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
                                       noise_weight=L.noise_w, act=ACT_LRELU)
             else:
-                z = ops.conv3x3(out, L.wpk, L.cout, CONV_T2, in_scale=s, out_scale=d)
+                if self.sform:
+                    xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
+                    z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
+                    del xs
+                else:
+                    z = ops.conv3x3(out, L.wpk, L.cout, CONV_T2, in_scale=s, out_scale=d)
                 H2 = 2 * out.shape[2] + 1
                 lat_idx = L.lat
                 if cond_hook is not None and cond_layers is not None and lat_idx in cond_layers:
@@ -211,7 +216,7 @@ class GeneratorEngine:
             d = _Cols(d_all, L.drow, L.cout)
             if L.kind == 'conv':
                 if self.sform:
-                    gs_ = ops.to_sform(g_pre, d, mul2)
+                    gs_ = ops.to_sform(g_pre, d, mul2, out=ops.sform_scratch(B, L.cout, g_pre.shape[2], g_pre.shape[3], self.device))
                     dx, dot = ops.conv3x3(gs_, L.wpk_bwd, L.cin, CONV_S1, out_scale=s, dotx=x_in, in_mul2=mul2)
                     del gs_
                 else:

@@ -212,6 +212,19 @@ class SForm:
         return (self.B, self.C, self.H, self.W)
 
 
+_SFORM_POOL = {}
+
+
+def sform_scratch(B, C, H, W, device, tag=0):
+    """Reusable S-form buffer (zero border written once at allocation; producers only touch the interior, so a
+    buffer can be recycled for any tensor of the same logical shape)."""
+    key = (B, C, H, W, str(device), tag)
+    buf = _SFORM_POOL.get(key)
+    if buf is None:
+        buf = _SFORM_POOL[key] = SForm(B, C, H, W, device)
+    return buf
+
+
 def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
     """fp32 NCHW -> S-form of x*scale[b,c]*mul2[1]."""
     x = _dev(x)

@@ -254,6 +254,10 @@ def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
     raw = F.conv2d(x * s[:, :, None, None], w, padding=1)
     close(y2, raw * d[:, :, None, None])
     close(dot, (raw * dotx).sum(dim=(2, 3)), 2e-4)
+    # transposed stride-2 conv from the same S-form input
+    reft = F.conv_transpose2d(x * s[:, :, None, None], w.transpose(0, 1), stride=2) * d[:, :, None, None]
+    zt = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
+    close(zt[..., :2 * W + 1], reft)
     if ys is not None:
         w2 = synth.normal('sf.w2', (Co, Co, 3, 3), 9, 1.0 / math.sqrt(Co * 9))
         wpk2 = ops.pack_conv3x3(w2.to(dev), precision='f16s')
