@@ -159,6 +159,7 @@ int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int C
                              int flip, void* stream);
 int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream);
 int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expected by oodgan_conv3x3_f16s */
+int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* same, for an S-form input */
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
@@ -167,6 +168,16 @@ int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expe
 long oodgan_sform_bytes(int B, int C, int H, int W);
 int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
                     int H, int W, int in_pitch, void* stream);
+/* Phase-split S-form for the stride-2 conv (mode S2 with x_sform): the (2H+1)x(2W+1) input is stored as its four
+ * parity images G[py][px][i][j] = x[2i+py][2j+px], each in S-form without border, so that the stride-2 conv
+ * becomes stride-1 taps on contiguous runs.  H,W = OUTPUT size of the S2 conv. */
+long oodgan_sform_phases_bytes(int B, int C, int H, int W);
+/* Fused producer: g (B,C,2H,2W) -> upfirdn2d(g, kernel, pad=(2,2)) (the adjoint of Blur(pad=(1,1)), src/ops/op/upfirdn2d.py:115-120)
+ * * scale[b,c] * mul2[1], written phase-split.  kernel (4,4): the op correlates with the FLIPPED kernel like upfirdn2d. */
+int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const float* scale, int scale_stride,
+                                 const float* mul2, void* out, int B, int C, int H, int W, void* stream);
+int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                           int C, int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
 /* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
 int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);

@@ -21,12 +21,15 @@
 #include <cstdlib>
 #include <cstdint>
 
+extern "C" int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);
+
 using namespace oodgan;
 
 namespace oodgan {
 int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -361,6 +364,11 @@ __global__ __launch_bounds__(256) void pack_f16s_kernel(const float* __restrict_
 
 }  // namespace
 
+extern "C" int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform) {
+    if (mode == OODGAN_CONV_S2 && x_sform) return (((Hin - 1) / 2 + 7) / 8) * (((Win - 1) / 2 + 31) / 32);
+    return oodgan_conv3x3_f16s_nparts(mode, Hin, Win);
+}
+
 extern "C" int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win) {
     if (mode == OODGAN_CONV_S1) return ((Hin + 7) / 8) * ((Win + 31) / 32) * (getenv("OODGAN_S1_LEGACY") ? 4 : 1);
     if (mode == OODGAN_CONV_S2) return (((Hin - 1) / 2 + 7) / 8) * (((Win - 1) / 2 + 31) / 32) * 4;
@@ -390,7 +398,6 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(args != nullptr, "conv3x3_f16s: null args");
     const oodgan_conv_args& a = *args;
     OODGAN_REQUIRE(a.x && a.wpk && unscale2 && (a.y || a.x_sform), "conv3x3_f16s: null tensor");
-    OODGAN_REQUIRE(!a.x_sform || a.mode != OODGAN_CONV_S2, "conv3x3_f16s: S-form input is implemented for modes S1 and T2");
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
@@ -407,6 +414,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
             return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
+            if (a.x_sform) return launch_s2v2(a, a.wpk, unscale2, st);
             return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);
         default: break;
     }

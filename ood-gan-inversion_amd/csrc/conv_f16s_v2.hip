@@ -37,6 +37,127 @@ struct SConv {
     int ys_scale_stride;
 };
 
+// Epilogue shared by the S1 and S2 S-form kernels: accumulators -> LDS [channel][256 pixels] -> 16-byte stores of
+// the fp32 NCHW output (fused out-scale / noise / bias / activation, optional style-gradient dot) and, optionally,
+// the S-form of the activated output for the next conv.  All threads of the workgroup must call it.
+template <int MT>
+__device__ __forceinline__ void tile_epilogue(const KArgs& p, const SConv& sc, f32x16 (&acc)[MT][2], const BlockCtx& ctx,
+                                              unsigned char* lx, bool active, int tid, int lane, int wave, int l31, int half) {
+    constexpr int MB = 32 * MT;
+    constexpr int NT = 2;
+    const oodgan_conv_args& a = p.a;
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+    // ---------------------------------------------------------------- epilogue through LDS
+    float* lo = reinterpret_cast<float*>(lx);
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    if (active) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    lo[m * OP + (wave * NT + nt) * 32 + l31] = acc[mt][nt][r] * us;
+                }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float* osc = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : nullptr;
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const long HWo = (long)p.Hout * p.Wout;
+    const float* nzp = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : nullptr;
+    const float* db = a.dotx ? a.dotx + (long)b * a.M * HWo : nullptr;
+    float* yb = a.y ? a.y + (long)b * a.M * p.out_plane : nullptr;
+    const bool vec = (p.Wout % 4 == 0) && (a.out_pitch % 4 == 0);
+    {
+        const int c4 = tid & 63;
+        const int prow = c4 >> 3, pcol = (c4 & 7) * 4;
+        const int py = r0 + prow, px = c0 + pcol;
+        const bool row_ok = py < p.Hout;
+#pragma unroll 4
+        for (int i = 0; i < MB / 4; ++i) {
+            const int ml = (tid >> 6) + 4 * i;
+            const int m = m0 + ml;
+            float4 v = *reinterpret_cast<const float4*>(lo + ml * OP + c4 * 4);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            float dsum = 0.f;
+            const bool m_ok = m < a.M;
+            if (m_ok && row_ok && (yb || db)) {
+                const long pix = (long)py * p.Wout + px;
+                const float scl = osc ? osc[m] : 1.f;
+                const float bv = a.bias ? a.bias[m] : 0.f;
+                const float sl = (a.act == OODGAN_ACT_PRELU) ? a.slope[m] : 0.f;
+                float* yp = yb ? yb + (long)m * p.out_plane + (long)py * a.out_pitch + px : nullptr;
+                if (vec && px + 3 < p.Wout) {
+                    if (db) {
+                        const float4 d4 = *reinterpret_cast<const float4*>(db + (long)m * HWo + pix);
+                        dsum = vv[0] * d4.x + vv[1] * d4.y + vv[2] * d4.z + vv[3] * d4.w;
+                    }
+                    if (yp) {
+                        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (nzp) n4 = *reinterpret_cast<const float4*>(nzp + pix);
+                        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float o = vv[j] * scl + nw * nn[j] + bv;
+                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                            vv[j] = o;
+                        }
+                        *reinterpret_cast<float4*>(yp) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (px + j >= p.Wout) continue;
+                        if (db) dsum += vv[j] * db[(long)m * HWo + pix + j];
+                        if (yp) {
+                            float o = vv[j] * scl + (nzp ? nw * nzp[pix + j] : 0.f) + bv;
+                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                            yp[j] = o;
+                        }
+                    }
+                }
+            }
+            if (db) {
+                dsum = wave_sum(dsum);
+                if (lane == 0 && m_ok) a.dot_part[((long)b * a.M + m) * a.dot_nparts + ctx.tile] = dsum;
+            }
+        }
+    }
+    // ---- optional S-form output: (activated output) * ys_scale[b,m], split hi/lo, 16 channels per 64-byte record
+    if (sc.ys) {
+        const float* ysc = sc.ys_scale ? sc.ys_scale + (long)b * sc.ys_scale_stride : nullptr;
+        // unit = (pixel of the 8x32 tile, 16-channel block): the thread activates 16 channels once and writes the
+        // whole 64-byte record (4 x 16 B, consecutive lanes -> consecutive records: 4 KB contiguous per wave)
+        for (int u = tid; u < 256 * (MB / 16); u += 256) {
+            const int pxl = u & 255, g16 = u >> 8;
+            const int py = r0 + (pxl >> 5), px = c0 + (pxl & 31);
+            if (py >= p.Hout || px >= p.Wout) continue;
+            const float nz = nzp ? nw * nzp[(long)py * p.Wout + px] : 0.f;
+            half8 hv[2], lv[2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ml = g16 * 16 + j, m = m0 + ml;
+                float o = 0.f;
+                if (m < a.M) {
+                    o = lo[ml * OP + pxl] * (osc ? osc[m] : 1.f) + nz + (a.bias ? a.bias[m] : 0.f);
+                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : a.slope[m] * o;
+                    if (ysc) o *= ysc[m];
+                }
+                const _Float16 h = (_Float16)o;
+                hv[j >> 3][j & 7] = h;
+                lv[j >> 3][j & 7] = (_Float16)(o - (float)h);
+            }
+            half8* rec = reinterpret_cast<half8*>(sc.ys + sform_unit(sc.yd, b, (m0 >> 4) + g16, py, px, 0));
+            rec[0] = hv[0]; rec[1] = hv[1]; rec[2] = lv[0]; rec[3] = lv[1];
+        }
+    }
+}
+
 template <int MT, int NG>
 __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
                                                              const SConv sc) {
@@ -173,117 +294,8 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
 #undef MFMA3
     __syncthreads();
 
-    // ---------------------------------------------------------------- epilogue through LDS
-    float* lo = reinterpret_cast<float*>(lx);
-    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
-    if (active) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    lo[m * OP + (wave * NT + nt) * 32 + l31] = acc[mt][nt][r] * us;
-                }
-    }
-    __syncthreads();
-    if (!active) return;
-    const float* osc = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : nullptr;
-    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
-    const long HWo = (long)p.Hout * p.Wout;
-    const float* nzp = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : nullptr;
-    const float* db = a.dotx ? a.dotx + (long)b * a.M * HWo : nullptr;
-    float* yb = a.y ? a.y + (long)b * a.M * p.out_plane : nullptr;
-    const bool vec = (p.Wout % 4 == 0) && (a.out_pitch % 4 == 0);
-    {
-        const int c4 = tid & 63;
-        const int prow = c4 >> 3, pcol = (c4 & 7) * 4;
-        const int py = r0 + prow, px = c0 + pcol;
-        const bool row_ok = py < p.Hout;
-#pragma unroll 4
-        for (int i = 0; i < MB / 4; ++i) {
-            const int ml = (tid >> 6) + 4 * i;
-            const int m = m0 + ml;
-            float4 v = *reinterpret_cast<const float4*>(lo + ml * OP + c4 * 4);
-            float vv[4] = {v.x, v.y, v.z, v.w};
-            float dsum = 0.f;
-            const bool m_ok = m < a.M;
-            if (m_ok && row_ok && (yb || db)) {
-                const long pix = (long)py * p.Wout + px;
-                const float scl = osc ? osc[m] : 1.f;
-                const float bv = a.bias ? a.bias[m] : 0.f;
-                const float sl = (a.act == OODGAN_ACT_PRELU) ? a.slope[m] : 0.f;
-                float* yp = yb ? yb + (long)m * p.out_plane + (long)py * a.out_pitch + px : nullptr;
-                if (vec && px + 3 < p.Wout) {
-                    if (db) {
-                        const float4 d4 = *reinterpret_cast<const float4*>(db + (long)m * HWo + pix);
-                        dsum = vv[0] * d4.x + vv[1] * d4.y + vv[2] * d4.z + vv[3] * d4.w;
-                    }
-                    if (yp) {
-                        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (nzp) n4 = *reinterpret_cast<const float4*>(nzp + pix);
-                        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float o = vv[j] * scl + nw * nn[j] + bv;
-                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
-                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
-                            vv[j] = o;
-                        }
-                        *reinterpret_cast<float4*>(yp) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (px + j >= p.Wout) continue;
-                        if (db) dsum += vv[j] * db[(long)m * HWo + pix + j];
-                        if (yp) {
-                            float o = vv[j] * scl + (nzp ? nw * nzp[pix + j] : 0.f) + bv;
-                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
-                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
-                            yp[j] = o;
-                        }
-                    }
-                }
-            }
-            if (db) {
-                dsum = wave_sum(dsum);
-                if (lane == 0 && m_ok) a.dot_part[((long)b * a.M + m) * a.dot_nparts + ctx.tile] = dsum;
-            }
-        }
-    }
-    // ---- optional S-form output: (activated output) * ys_scale[b,m], split hi/lo, 16 channels per 64-byte record
-    if (sc.ys) {
-        const float* ysc = sc.ys_scale ? sc.ys_scale + (long)b * sc.ys_scale_stride : nullptr;
-        // unit = (pixel of the 8x32 tile, 16-channel block): the thread activates 16 channels once and writes the
-        // whole 64-byte record (4 x 16 B, consecutive lanes -> consecutive records: 4 KB contiguous per wave)
-        for (int u = tid; u < 256 * (MB / 16); u += 256) {
-            const int pxl = u & 255, g16 = u >> 8;
-            const int py = r0 + (pxl >> 5), px = c0 + (pxl & 31);
-            if (py >= p.Hout || px >= p.Wout) continue;
-            const float nz = nzp ? nw * nzp[(long)py * p.Wout + px] : 0.f;
-            half8 hv[2], lv[2];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int ml = g16 * 16 + j, m = m0 + ml;
-                float o = 0.f;
-                if (m < a.M) {
-                    o = lo[ml * OP + pxl] * (osc ? osc[m] : 1.f) + nz + (a.bias ? a.bias[m] : 0.f);
-                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
-                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : a.slope[m] * o;
-                    if (ysc) o *= ysc[m];
-                }
-                const _Float16 h = (_Float16)o;
-                hv[j >> 3][j & 7] = h;
-                lv[j >> 3][j & 7] = (_Float16)(o - (float)h);
-            }
-            half8* rec = reinterpret_cast<half8*>(sc.ys + sform_unit(sc.yd, b, (m0 >> 4) + g16, py, px, 0));
-            rec[0] = hv[0]; rec[1] = hv[1]; rec[2] = lv[0]; rec[3] = lv[1];
-        }
-    }
+    tile_epilogue<MT>(p, sc, acc, ctx, lx, active, tid, lane, wave, l31, half);
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Transposed 3x3 stride-2 conv (the up-sampling ModulatedConv2d before its blur) with S-form input: block = 4 waves,
@@ -399,6 +411,279 @@ __global__ __launch_bounds__(256) void conv_f16s_t2v2_kernel(const KArgs p, cons
     conv_epilogue<OODGAN_CONV_T2, MT, 1, 4>(p, acc, ctx, wave, l31, half);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-2 conv (input gradient of the transposed up-conv) on a PHASE-SPLIT S-form input:
+//   dx[m,i,j] = sum_{k,ky,kx} g2[k, 2i+ky, 2j+kx] W[ky,kx]  =  sum over the four parity images
+//   G_{py,px}[i,j] = g2[2i+py, 2j+px]  of stride-1 taps  G_{py,px}[i+a, j+b] W[2a+py, 2b+px]   (a <= (2-py)/2, ...)
+// so every tile row is again one contiguous run.  SP[b][kc][ph=py*2+px][Hq][Wq][4 slots].
+// K stage = (16-channel chunk, row parity py): x tile = 9 rows x {px=0,1} x 33 cols (594 records), taps ky = py, py+2.
+// Two anti-phase groups as in the S1 kernel; same LDS epilogue.
+constexpr int S2_ROWS = 9, S2_C = 33, S2_NPOS = S2_ROWS * 2 * S2_C;          // 594
+constexpr int S2_XPIECES = (S2_NPOS * 5 + 63) / 64;                          // 47
+constexpr int S2_XBYTES = S2_XPIECES * 1024;
+
+template <int MT>
+constexpr int s2_group_bytes() {
+    constexpr int stage = S2_XBYTES + 6 * 4 * 32 * MT * 16;
+    constexpr int epi = 32 * MT * OP * 4;
+    return (stage > epi ? stage : epi);
+}
+
+struct SPDims { int KC, Hq, Wq; long plane; };   // plane = Hq*Wq*4 (16-byte units) per (b,kc,phase)
+
+__host__ __device__ inline SPDims sp_dims(int C, int H, int W) {    // H,W = S2 OUTPUT size
+    SPDims d;
+    d.KC = (C + 15) / 16;
+    d.Hq = (H + 7) / 8 * 8 + 2;
+    d.Wq = (W + 31) / 32 * 32 + 2;
+    d.plane = (long)d.Hq * d.Wq * 4;
+    return d;
+}
+
+template <int MT>
+__global__ __launch_bounds__(512) void conv_f16s_s2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
+                                                             const SConv sc, const SPDims sp) {
+    constexpr int MB = 32 * MT;
+    constexpr int GB = s2_group_bytes<MT>();
+    constexpr int XPW = (S2_XPIECES + 3) / 4;       // 12
+    constexpr int TPP = 4 * MB * 16 / 1024;         // DMA pieces per tap (hi|lo x h x MB x 16 B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int grp = threadIdx.x >> 8;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    unsigned char* lx = smem + grp * GB;
+    unsigned char* lw = lx + S2_XBYTES;
+    const int wi = 2 * xcd_remap(blockIdx.x, gridDim.x) + grp;
+    const bool active = wi < total_items;
+    BlockCtx ctx;
+    {
+        int w = active ? wi : 0;
+        const int ntile = p.tiles_x * p.tiles_y;
+        ctx.mblk = w % p.mblocks;
+        w /= p.mblocks;
+        ctx.tile = w % ntile;
+        ctx.b = w / ntile;
+        ctx.r0 = (ctx.tile / p.tiles_x) * 8;
+        ctx.c0 = (ctx.tile % p.tiles_x) * 32;
+        ctx.m0 = ctx.mblk * MB;
+    }
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+    // per-lane DMA source offsets for py = 0 (add 2*plane for py = 1)
+    long xsrc[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int pc = wave + 4 * i;
+        int P = pc * 64 + lane;
+        if (P >= S2_NPOS * 5) P = S2_NPOS * 5 - 1;
+        const int pos = P / 5;
+        int s = P % 5;
+        if (s == 4) s = 0;
+        const int rr = pos / (2 * S2_C), px = (pos % (2 * S2_C)) / S2_C, cc = pos % S2_C;
+        xsrc[i] = (long)px * sp.plane + ((long)(r0 + rr) * sp.Wq + (c0 + cc)) * 4 + s;
+    }
+    const uint4* xb0 = sc.xs + (long)b * sp.KC * 4 * sp.plane;
+    const int nchunk = (a.K + CK - 1) / CK;
+    const long wchunk = (long)36 * p.Mp;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+    const unsigned char* lwh = lw + (half * MB + l31) * 16;
+    const unsigned char* lxh = lx + ((wave * 2) * 2 * S2_C + l31) * REC + half * 16;
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
+#define WSLOT(slot, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((slot) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
+#define MFMA3(accv, ah, al, bh, bl)                                              \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+
+    const int nstage = 2 * nchunk;                 // (chunk, py)
+    const int nsteps = 2 * nstage + 1;
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();
+        const int sidx = step - grp;
+        if (!active || sidx < 0 || sidx >= 2 * nstage) continue;
+        const int q = sidx >> 1, t = q >> 1, py = q & 1;
+        if ((sidx & 1) == 0) {
+            const uint4* base = xb0 + ((long)t * 4 + py * 2) * sp.plane;
+#pragma unroll
+            for (int i = 0; i < XPW; ++i) {
+                const int pc = wave + 4 * i;
+                if (pc < S2_XPIECES)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
+                                                     (lds_void*)(lx + pc * 1024), 16, 0, 0);
+            }
+            // weights of the taps with ky parity py: py=0 -> ky in {0,2} (6 taps), py=1 -> ky = 1 (3 taps);
+            // LDS slot order: slot = (ky>>1)*3 + kx
+            const int ntap = py ? 3 : 6;
+            for (int pc = wave; pc < ntap * TPP; pc += 4) {
+                const int slot = pc / TPP;
+                const int tap = py ? (3 + slot) : ((slot / 3) * 6 + slot % 3);
+                const int u = (pc % TPP) * 64 + lane;                 // 16-byte unit inside the tap block [hl][h][MB]
+                const int row = u / MB, j = u % MB;
+                const uint4* src = wpk16 + (long)t * wchunk + (long)(tap * 4 + row) * p.Mp + m0 + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (lds_void*)(lw + pc * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // taps (a, kx): LDS slot = a*3 + kx; x position: row nt + a, plane px = kx&1, col shift kx>>1
+#define S2_TAP(slot_, a_, kx_)                                                                                   \
+    {                                                                                                            \
+        half8 ahv[MT], alv[MT];                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { ahv[mt] = WSLOT(slot_, 0, mt); alv[mt] = WSLOT(slot_, 1, mt); } \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                       \
+            const half8 bhv = XFRAG(((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 0);                   \
+            const half8 blv = XFRAG(((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 1);                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { MFMA3(acc[mt][nt], ahv[mt], alv[mt], bhv, blv); } \
+        }                                                                                                        \
+    }
+            S2_TAP(0, 0, 0) S2_TAP(1, 0, 1) S2_TAP(2, 0, 2)
+            if (py == 0) { S2_TAP(3, 1, 0) S2_TAP(4, 1, 1) S2_TAP(5, 1, 2) }
+#undef S2_TAP
+        }
+    }
+#undef XFRAG
+#undef WSLOT
+#undef MFMA3
+    __syncthreads();
+    tile_epilogue<MT>(p, sc, acc, ctx, lx, active, tid, lane, wave, l31, half);
+}
+
+// pitched fp32 g2 (B,C,2H+1,pitch) -> phase-split S-form of g2*scale[b,c]*mul2[1]; thread = one 64-byte record
+__global__ __launch_bounds__(256) void to_sform_phases_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              int scale_stride, const float* __restrict__ mul2,
+                                                              uint4* __restrict__ out, int B, int C, int H, int W, int Hin, int Win,
+                                                              int in_pitch, SPDims sp) {
+    const int Hh = H + 1, Wh = W + 1;
+    const long total = (long)B * sp.KC * 4 * Hh * Wh;
+    const float gm = mul2 ? mul2[1] : 1.f;
+    const long in_plane = (long)Hin * in_pitch;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int j = (int)(e % Wh);
+        const int i = (int)((e / Wh) % Hh);
+        const int ph = (int)((e / ((long)Wh * Hh)) % 4);
+        const int kc = (int)((e / ((long)Wh * Hh * 4)) % sp.KC);
+        const int b = (int)(e / ((long)Wh * Hh * 4 * sp.KC));
+        const int yy = 2 * i + (ph >> 1), xx = 2 * j + (ph & 1);
+        const bool inb = yy < Hin && xx < Win;
+        half8 h0, h1, l0, l1;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int c = kc * 16 + jj;
+            float v = 0.f;
+            if (inb && c < C) v = x[((long)b * C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) * gm;
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)(v - (float)h);
+            if (jj < 8) { h0[jj] = h; l0[jj] = l; } else { h1[jj - 8] = h; l1[jj - 8] = l; }
+        }
+        half8* o = reinterpret_cast<half8*>(out + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
+        o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// blur^T + phase split + f16 split in one pass: the producer of the S2 conv's input.
+//   g2 = upfirdn2d(g, flip(k), pad=(2,2))  ((2H)x(2W) -> (2H+1)x(2W+1), the adjoint of Blur(pad=(1,1)), reference
+//   src/ops/op/upfirdn2d.py:115-120), times scale[b,c]*mul2[1], written as SP[b][kc][py*2+px][i][j] records.
+// Block = one (b, 16-channel block) x a tile of 4x32 (i,j) positions = g2 rows 2*i0..2*i0+7, cols 2*j0..2*j0+63.
+//   A  load g rows [2*i0-2, 2*i0+8], cols [2*j0-4, 2*j0+68) for 16 channels into LDS (float4, zero fill)
+//   B  thread (channel, row, half-row) filters 32 horizontally adjacent outputs from a sliding register window
+//   C  results are exchanged through LDS ([channel][position], reusing the input region) so that one thread owns
+//      one position with all 16 channels, splits hi/lo and writes the 64-byte record (coalesced 4 KB per wave).
+constexpr int BT_R = 11, BT_C = 72;            // input tile rows / cols (cols: global 2*j0-4 ..)
+
+__global__ __launch_bounds__(256) void blurT_sp_kernel(const float* __restrict__ g, const float* __restrict__ kern,
+                                                       const float* __restrict__ scale, int scale_stride,
+                                                       const float* __restrict__ mul2, uint4* __restrict__ out, int C, int H,
+                                                       int W, SPDims sp, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float lin[16 * BT_R * BT_C];     // 50688 B; reused as [16][512] in phase C
+    __shared__ float kf[16];
+    const int tid = threadIdx.x;
+    int w = blockIdx.x;
+    const int tx = w % tiles_x; w /= tiles_x;
+    const int ty = w % tiles_y; w /= tiles_y;
+    const int kc = w % sp.KC;
+    const int b = w / sp.KC;
+    const int i0 = ty * 4, j0 = tx * 32;
+    const int Hg = 2 * H, Wg = 2 * W;                      // size of g
+    if (tid < 16) kf[tid] = kern[tid];                     // the op flips the kernel it is given; pass flip(k) (symmetric anyway)
+    // ---- A
+    const int gy0 = 2 * i0 - 2, gx0 = 2 * j0 - 4;
+    for (int e = tid; e < 16 * BT_R * (BT_C / 4); e += 256) {
+        const int c4 = e % (BT_C / 4);
+        const int r = (e / (BT_C / 4)) % BT_R;
+        const int ch = e / ((BT_C / 4) * BT_R);
+        const int c = kc * 16 + ch;
+        const int gy = gy0 + r, gx = gx0 + 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg)
+            v = *reinterpret_cast<const float4*>(g + (((long)b * C + c) * Hg + gy) * Wg + gx);
+        *reinterpret_cast<float4*>(lin + (ch * BT_R + r) * BT_C + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- B: g2[Y,X] = sum_{a,b} kflip[a][b] * g[Y+a-2, X+b-2], kflip[a][b] = kern[3-a][3-b]
+    const int ch = tid >> 4, tq = tid & 15;
+    const int yrow = tq >> 1, xh = tq & 1;                 // g2 row 2*i0 + yrow, cols 2*j0 + 32*xh .. +31
+    float o[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float* row = lin + (ch * BT_R + yrow + a) * BT_C + 32 * xh + 2;   // col index of X+0-2 relative to gx0: X - 2*j0 + 4 - 2
+        float win[35];
+#pragma unroll
+        for (int j = 0; j < 35; ++j) win[j] = row[j];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float kv = kf[(3 - a) * 4 + (3 - bb)];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) o[j] += kv * win[j + bb];
+        }
+    }
+    const int c_glob = kc * 16 + ch;
+    const float sc_ = (c_glob < C ? (scale ? scale[(long)b * scale_stride + c_glob] : 1.f) : 0.f) * (mul2 ? mul2[1] : 1.f);
+    __syncthreads();                                       // everyone done reading the input tile
+    // ---- exchange: lst[ch][pos], pos = ((ph*4 + il)*32 + jl), ph = (Y&1)*2 + (X&1)
+    float* lst = lin;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int Xl = 32 * xh + j;                        // 0..63
+        const int ph = (yrow & 1) * 2 + (Xl & 1);
+        const int pos = (ph * 4 + (yrow >> 1)) * 32 + (Xl >> 1);
+        lst[ch * 512 + pos] = o[j] * sc_;
+    }
+    __syncthreads();
+    // ---- C: thread -> positions tid and tid+256
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int pos = tid + rep * 256;
+        const int ph = pos >> 7, il = (pos >> 5) & 3, jl = pos & 31;
+        const int i = i0 + il, j = j0 + jl;
+        if (i > H || j > W) continue;                      // phase images are (H+1) x (W+1)
+        half8 h0, h1, l0, l1;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            float v = lst[cc * 512 + pos];
+            // entries outside the (2H+1)x(2W+1) support are exact zeros by construction except the row/col 2H / 2W parity
+            const int Y = 2 * i + (ph >> 1), X = 2 * j + (ph & 1);
+            if (Y > 2 * H || X > 2 * W) v = 0.f;
+            const _Float16 hh = (_Float16)v;
+            const _Float16 ll = (_Float16)(v - (float)hh);
+            if (cc < 8) { h0[cc] = hh; l0[cc] = ll; } else { h1[cc - 8] = hh; l1[cc - 8] = ll; }
+        }
+        half8* rec = reinterpret_cast<half8*>(out + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
+        rec[0] = h0; rec[1] = h1; rec[2] = l0; rec[3] = l1;
+    }
+}
+
 // F-form (B,C,H,W) fp32 -> S-form, value = x*scale[b,c]*mul2[1]; one thread per (b,kc,y,x) record
 __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        int scale_stride, const float* __restrict__ mul2, uint4* __restrict__ out,
@@ -443,6 +728,38 @@ extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_str
     hipLaunchKernelGGL(to_sform_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale, scale_stride,
                        mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch);
     return check_launch("to_sform");
+}
+
+
+
+extern "C" int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const float* scale, int scale_stride,
+                                            const float* mul2, void* out, int B, int C, int H, int W, void* stream) {
+    OODGAN_REQUIRE(g && kernel && out && B > 0 && C > 0 && H > 0 && W > 0, "blurT_to_sform_phases: bad args");
+    OODGAN_REQUIRE((W % 2) == 0 && ((reinterpret_cast<uintptr_t>(g) & 15) == 0), "blurT_to_sform_phases: needs even W and an aligned input");
+    const SPDims d = sp_dims(C, H, W);
+    const int tiles_x = (W + 1 + 31) / 32, tiles_y = (H + 1 + 3) / 4;
+    const long nb = (long)tiles_x * tiles_y * d.KC * B;
+    OODGAN_REQUIRE(nb < (1L << 31), "blurT_to_sform_phases: grid too large");
+    hipLaunchKernelGGL(blurT_sp_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), g, kernel, scale, scale_stride, mul2,
+                       reinterpret_cast<uint4*>(out), C, H, W, d, tiles_x, tiles_y);
+    return check_launch("blurT_to_sform_phases");
+}
+
+extern "C" long oodgan_sform_phases_bytes(int B, int C, int H, int W) {
+    const SPDims d = sp_dims(C, H, W);
+    return (long)B * d.KC * 4 * d.plane * 16;
+}
+
+extern "C" int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                                      int C, int H, int W, int in_pitch, void* stream) {
+    OODGAN_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "to_sform_phases: bad args");
+    const SPDims d = sp_dims(C, H, W);
+    const int Hin = 2 * H + 1, Win = 2 * W + 1;
+    if (in_pitch == 0) in_pitch = Win;
+    const long total = (long)B * d.KC * 4 * (H + 1) * (W + 1);
+    hipLaunchKernelGGL(to_sform_phases_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
+                       scale_stride, mul2, reinterpret_cast<uint4*>(out), B, C, H, W, Hin, Win, in_pitch, d);
+    return check_launch("to_sform_phases");
 }
 
 namespace oodgan {
@@ -536,6 +853,51 @@ int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         hipLaunchKernelGGL((conv_f16s_t2v2_kernel<1>), grid, block, sm, st, p, w16, sc);
     }
     return check_launch("conv3x3_f16s_t2v2");
+}
+
+int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st) {
+    KArgs p;
+    p.a = a;
+    p.w_unscale = unscale;
+    p.ablate = 0;
+    p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn;
+    OODGAN_REQUIRE(a.in_scale == nullptr && a.in_shift == nullptr, "conv3x3 S-form input: scales are applied by the producer");
+    OODGAN_REQUIRE(a.ys == nullptr, "conv3x3 S2: S-form output not supported");
+    if (p.a.out_pitch == 0) p.a.out_pitch = p.Wout;
+    p.in_plane = 0;
+    p.out_plane = (long)p.Hout * p.a.out_pitch;
+    p.tiles_y = (p.Hn + 7) / 8;
+    p.tiles_x = (p.Wn + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    const bool mt2 = a.M > 32;
+    const int MB = mt2 ? 64 : 32;
+    p.mblocks = (a.M + MB - 1) / MB;
+    if (a.dotx) {
+        OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
+        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 f16s S2: dot_nparts %d != %d", a.dot_nparts,
+                       p.tiles_x * p.tiles_y);
+    }
+    SConv sc;
+    sc.xs = reinterpret_cast<const uint4*>(a.x);
+    sc.xd = sform_dims(a.K, p.Hn, p.Wn);
+    sc.ys = nullptr; sc.yd = sc.xd; sc.ys_scale = nullptr; sc.ys_scale_stride = 0;
+    const SPDims sp = sp_dims(a.K, p.Hn, p.Wn);
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    const int items = (int)total;
+    dim3 grid((unsigned)((total + 1) / 2)), block(512);
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+#define OODGAN_LAUNCH(MT_)                                                                                         \
+    {                                                                                                              \
+        constexpr int sm = 2 * s2_group_bytes<MT_>();                                                              \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2v2_kernel<MT_>),  \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);      \
+        (void)once;                                                                                                \
+        hipLaunchKernelGGL((conv_f16s_s2v2_kernel<MT_>), grid, block, sm, st, p, w16, items, sc, sp);              \
+    }
+    if (mt2) OODGAN_LAUNCH(2) else OODGAN_LAUNCH(1)
+#undef OODGAN_LAUNCH
+    return check_launch("conv3x3_f16s_s2v2");
 }
 
 }  // namespace oodgan

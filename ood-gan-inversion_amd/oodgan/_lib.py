@@ -49,7 +49,11 @@ _SIGS = {
     'oodgan_pack_conv3x3_f16s': (c_int, [P, P, P, c_int, c_int, c_float, c_int, c_int, P]),
     'oodgan_conv3x3_f16s': (c_int, [POINTER(ConvArgs), P, P]),
     'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
+    'oodgan_conv3x3_f16s_nparts2': (c_int, [c_int, c_int, c_int, c_int]),
     'oodgan_sform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
+    'oodgan_sform_phases_bytes': (c_long, [c_int, c_int, c_int, c_int]),
+    'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_to_sform_phases': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),

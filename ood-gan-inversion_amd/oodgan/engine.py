@@ -222,12 +222,20 @@ class GeneratorEngine:
                 else:
                     dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in, in_mul2=mul2)
             else:
-                H2 = 2 * x_in.shape[2] + 1
-                P2 = (H2 + 3) // 4 * 4
-                g2 = ops.upfirdn2d(g_pre, self.k4x4_flip, pad=(2, 2), out_pitch=P2)
-                dx, dot = ops.conv3x3(g2, L.wpk_bwd, L.cin, CONV_S2, in_scale=d, out_scale=s, dotx=x_in, in_hw=(H2, H2),
-                                      in_pitch=P2, in_mul2=mul2)
-                del g2
+                Hd = x_in.shape[2]
+                if self.sform and Hd >= 4:
+                    # blur^T, demodulation scale, range scale, phase split and f16 split in one pass, then the
+                    # stride-2 conv as stride-1 taps on the four parity images
+                    gp = ops.blurT_to_sform_phases(g_pre, self.k4x4_flip, d, mul2,
+                                                   out=ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device))
+                    dx, dot = ops.conv3x3(gp, L.wpk_bwd, L.cin, CONV_S2, out_scale=s, dotx=x_in, in_mul2=mul2)
+                else:
+                    H2 = 2 * Hd + 1
+                    P2 = (H2 + 3) // 4 * 4
+                    g2 = ops.upfirdn2d(g_pre, self.k4x4_flip, pad=(2, 2), out_pitch=P2)
+                    dx, dot = ops.conv3x3(g2, L.wpk_bwd, L.cin, CONV_S2, in_scale=d, out_scale=s, dotx=x_in, in_hw=(H2, H2),
+                                          in_pitch=P2, in_mul2=mul2)
+                    del g2
             gs_all[:, L.row:L.row + L.cin] += dot
             g_feat = dx
             del g_pre

@@ -212,7 +212,56 @@ class SForm:
         return (self.B, self.C, self.H, self.W)
 
 
+class SFormPhases:
+    """Phase-split S-form of a (B, C, 2H+1, 2W+1) tensor (input of the stride-2 conv); H, W = conv output size."""
+    __slots__ = ('data', 'B', 'C', 'H', 'W')
+
+    def __init__(self, B, C, H, W, device):
+        n = _lib.lib().oodgan_sform_phases_bytes(B, C, H, W)
+        self.data = torch.zeros(n // 2, device=device, dtype=torch.float16)
+        self.B, self.C, self.H, self.W = B, C, H, W
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    @property
+    def shape(self):
+        return (self.B, self.C, 2 * self.H + 1, 2 * self.W + 1)
+
+
+def to_sform_phases(x, H, W, scale=None, mul2=None, out=None, in_pitch=0):
+    """pitched fp32 (B,C,2H+1,pitch) -> phase-split S-form of x*scale[b,c]*mul2[1]."""
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    if out is None:
+        out = SFormPhases(B, C, H, W, x.device)
+    check(_lib.lib().oodgan_to_sform_phases(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2),
+                                            _p(out), B, C, H, W, in_pitch, _stream()), 'to_sform_phases')
+    return out
+
+
+def blurT_to_sform_phases(g, kernel, scale=None, mul2=None, out=None):
+    """g (B,C,2H,2W) -> phase-split S-form of upfirdn2d(g, kernel, pad=(2,2)) * scale[b,c] * mul2[1]."""
+    g = _dev(g)
+    B, C = g.shape[0], g.shape[1]
+    H, W = g.shape[2] // 2, g.shape[3] // 2
+    if out is None:
+        out = SFormPhases(B, C, H, W, g.device)
+    check(_lib.lib().oodgan_blurT_to_sform_phases(_p(g), _p(_dev(kernel)), _p(_opt(scale, 'scale')),
+                                                  0 if scale is None else scale.shape[1], _p(mul2), _p(out), B, C, H, W,
+                                                  _stream()), 'blurT_to_sform_phases')
+    return out
+
+
 _SFORM_POOL = {}
+
+
+def sform_phases_scratch(B, C, H, W, device):
+    key = ('ph', B, C, H, W, str(device))
+    buf = _SFORM_POOL.get(key)
+    if buf is None:
+        buf = _SFORM_POOL[key] = SFormPhases(B, C, H, W, device)
+    return buf
 
 
 def sform_scratch(B, C, H, W, device, tag=0):
@@ -278,7 +327,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
-    sform_in = isinstance(x, SForm)
+    sform_in = isinstance(x, (SForm, SFormPhases))
     if not sform_in:
         x = _dev(x)
     B, K = x.shape[0], x.shape[1]
@@ -311,7 +360,10 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     part = None
     if dotx is not None:
         dx_ = _dev(dotx, 'dotx')
-        npart = (_lib.lib().oodgan_conv3x3_f16s_nparts if wpk.precision == 'f16s' else _lib.lib().oodgan_conv3x3_nparts)(mode, H, W)
+        if wpk.precision == 'f16s':
+            npart = _lib.lib().oodgan_conv3x3_f16s_nparts2(mode, H, W, 1 if sform_in else 0)
+        else:
+            npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
         part = torch.empty(B, M, npart, device=dx_.device, dtype=torch.float32)
         a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
     if wpk.precision == 'f16s':

@@ -228,7 +228,7 @@ def test_mse_and_adam(dev):
         close(wd, w.detach(), 1e-6)
 
 
-@pytest.mark.parametrize('B,Ci,Co,H,W', [(1, 16, 32, 4, 4), (2, 24, 40, 9, 37), (2, 64, 64, 16, 16), (1, 32, 96, 33, 64)])
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(1, 16, 32, 4, 4), (2, 24, 40, 9, 37), (2, 64, 64, 16, 16), (1, 32, 96, 33, 64), (1, 40, 24, 10, 36)])
 def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
     """S-form path: F->S conversion (style folded in), S1 conv by LDS-DMA, fused epilogue, dot epilogue, and the
     S-form output consumed by a second conv (the conv->conv hand-off of the generator)."""
@@ -258,6 +258,26 @@ def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
     reft = F.conv_transpose2d(x * s[:, :, None, None], w.transpose(0, 1), stride=2) * d[:, :, None, None]
     zt = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
     close(zt[..., :2 * W + 1], reft)
+    # stride-2 conv (input gradient of T2) on the phase-split S-form, with the dot epilogue
+    gz = synth.normal('sf.gz', (B, Co, 2 * H + 1, 2 * W + 1), 11)
+    xs_ = (x * s[:, :, None, None]).clone().requires_grad_(True)
+    (F.conv_transpose2d(xs_, w.transpose(0, 1), stride=2) * d[:, :, None, None] * gz).sum().backward()
+    wpk_t = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=False, precision='f16s')
+    gp = ops.to_sform_phases(gz.to(dev), H, W, d.to(dev))
+    dxs, dots = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev))
+    close(dxs, xs_.grad * s[:, :, None, None], 2e-4)
+    close(dots, (xs_.grad * x).sum(dim=(2, 3)), 2e-4)
+    if H % 2 == 0 and W % 4 == 0:
+        # fused blur^T + phase split producer == upfirdn2d(pad=(2,2)) followed by the plain conversion
+        k4 = R.make_kernel([1, 3, 3, 1]) * 4
+        gq = synth.normal('sf.gq', (B, Co, 2 * H, 2 * W), 12)
+        g2r = R.upfirdn2d(gq, torch.flip(k4, [0, 1]), pad=(2, 2))
+        gp2 = ops.blurT_to_sform_phases(gq.to(dev), torch.flip(k4, [0, 1]).contiguous().to(dev), d.to(dev))
+        gp3 = ops.to_sform_phases(g2r.to(dev), H, W, d.to(dev))
+        assert (gp2.data.float() - gp3.data.float()).abs().max().item() < 2e-3 * g2r.abs().max().item()
+        dxa = ops.conv3x3(gp2, wpk_t, Ci, ops.CONV_S2)
+        dxb = ops.conv3x3(gp3, wpk_t, Ci, ops.CONV_S2)
+        close(dxa, dxb.cpu(), 1e-5)
     if ys is not None:
         w2 = synth.normal('sf.w2', (Co, Co, 3, 3), 9, 1.0 / math.sqrt(Co * 9))
         wpk2 = ops.pack_conv3x3(w2.to(dev), precision='f16s')
