@@ -47,8 +47,10 @@ def parse():
 
 
 class ConvProbe:
-    """HIP-event timing of every launch of the dominant kernel (plain 3x3 implicit-GEMM conv,
-    template instance conv_mfma_kernel<S1, MT=2>: M > 32 output channels) inside the timed region.
+    """HIP-event timing of every launch of the dominant kernel inside the timed region.  Dominant kernel (largest
+    share of GPU time in profiles/): the plain 3x3 stride-1 implicit-GEMM conv with S-form input and >= 128 input
+    channels — template instance ``conv_f16s_s1v2_kernel<2, 2>`` (split-f16) / ``conv_mfma_kernel<0, 2>`` (fp32):
+    forward of the plain ModulatedConv2d layers, their input gradients, and the dense AlignNet convs.
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
     def __init__(self, ops):
@@ -58,13 +60,14 @@ class ConvProbe:
         probe = self
 
         def conv3x3(x, wpk, M, mode=0, **kw):
-            if not (probe.on and mode == probe.ops.CONV_S1 and M > 32):
+            B, K, H, W = x.shape
+            if not (probe.on and mode == probe.ops.CONV_S1 and M > 32 and K >= 128 and
+                    (wpk.precision == 'f32' or isinstance(x, probe.ops.SForm))):
                 return probe.orig(x, wpk, M, mode, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = probe.orig(x, wpk, M, mode, **kw)
             e1.record()
-            B, K, H, W = x.shape
             probe.recs.append((e0, e1, 2.0 * B * K * M * 9 * H * W, 4.0 * (B * K * H * W + B * M * H * W + K * M * 9)))
             return r
 
@@ -77,8 +80,24 @@ class ConvProbe:
             return None
         ms = sum(a.elapsed_time(b) for a, b, _, _ in self.recs)
         flops = sum(f for _, _, f, _ in self.recs)
+        byts = sum(g for _, _, _, g in self.recs)
         n = len(self.recs)
-        return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n)
+        return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n,
+                    bytes_per_launch=byts / n)
+
+
+def pmc_traffic(a):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md §HBM), measured on this same command and committed under profiles/ (a PMC pass cannot run
+    inside the timed bench); None when no measurement for this configuration is on file."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        key = f'{a.precision}_b{a.batch}_s{a.size}'
+        return rec.get(key, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(size):
@@ -165,9 +184,10 @@ def main():
             f16s = a.precision == 'f16s'
             peak = MFMA_F16_PEAK_TFLOPS if f16s else MFMA_F32_PEAK_TFLOPS
             roof = dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
-                        frac=round(ps['tflops'] / peak, 4), traffic=None,
-                        kernel=('conv_f16s_kernel<S1,MT=2>' if f16s else 'conv_mfma_kernel<S1,MT=2>') +
-                               ' (plain 3x3 implicit GEMM, fwd + input-gradient, M>32)',
+                        frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a),
+                        kernel=('conv_f16s_s1v2_kernel<2, 2>' if f16s else 'conv_mfma_kernel<0, 2>') +
+                               ' (plain 3x3 stride-1 implicit GEMM, >=128 input channels: forward + input gradient)',
+                        alg_bytes_per_launch=ps['bytes_per_launch'],
                         note=('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product, so its own ceiling is '
                               'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
                         launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
