@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
+    ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
     return ap.parse_args()
 
@@ -141,13 +142,20 @@ def main():
                             cycle_align=2, blend_with_gen=True, ModSize=256)
     model.load_state_dict(synth.ood_state(size, seed=0), strict=True)
     model = model.to(dev).eval()
-    # per-rank shard of the global synthetic batch (global batch = B*world, contiguous slices by rank)
+    # per-rank shard of the global synthetic batch (global batch = B*world, contiguous slices by rank); every image,
+    # latent, feature pyramid and noise set is generated from its GLOBAL index, so a rank only materialises its own
+    # slice and the data of image g does not depend on the number of ranks
     gB = B * world
     sl = shard_slice(gB, rank, world)
-    x = synth.make_images(size, gB, seed=1)[sl].to(dev)
-    enc_lats = synth.make_latents(size, gB, seed=3, std=0.3)[sl].to(dev)
-    enc_feats = [f[sl].to(dev) for f in synth.make_encoder_feats(gB, seed=4)]
-    noises = [n[sl].to(dev) for n in synth.make_noises(size, gB, seed=2)]
+    gidx = list(range(sl.start, sl.stop))
+    cat = lambda parts: torch.cat(parts, 0).to(dev)
+    x = cat([synth.make_images(size, 1, seed=1000 + g) for g in gidx])
+    enc_lats = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx])
+    feats_per = [synth.make_encoder_feats(1, seed=4000 + g) for g in gidx]
+    enc_feats = [cat([f[i] for f in feats_per]) for i in range(4)]
+    noise_per = [synth.make_noises(size, 1, seed=2000 + g) for g in gidx]
+    noises = [cat([n[i] for n in noise_per]) for i in range(len(noise_per[0]))]
+    del feats_per, noise_per
     torch.cuda.synchronize()
 
     probe = ConvProbe(ops)
@@ -155,7 +163,7 @@ def main():
         probe.install()
 
     def one_step():
-        out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, enc_lats=enc_lats, enc_feats=enc_feats)
+        out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, streams=a.streams, enc_lats=enc_lats, enc_feats=enc_feats)
         return gather_latents(lats) if dist_on else lats, losses
 
     for _ in range(a.warmup):

@@ -105,6 +105,13 @@ class GeneratorEngine:
         self.stored_noises = [g(f'noises.noise_{k}') for k in range(self.num_layers)] if (prefix + 'noises.noise_0') in state else None
         self.saved = None
 
+    def clone_shared(self):
+        """A second engine over the SAME prepared weights (read-only) with its own per-step state."""
+        import copy
+        e = copy.copy(self)
+        e.saved = None
+        return e
+
     # ------------------------------------------------------------------ forward
     def styles(self, latent):
         """(B, n_latent, S) -> all style vectors (B, R) in one contraction."""
@@ -252,7 +259,50 @@ class WPlusInverter:
     def __init__(self, engine, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
         self.engine, self.lr, self.betas, self.eps = engine, lr, betas, eps
 
-    def invert(self, target, w0, noises, steps=100, return_trajectory=False):
+    def invert(self, target, w0, noises, steps=100, return_trajectory=False, streams=1):
+        """``streams`` > 1 splits the batch into that many independent sub-batches, each advanced on its own HIP
+        stream (images are independent): the HBM-bound layout/activation kernels of one sub-batch
+        then share the GPU with the matrix kernels of the other instead of running back to back."""
+        B = w0.shape[0]
+        streams = max(1, min(int(streams), B))
+        if streams == 1 or return_trajectory:
+            return self._invert_one(target, w0, noises, steps, return_trajectory)
+        cur = torch.cuda.current_stream()
+        side = [torch.cuda.Stream(device=w0.device) for _ in range(streams)]
+        cuts = [(i * B) // streams for i in range(streams + 1)]
+        parts = []
+        for i, st in enumerate(side):
+            st.wait_stream(cur)
+            sl = slice(cuts[i], cuts[i + 1])
+            parts.append(dict(target=target[sl].contiguous(), w=w0[sl].detach().clone().contiguous(),
+                              noises=[n[sl].contiguous() if n.shape[0] == B else n for n in noises], losses=[]))
+            parts[-1]['m'] = torch.zeros_like(parts[-1]['w'])
+            parts[-1]['v'] = torch.zeros_like(parts[-1]['w'])
+        gmul = ops.loss_scale_for(target.numel() // B)
+        engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
+        for t in range(1, steps + 1):
+            for i, st in enumerate(side):
+                pr, eng = parts[i], engines[i]
+                with torch.cuda.stream(st):
+                    img = eng.forward(pr['w'], pr['noises'], save=True)
+                    loss, gimg = ops.mse_loss_grad(img, pr['target'], gmul)
+                    g = eng.backward(gimg, gmul)
+                    ops.adam_step(pr['w'], g, pr['m'], pr['v'], t, self.lr, self.betas, self.eps)
+                    pr['losses'].append(loss)
+        for i, st in enumerate(side):
+            with torch.cuda.stream(st):
+                parts[i]['lstack'] = torch.stack(parts[i]['losses'])
+            cur.wait_stream(st)
+        for eng in engines:
+            eng.saved = None
+        w = torch.cat([pr['w'] for pr in parts], 0)
+        losses = torch.cat([pr['lstack'] for pr in parts], 1)
+        for pr in parts:                    # tensors produced on side streams are consumed on the caller's stream
+            pr['w'].record_stream(cur)
+            pr['lstack'].record_stream(cur)
+        return w, losses
+
+    def _invert_one(self, target, w0, noises, steps, return_trajectory):
         w = w0.detach().clone().contiguous()
         m = torch.zeros_like(w)
         v = torch.zeros_like(w)

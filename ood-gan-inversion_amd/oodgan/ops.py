@@ -257,7 +257,7 @@ _SFORM_POOL = {}
 
 
 def sform_phases_scratch(B, C, H, W, device):
-    key = ('ph', B, C, H, W, str(device))
+    key = ('ph', B, C, H, W, str(device), torch.cuda.current_stream().cuda_stream)
     buf = _SFORM_POOL.get(key)
     if buf is None:
         buf = _SFORM_POOL[key] = SFormPhases(B, C, H, W, device)
@@ -267,7 +267,7 @@ def sform_phases_scratch(B, C, H, W, device):
 def sform_scratch(B, C, H, W, device, tag=0):
     """Reusable S-form buffer (zero border written once at allocation; producers only touch the interior, so a
     buffer can be recycled for any tensor of the same logical shape)."""
-    key = (B, C, H, W, str(device), tag)
+    key = (B, C, H, W, str(device), tag, torch.cuda.current_stream().cuda_stream)
     buf = _SFORM_POOL.get(key)
     if buf is None:
         buf = _SFORM_POOL[key] = SForm(B, C, H, W, device)
