@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
     ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
+    ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
     return ap.parse_args()
 
@@ -62,7 +63,7 @@ class ConvProbe:
 
         def conv3x3(x, wpk, M, mode=0, **kw):
             B, K, H, W = x.shape
-            if not (probe.on and mode == probe.ops.CONV_S1 and M > 32 and K >= 128 and
+            if torch.cuda.is_current_stream_capturing() or not (probe.on and mode == probe.ops.CONV_S1 and M > 32 and K >= 128 and
                     (wpk.precision == 'f32' or isinstance(x, probe.ops.SForm))):
                 return probe.orig(x, wpk, M, mode, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,7 +164,7 @@ def main():
         probe.install()
 
     def one_step():
-        out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, streams=a.streams, enc_lats=enc_lats, enc_feats=enc_feats)
+        out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, streams=a.streams, use_graph=bool(a.graph), enc_lats=enc_lats, enc_feats=enc_feats)
         return gather_latents(lats) if dist_on else lats, losses
 
     for _ in range(a.warmup):
@@ -208,7 +209,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
                                    f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
-                       'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}',
+                       'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}', 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(size),

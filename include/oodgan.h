@@ -227,6 +227,9 @@ int oodgan_mse_nparts(long CHW);
  * anchors: get_optimizer (src/models/OOD_faceGAN_model.py:398-400). */
 int oodgan_adam_step(float* w, const float* g, float* m, float* v, long n, float lr, float beta1,
                      float beta2, float eps, int t, void* stream);
+/* same with the step index on the device: increments t_dev[0] first, then uses it (hipGraph-replayable W+ step) */
+int oodgan_adam_step_dev(float* w, const float* g, float* m, float* v, long n, float lr, float beta1,
+                         float beta2, float eps, int* t_dev, void* stream);
 
 /* ------------------------------------------------------------------ A7/A10 SAMM / SAIM ----- */
 

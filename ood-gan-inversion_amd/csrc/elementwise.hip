@@ -237,7 +237,38 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
     }
 }
 
+// Adam with the step index kept on the device (so that a whole W+ step can be replayed from a hipGraph):
+// t_dev[0] is incremented by a one-thread kernel, then every thread derives the bias corrections from it.
+__global__ void counter_inc_kernel(int* __restrict__ t) { t[0] += 1; }
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, float lr, float beta1, float beta2,
+                                                       float eps, const int* __restrict__ t_dev) {
+    const int t = t_dev[0];
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    }
+}
+
 }  // namespace
+
+extern "C" int oodgan_adam_step_dev(float* w, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                                    float eps, int* t_dev, void* stream) {
+    OODGAN_REQUIRE(w && g && m && v && t_dev && n > 0, "adam_dev: bad args");
+    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, as_stream(stream), t_dev);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), w, g, m, v, n, lr, beta1,
+                       beta2, eps, t_dev);
+    return check_launch("adam_dev");
+}
 
 extern "C" int oodgan_bias_act_fwd(const float* x, const float* bias, const float* noise, const float* noise_w, float* y,
                                    int B, int C, long HW, int noise_batch, float slope, float scale, void* stream) {

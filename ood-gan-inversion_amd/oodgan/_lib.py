@@ -64,6 +64,7 @@ _SIGS = {
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_nparts': (c_int, [c_long]),
     'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),
+    'oodgan_adam_step_dev': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, P, P]),
 }
 
 _lib = None

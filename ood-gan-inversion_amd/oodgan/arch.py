@@ -238,7 +238,7 @@ class ood_faceGAN_e4e(nn.Module):
         return out
 
     # ---------------------------------------------------------------- build-defined: W+ refinement
-    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, **kwargs):
+    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, use_graph=False, **kwargs):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
         latents (masks + blend).  Returns (out, lats, losses[steps,B])."""
@@ -247,7 +247,7 @@ class ood_faceGAN_e4e(nn.Module):
         if noise is None:
             noise = [n.expand(B, -1, -1, -1).contiguous() for n in self.generator.make_noise()]
         inv = WPlusInverter(self.generator.engine(), lr=lr)
-        w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams)
+        w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams, use_graph=use_graph)
         kw = dict(kwargs)
         kw.update({'enc_lats': lats0, 'enc_feats': enc_feats, 'lats': w, 'noise': noise})
         out, lats = self.forward(x, **kw)

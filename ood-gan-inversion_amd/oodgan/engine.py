@@ -259,13 +259,13 @@ class WPlusInverter:
     def __init__(self, engine, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
         self.engine, self.lr, self.betas, self.eps = engine, lr, betas, eps
 
-    def invert(self, target, w0, noises, steps=100, return_trajectory=False, streams=1):
+    def invert(self, target, w0, noises, steps=100, return_trajectory=False, streams=1, use_graph=False):
         """``streams`` > 1 splits the batch into that many independent sub-batches, each advanced on its own HIP
         stream (images are independent): the HBM-bound layout/activation kernels of one sub-batch
         then share the GPU with the matrix kernels of the other instead of running back to back."""
         B = w0.shape[0]
         streams = max(1, min(int(streams), B))
-        if streams == 1 or return_trajectory:
+        if (streams == 1 and not use_graph) or return_trajectory:
             return self._invert_one(target, w0, noises, steps, return_trajectory)
         cur = torch.cuda.current_stream()
         side = [torch.cuda.Stream(device=w0.device) for _ in range(streams)]
@@ -280,26 +280,51 @@ class WPlusInverter:
             parts[-1]['v'] = torch.zeros_like(parts[-1]['w'])
         gmul = ops.loss_scale_for(target.numel() // B)
         engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
-        for t in range(1, steps + 1):
-            for i, st in enumerate(side):
-                pr, eng = parts[i], engines[i]
-                with torch.cuda.stream(st):
-                    img = eng.forward(pr['w'], pr['noises'], save=True)
-                    loss, gimg = ops.mse_loss_grad(img, pr['target'], gmul)
-                    g = eng.backward(gimg, gmul)
-                    ops.adam_step(pr['w'], g, pr['m'], pr['v'], t, self.lr, self.betas, self.eps)
-                    pr['losses'].append(loss)
+        dev = w0.device
+
+        def one_step(pr, eng):
+            img = eng.forward(pr['w'], pr['noises'], save=True)
+            loss, gimg = ops.mse_loss_grad(img, pr['target'], gmul)
+            g = eng.backward(gimg, gmul)
+            ops.adam_step_dev(pr['w'], g, pr['m'], pr['v'], pr['t'], self.lr, self.betas, self.eps)
+            return loss
+
+        for i, st in enumerate(side):
+            pr = parts[i]
+            pr['t'] = torch.zeros(1, dtype=torch.int32, device=dev)
+            pr['lbuf'] = torch.empty(steps, pr['w'].shape[0], device=dev, dtype=torch.float32)
+        # step 1 eagerly (also warms allocator pools / scratch buffers of every stream) ...
         for i, st in enumerate(side):
             with torch.cuda.stream(st):
-                parts[i]['lstack'] = torch.stack(parts[i]['losses'])
+                parts[i]['lbuf'][0].copy_(one_step(parts[i], engines[i]))
+        graphs = [None] * streams
+        if use_graph and steps > 1:
+            # ... then ONE W+ step is captured per stream into a hipGraph and replayed: the ~170 launches of a step
+            # cost one host call, so several sub-batches can be kept in flight without the host becoming the limit
+            for i, st in enumerate(side):
+                st.synchronize()
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=st):
+                    parts[i]['lstat'] = one_step(parts[i], engines[i])
+                graphs[i] = gph
+        for t in range(2, steps + 1):
+            for i, st in enumerate(side):
+                with torch.cuda.stream(st):
+                    if graphs[i] is not None:
+                        graphs[i].replay()
+                        parts[i]['lbuf'][t - 1].copy_(parts[i]['lstat'])
+                    else:
+                        parts[i]['lbuf'][t - 1].copy_(one_step(parts[i], engines[i]))
+        for i, st in enumerate(side):
             cur.wait_stream(st)
         for eng in engines:
             eng.saved = None
         w = torch.cat([pr['w'] for pr in parts], 0)
-        losses = torch.cat([pr['lstack'] for pr in parts], 1)
+        losses = torch.cat([pr['lbuf'] for pr in parts], 1)
         for pr in parts:                    # tensors produced on side streams are consumed on the caller's stream
             pr['w'].record_stream(cur)
-            pr['lstack'].record_stream(cur)
+            pr['lbuf'].record_stream(cur)
+        self._graphs = graphs               # keep the graphs (and their private pools) alive until the next call
         return w, losses
 
     def _invert_one(self, target, w0, noises, steps, return_trajectory):

@@ -453,3 +453,10 @@ def adam_step(w, g, m, v, step, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
     check(_lib.lib().oodgan_adam_step(_p(w), _p(_dev(g)), _p(m), _p(v), w.numel(), float(lr), float(betas[0]), float(betas[1]),
                                       float(eps), int(step), _stream()), 'adam')
     return w
+
+
+def adam_step_dev(w, g, m, v, t_dev, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+    """Adam with the step counter on the device (t_dev int32[1] is incremented first): graph-replayable."""
+    check(_lib.lib().oodgan_adam_step_dev(_p(w), _p(_dev(g)), _p(m), _p(v), w.numel(), float(lr), float(betas[0]),
+                                          float(betas[1]), float(eps), _p(t_dev), _stream()), 'adam_dev')
+    return w
