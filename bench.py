@@ -140,7 +140,7 @@ def main():
 
     size, B = a.size, a.batch
     model = ood_faceGAN_e4e(out_size=size, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
-                            cycle_align=2, blend_with_gen=True, ModSize=256)
+                            cycle_align=2, blend_with_gen=True, ModSize=256, build_encoder=False)
     model.load_state_dict(synth.ood_state(size, seed=0), strict=True)
     model = model.to(dev).eval()
     # per-rank shard of the global synthetic batch (global batch = B*world, contiguous slices by rank); every image,

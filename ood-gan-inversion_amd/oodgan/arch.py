@@ -90,7 +90,12 @@ class ood_faceGAN_e4e(nn.Module):
         self.style_cnt = log_outsize * 2 - 2
         self.style_dim = style_dim
         self.channels = generator_channels(channel_multiplier, narrow)
-        self.encoder = _MissingEncoder()
+        if kwargs.get('build_encoder', True):
+            from .encoder import Encoder4Editing, ProgressiveStage
+            self.encoder = Encoder4Editing(num_layers=50, mode='ir_se', opts={'stylegan_size': out_size}, bn=True)
+            self.encoder.progressive_stage = ProgressiveStage[stage]
+        else:
+            self.encoder = _MissingEncoder()   # encoder outputs are then passed to forward() as enc_lats / enc_feats
         self.aligns = {}
         self.log_outsize = int(math.log(256, 2))
         self.stage = stage
@@ -133,7 +138,10 @@ class ood_faceGAN_e4e(nn.Module):
             from .io import load_generator_checkpoint
             load_generator_checkpoint(self.generator, StyleGAN_pth, StyleGAN_pth_key)
         if E4E_pth is not None:
-            raise NotImplementedError('loading e4e_ffhq_encode.pt needs the e4e encoder (SURVEY.md §8f N1)')
+            from collections import OrderedDict
+            enc_ckpt = torch.load(E4E_pth, map_location='cpu')
+            enc_dict = OrderedDict((k[len('encoder.'):], v) for k, v in enc_ckpt['state_dict'].items() if k.startswith('encoder.'))
+            self.encoder.load_state_dict(enc_dict, strict=True)
         if avg_latent_pth is not None:
             self.avg_latent.data = torch.load(avg_latent_pth, map_location='cpu')
         if delta_latent_pth is not None:
@@ -182,7 +190,9 @@ class ood_faceGAN_e4e(nn.Module):
         enc_lats, enc_feats = kwargs.get('enc_lats', None), kwargs.get('enc_feats', None)
         if enc_lats is None or (self.modulation is not None and enc_feats is None):
             x256 = samm.resize_bilinear(x, 256)
-            enc_lats, enc_feats = self.encoder(x256, return_feats=True)
+            with torch.no_grad():
+                self.encoder.eval()
+                enc_lats, enc_feats = self.encoder(x256, return_feats=True)
         lats = enc_lats + self.avg_latent.reshape(1, 1, -1) + self.delta_latent
         truncation = kwargs.get('truncation', 1.0)
         if truncation < 1.0:

@@ -1,0 +1,203 @@
+"""e4e encoder — the step immediately BEFORE the accelerated path.
+
+Mirror of ``Encoder4Editing(num_layers, mode='ir_se', opts, bn=True)`` (reference
+src/ops/e4e/encoders/psp_encoders.py:125-216; IR-SE-50 backbone helpers.py:33-57,60-76,479-501; FPN
+``_upsample_add`` :504-521; ``GradualStyleBlock`` psp_encoders.py:35-57) with the same state-dict keys
+(621 entries for num_layers=50), forward signature and ``channels`` / ``progressive_stage`` attributes.
+
+STATUS: interim implementation on plain torch-ROCm ops (MIOpen / rocBLAS through ``torch.nn.functional``), as
+SURVEY.md §8f N1 allows until the HIP version exists; it runs once per image at 256² under ``no_grad`` and is
+not part of the measured inversion loop.  It is NOT a fallback for the hot path — generator, SAMM and the W+
+loop have none."""
+import math
+from collections import namedtuple
+from enum import Enum
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class ProgressiveStage(Enum):
+    WTraining = 0
+    Delta1Training = 1
+    Delta2Training = 2
+    Delta3Training = 3
+    Delta4Training = 4
+    Delta5Training = 5
+    Delta6Training = 6
+    Delta7Training = 7
+    Delta8Training = 8
+    Delta9Training = 9
+    Delta10Training = 10
+    Delta11Training = 11
+    Delta12Training = 12
+    Delta13Training = 13
+    Delta14Training = 14
+    Delta15Training = 15
+    Delta16Training = 16
+    Delta17Training = 17
+    Inference = 18
+
+
+_Unit = namedtuple('_Unit', ['in_channel', 'depth', 'stride'])
+
+
+def _stage(in_channel, depth, num_units, stride=2):
+    return [_Unit(in_channel, depth, stride)] + [_Unit(depth, depth, 1) for _ in range(num_units - 1)]
+
+
+def get_blocks(num_layers):
+    """helpers.py:33-57."""
+    table = {50: (3, 4, 14, 3), 100: (3, 13, 30, 3), 152: (3, 8, 36, 3)}
+    if num_layers not in table:
+        raise ValueError(f'Invalid number of layers: {num_layers}. Must be one of [50, 100, 152]')
+    n = table[num_layers]
+    return [_stage(64, 64, n[0]), _stage(64, 128, n[1]), _stage(128, 256, n[2]), _stage(256, 512, n[3])]
+
+
+class SEModule(nn.Module):
+    """Squeeze-excitation gate (helpers.py:60-76)."""
+
+    def __init__(self, channels, reduction):
+        super().__init__()
+        self.fc1 = nn.Conv2d(channels, channels // reduction, kernel_size=1, padding=0, bias=False)
+        self.fc2 = nn.Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
+
+    def forward(self, x):
+        g = x.mean(dim=(2, 3), keepdim=True)
+        g = torch.sigmoid(self.fc2(F.relu(self.fc1(g))))
+        return x * g
+
+
+class bottleneck_IR_SE(nn.Module):
+    """helpers.py:479-501: BN -> conv3x3 -> PReLU -> conv3x3(stride) -> BN -> SE, plus identity / 1x1+BN shortcut."""
+
+    def __init__(self, in_channel, depth, stride, bn=True):
+        super().__init__()
+        if in_channel == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = nn.Sequential(nn.Conv2d(in_channel, depth, (1, 1), stride, bias=False), nn.BatchNorm2d(depth))
+        self.res_layer = nn.Sequential(nn.BatchNorm2d(in_channel), nn.Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+                                       nn.PReLU(depth), nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+                                       nn.BatchNorm2d(depth), SEModule(depth, 16))
+
+    def forward(self, x):
+        return self.res_layer(x) + self.shortcut_layer(x)
+
+
+class bottleneck_IR(nn.Module):
+    def __init__(self, in_channel, depth, stride, bn=True):
+        super().__init__()
+        if in_channel == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = nn.Sequential(nn.Conv2d(in_channel, depth, (1, 1), stride, bias=False), nn.BatchNorm2d(depth))
+        self.res_layer = nn.Sequential(nn.BatchNorm2d(in_channel), nn.Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+                                       nn.PReLU(depth), nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+                                       nn.BatchNorm2d(depth))
+
+    def forward(self, x):
+        return self.res_layer(x) + self.shortcut_layer(x)
+
+
+class _EqualLinear(nn.Module):
+    """EqualLinear of src/ops/StyleGAN/modules.py:136-170 (no activation on this path)."""
+
+    def __init__(self, in_dim, out_dim, lr_mul=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, x):
+        return F.linear(x, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+class GradualStyleBlock(nn.Module):
+    """psp_encoders.py:35-57: log2(spatial) stride-2 convs + LeakyReLU(0.01), then EqualLinear."""
+
+    def __init__(self, in_c, out_c, spatial):
+        super().__init__()
+        self.out_c, self.spatial = out_c, spatial
+        mods = [nn.Conv2d(in_c, out_c, kernel_size=3, stride=2, padding=1), nn.LeakyReLU()]
+        for _ in range(int(np.log2(spatial)) - 1):
+            mods += [nn.Conv2d(out_c, out_c, kernel_size=3, stride=2, padding=1), nn.LeakyReLU()]
+        self.convs = nn.Sequential(*mods)
+        self.linear = _EqualLinear(out_c, out_c, lr_mul=1)
+
+    def forward(self, x):
+        return self.linear(self.convs(x).view(-1, self.out_c))
+
+
+def _upsample_add(x, y):
+    """helpers.py:504-521: bicubic(align_corners=True) to y's size, plus y."""
+    return F.interpolate(x, size=y.shape[-2:], mode='bicubic', align_corners=True) + y
+
+
+class Encoder4Editing(nn.Module):
+    def __init__(self, num_layers, mode='ir', opts=None, bn=True):
+        super().__init__()
+        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
+        self.input_layer = nn.Sequential(nn.Conv2d(3, 64, (3, 3), 1, 1, bias=False), nn.BatchNorm2d(64), nn.PReLU(64))
+        self.channels = [64]
+        mods = []
+        for block in get_blocks(num_layers):
+            for u in block:
+                mods.append(unit(u.in_channel, u.depth, u.stride, bn=bn))
+            self.channels.append(block[-1].depth)
+        self.body = nn.Sequential(*mods)
+        size = opts.stylegan_size if hasattr(opts, 'stylegan_size') else opts['stylegan_size']
+        self.style_count = 2 * int(math.log(size, 2)) - 2
+        self.coarse_ind, self.middle_ind = 3, 7
+        self.styles = nn.ModuleList()
+        for i in range(self.style_count):
+            spatial = 16 if i < self.coarse_ind else (32 if i < self.middle_ind else 64)
+            self.styles.append(GradualStyleBlock(512, 512, spatial))
+        self.latlayer1 = nn.Conv2d(256, 512, kernel_size=1, stride=1, padding=0)
+        self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
+        self.progressive_stage = ProgressiveStage.Inference
+
+    def get_deltas_starting_dimensions(self):
+        return list(range(self.style_count))
+
+    def set_progressive_stage(self, new_stage):
+        self.progressive_stage = new_stage
+
+    def forward(self, x, **kwargs):
+        x = self.input_layer(x)
+        feats = [x]
+        c1 = c2 = c3 = None
+        for i, layer in enumerate(self.body):
+            x = layer(x)
+            if i == 2:
+                feats.append(x)
+            if i == 6:
+                c1 = x
+                feats.append(x)
+            elif i == 20:
+                c2 = x
+                feats.append(x)
+            elif i == 23:
+                c3 = x
+                feats.append(x)
+        w0 = self.styles[0](c3)
+        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2)
+        stage = self.progressive_stage.value
+        features = c3
+        p2 = None
+        for i in range(1, min(stage + 1, self.style_count)):
+            if i == self.coarse_ind:
+                p2 = _upsample_add(c3, self.latlayer1(c2))
+                features = p2
+            elif i == self.middle_ind:
+                features = _upsample_add(p2, self.latlayer2(c1))
+            w[:, i] += self.styles[i](features)
+        if kwargs.get('return_feats', False):
+            return w, feats
+        return w

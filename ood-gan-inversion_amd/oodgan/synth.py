@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 __all__ = [
+    'encoder_state',
     'normal', 'uniform', 'make_kernel', 'generator_channels', 'generator_state', 'samm_state',
     'ood_state', 'make_noises', 'make_latents', 'make_images', 'make_encoder_feats',
 ]
@@ -195,3 +196,31 @@ def make_images(size, batch, seed=1):
 def make_encoder_feats(batch, seed=4, channels=(64, 64, 128, 256), sizes=(256, 128, 64, 32)):
     """Stand-ins for the e4e feature pyramid taps (reference psp_encoders.py:186-214)."""
     return [normal(f'enc_feat.{i}', (batch, c, s, s), seed) for i, (c, s) in enumerate(zip(channels, sizes))]
+
+
+def encoder_state(shapes, seed=0, prefix=''):
+    """Deterministic parameters for the e4e encoder from its (key -> shape) table (``{k: v.shape for k, v in
+    Encoder4Editing(...).state_dict().items()}``): He-normal conv weights, BatchNorm affine/statistics near
+    identity (running_var in [0.5,1.5]), PReLU slopes ~0.25, EqualLinear weights N(0,1)."""
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        name = prefix + k
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith('running_mean'):
+            sd[k] = normal(name, shp, seed, 0.1)
+        elif k.endswith('running_var'):
+            sd[k] = uniform(name, shp, seed, 0.5, 1.5)
+        elif len(shp) == 4:
+            fan_in = shp[1] * shp[2] * shp[3]
+            sd[k] = normal(name, shp, seed, math.sqrt(2.0 / fan_in))
+        elif len(shp) == 2:
+            sd[k] = normal(name, shp, seed, 1.0)
+        elif k.endswith('.bias'):
+            sd[k] = normal(name, shp, seed, 0.1)
+        elif '.res_layer.2.' in k or k.startswith('input_layer.2.'):
+            sd[k] = normal(name, shp, seed, 0.05, 0.25)           # PReLU slopes
+        else:
+            sd[k] = normal(name, shp, seed, 0.1, 1.0)             # BatchNorm weight
+    return sd

@@ -315,7 +315,7 @@ def gold_ood(B=1):
 def main():
     install_stubs()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['ops', 'gen', 'wplus', 'samm', 'ood']
+    which = sys.argv[1:] or ['ops', 'gen', 'wplus', 'samm', 'ood', 'enc']
     if 'ops' in which:
         gold_ops()
     if 'gen' in which:
@@ -326,6 +326,30 @@ def main():
         gold_samm()
     if 'ood' in which:
         gold_ood(1)
+    if 'enc' in which:
+        gold_encoder()
+
+
+
+
+def gold_encoder():
+    """e4e encoder (IR-SE-50 + FPN + 18 GradualStyleBlocks) at 256², B=1, eval mode, recipe weights."""
+    from src.ops.e4e.encoders.psp_encoders import Encoder4Editing
+
+    class O(dict):
+        __getattr__ = dict.__getitem__
+    enc = Encoder4Editing(50, 'ir_se', O(stylegan_size=1024), bn=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    print('encoder load:', enc.load_state_dict(synth.encoder_state(shapes, seed=41), strict=True))
+    x = synth.make_images(256, 1, seed=42)
+    with torch.no_grad():
+        w, feats = enc(x, return_feats=True)
+    g = dict(w=w)
+    for i, f in enumerate(feats):
+        step = max(1, f.shape[-1] // 16)
+        g[f'feat{i}_sub'] = f[:, ::8, ::step, ::step]
+        g[f'feat{i}_mean'] = f.mean(dim=(2, 3))
+    save('encoder_256.npz', **g)
 
 
 if __name__ == '__main__':

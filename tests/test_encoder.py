@@ -1,0 +1,76 @@
+"""e4e encoder: the mirror module against vectors produced by the reference encoder
+(tests/golden/make_golden.py gold_encoder).  CPU test = structure/key parity + numerics of the restated
+graph; GPU test = the same module on ROCm and the end-to-end ``ood_faceGAN_e4e.forward(x)`` from an image."""
+import pytest
+import torch
+
+from oodgan import synth
+
+
+def _build():
+    from oodgan.encoder import Encoder4Editing
+    enc = Encoder4Editing(50, 'ir_se', {'stylegan_size': 1024}, bn=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert len(shapes) == 621                       # same state-dict size as the reference (probe in SURVEY App. C)
+    enc.load_state_dict(synth.encoder_state(shapes, seed=41), strict=True)
+    return enc
+
+
+def _check(w, feats, g, tol):
+    def close(a, b):
+        a = a.detach().cpu()
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+    close(w, g['w'])
+    assert len(feats) == 5
+    for i, f in enumerate(feats):
+        step = max(1, f.shape[-1] // 16)
+        close(f[:, ::8, ::step, ::step], g[f'feat{i}_sub'])
+        close(f.mean(dim=(2, 3)), g[f'feat{i}_mean'])
+
+
+def test_encoder_cpu_vs_reference_golden(golden):
+    g = golden('encoder_256.npz')
+    enc = _build()
+    x = synth.make_images(256, 1, seed=42)
+    with torch.no_grad():
+        w, feats = enc(x, return_feats=True)
+    assert enc.channels == [64, 64, 128, 256, 512] and w.shape == (1, 18, 512)
+    _check(w, feats, g, 1e-4)
+
+
+@pytest.mark.gpu
+def test_encoder_gpu_vs_reference_golden(golden):
+    g = golden('encoder_256.npz')
+    dev = torch.device('cuda:0')
+    enc = _build().to(dev)
+    x = synth.make_images(256, 1, seed=42).to(dev)
+    with torch.no_grad():
+        w, feats = enc(x, return_feats=True)
+    _check(w, feats, g, 1e-3)
+
+
+@pytest.mark.gpu
+def test_arch_forward_from_image_end_to_end():
+    """forward(x) with the encoder attached == forward with its outputs passed explicitly; invert() runs."""
+    from oodgan.arch import ood_faceGAN_e4e
+    dev = torch.device('cuda:0')
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
+                        cycle_align=2, blend_with_gen=True, ModSize=256)
+    sd = synth.ood_state(1024, seed=31)
+    shapes = {k: tuple(v.shape) for k, v in m.encoder.state_dict().items()}
+    sd.update({'encoder.' + k: v for k, v in synth.encoder_state(shapes, seed=41).items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    x = synth.make_images(1024, 1, seed=34).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(1024, 1, seed=35)]
+    out, lats = m(x, noise=noises)
+    assert out.shape == (1, 3, 1024, 1024) and lats.shape == (1, 18, 512) and torch.isfinite(out).all()
+    with torch.no_grad():
+        from oodgan import samm
+        el, ef = m.encoder(samm.resize_bilinear(x, 256), return_feats=True)
+    out2, lats2 = m(x, noise=noises, enc_lats=el, enc_feats=ef)
+    assert torch.equal(lats, lats2) and (out - out2).abs().max().item() < 1e-5
+    assert sorted(m.aligns.keys()) == [1, 2, 3, 4, 1024]
+    out3, lats3, losses = m.invert(x, steps=3, noise=noises)
+    assert losses.shape == (3, 1) and losses[-1].item() < losses[0].item() and torch.isfinite(out3).all()

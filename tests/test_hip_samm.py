@@ -110,7 +110,7 @@ def test_ood_forward_1024_vs_golden(dev, golden):
     from oodgan.arch import ood_faceGAN_e4e
     g = golden('ood_1024.npz')
     m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
-                        cycle_align=2, blend_with_gen=True, ModSize=256)
+                        cycle_align=2, blend_with_gen=True, ModSize=256, build_encoder=False)
     res = m.load_state_dict(synth.ood_state(1024, seed=31), strict=True)
     m = m.to(dev).eval()
     enc_lats = synth.make_latents(1024, 1, seed=32, std=0.3).to(dev)
