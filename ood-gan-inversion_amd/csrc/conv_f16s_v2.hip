@@ -135,7 +135,7 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, const SConv& sc, f
         for (int u = tid; u < 256 * (MB / 16); u += 256) {
             const int pxl = u & 255, g16 = u >> 8;
             const int py = r0 + (pxl >> 5), px = c0 + (pxl & 31);
-            if (py >= p.Hout || px >= p.Wout) continue;
+            if (py >= p.Hout || px >= p.Wout || (m0 >> 4) + g16 >= sc.yd.KC) continue;   // last M block may be partial
             const float nz = nzp ? nw * nzp[(long)py * p.Wout + px] : 0.f;
             half8 hv[2], lv[2];
 #pragma unroll

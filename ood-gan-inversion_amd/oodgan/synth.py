@@ -221,6 +221,10 @@ def encoder_state(shapes, seed=0, prefix=''):
             sd[k] = normal(name, shp, seed, 0.1)
         elif '.res_layer.2.' in k or k.startswith('input_layer.2.'):
             sd[k] = normal(name, shp, seed, 0.05, 0.25)           # PReLU slopes
+        elif '.res_layer.4.weight' in k:
+            # last BatchNorm of the residual branch: small gain, so the 24 un-normalised residual units stay
+            # O(1) and well-conditioned (with gain 1 the net amplifies a 1e-6 input perturbation to O(1))
+            sd[k] = normal(name, shp, seed, 0.03, 0.25)
         else:
             sd[k] = normal(name, shp, seed, 0.1, 1.0)             # BatchNorm weight
     return sd
