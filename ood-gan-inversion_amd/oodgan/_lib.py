@@ -55,6 +55,12 @@ _SIGS = {
     'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform_phases': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_hform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
+    'oodgan_to_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_from_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_modconv_f16_wbytes': (c_long, [c_int, c_int, c_int]),
+    'oodgan_modconv_f16_pack': (c_int, [P, P, c_int, c_float, c_int, P, c_int, c_int, c_int, P]),
+    'oodgan_modconv_f16': (c_int, [P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),

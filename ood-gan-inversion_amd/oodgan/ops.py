@@ -286,6 +286,62 @@ def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
     return out
 
 
+class HForm:
+    """f16 channel-blocked activations of the fp16 modulated conv (include/oodgan.h, oodgan_modconv_f16)."""
+    __slots__ = ('buf', 'B', 'C', 'H', 'W')
+
+    def __init__(self, B, C, H, W, device):
+        self.B, self.C, self.H, self.W = B, C, H, W
+        self.buf = torch.zeros(_lib.lib().oodgan_hform_bytes(B, C, H, W) // 2, dtype=torch.float16, device=device)
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def to_nchw(self):
+        y = torch.empty(self.B, self.C, self.H, self.W, device=self.buf.device, dtype=torch.float32)
+        check(_lib.lib().oodgan_from_hform(_p(self), _p(y), self.B, self.C, self.H, self.W, _stream()), 'from_hform')
+        return y
+
+
+def to_hform(x, out=None):
+    """fp32 NCHW -> H-form (f16)."""
+    x = _dev(x)
+    B, C, H, W = x.shape
+    if out is None:
+        out = HForm(B, C, H, W, x.device)
+    check(_lib.lib().oodgan_to_hform(_p(x), _p(out), B, C, H, W, _stream()), 'to_hform')
+    return out
+
+
+def modconv_f16_pack(weight, style, demodulate=True):
+    """Per-sample modulated (+demodulated) f16 weights of ModulatedConv2d (model.py:236-241) in MFMA fragment order.
+    weight (M,K,3,3) or (1,M,K,3,3) fp32 master, style (B,K) fp32 (already through the modulation EqualLinear)."""
+    weight = _dev(weight).reshape(weight.shape[-4:])
+    style = _dev(style)
+    M, K = weight.shape[0], weight.shape[1]
+    B = style.shape[0]
+    wpk = torch.empty(_lib.lib().oodgan_modconv_f16_wbytes(B, M, K) // 2, dtype=torch.float16, device=weight.device)
+    check(_lib.lib().oodgan_modconv_f16_pack(_p(weight), _p(style), style.stride(0), 1.0 / math.sqrt(K * 9), int(demodulate),
+                                             _p(wpk), B, M, K, _stream()), 'modconv_f16_pack')
+    return wpk, M, K
+
+
+def modconv_f16(x, packed, noise=None, noise_w=None, bias=None, act='none', out=None):
+    """fp16 modulated 3x3 conv + noise + bias + activation on H-form activations (32 -> 32 channels class)."""
+    wpk, M, K = packed
+    assert isinstance(x, HForm) and x.C == K
+    if out is None:
+        out = HForm(x.B, M, x.H, x.W, x.buf.device)
+    nb = 0
+    if noise is not None:
+        noise = _dev(noise)
+        nb = noise.shape[0]
+        assert noise.numel() == nb * x.H * x.W and nb in (1, x.B)
+    check(_lib.lib().oodgan_modconv_f16(_p(x), _p(wpk), _p(noise), nb, _p(_opt(noise_w, 'noise_w')), _p(_opt(bias, 'bias')),
+                                        {'none': ACT_NONE, 'lrelu': ACT_LRELU}[act], _p(out), x.B, K, M, x.H, x.W, _stream()), 'modconv_f16')
+    return out
+
+
 USE_SFORM = True     # S1 convs of the generator engine take their input through an S-form conversion + LDS-DMA kernel
 PRECISION = 'f16s'   # default conv arithmetic: 'f16s' (split-f16, 3 MFMAs per product) or 'f32' (exact fp32 MFMA)
 

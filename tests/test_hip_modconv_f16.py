@@ -1,0 +1,79 @@
+"""fp16 modulated conv of the high-resolution layers (BASELINE.json configs[4]) against the oracle's
+ModulatedConv2d + NoiseInjection + FusedLeakyReLU on the same f16-rounded input.
+
+Tolerance: the kernel rounds the per-sample weights and the result to f16 (unit round-off 2^-11 = 4.9e-4) and
+accumulates in fp32, so |diff| <= 4e-3 * max|ref| element-wise and <= 5e-4 * max|ref| on average."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oodgan import synth  # noqa: E402
+
+
+def _case(B, K, M, H, W, seed, noise_batch, act):
+    x = synth.normal('x', (B, K, H, W), seed).half().float()
+    wgt = synth.normal('w', (1, M, K, 3, 3), seed)
+    s = synth.normal('s', (B, K), seed, 0.3, 1.0)
+    noise = synth.normal('n', (noise_batch, 1, H, W), seed) if noise_batch else None
+    bias = synth.normal('b', (M,), seed, 0.2)
+    nw = torch.tensor([0.37])
+    y = R.modulated_conv2d(x, s, wgt, torch.eye(K) * math.sqrt(K), torch.zeros(K))
+    if noise is not None:
+        y = y + nw * noise
+    y = R.fused_leaky_relu(y, bias) if act == 'lrelu' else y + bias.reshape(1, -1, 1, 1)
+    return x, wgt, s, noise, bias, nw, y
+
+
+@pytest.mark.parametrize('B,K,M,H,W,noise_batch,act', [
+    (2, 32, 32, 16, 32, 2, 'lrelu'),      # exact tiles
+    (3, 32, 32, 24, 64, 1, 'lrelu'),      # shared noise, several tiles per sample
+    (2, 16, 32, 13, 45, 2, 'none'),       # ragged tile edges, one channel block in
+    (1, 32, 16, 9, 33, 0, 'lrelu'),       # one channel block out, no noise
+    (2, 24, 20, 40, 70, 2, 'lrelu'),      # channel counts that are not multiples of 16
+])
+def test_modconv_f16_vs_oracle(B, K, M, H, W, noise_batch, act):
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    x, wgt, s, noise, bias, nw, ref = _case(B, K, M, H, W, 7 + B + H, noise_batch, act)
+    xh = ops.to_hform(x.to(dev))
+    assert torch.equal(xh.to_nchw().cpu(), x)                     # layout round trip is exact
+    packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev))
+    out = ops.modconv_f16(xh, packed, None if noise is None else noise.to(dev), nw.to(dev), bias.to(dev), act)
+    y = out.to_nchw().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    err = (y - ref).abs()
+    assert err.max().item() <= 4e-3 * scale, err.max().item()
+    assert err.mean().item() <= 5e-4 * scale, err.mean().item()
+    # the border / padding of the output must stay zero (the next conv reads it as its halo)
+    full = out.buf.clone()
+    ops.to_hform(torch.zeros_like(out.to_nchw()), out=out)
+    assert out.buf.abs().max().item() == 0.0
+    del full
+
+
+def test_modconv_f16_is_deterministic_and_persistent_grid_covers_all_tiles():
+    """many more tiles than resident workgroups: every tile written exactly once, run-to-run identical."""
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    B, K, M, H, W = 2, 32, 32, 512, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, K, H, W, generator=g).half().float()
+    wgt = torch.randn(1, M, K, 3, 3, generator=g)
+    s = 1 + 0.3 * torch.randn(B, K, generator=g)
+    xh = ops.to_hform(x.to(dev))
+    packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev))
+    y1 = ops.modconv_f16(xh, packed, act='none').to_nchw()
+    y2 = ops.modconv_f16(xh, packed, act='none').to_nchw()
+    assert torch.equal(y1, y2)
+    ref = R.modulated_conv2d(x[:, :, :64, :96], s, wgt, torch.eye(K) * math.sqrt(K), torch.zeros(K))
+    # interior of the crop (its last row/col see different neighbours than the full image)
+    err = (y1[:, :, :63, :95].cpu() - ref[:, :, :63, :95]).abs().max().item()
+    assert err <= 4e-3 * max(1.0, ref.abs().max().item())
+    # linearity in the activations (size-independent property): conv(2x) == 2 conv(x) exactly in f16/f32 arithmetic
+    x2 = ops.to_hform((2 * x).to(dev))
+    y3 = ops.modconv_f16(x2, packed, act='none').to_nchw()
+    assert (y3 - 2 * y1).abs().max().item() <= 2.0 ** -23      # equal up to f16 subnormal rounding of tiny outputs
