@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
+    ap.add_argument('--no-modconv', action='store_true', help='skip the fp16 modulated-conv roofline leg (BASELINE configs[4])')
     ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
@@ -100,6 +101,24 @@ def pmc_traffic(a):
         return rec.get(key, {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         return None
+
+
+def modconv_roofline():
+    """BASELINE.json's second metric ("modulated-conv2d GB/s", configs[4]): the fp16 modulated conv of the 1024² layer,
+    x (16,32,1024,1024) f16, 32 -> 32 channels, noise + bias + leaky ReLU fused; algorithmic bytes per SURVEY.md §8(d)
+    (2.147 GB) over the HIP-event time of the launch, against the 8 TB/s HBM peak.  Runs after the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_modconv_f16
+    r = bench_modconv_f16.run(B=16, C=32, H=1024, iters=30, warmup=3)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            traffic = json.load(f).get('modconv_f16_b16_s1024', {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        pass
+    return dict(workload='fp16 ModulatedConv2d 3x3 32->32 @1024x1024, batch 16 (+noise, bias, lrelu)', kernel='modconv_f16_strip_kernel',
+                bound='hbm', achieved=round(r['GBps'], 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(r['hbm_frac'], 4),
+                ms=round(r['ms'], 4), alg_bytes=r['alg_bytes'], traffic=traffic, tflops=round(r['TFLOPs'], 1))
 
 
 def cpu_baseline(size):
@@ -201,6 +220,9 @@ def main():
                               'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
                         launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
                         alg_flops_per_launch=ps['flops_per_launch'])
+        modconv = None
+        if not a.no_modconv and world == 1:
+            modconv = modconv_roofline()
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
@@ -212,6 +234,7 @@ def main():
                        'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}', 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
+            'modconv2d': modconv,
             'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(size),
         }
         print(json.dumps(line, ensure_ascii=False))

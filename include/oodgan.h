@@ -185,13 +185,14 @@ int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
  *   X[b][ceil(C/16)][Hp][Wp][16 x f16]  (32-byte record per pixel and 16-channel block; pixel (y,x) at [y+1][x+1];
  *   zero border + tile padding as the S-form; buffers must be zero-initialised once).
  * As in the reference the modulation and demodulation are folded into per-sample weights (model.py:236-241), which
- * oodgan_modconv_f16_pack builds from the fp32 master weight (M,K,3,3) and the style (B,K).  K, M <= 32. */
+ * oodgan_modconv_f16_pack builds from the fp32 master weight (M,K,3,3) and the style (B,K).  K, M <= 32.
+ * `act` given to the pack and to the conv must agree: the leaky ReLU's sqrt(2) gain is folded into the weights. */
 long oodgan_hform_bytes(int B, int C, int H, int W);
 int oodgan_to_hform(const float* x, void* out, int B, int C, int H, int W, void* stream);      /* fp32 NCHW -> H-form */
 int oodgan_from_hform(const void* in, float* y, int B, int C, int H, int W, void* stream);    /* H-form -> fp32 NCHW */
 long oodgan_modconv_f16_wbytes(int B, int M, int K);
 int oodgan_modconv_f16_pack(const float* weight, const float* style, int style_stride, float scale, int demodulate,
-                            void* wpk, int B, int M, int K, void* stream);
+                            int act, void* wpk, int B, int M, int K, void* stream);
 /* y = act(conv3x3(x, w[b]) + noise_w*noise + bias); noise (noise_batch,H,W) fp32 or NULL, act = OODGAN_ACT_NONE|LRELU */
 int oodgan_modconv_f16(const void* x, const void* wpk, const float* noise, int noise_batch, const float* noise_w,
                        const float* bias, int act, void* y, int B, int K, int M, int H, int W, void* stream);

@@ -51,9 +51,11 @@ constexpr int SLOTS_PER_KC = NPOS * 2;                       // 16-byte slots pe
 template <int KC>
 struct Geo {
     static constexpr int slots = KC * SLOTS_PER_KC;
-    static constexpr int pieces = (slots + 63) / 64;         // 1 KiB DMA pieces (KC=2: 22)
-    static constexpr int buf_bytes = pieces * 1024;
-    static constexpr int ppw = (pieces + 3) / 4;             // pieces per wave
+    static constexpr int pieces = ((slots + 63) / 64 + 3) / 4 * 4;   // 1 KiB DMA pieces, the same number for every wave
+    static constexpr int buf_bytes = pieces * 1024;                  // (KC=2: 24; the tail pieces land in padding)
+    static constexpr int ppw = pieces / 4;                           // pieces per wave
+    static constexpr int noise_off = pieces * 1024;                  // + one KiB: the tile's 8x32 fp32 noise values
+    static constexpr int buf_total = noise_off + 1024;
 };
 
 struct MCArgs {
@@ -66,11 +68,12 @@ struct MCArgs {
     int noise_batch, act;
     int B, K, M, H, W;
     int tiles_x, tiles_y;
+    int flags;               // bit0: do not wait for the previous tile's stores at the top of the loop
     HDims xd, yd;
 };
 
-template <int KC>
-__global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
+template <int KC, bool LRELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void modconv_f16_kernel(const MCArgs p) {
     using G = Geo<KC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,6 +88,21 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
     const int start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
     const int cnt = q + (xcd < rem ? 1 : 0);
     if (lb >= cnt) return;
+
+    // ---- constants of the epilogue.  With the leaky ReLU the sqrt(2) gain is already in the packed weights
+    // (oodgan_modconv_f16_pack) and is folded into bias and noise weight here: sqrt2*lrelu(v) = lrelu(sqrt2*v), and
+    // lrelu(u) = max(u, 0.2u), so the activation costs two VALU operations per value.
+    const float gain = LRELU ? kSqrt2 : 1.f;
+    float bias_g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        bias_g[r] = (p.bias && m < p.M) ? gain * p.bias[m] : 0.f;
+    }
+    const float nwg = p.noise ? gain * (p.noise_w ? p.noise_w[0] : 1.f) : 0.f;
+    const int MC = (p.M + 15) / 16;
+    const float* nzp = p.noise ? p.noise : reinterpret_cast<const float*>(p.x);
+    const bool use_vm4 = p.flags & 1;
 
     // ---- per-lane DMA source offsets relative to the tile origin (16-byte units)
     long xoff[G::ppw];
@@ -108,37 +126,42 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
         int b, r0, c0;
         tile_coords(item, b, r0, c0);
         const uint4* base = p.x + (long)b * KC * p.xd.plane + ((long)r0 * p.xd.Wp + c0) * 2;
-        unsigned char* dst = smem + buf * G::buf_bytes;
+        unsigned char* dst = smem + buf * G::buf_total;
 #pragma unroll
-        for (int i = 0; i < G::ppw; ++i) {
-            const int pc = wave + 4 * i;
-            if (pc < G::pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xoff[i]),
-                                                 (lds_void*)(dst + pc * 1024), 16, 0, 0);
+        for (int i = 0; i < G::ppw; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xoff[i]),
+                                             (lds_void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+        {   // noise: each wave fetches the two rows it will use itself, one dword per lane, clamped inside the image
+            const int ny = min(r0 + wave * 2 + half, p.H - 1), nx = min(c0 + l31, p.W - 1);
+            const float* src = nzp + ((long)(p.noise_batch > 1 ? b : 0) * p.H + ny) * p.W + nx;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(dst + G::noise_off + wave * 256), 4, 0, 0);
         }
     };
-
-    // ---- constants of the epilogue
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias_r[r] = (p.bias && m < p.M) ? p.bias[m] : 0.f;
-    }
-    const float nw = p.noise ? (p.noise_w ? p.noise_w[0] : 1.f) : 0.f;
-    const int MC = (p.M + 15) / 16;
 
     half8 areg[9][KC];
     int cur_b = -1;
 
+    // s_waitcnt immediates (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8); issued through the
+    // builtin so that the compiler's own wait-count bookkeeping sees them
+    constexpr int kVm0 = 0x0F70, kVm4 = 0x0F74;
+    __builtin_amdgcn_s_waitcnt(kVm0);        // bias / noise-weight loads: retire them here, not inside the loop
     dma(lb, 0);
     int it = 0;
+    bool prev_full = false;
     for (int item = lb; item < cnt; item += LB, ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // LDS-DMA is not covered by the barrier
-        __syncthreads();
-        if (item + LB < cnt) dma(item + LB, (it + 1) & 1);
+        // the prefetched tile must have landed (LDS-DMA is not covered by the barrier).  Memory operations retire
+        // in issue order, so when the previous tile issued exactly its 4 stores AFTER the prefetch, vmcnt(4) already
+        // guarantees the DMA; the stores themselves may still be in flight.
+        if (prev_full) __builtin_amdgcn_s_waitcnt(kVm4);
+        else __builtin_amdgcn_s_waitcnt(kVm0);
+        __builtin_amdgcn_s_barrier();        // plain barrier: __syncthreads() would add its own vmcnt(0) fence
         int b, r0, c0;
         tile_coords(item, b, r0, c0);
+        const int px = c0 + l31;
+        // always issued (the last iteration re-fetches its own tile into the idle buffer)
+        if (!(p.flags & 4)) dma(item + LB < cnt ? item + LB : item, (it + 1) & 1);
+        prev_full = use_vm4 && MC == 2 && r0 + 8 <= p.H && c0 + 32 <= p.W;
         if (b != cur_b) {
             cur_b = b;
             const half8* wb = reinterpret_cast<const half8*>(p.wpk) + (long)b * 9 * KC * 64;
@@ -146,13 +169,18 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
             for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) areg[tp][kc] = wb[((tp * KC + kc) * 2 + half) * 32 + l31];
+            __builtin_amdgcn_s_waitcnt(kVm0);      // once per sample; keeps the wait out of the common path
         }
-        const unsigned char* lx = smem + (it & 1) * G::buf_bytes + ((wave * 2) * IN_C + l31) * 32 + half * 16;
+        const unsigned char* lbuf = smem + (it & 1) * G::buf_total;
+        const unsigned char* lx = lbuf + ((wave * 2) * IN_C + l31) * 32 + half * 16;
+        // accumulators start at bias + noise (the tile's noise values arrived with the tile)
         f32x16 acc[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const float nz = reinterpret_cast<const float*>(lbuf + G::noise_off)[(wave * 2 + nt) * 32 + l31];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[nt][r] = fmaf(nwg, nz, bias_g[r]);
+        }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             half8 bf[4][3];
@@ -168,26 +196,27 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[tp][kc], bf[nt + tp / 3][tp % 3], acc[nt], 0, 0, 0);
         }
         // ---- epilogue straight from the accumulators
-        const int px = c0 + l31;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int py = r0 + wave * 2 + nt;
             const bool ok = py < p.H && px < p.W;
-            float nz = 0.f;
-            if (p.noise && ok) nz = nw * p.noise[((long)(p.noise_batch > 1 ? b : 0) * p.H + py) * p.W + px];
             unsigned pk[8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
                 float o[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int r = 2 * r2 + e;
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[nt][r] + nz + bias_r[r];
-                    if (p.act == OODGAN_ACT_LRELU) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
-                    o[e] = m < p.M ? v : 0.f;
+                    const float v = acc[nt][2 * r2 + e];
+                    o[e] = LRELU ? fmaxf(v, 0.2f * v) : v;
                 }
-                half2v h;
+                if (p.M < 32) {          // partial channel block: keep the padding channels at zero
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * r2 + e;
+                        if ((r & 3) + 8 * (r >> 2) + 4 * half >= p.M) o[e] = 0.f;
+                    }
+                }
+                half2v h;                 // round-to-nearest-even pair conversion (v_cvt_pk_f16_f32 on gfx950)
                 h[0] = (_Float16)o[0];
                 h[1] = (_Float16)o[1];
                 pk[r2] = __builtin_bit_cast(unsigned, h);
@@ -198,7 +227,7 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
                 // lanes 0-31 hold channels {0-3, 8-11} of the block, lanes 32-63 {4-7, 12-15}: complete the halves
                 auto s0 = __builtin_amdgcn_permlane32_swap(pk[cb * 4 + 0], pk[cb * 4 + 2], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(pk[cb * 4 + 1], pk[cb * 4 + 3], false, false);
-                if (ok) {
+                if (ok && !(p.flags & 2)) {
                     uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     p.y[((long)b * MC + cb) * p.yd.plane + ((long)(py + 1) * p.yd.Wp + (px + 1)) * 2 + half] = v;
                 }
@@ -207,9 +236,219 @@ __global__ __launch_bounds__(256) void modconv_f16_kernel(const MCArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Strip kernel (32 input channels): one workgroup walks DOWN a 32-pixel-wide strip of the image, so the two halo
+// rows a tile shares with its upper neighbour are already in LDS — every input row is fetched once per strip.
+//   LDS ring of 32 image rows x [kc 2][34 records][32 B] (2176 B per row) = 4 groups of 8 rows; group g holds the
+//   rows r' in [8g, 8g+8), r' = (padded row) - (first padded row of the segment) - 2, so tile t needs the last two
+//   rows of group t-1 and all of group t.  Groups are fetched two ahead (3 x 17 KB in flight per workgroup).
+//   Inside a row the two 16-byte halves of record c are stored swapped when (c>>3)&1: with 32-byte records the
+//   ds_read_b128 lane groups would otherwise hit every bank twice.  The swap is done for free by the per-lane
+//   SOURCE address of the LDS-DMA.
+constexpr int RG_ROW_BYTES = 2 * IN_C * 32;          // 2176
+constexpr int RG_GROUP_SLOTS = 8 * RG_ROW_BYTES / 16;  // 1088 = 17 pieces
+constexpr int RG_PIECES = 17;
+constexpr int RG_RING_BYTES = 32 * RG_ROW_BYTES;      // 69632
+constexpr int RG_NOISE_OFF = RG_RING_BYTES;           // 4 x 1 KiB noise tiles
+constexpr int RG_SMEM = RG_RING_BYTES + 4096;
+
+struct StripArgs {
+    MCArgs m;
+    int seg_tiles;        // tiles per work item (a strip is cut into ceil(tiles_y/seg_tiles) segments)
+    int nseg;
+};
+
+template <bool LRELU>
+__global__ __launch_bounds__(256) void modconv_f16_strip_kernel(const StripArgs sa) {
+    const MCArgs& p = sa.m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // ---- work item: (b, segment, strip column); neighbouring columns go to the same XCD and run together
+    int w = blockIdx.x;
+    {
+        const int total = gridDim.x, xcd = w & 7, idx = w >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = w % p.tiles_x;
+    const int seg = (w / p.tiles_x) % sa.nseg;
+    const int b = w / (p.tiles_x * sa.nseg);
+    const int t0 = seg * sa.seg_tiles;
+    const int n = min(sa.seg_tiles, p.tiles_y - t0);
+    const int c0 = tx * 32;
+    const int R0 = 8 * t0;                                  // first image row = first padded row of the segment
+
+    // ---- epilogue constants (see modconv_f16_kernel)
+    const float gain = LRELU ? kSqrt2 : 1.f;
+    float bias_g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        bias_g[r] = (p.bias && m < p.M) ? gain * p.bias[m] : 0.f;
+    }
+    const float nwg = p.noise ? gain * (p.noise_w ? p.noise_w[0] : 1.f) : 0.f;
+    const int MC = (p.M + 15) / 16;
+    const float* nzb = (p.noise ? p.noise : reinterpret_cast<const float*>(p.x)) + (long)(p.noise_batch > 1 ? b : 0) * p.H * p.W;
+
+    // ---- weights: the whole per-sample tensor in registers
+    half8 areg[9][2];
+    {
+        const half8* wb = reinterpret_cast<const half8*>(p.wpk) + (long)b * 9 * 2 * 64;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) areg[tp][kc] = wb[((tp * 2 + kc) * 2 + half) * 32 + l31];
+    }
+
+    // ---- per-lane DMA source offsets inside a group (bytes relative to the group's first row at column c0)
+    // piece pc = wave + 4*i (i < 5; only wave 0 has a fifth piece)
+    unsigned xoff[5];
+    int xrow[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int P = (wave + 4 * i) * 64 + lane;
+        if (P >= RG_GROUP_SLOTS) P = RG_GROUP_SLOTS - 1;
+        const int row = P / 136, q = P % 136;
+        const int kc = q / 68, c2 = q % 68;
+        const int c = c2 >> 1, s = (c2 & 1) ^ ((c >> 3) & 1);
+        xrow[i] = row;
+        xoff[i] = (unsigned)(((long)kc * p.xd.plane + ((long)row * p.xd.Wp + c) * 2 + s) * 16);
+    }
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + ((long)b * 2 * p.xd.plane + (long)c0 * 2) * 16;
+    const long row_bytes = (long)p.xd.Wp * 32;
+    const int npc = wave == 0 ? 5 : 4;
+
+    auto dma_group = [&](int g) {            // g in [0, n): rows R0 + 2 + 8g .. +7 (padded), ring group g & 3
+        const int gg = min(g, n - 1);        // past the end: re-fetch the last group into a dead ring group
+        const unsigned char* base = xb + (long)(R0 + 2 + 8 * gg) * row_bytes;
+        unsigned char* dst = smem + (g & 3) * (8 * RG_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xoff[i]),
+                                             (lds_void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xoff[4]),
+                                             (lds_void*)(dst + 16 * 1024), 16, 0, 0);
+        // noise of tile g: each wave its own two rows, one dword per lane, clamped inside the image
+        const int ny = min(R0 + 8 * gg + wave * 2 + half, p.H - 1), nx = min(c0 + l31, p.W - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nzb + (long)ny * p.W + nx),
+                                         (lds_void*)(smem + RG_NOISE_OFF + (g & 3) * 1024 + wave * 256), 4, 0, 0);
+    };
+
+    constexpr int kVm0 = 0x0F70;
+    __builtin_amdgcn_s_waitcnt(kVm0);        // weights, bias: retired here, never inside the loop
+    {   // prologue: the two halo rows above the first tile (ring rows 30,31 = tail of group "-1"), then groups 0, 1
+        const int Rm = R0 + 2 - 8;           // first padded row of group -1 (may be negative: clamp per lane)
+        unsigned char* dst = smem + 3 * (8 * RG_ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i == 4 && wave != 0) break;
+            const int rr = max(Rm + xrow[i], 0) - (Rm + xrow[i]);       // rows above the image -> row 0 (never used)
+            const unsigned char* src = xb + (long)Rm * row_bytes + xoff[i] + (long)rr * row_bytes;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+        dma_group(0);
+        dma_group(1);
+    }
+
+    // lane-constant parts of the LDS read addresses (with the half swap) and of the store offsets
+    unsigned lrd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) lrd[kx] = (kx + l31) * 32 + ((half ^ (((kx + l31) >> 3) & 1)) << 4);
+    unsigned lst[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) lst[nt] = ((unsigned)((wave * 2 + nt + 1) * p.yd.Wp + l31 + 1) * 2 + half) * 16;
+    unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + ((long)b * MC * p.yd.plane + ((long)R0 * p.yd.Wp + c0) * 2) * 16;
+    const long yrow8 = (long)p.yd.Wp * 32 * 8, ycb = p.yd.plane * 16;
+    const bool col_full = c0 + 32 <= p.W && MC == 2 && (p.flags & 1);
+    const int px = c0 + l31;
+    int ragged = 3;                           // bit0/bit1: one of the last two tiles did not issue its 4 stores
+
+    for (int t = 0; t < n; ++t) {
+        // group t (issued two iterations ago) must have landed.  Memory operations retire in issue order; behind it
+        // there may be: the stores of tile t-2 (4), group t+1 with its noise (npc+1), the stores of tile t-1 (4).
+        if (t == 0) {
+            if (wave == 0) __builtin_amdgcn_s_waitcnt(0x0F76); else __builtin_amdgcn_s_waitcnt(0x0F75);
+        } else if (ragged) {
+            __builtin_amdgcn_s_waitcnt(kVm0);
+        } else {
+            if (wave == 0) __builtin_amdgcn_s_waitcnt(0x0F7E); else __builtin_amdgcn_s_waitcnt(0x0F7D);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (!(p.flags & 4)) dma_group(t + 2);
+        const bool full = col_full && R0 + 8 * t + 8 <= p.H;
+        ragged = ((ragged << 1) | (full ? 0 : 1)) & 3;
+        if (t == 0) ragged |= 2;             // tile -1 issued no stores: iteration 1 cannot use the counted wait
+
+        const unsigned char* nzl = smem + RG_NOISE_OFF + (t & 3) * 1024;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float nz = reinterpret_cast<const float*>(nzl)[(wave * 2 + nt) * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = fmaf(nwg, nz, bias_g[r]);
+        }
+        unsigned rbase[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) rbase[rr] = ((8 * t + 30 + 2 * wave + rr) & 31) * RG_ROW_BYTES;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            half8 bf[4][3];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    bf[rr][kx] = *reinterpret_cast<const half8*>(smem + rbase[rr] + kc * (IN_C * 32) + lrd[kx]);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[tp][kc], bf[nt + tp / 3][tp % 3], acc[nt], 0, 0, 0);
+        }
+        unsigned char* yt = yb + (long)t * yrow8;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int py = R0 + 8 * t + wave * 2 + nt;
+            const bool ok = py < p.H && px < p.W;
+            unsigned pk[8];
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                float o[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = acc[nt][2 * r2 + e];
+                    o[e] = LRELU ? fmaxf(v, 0.2f * v) : v;
+                }
+                if (p.M < 32) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * r2 + e;
+                        if ((r & 3) + 8 * (r >> 2) + 4 * half >= p.M) o[e] = 0.f;
+                    }
+                }
+                half2v h;
+                h[0] = (_Float16)o[0];
+                h[1] = (_Float16)o[1];
+                pk[r2] = __builtin_bit_cast(unsigned, h);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                if (cb >= MC) break;
+                auto s0 = __builtin_amdgcn_permlane32_swap(pk[cb * 4 + 0], pk[cb * 4 + 2], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(pk[cb * 4 + 1], pk[cb * 4 + 3], false, false);
+                if (ok && !(p.flags & 2))
+                    *reinterpret_cast<uint4*>(yt + cb * ycb + lst[nt]) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        }
+    }
+}
+
 // per-sample packed weights: out[b][tap][kc][half][m 32][8 f16], value demod[b,m]*scale*W[m,k,tap]*s[b,k]
 __global__ __launch_bounds__(256) void modconv_f16_pack_kernel(const float* __restrict__ w, const float* __restrict__ style,
-                                                               int style_stride, float scale, int demodulate,
+                                                               int style_stride, float scale, int demodulate, float gain,
                                                                half8* __restrict__ out, int B, int M, int K, int KC) {
     __shared__ float dm[32];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -236,7 +475,7 @@ __global__ __launch_bounds__(256) void modconv_f16_pack_kernel(const float* __re
         for (int j = 0; j < 8; ++j) {
             const int k = kc * 16 + hf * 8 + j;
             float f = 0.f;
-            if (m < M && k < K) f = dm[m] * scale * w[((long)m * K + k) * 9 + tp] * s[k];
+            if (m < M && k < K) f = gain * dm[m] * scale * w[((long)m * K + k) * 9 + tp] * s[k];
             v[j] = (_Float16)f;
         }
         out[(long)b * n + u] = v;
@@ -304,11 +543,11 @@ extern "C" long oodgan_modconv_f16_wbytes(int B, int M, int K) {
 }
 
 extern "C" int oodgan_modconv_f16_pack(const float* weight, const float* style, int style_stride, float scale, int demodulate,
-                                       void* wpk, int B, int M, int K, void* stream) {
+                                       int act, void* wpk, int B, int M, int K, void* stream) {
     OODGAN_REQUIRE(weight && style && wpk && B > 0, "modconv_f16_pack: bad args");
     OODGAN_REQUIRE(M >= 1 && M <= 32 && K >= 1 && K <= 32, "modconv_f16: supports up to 32 -> 32 channels (got %d -> %d)", K, M);
     hipLaunchKernelGGL(modconv_f16_pack_kernel, dim3(B), dim3(256), 0, as_stream(stream), weight, style, style_stride, scale,
-                       demodulate, reinterpret_cast<half8*>(wpk), B, M, K, (K + 15) / 16);
+                       demodulate, act == OODGAN_ACT_LRELU ? kSqrt2 : 1.f, reinterpret_cast<half8*>(wpk), B, M, K, (K + 15) / 16);
     return check_launch("modconv_f16_pack");
 }
 
@@ -327,6 +566,9 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
     p.tiles_x = (W + 31) / 32;
     p.xd = hform_dims(K, H, W);
     p.yd = hform_dims(M, H, W);
+    static const int no_vm4 = getenv("OODGAN_F16_NO_VM4") ? atoi(getenv("OODGAN_F16_NO_VM4")) : 0;
+    static const int ablate = getenv("OODGAN_F16_ABLATE") ? atoi(getenv("OODGAN_F16_ABLATE")) : 0;   // debug: 2 no stores, 4 no loads
+    p.flags = (no_vm4 ? 0 : 1) | ablate;
     const long T = (long)p.tiles_x * p.tiles_y * B;
     OODGAN_REQUIRE(T < (1L << 31), "modconv_f16: too many tiles");
     static int num_cu = 0;
@@ -341,22 +583,51 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
     }
     static const int force_bpc = getenv("OODGAN_F16_BLOCKS_PER_CU") ? atoi(getenv("OODGAN_F16_BLOCKS_PER_CU")) : 0;
     const int KC = (K + 15) / 16;
-#define OODGAN_LAUNCH(KC_)                                                                                              \
+#define OODGAN_LAUNCH(KC_, LR_)                                                                                            \
     {                                                                                                                   \
-        constexpr int sm = 2 * Geo<KC_>::buf_bytes;                                                                     \
+        constexpr int sm = 2 * Geo<KC_>::buf_total;                                                                     \
         static int occ = 0;                                                                                             \
         if (!occ) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_f16_kernel<KC_>),                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_f16_kernel<KC_, LR_>),                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, sm);                                  \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, modconv_f16_kernel<KC_>, 256, sm) != hipSuccess || occ < 1) \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, modconv_f16_kernel<KC_, LR_>, 256, sm) != hipSuccess || occ < 1) \
                 occ = 1;                                                                                                \
         }                                                                                                               \
+        static const bool dbg = getenv("OODGAN_DEBUG") != nullptr;                                                     \
+        if (dbg) fprintf(stderr, "modconv_f16: occupancy %d blocks/CU, %d CUs, smem %d\n", occ, num_cu, sm);            \
         long g = (long)num_cu * (force_bpc ? force_bpc : occ);                                                          \
         g = (g + 7) / 8 * 8;                                                                                            \
         if (g > T) g = T;                                                                                               \
-        hipLaunchKernelGGL((modconv_f16_kernel<KC_>), dim3((unsigned)g), dim3(256), sm, as_stream(stream), p);          \
+        hipLaunchKernelGGL((modconv_f16_kernel<KC_, LR_>), dim3((unsigned)g), dim3(256), sm, as_stream(stream), p);          \
     }
-    if (KC == 2) OODGAN_LAUNCH(2) else OODGAN_LAUNCH(1)
+    const bool lr = act == OODGAN_ACT_LRELU;
+    static const int no_strip = getenv("OODGAN_F16_NO_STRIP") ? atoi(getenv("OODGAN_F16_NO_STRIP")) : 0;
+    if (KC == 2 && !no_strip) {
+        // strips of 32 columns; cut into segments only when there are fewer strips than ~2 workgroups per CU
+        StripArgs sa;
+        sa.m = p;
+        const long strips = (long)B * p.tiles_x;
+        int nseg = (int)((2L * num_cu + strips - 1) / strips);
+        if (nseg < 1) nseg = 1;
+        int seg_tiles = (p.tiles_y + nseg - 1) / nseg;
+        if (seg_tiles < 4) seg_tiles = p.tiles_y < 4 ? p.tiles_y : 4;
+        static const int force_seg = getenv("OODGAN_F16_SEG_TILES") ? atoi(getenv("OODGAN_F16_SEG_TILES")) : 0;
+        if (force_seg > 0) seg_tiles = force_seg < p.tiles_y ? force_seg : p.tiles_y;
+        sa.seg_tiles = seg_tiles;
+        sa.nseg = (p.tiles_y + seg_tiles - 1) / seg_tiles;
+        const long nblk = strips * sa.nseg;
+        OODGAN_REQUIRE(nblk < (1L << 31), "modconv_f16: grid too large");
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_f16_strip_kernel<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, RG_SMEM),
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&modconv_f16_strip_kernel<false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, RG_SMEM), true);
+        (void)once;
+        if (lr) hipLaunchKernelGGL((modconv_f16_strip_kernel<true>), dim3((unsigned)nblk), dim3(256), RG_SMEM, as_stream(stream), sa);
+        else hipLaunchKernelGGL((modconv_f16_strip_kernel<false>), dim3((unsigned)nblk), dim3(256), RG_SMEM, as_stream(stream), sa);
+        return check_launch("modconv_f16_strip");
+    }
+    if (KC == 2) { if (lr) OODGAN_LAUNCH(2, true) else OODGAN_LAUNCH(2, false) }
+    else { if (lr) OODGAN_LAUNCH(1, true) else OODGAN_LAUNCH(1, false) }
 #undef OODGAN_LAUNCH
     return check_launch("modconv_f16");
 }

@@ -313,7 +313,7 @@ def to_hform(x, out=None):
     return out
 
 
-def modconv_f16_pack(weight, style, demodulate=True):
+def modconv_f16_pack(weight, style, demodulate=True, act='none'):
     """Per-sample modulated (+demodulated) f16 weights of ModulatedConv2d (model.py:236-241) in MFMA fragment order.
     weight (M,K,3,3) or (1,M,K,3,3) fp32 master, style (B,K) fp32 (already through the modulation EqualLinear)."""
     weight = _dev(weight).reshape(weight.shape[-4:])
@@ -322,13 +322,16 @@ def modconv_f16_pack(weight, style, demodulate=True):
     B = style.shape[0]
     wpk = torch.empty(_lib.lib().oodgan_modconv_f16_wbytes(B, M, K) // 2, dtype=torch.float16, device=weight.device)
     check(_lib.lib().oodgan_modconv_f16_pack(_p(weight), _p(style), style.stride(0), 1.0 / math.sqrt(K * 9), int(demodulate),
-                                             _p(wpk), B, M, K, _stream()), 'modconv_f16_pack')
-    return wpk, M, K
+                                             _F16_ACT[act], _p(wpk), B, M, K, _stream()), 'modconv_f16_pack')
+    return wpk, M, K, act
 
 
-def modconv_f16(x, packed, noise=None, noise_w=None, bias=None, act='none', out=None):
+_F16_ACT = {'none': ACT_NONE, 'lrelu': ACT_LRELU}
+
+
+def modconv_f16(x, packed, noise=None, noise_w=None, bias=None, out=None):
     """fp16 modulated 3x3 conv + noise + bias + activation on H-form activations (32 -> 32 channels class)."""
-    wpk, M, K = packed
+    wpk, M, K, act = packed       # the activation is fixed at pack time (its gain is folded into the weights)
     assert isinstance(x, HForm) and x.C == K
     if out is None:
         out = HForm(x.B, M, x.H, x.W, x.buf.device)
@@ -338,7 +341,7 @@ def modconv_f16(x, packed, noise=None, noise_w=None, bias=None, act='none', out=
         nb = noise.shape[0]
         assert noise.numel() == nb * x.H * x.W and nb in (1, x.B)
     check(_lib.lib().oodgan_modconv_f16(_p(x), _p(wpk), _p(noise), nb, _p(_opt(noise_w, 'noise_w')), _p(_opt(bias, 'bias')),
-                                        {'none': ACT_NONE, 'lrelu': ACT_LRELU}[act], _p(out), x.B, K, M, x.H, x.W, _stream()), 'modconv_f16')
+                                        _F16_ACT[act], _p(out), x.B, K, M, x.H, x.W, _stream()), 'modconv_f16')
     return out
 
 

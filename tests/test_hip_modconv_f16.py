@@ -41,8 +41,8 @@ def test_modconv_f16_vs_oracle(B, K, M, H, W, noise_batch, act):
     x, wgt, s, noise, bias, nw, ref = _case(B, K, M, H, W, 7 + B + H, noise_batch, act)
     xh = ops.to_hform(x.to(dev))
     assert torch.equal(xh.to_nchw().cpu(), x)                     # layout round trip is exact
-    packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev))
-    out = ops.modconv_f16(xh, packed, None if noise is None else noise.to(dev), nw.to(dev), bias.to(dev), act)
+    packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev), act=act)
+    out = ops.modconv_f16(xh, packed, None if noise is None else noise.to(dev), nw.to(dev), bias.to(dev))
     y = out.to_nchw().cpu()
     scale = max(1.0, ref.abs().max().item())
     err = (y - ref).abs()
@@ -66,8 +66,8 @@ def test_modconv_f16_is_deterministic_and_persistent_grid_covers_all_tiles():
     s = 1 + 0.3 * torch.randn(B, K, generator=g)
     xh = ops.to_hform(x.to(dev))
     packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev))
-    y1 = ops.modconv_f16(xh, packed, act='none').to_nchw()
-    y2 = ops.modconv_f16(xh, packed, act='none').to_nchw()
+    y1 = ops.modconv_f16(xh, packed).to_nchw()
+    y2 = ops.modconv_f16(xh, packed).to_nchw()
     assert torch.equal(y1, y2)
     ref = R.modulated_conv2d(x[:, :, :64, :96], s, wgt, torch.eye(K) * math.sqrt(K), torch.zeros(K))
     # interior of the crop (its last row/col see different neighbours than the full image)
@@ -75,5 +75,5 @@ def test_modconv_f16_is_deterministic_and_persistent_grid_covers_all_tiles():
     assert err <= 4e-3 * max(1.0, ref.abs().max().item())
     # linearity in the activations (size-independent property): conv(2x) == 2 conv(x) exactly in f16/f32 arithmetic
     x2 = ops.to_hform((2 * x).to(dev))
-    y3 = ops.modconv_f16(x2, packed, act='none').to_nchw()
+    y3 = ops.modconv_f16(x2, packed).to_nchw()
     assert (y3 - 2 * y1).abs().max().item() <= 2.0 ** -23      # equal up to f16 subnormal rounding of tiny outputs

@@ -22,15 +22,15 @@ def run(B=16, C=32, H=1024, iters=50, warmup=5):
     noise = torch.randn(B, 1, H, H, generator=g).to(dev)
     bias = (0.1 * torch.randn(C, generator=g)).to(dev)
     nw = torch.tensor([0.1], device=dev)
-    packed = ops.modconv_f16_pack(wgt, s)
+    packed = ops.modconv_f16_pack(wgt, s, act='lrelu')
     out = ops.HForm(B, C, H, H, dev)
     for _ in range(warmup):
-        ops.modconv_f16(xh, packed, noise, nw, bias, 'lrelu', out=out)
+        ops.modconv_f16(xh, packed, noise, nw, bias, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.modconv_f16(xh, packed, noise, nw, bias, 'lrelu', out=out)
+        ops.modconv_f16(xh, packed, noise, nw, bias, out=out)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
