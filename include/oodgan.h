@@ -179,6 +179,28 @@ int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const floa
 int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
                            int C, int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
+/* ---- fused backward producers (csrc/bwd_producers.hip): oodgan_act_bwd_fused's arithmetic (autograd of NoiseInjection +
+ * FusedLeakyReLU merged with the ToRGB branch, src/ops/StyleGAN/model.py:283-292,343-372) written directly as the
+ * S-form input of the next matrix kernel — value g_pre * dscale[b,c] * mul2[1] — so the fp32 g_pre never goes to HBM.
+ * mul2 = {unscale, scale} is the range scale measured on the PREVIOUS optimisation step; part_max receives this pass's
+ * per-block max|g_pre| and oodgan_absmax_scale_check (a) sets flag bit0 if max*scale left [2^-8, 2^15), bit1 on a
+ * non-finite value, (b) overwrites state = {2^-e, 2^e} with max*2^e in [512,1024) for the next step.
+ * part_r / part_t: (B,C,nparts) partial sums to be reduced with oodgan_reduce_parts. */
+int oodgan_act_bwd_sform_nparts(int H, int W);
+int oodgan_act_bwd_sform(const float* g_feat, const float* out, const float* noise, int noise_batch, const float* noise_w,
+                         const float* bias, const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride,
+                         float rgb_scale, const float* dscale, int dscale_stride, const float* mul2, void* ys, float* part_r,
+                         float* part_t, float* part_max, int B, int C, int H, int W, void* stream);
+/* same, followed by blur^T (adjoint of Blur(pad=(1,1)), src/ops/op/upfirdn2d.py:115-120) and the phase split of
+ * oodgan_blurT_to_sform_phases; H,W = size of the up-conv's INPUT, the tensors are (B,C,2H,2W). */
+int oodgan_act_bwd_blurT_nparts(int H, int W);
+int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                                      const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
+                                      const float* s_rgb, int s_rgb_stride, float rgb_scale, const float* dscale,
+                                      int dscale_stride, const float* mul2, const float* kernel, void* out_phases,
+                                      float* part_r, float* part_t, float* part_max, int B, int C, int H, int W, void* stream);
+int oodgan_absmax_scale_check(const float* part, long n, float* state, int* flag, void* stream);
+
 /* ---- fp16 modulated conv for the high-resolution, low-channel layers (BASELINE.json configs[4] / SURVEY §8 C5) ----
  * ModulatedConv2d.forward, plain 3x3 (src/ops/StyleGAN/model.py:233-245,268-274) + NoiseInjection + FusedLeakyReLU
  * (model.py:283-292,343-350) in f16 operands / fp32 accumulate / f16 result.  Activations live in "H-form":

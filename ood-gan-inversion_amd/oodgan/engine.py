@@ -77,6 +77,14 @@ class GeneratorEngine:
             rgb(f'to_rgbs.{j}', cout, res, i + 2)
             cin, i = cout, i + 2
         self.layers = layers
+        # conv -> following up-conv pairs: the conv's epilogue can write the up-conv's S-form input directly
+        import os
+        self.ys_handoff = os.environ.get('OODGAN_YS_HANDOFF', '0') != '0'
+        # fused backward producers (csrc/bwd_producers.hip): per-layer range scale carried from one W+ step to the next
+        self.fused_bwd = os.environ.get('OODGAN_FUSED_BWD', '1') != '0'
+        self.bwd_state, self.bwd_flag = {}, None
+        styled = [L for L in layers if L.kind != 'rgb']
+        self.next_styled = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'conv' and b.kind == 'up'}
         src = 'input'
         for L in layers:            # producer of every layer's input feature
             L.src = src
@@ -110,7 +118,18 @@ class GeneratorEngine:
         import copy
         e = copy.copy(self)
         e.saved = None
+        e.bwd_state, e.bwd_flag = {}, None
         return e
+
+    def reset_bwd_state(self):
+        """Forget the carried range scales (new images / new batch): the next backward measures them exactly."""
+        self.bwd_state = {}
+        if self.bwd_flag is not None:
+            self.bwd_flag.zero_()
+
+    def bwd_scale_violated(self):
+        """True if a carried range scale left the exact window in any step since reset_bwd_state() (host sync)."""
+        return self.bwd_flag is not None and int(self.bwd_flag.item()) != 0
 
     # ------------------------------------------------------------------ forward
     def styles(self, latent):
@@ -131,6 +150,7 @@ class GeneratorEngine:
         x = self.const_input.expand(B, -1, -1, -1).contiguous()
         acts['input'] = x
         skip, out = None, x
+        pending = None
         i = 1
         for L in self.layers:
             s = _Cols(s_all, L.row, L.cin)
@@ -143,15 +163,24 @@ class GeneratorEngine:
                 if self.sform:
                     # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA
                     xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
+                    Ln = self.next_styled.get(L.name) if self.ys_handoff else None
+                    ys = ys_scale = None
+                    if Ln is not None:      # the epilogue also emits the next up-conv's input (x * its style) in S-form
+                        ys = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device, tag=1)
+                        ys_scale = _Cols(s_all, Ln.row, Ln.cin)
                     out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
-                                      noise_weight=L.noise_w, act=ACT_LRELU)
+                                      noise_weight=L.noise_w, act=ACT_LRELU, ys=ys, ys_scale=ys_scale)
+                    pending = ys
                     del xs
                 else:
                     out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
                                       noise_weight=L.noise_w, act=ACT_LRELU)
             else:
                 if self.sform:
-                    xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
+                    if pending is not None:
+                        xs, pending = pending, None
+                    else:
+                        xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
                     z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
                     del xs
                 else:
@@ -182,10 +211,13 @@ class GeneratorEngine:
                                      ops._stream()), 'demod_fwd')
 
     # ------------------------------------------------------------------ backward (w.r.t. latents only)
-    def backward(self, gimg, grad_scale=1.0):
+    def backward(self, gimg, grad_scale=1.0, carry_scale=False):
         """gimg (B,3,size,size), already multiplied by ``grad_scale`` -> dL/dlatent (B,n_latent,S).
         Needs forward(..., save=True).  Every step is linear in the gradient, so a power-of-two
-        grad_scale is undone exactly at the end."""
+        grad_scale is undone exactly at the end.
+        ``carry_scale`` (set by the W+ loop): from the second call on, the activation gradients are produced directly
+        in the matrix kernels' input layout with the range scale measured on the previous call (fused producers);
+        the caller must start a new sequence with reset_bwd_state() and check bwd_scale_violated() at its end."""
         from ._lib import lib, check
         import ctypes
         sv = self.saved
@@ -206,22 +238,47 @@ class GeneratorEngine:
                 prev_rgb = L
                 continue
             out, x_in, nz = acts[L.name], acts[L.src], noises[L.noise_idx]
-            if prev_rgb is not None:
-                Rg = prev_rgb
-                g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
-                                                            _Cols(s_all, Rg.row, Rg.cin), want_scale=True)
-                gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
-                prev_rgb = None
+            s = _Cols(s_all, L.row, L.cin)
+            d = _Cols(d_all, L.drow, L.cout)
+            Hd = x_in.shape[2]
+            carry = carry_scale and self.fused_bwd and self.sform and (L.kind == 'conv' or Hd >= 4)
+            st = self.bwd_state.get(L.name) if carry else None
+            Rg, prev_rgb = prev_rgb, None
+            rgb_kw = {} if Rg is None else dict(g_rgb=gskip[L.res], w_rgb=Rg.w_rgb, s_rgb=_Cols(s_all, Rg.row, Rg.cin))
+            if st is not None:
+                # fused producer: g_pre goes straight into the next matrix kernel's input layout, scaled with the
+                # range scale measured on the previous step (verified below, after the conv has consumed it)
+                if L.kind == 'conv':
+                    gin = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device)
+                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, **rgb_kw)
+                else:
+                    gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
+                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin,
+                                                              blur_kernel=self.k4x4_flip, **rgb_kw)
+                mul2, g_pre = st, None
             else:
-                g_pre, rsum, _, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, want_scale=True)
+                if Rg is not None:
+                    g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
+                                                                _Cols(s_all, Rg.row, Rg.cin), want_scale=True)
+                else:
+                    g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, want_scale=True)
+                if carry:
+                    self.bwd_state[L.name] = mul2            # exact this step; carried to the next one
+                    if self.bwd_flag is None:
+                        self.bwd_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if Rg is not None:
+                gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
             # demodulation gradient
             check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
                                          ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
                                          ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
                                          ops._stream()), 'demod_bwd')
-            s = _Cols(s_all, L.row, L.cin)
-            d = _Cols(d_all, L.drow, L.cout)
-            if L.kind == 'conv':
+            if st is not None:
+                dx, dot = ops.conv3x3(gin, L.wpk_bwd, L.cin, CONV_S1 if L.kind == 'conv' else CONV_S2, out_scale=s, dotx=x_in,
+                                      in_mul2=mul2)
+                del gin
+                ops.absmax_scale_check(part_m, st, self.bwd_flag)
+            elif L.kind == 'conv':
                 if self.sform:
                     gs_ = ops.to_sform(g_pre, d, mul2, out=ops.sform_scratch(B, L.cout, g_pre.shape[2], g_pre.shape[3], self.device))
                     dx, dot = ops.conv3x3(gs_, L.wpk_bwd, L.cin, CONV_S1, out_scale=s, dotx=x_in, in_mul2=mul2)
@@ -229,7 +286,6 @@ class GeneratorEngine:
                 else:
                     dx, dot = ops.conv3x3(g_pre, L.wpk_bwd, L.cin, CONV_S1, in_scale=d, out_scale=s, dotx=x_in, in_mul2=mul2)
             else:
-                Hd = x_in.shape[2]
                 if self.sform and Hd >= 4:
                     # blur^T, demodulation scale, range scale, phase split and f16 split in one pass, then the
                     # stride-2 conv as stride-1 taps on the four parity images
@@ -280,12 +336,14 @@ class WPlusInverter:
             parts[-1]['v'] = torch.zeros_like(parts[-1]['w'])
         gmul = ops.loss_scale_for(target.numel() // B)
         engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
+        for eng in engines:
+            eng.reset_bwd_state()
         dev = w0.device
 
         def one_step(pr, eng):
             img = eng.forward(pr['w'], pr['noises'], save=True)
             loss, gimg = ops.mse_loss_grad(img, pr['target'], gmul)
-            g = eng.backward(gimg, gmul)
+            g = eng.backward(gimg, gmul, carry_scale=True)
             ops.adam_step_dev(pr['w'], g, pr['m'], pr['v'], pr['t'], self.lr, self.betas, self.eps)
             return loss
 
@@ -325,6 +383,12 @@ class WPlusInverter:
             pr['w'].record_stream(cur)
             pr['lbuf'].record_stream(cur)
         self._graphs = graphs               # keep the graphs (and their private pools) alive until the next call
+        if any(eng.bwd_scale_violated() for eng in engines):
+            self.engine.fused_bwd = False       # clones copy the flag
+            try:
+                return self.invert(target, w0, noises, steps, False, streams, use_graph)
+            finally:
+                self.engine.fused_bwd = True
         return w, losses
 
     def _invert_one(self, target, w0, noises, steps, return_trajectory):
@@ -333,15 +397,23 @@ class WPlusInverter:
         v = torch.zeros_like(w)
         losses, traj = [], []
         gmul = ops.loss_scale_for(target.numel() // target.shape[0])
+        self.engine.reset_bwd_state()
         for t in range(1, steps + 1):
             img = self.engine.forward(w, noises, save=True)
             loss, gimg = ops.mse_loss_grad(img, target, gmul)
-            g = self.engine.backward(gimg, gmul)
+            g = self.engine.backward(gimg, gmul, carry_scale=True)
             ops.adam_step(w, g, m, v, t, self.lr, self.betas, self.eps)
             losses.append(loss)
             if return_trajectory:
                 traj.append(w.clone())
         self.engine.saved = None
+        if self.engine.bwd_scale_violated():
+            # a gradient range moved by more than the format's head-room within one step: redo with per-step exact scales
+            self.engine.fused_bwd = False
+            try:
+                return self._invert_one(target, w0, noises, steps, return_trajectory)
+            finally:
+                self.engine.fused_bwd = True
         if return_trajectory:
             return w, torch.stack(losses), traj
         return w, torch.stack(losses)

@@ -286,6 +286,48 @@ def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
     return out
 
 
+def _reduce_parts(part, rows, npart):
+    out = torch.empty(part.shape[0], part.shape[1], device=part.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_reduce_parts(_p(part), _p(out), rows, npart, 0, _stream()), 'reduce')
+    return out
+
+
+def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, g_rgb=None, w_rgb=None, s_rgb=None,
+                     blur_kernel=None):
+    """Fused backward producer (include/oodgan.h): the gradient of bias+noise+lrelu*sqrt2 (+ToRGB branch) of ``out``
+    written straight into ``dst`` — an ``SForm`` (plain conv layer) or, with ``blur_kernel``, an ``SFormPhases``
+    (up-conv layer: blur^T and phase split fused) — scaled by ``dscale[b,c] * mul2[1]``.
+    Returns (r[B,C], t[B,C] or None, part_max) — ``part_max`` goes to ``absmax_scale_check``."""
+    o = _dev(out, 'out')
+    B, C, H, W = o.shape
+    L = _lib.lib()
+    up = blur_kernel is not None
+    npart = L.oodgan_act_bwd_blurT_nparts(H // 2, W // 2) if up else L.oodgan_act_bwd_sform_nparts(H, W)
+    KC = (C + 15) // 16
+    part_r = torch.empty(B, C, npart, device=o.device, dtype=torch.float32)
+    part_t = torch.empty(B, C, npart, device=o.device, dtype=torch.float32) if g_rgb is not None else None
+    part_m = torch.empty(B * KC * npart, device=o.device, dtype=torch.float32)
+    nz = _opt(noise, 'noise')
+    common = [_p(_opt(g_feat, 'g_feat')), _p(o), _p(nz), 1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
+              _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')), _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)),
+              _p(_opt(s_rgb, 's_rgb')), 0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(_dev(dscale, 'dscale')),
+              dscale.shape[1], _p(mul2)]
+    if up:
+        check(L.oodgan_act_bwd_blurT_sform_phases(*common, _p(_dev(blur_kernel)), _p(dst), _p(part_r), _p(part_t), _p(part_m),
+                                                  B, C, H // 2, W // 2, _stream()), 'act_bwd_blurT_sform_phases')
+    else:
+        check(L.oodgan_act_bwd_sform(*common, _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()),
+              'act_bwd_sform')
+    r = _reduce_parts(part_r, B * C, npart)
+    t = _reduce_parts(part_t, B * C, npart) if part_t is not None else None
+    return r, t, part_m
+
+
+def absmax_scale_check(part_max, state, flag):
+    """state {unscale, scale} (device, 2 floats) is verified against this pass's maxima and replaced by the next scale."""
+    check(_lib.lib().oodgan_absmax_scale_check(_p(part_max), part_max.numel(), _p(state), _p(flag), _stream()), 'absmax_scale_check')
+
+
 class HForm:
     """f16 channel-blocked activations of the fp16 modulated conv (include/oodgan.h, oodgan_modconv_f16)."""
     __slots__ = ('buf', 'B', 'C', 'H', 'W')

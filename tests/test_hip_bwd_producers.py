@@ -1,0 +1,133 @@
+"""Fused backward producers (csrc/bwd_producers.hip): the activation gradient written directly in the next matrix
+kernel's input layout must be the SAME data as the two-pass path (act_bwd_fused -> to_sform / blurT_to_sform_phases)
+when both use the same power-of-two range scale; the carried-scale W+ loop must follow the exact-scale loop."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oodgan import synth  # noqa: E402
+
+
+def _same_sform(a, b, tol=5e-7):
+    """S-form buffers as values hi+lo (records of 4 x 8 f16: hi, hi, lo, lo).  The fused kernel and the two-pass path
+    may contract their fp32 expressions differently (1 ulp of fp32), so compare values, plus exact zeros in the same
+    places (border / padding)."""
+    va = a.data.view(-1, 4, 8).float()
+    vb = b.data.view(-1, 4, 8).float()
+    va, vb = va[:, :2] + va[:, 2:], vb[:, :2] + vb[:, 2:]
+    assert torch.equal(va == 0, vb == 0)
+    assert (va - vb).abs().max().item() <= tol * vb.abs().max().item()
+
+
+def _inputs(B, C, H, W, seed, rgb, dev):
+    t = lambda name, shape, *a: synth.normal(name, shape, seed, *a).to(dev)
+    out = t('out', (B, C, H, W))
+    g_feat = t('g', (B, C, H, W), 3e-4)
+    noise = t('nz', (B, 1, H, W))
+    nw = torch.tensor([0.1], device=dev)
+    bias = t('bias', (C,), 0.1)
+    d = t('d', (B, C), 0.2, 1.0).abs()
+    kw = {}
+    if rgb:
+        kw = dict(g_rgb=t('grgb', (B, 3, H, W), 1e-3), w_rgb=t('wrgb', (3, C)), s_rgb=t('srgb', (B, C), 0.3, 1.0))
+    return out, g_feat, noise, nw, bias, d, kw
+
+
+@pytest.mark.parametrize('B,C,H,W,rgb', [(2, 32, 16, 16, True), (1, 48, 8, 20, False), (2, 16, 4, 4, True), (1, 24, 40, 36, True)])
+def test_act_bwd_sform_matches_two_pass(B, C, H, W, rgb):
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    out, g_feat, noise, nw, bias, d, kw = _inputs(B, C, H, W, 11 + C, rgb, dev)
+    if rgb:
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True)
+    else:
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True)
+    ref = ops.to_sform(g_pre, d, mul2)
+    dst = ops.SForm(B, C, H, W, dev)
+    state = mul2.clone()
+    r1, t1, part_m = ops.act_bwd_producer(out, g_feat, noise, nw, bias, d, state, dst, **kw)
+    _same_sform(dst, ref)
+    scale = max(1e-30, r0.abs().max().item())
+    assert (r1 - r0).abs().max().item() <= 1e-5 * scale
+    if rgb:
+        assert (t1 - t0).abs().max().item() <= 1e-5 * max(1e-30, t0.abs().max().item())
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.absmax_scale_check(part_m, state, flag)
+    assert flag.item() == 0 and torch.equal(state, mul2)        # same maximum -> same next scale, inside the window
+    # a scale that is off by 2^20 must be reported
+    bad = mul2 * torch.tensor([2.0 ** -20, 2.0 ** 20], device=dev)
+    ops.absmax_scale_check(part_m, bad, flag)
+    assert flag.item() == 1 and torch.equal(bad, mul2)
+
+
+@pytest.mark.parametrize('B,C,H,W,rgb', [(2, 32, 8, 8, False), (1, 16, 4, 4, False), (1, 40, 18, 32, True)])
+def test_act_bwd_blurT_phases_matches_two_pass(B, C, H, W, rgb):
+    """H,W = input size of the up-conv; the activations are (2H,2W)."""
+    from oodgan import ops
+    from oracle import ref_cpu as R
+    dev = torch.device('cuda:0')
+    out, g_feat, noise, nw, bias, d, kw = _inputs(B, C, 2 * H, 2 * W, 5 + C, rgb, dev)
+    k = torch.flip(R.make_kernel([1, 3, 3, 1]) * 4.0, [0, 1]).contiguous().to(dev)
+    if rgb:
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True)
+    else:
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True)
+    ref = ops.blurT_to_sform_phases(g_pre, k, d, mul2)
+    dst = ops.SFormPhases(B, C, H, W, dev)
+    r1, t1, part_m = ops.act_bwd_producer(out, g_feat, noise, nw, bias, d, mul2.clone(), dst, blur_kernel=k, **kw)
+    _same_sform(dst, ref)
+    assert (r1 - r0).abs().max().item() <= 1e-5 * max(1e-30, r0.abs().max().item())
+    if rgb:
+        assert (t1 - t0).abs().max().item() <= 1e-5 * max(1e-30, t0.abs().max().item())
+    state, flag = mul2.clone(), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.absmax_scale_check(part_m, state, flag)
+    assert flag.item() == 0 and torch.equal(state, mul2)
+
+
+def test_wplus_loop_with_carried_scales_follows_exact_loop():
+    """6 W+ steps with the fused producers (scale carried from step t-1) vs the per-step exact scales."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    dev = torch.device('cuda:0')
+    size, B = 64, 2
+    P = synth.generator_state(size, seed=5)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    target = synth.make_images(size, B, seed=9).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    w0 = synth.make_latents(size, B, seed=14).to(dev)
+    assert eng.fused_bwd
+    w1, l1 = WPlusInverter(eng).invert(target, w0, noises, steps=6)
+    assert len(eng.bwd_state) == 2 * (6 - 2) + 1 and not eng.bwd_scale_violated()
+    eng.fused_bwd = False
+    w2, l2 = WPlusInverter(eng).invert(target, w0, noises, steps=6)
+    eng.fused_bwd = True
+    assert (l1 - l2).abs().max().item() <= 1e-5 * l2.abs().max().item()
+    dw = (w1 - w2).abs()
+    assert (dw < 1e-4).float().mean().item() > 0.999, dw.max().item()
+
+
+def test_violated_scale_falls_back_to_exact_loop():
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    dev = torch.device('cuda:0')
+    size, B = 32, 1
+    P = synth.generator_state(size, seed=5)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    target = synth.make_images(size, B, seed=9).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    w0 = synth.make_latents(size, B, seed=14).to(dev)
+    inv = WPlusInverter(eng)
+    w_ref, l_ref = inv.invert(target, w0, noises, steps=4)
+    # sabotage: after the first backward, blow one carried scale out of range
+    orig, calls = eng.backward, {'n': 0}
+
+    def sabotaged(gimg, gs=1.0, carry_scale=False):
+        g = orig(gimg, gs, carry_scale=carry_scale)
+        calls['n'] += 1
+        if calls['n'] == 1 and eng.fused_bwd:
+            next(iter(eng.bwd_state.values())).mul_(torch.tensor([2.0 ** 30, 2.0 ** -30], device=dev))
+        return g
+    eng.backward = sabotaged
+    w, l = inv.invert(target, w0, noises, steps=4)
+    del eng.backward
+    assert calls['n'] == 8                                   # 4 flagged steps + the 4 steps of the exact re-run
+    assert torch.isfinite(w).all() and (l - l_ref).abs().max().item() <= 1e-5 * l_ref.abs().max().item()
