@@ -1,0 +1,124 @@
+"""``python -m oodgan.cli --opt options/test/E4E_Face_test.yml`` — the harness around the accelerated path, with the
+YAML option surface of the reference's run_ood_faceGAN_inversion.py:
+
+    name, save_dir, directions_dir
+    datasets: {<name>: {dataroot, editing: {direction, intensity}}}
+    network_g: {type: ood_faceGAN_e4e, ...constructor kwargs...}
+    path: {pretrain_network_g, param_key_g, strict_load_g}
+    metrics: {psnr|ssim|lpips|identity: {crop_border, test_y_channel[, model_path]}}
+
+Per image it does what the reference does (read -> [-1,1] RGB 1024² -> model -> save inversion + mask strip -> metrics)
+and, when the build-defined block ``inversion: {wplus_steps: N, lr: 0.01, batch: B}`` (or ``--wplus-steps``) is
+present, refines the encoder latents with N W+ Adam steps before the OOD forward.
+Only ``ood_faceGAN_e4e`` is registered (ReStyle / FeatureStyle are §8f N4).  LPIPS / identity need third-party
+weights that do not ship: they are reported as skipped."""
+import argparse
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from . import imgio
+from .arch import ood_faceGAN_e4e
+from .io import load_direction, load_network_g
+
+model_dict = {'ood_faceGAN_e4e': ood_faceGAN_e4e}
+IMG_EXT = ('.png', '.jpg', '.jpeg', '.bmp', '.webp')
+
+
+def load_model(opts):
+    """run_ood_faceGAN_inversion.py:30-47."""
+    opt = dict(opts['network_g'])
+    model_type = opt.pop('type')
+    if model_type not in model_dict:
+        raise KeyError(f'network_g.type {model_type!r} is not available in this build (have: {sorted(model_dict)})')
+    model = model_dict[model_type](**opt)
+    p = opts.get('path') or {}
+    if p.get('pretrain_network_g'):
+        load_network_g(model, p['pretrain_network_g'], p.get('param_key_g', 'params_ema'), p.get('strict_load_g', False))
+    return model
+
+
+def load_files_from_path(opt, directions_dir=None):
+    """:49-62 — sorted by file name without its extension."""
+    root = opt['dataroot']
+    names = [n for n in os.listdir(root) if n.lower().endswith(IMG_EXT)]
+    names = sorted(names, key=lambda x: x[:-4])
+    return [os.path.join(root, n) for n in names], load_direction(directions_dir, opt.get('editing'))
+
+
+def evaluate(gt_bgr, res_bgr, metrics, opt):
+    """:89-126 — gt and result as [0,255] BGR arrays."""
+    if metrics is None:
+        metrics = {'psnr': [], 'ssim': [], 'lpips': [], 'identity': []}
+    opt = opt or {}
+    if opt.get('psnr'):
+        metrics['psnr'].append(imgio.calculate_psnr(gt_bgr, res_bgr, crop_border=opt['psnr']['crop_border'],
+                                                    test_y_channel=opt['psnr']['test_y_channel']))
+    if opt.get('ssim'):
+        metrics['ssim'].append(imgio.calculate_ssim(gt_bgr, res_bgr, crop_border=opt['ssim']['crop_border'],
+                                                    test_y_channel=opt['ssim']['test_y_channel']))
+    return metrics
+
+
+def run(opts, wplus_steps=None, log=None):
+    log = log or logging.getLogger('oodgan.cli')
+    if not torch.cuda.is_available():
+        raise RuntimeError('oodgan.cli needs a ROCm GPU: the HIP path has no CPU fallback')
+    model = load_model(opts).cuda().eval()
+    directions_dir = opts.get('directions_dir', './directions')
+    save_root = os.path.join(opts.get('save_dir', './results'), opts['name'])
+    inv = opts.get('inversion') or {}
+    steps = int(wplus_steps if wplus_steps is not None else inv.get('wplus_steps', 0))
+    lr = float(inv.get('lr', 0.01))
+    size = model.generator.size
+    summary = {}
+    for name, dopt in opts['datasets'].items():
+        files, direction = load_files_from_path(dopt, directions_dir)
+        save_dir = os.path.join(save_root, name)
+        model.delta_latent.data += direction.cuda()
+        times, metrics = [], None
+        for f in files:
+            bgr = imgio.imread(f).astype(np.float64)
+            x = imgio.image_to_input(bgr, size).cuda()
+            with torch.no_grad():
+                t0 = time.time()
+                out = model.invert(x, steps=steps, lr=lr)[0] if steps > 0 else model(x)[0]
+                torch.cuda.synchronize()
+                times.append(time.time() - t0)
+            res = imgio.tensor2img(out, rgb2bgr=True, min_max=(-1, 1))
+            imgio.imwrite(os.path.join(save_dir, 'inversion', os.path.basename(f)), res)
+            gt = bgr if bgr.shape[0] == size else imgio.tensor2img(x, rgb2bgr=True, min_max=(-1, 1)).astype(np.float64)
+            metrics = evaluate(gt, res, metrics, opts.get('metrics'))
+            masks = imgio.extract_masks(model.aligns, size)
+            if masks is not None:
+                imgio.imwrite(os.path.join(save_dir, 'masks', os.path.basename(f)), masks)
+        model.delta_latent.data -= direction.cuda()
+        mean = lambda v: float(np.mean(v)) if v else float('nan')
+        summary[name] = dict(n=len(files), time=mean(times), psnr=mean((metrics or {}).get('psnr')),
+                             ssim=mean((metrics or {}).get('ssim')))
+        log.info('Average process time of %s: %f', name, summary[name]['time'])
+        log.info('Average PSNR of %s: %f', name, summary[name]['psnr'])
+        log.info('Average SSIM of %s: %f', name, summary[name]['ssim'])
+        for skipped in ('lpips', 'identity'):
+            if (opts.get('metrics') or {}).get(skipped):
+                log.info('%s of %s: skipped (third-party weights not available in this build)', skipped.upper(), name)
+    return summary
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--opt', default=None, required=True, help='the testing option file path')
+    ap.add_argument('--wplus-steps', type=int, default=None, help='W+ refinement steps per image (default: inversion.wplus_steps or 0)')
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format='%(asctime)s - %(name)s - %(levelname)s - %(message)s')
+    with open(args.opt) as f:
+        opts = yaml.load(f, Loader=yaml.FullLoader)
+    return run(opts, args.wplus_steps)
+
+
+if __name__ == '__main__':
+    main()
