@@ -179,6 +179,14 @@ int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const floa
 int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
                            int C, int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
+/* ---- fused forward producer (csrc/fwd_producers.hip): the tail of the up-sampling StyledConv in one pass —
+ * Blur(pad=(1,1)) of the transposed-conv output z (B,C,2H+1,in_pitch) (model.py:72-88,199-205), + noise_w*noise + bias,
+ * leaky-ReLU*sqrt2 (model.py:283-292,343-350) -> y (B,C,2H,2W) fp32 AND, if ys != NULL, the S-form of y*ys_scale[b,c]
+ * (the next conv's input).  in_pitch %% 4 == 0 (what oodgan_conv3x3 mode T2 produces). */
+int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale, int ys_scale_stride,
+                          const float* bias, const float* noise, int noise_batch, const float* noise_w, int act, int B, int C,
+                          int H, int W, int in_pitch, void* stream);
+
 /* ---- fused backward producers (csrc/bwd_producers.hip): oodgan_act_bwd_fused's arithmetic (autograd of NoiseInjection +
  * FusedLeakyReLU merged with the ToRGB branch, src/ops/StyleGAN/model.py:283-292,343-372) written directly as the
  * S-form input of the next matrix kernel — value g_pre * dscale[b,c] * mul2[1] — so the fp32 g_pre never goes to HBM.

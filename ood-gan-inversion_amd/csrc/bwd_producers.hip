@@ -153,13 +153,7 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
 #pragma unroll
         for (int cp = 0; cp < 8; ++cp) {
             const float v0 = lst[(2 * cp) * kP1Pitch + lp], v1 = lst[(2 * cp + 1) * kP1Pitch + lp];
-            half2v h, l;
-            h[0] = (_Float16)v0;
-            h[1] = (_Float16)v1;
-            l[0] = (_Float16)(v0 - (float)h[0]);
-            l[1] = (_Float16)(v1 - (float)h[1]);
-            hp[cp] = __builtin_bit_cast(unsigned, h);
-            lq[cp] = __builtin_bit_cast(unsigned, l);
+            split_pair(v0, v1, hp[cp], lq[cp]);
         }
         const int y = (int)(p / a.W), x = (int)(p % a.W);
         uint4* rec = ys + sform_unit(yd, b, kc, y, x, 0);

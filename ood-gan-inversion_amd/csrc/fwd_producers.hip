@@ -1,0 +1,189 @@
+// Forward "producer" of the up-sampling StyledConv tail: Blur(pad=(1,1)) of the transposed-conv output
+// (reference src/ops/StyleGAN/model.py:72-88,199-205 -> upfirdn2d(kernel*4, pad=(1,1))), NoiseInjection, bias and
+// leaky-ReLU*sqrt2 (model.py:283-292,343-350) in ONE pass that writes
+//   * y  (B,C,2H,2W) fp32 — the saved activation (needed by the W+ backward and by ToRGB), and
+//   * ys — the same values times the next layer's style, split hi/lo, as that conv's S-form input (sform.hpp),
+// so the separate fp32 -> S-form conversion pass (one more read of the tensor) disappears.
+// Tiling as blurT_sp_kernel: block = (b, 16-channel block) x an 8 x 64 output tile; the input tile goes to LDS once,
+// the 4x4 FIR runs from registers (rank-1 kernels as a vertical then a horizontal pass), results are exchanged through
+// LDS so that one thread owns one pixel with its 16 channels.
+#include "common.hpp"
+#include "sform.hpp"
+#include <cstdint>
+
+using namespace oodgan;
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int FT_R = 11, FT_C = 72;      // input tile: rows Y0-1..Y0+9, cols X0-4..X0+67
+
+struct BlurArgs {
+    const float* z;          // (B,C,Hz,pitch), Hz = 2H+1, valid width Wz = 2W+1
+    const float* kern;       // 4x4 (the op flips it, as upfirdn2d does)
+    float* y;                // (B,C,2H,2W)
+    uint4* ys;               // S-form of y*ys_scale or null
+    const float* ys_scale;   // (B,*) stride ys_scale_stride or null
+    const float* bias;       // (C) or null
+    const float* noise;      // (noise_batch,2H,2W) or null
+    const float* noise_w;
+    int ys_scale_stride, noise_batch, act;
+    int B, C, H, W, pitch;
+    int tiles_x, tiles_y;
+    SDims yd;
+};
+
+__global__ __launch_bounds__(256) void blur_act_sform_kernel(const BlurArgs a) {
+    __shared__ __attribute__((aligned(16))) float lin[16 * FT_R * FT_C];     // reused as lst[16][512]
+    __shared__ float kf[16];
+    __shared__ float ksep[9];
+    __shared__ float cb[2][16];          // bias, ys_scale of the block's channels
+    const int tid = threadIdx.x;
+    int w;
+    {   // contiguous chunk of the tile list per XCD (halo rows/cols are the neighbours' interiors)
+        const int total = gridDim.x, bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = w % a.tiles_x; w /= a.tiles_x;
+    const int ty = w % a.tiles_y; w /= a.tiles_y;
+    const int KC = a.yd.KC;
+    const int kc = w % KC, b = w / KC;
+    const int Y0 = ty * 8, X0 = tx * 64;
+    const int Ho = 2 * a.H, Wo = 2 * a.W, Hz = Ho + 1, Wz = Wo + 1;
+    if (tid < 16) {
+        kf[tid] = a.kern[15 - tid];          // flipped: kf[ky][kx] = k[3-ky][3-kx]
+        const int c = kc * 16 + tid;
+        cb[0][tid] = (a.bias && c < a.C) ? a.bias[c] : 0.f;
+        cb[1][tid] = (a.ys_scale && c < a.C) ? a.ys_scale[(long)b * a.ys_scale_stride + c] : (c < a.C ? 1.f : 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool ok = kf[0] != 0.f;
+        for (int i = 0; i < 4 && ok; ++i) { ksep[i] = kf[i * 4] / kf[0]; ksep[4 + i] = kf[i]; }
+        for (int i = 0; i < 16 && ok; ++i) ok = fabsf(ksep[i >> 2] * ksep[4 + (i & 3)] - kf[i]) <= 1e-7f * fabsf(kf[0]);
+        ksep[8] = ok ? 1.f : 0.f;
+    }
+    // ---- A: 16 threads per channel sweep its 11 x 18 float4 tile (zero outside the (2H+1)x(2W+1) support)
+    {
+        const int ch = tid >> 4, c = kc * 16 + ch;
+        const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
+        for (int e = tid & 15; e < FT_R * (FT_C / 4); e += 16) {
+            const int c4 = e % (FT_C / 4), r = e / (FT_C / 4);
+            const int gy = Y0 - 1 + r, gx = X0 - 4 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < a.C && gy >= 0 && gy < Hz && gx >= 0 && gx + 3 < a.pitch) {
+                v = *reinterpret_cast<const float4*>(zp + (long)gy * a.pitch + gx);
+                if (gx + 3 >= Wz) {          // columns between the valid width and the pitch are not defined
+                    if (gx + 0 >= Wz) v.x = 0.f;
+                    if (gx + 1 >= Wz) v.y = 0.f;
+                    if (gx + 2 >= Wz) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(lin + (ch * FT_R + r) * FT_C + 4 * c4) = v;
+        }
+    }
+    __syncthreads();
+    // ---- B: out[Y][X] = sum kf[ky][kx] z[Y-1+ky][X-1+kx]; thread = (channel, output row, half row of 32)
+    const int ch = tid >> 4, tq = tid & 15;
+    const int yrow = tq >> 1, xh = tq & 1;
+    float o[32];
+    if (ksep[8] != 0.f) {
+        float tmp[36];
+#pragma unroll
+        for (int j = 0; j < 36; ++j) tmp[j] = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            // tile column of X-1 is (X - X0) + 3; read the aligned pairs from column 32*xh + 2 and skip one
+            const float2* row = reinterpret_cast<const float2*>(lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 2);
+            const float kv = ksep[aa];
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const float2 v = row[j];
+                tmp[2 * j] += kv * v.x;
+                tmp[2 * j + 1] += kv * v.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            o[j] = ksep[4] * tmp[j + 1] + ksep[5] * tmp[j + 2] + ksep[6] * tmp[j + 3] + ksep[7] * tmp[j + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const float* row = lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 3;
+            float win[35];
+#pragma unroll
+            for (int j = 0; j < 35; ++j) win[j] = row[j];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float kv = kf[aa * 4 + bb];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) o[j] += kv * win[j + bb];
+            }
+        }
+    }
+    __syncthreads();
+    float* lst = lin;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) lst[ch * 512 + yrow * 64 + 32 * xh + j] = o[j];
+    __syncthreads();
+    // ---- C: thread = pixel: noise + bias + activation for its 16 channels, fp32 store per channel plane, one record
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const long HWo = (long)Ho * Wo;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int pos = tid + rep * 256;
+        const int Y = Y0 + (pos >> 6), X = X0 + (pos & 63);
+        if (Y >= Ho || X >= Wo) continue;
+        const float nz = a.noise ? nw * a.noise[(long)(a.noise_batch > 1 ? b : 0) * HWo + (long)Y * Wo + X] : 0.f;
+        float* yp = a.y + ((long)b * a.C + kc * 16) * HWo + (long)Y * Wo + X;
+        unsigned hp[8], lp[8];
+#pragma unroll
+        for (int cp = 0; cp < 8; ++cp) {
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int cc = 2 * cp + e;
+                float t = lst[cc * 512 + pos] + nz + cb[0][cc];
+                if (a.act == OODGAN_ACT_LRELU) t = (t > 0.f ? t : 0.2f * t) * kSqrt2;
+                if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
+                v[e] = t * cb[1][cc];
+            }
+            split_pair(v[0], v[1], hp[cp], lp[cp]);
+        }
+        if (a.ys) {
+            uint4* rec = a.ys + sform_unit(a.yd, b, kc, Y, X, 0);
+            rec[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            rec[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+            rec[2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            rec[3] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
+                                     int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
+                                     const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, void* stream) {
+    OODGAN_REQUIRE(z && kernel && y && B > 0 && C > 0 && H > 0 && W > 0, "blur_act_sform: bad args");
+    OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "blur_act_sform: noise_batch");
+    OODGAN_REQUIRE(act == OODGAN_ACT_NONE || act == OODGAN_ACT_LRELU, "blur_act_sform: act must be none or lrelu");
+    if (in_pitch == 0) in_pitch = 2 * W + 1;
+    OODGAN_REQUIRE(in_pitch >= 2 * W + 1 && (in_pitch % 4) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0,
+                   "blur_act_sform: the input needs 16-byte aligned rows (pitch %% 4 == 0)");
+    BlurArgs a;
+    a.z = z; a.kern = kernel; a.y = y; a.ys = reinterpret_cast<uint4*>(ys); a.ys_scale = ys_scale;
+    a.ys_scale_stride = ys_scale_stride; a.bias = bias; a.noise = noise; a.noise_w = noise_w; a.noise_batch = noise_batch;
+    a.act = act; a.B = B; a.C = C; a.H = H; a.W = W; a.pitch = in_pitch;
+    a.tiles_x = (2 * W + 63) / 64;
+    a.tiles_y = (2 * H + 7) / 8;
+    a.yd = sform_dims(C, 2 * H, 2 * W);
+    const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
+    OODGAN_REQUIRE(nb < (1L << 31), "blur_act_sform: grid too large");
+    hipLaunchKernelGGL(blur_act_sform_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);
+    return check_launch("blur_act_sform");
+}

@@ -34,4 +34,22 @@ __host__ __device__ inline long sform_unit(const SDims& d, int b, int kc, int y,
     return (((long)b * d.KC + kc) * d.Hp + (y + 1)) * (long)d.Wp * 4 + (long)(x + 1) * 4 + s;
 }
 
+typedef _Float16 oodgan_half2v __attribute__((ext_vector_type(2)));
+
+// hi/lo split of two values into packed f16 pairs.  The lo halves MUST be derived from the hi bits that are actually
+// stored: the packed conversion (v_cvt_pk_f16_f32) and the scalar one the compiler would otherwise re-derive
+// `(float)(_Float16)v` with do not agree on exact ties, which would leave hi and lo inconsistent (error 2^-11).
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+    oodgan_half2v h;
+    h[0] = (_Float16)v0;
+    h[1] = (_Float16)v1;
+    hi = __builtin_bit_cast(unsigned, h);
+    asm volatile("" : "+v"(hi));            // opaque: the halves below are read back from the packed register
+    const oodgan_half2v hb = __builtin_bit_cast(oodgan_half2v, hi);
+    oodgan_half2v l;
+    l[0] = (_Float16)(v0 - (float)hb[0]);
+    l[1] = (_Float16)(v1 - (float)hb[1]);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 }  // namespace oodgan

@@ -84,6 +84,8 @@ class GeneratorEngine:
         self.fused_bwd = os.environ.get('OODGAN_FUSED_BWD', '1') != '0'
         self.bwd_state, self.bwd_flag = {}, None
         styled = [L for L in layers if L.kind != 'rgb']
+        self.fused_fwd = os.environ.get('OODGAN_FUSED_FWD', '1') != '0'
+        self.next_conv = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b.kind == 'conv'}
         self.next_styled = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'conv' and b.kind == 'up'}
         src = 'input'
         for L in layers:            # producer of every layer's input feature
@@ -162,7 +164,10 @@ class GeneratorEngine:
             if L.kind == 'conv':
                 if self.sform:
                     # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA
-                    xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
+                    if pending is not None:     # written by the up-conv tail that produced `out`
+                        xs, pending = pending, None
+                    else:
+                        xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
                     Ln = self.next_styled.get(L.name) if self.ys_handoff else None
                     ys = ys_scale = None
                     if Ln is not None:      # the epilogue also emits the next up-conv's input (x * its style) in S-form
@@ -191,6 +196,13 @@ class GeneratorEngine:
                     raw = ops.blur_bias_act(z, self.k4x4, (1, 1), act=False, in_hw=(H2, H2), in_pitch=z.shape[3])
                     cond = cond_hook(cond_layers.index(lat_idx), raw, latent[:, lat_idx], nz, L.noise_w)
                     out = ops.bias_noise_act(cond, L.bias, nz, L.noise_w)
+                elif self.sform and self.fused_fwd and L.name in self.next_conv:
+                    # blur + noise + bias + activation, and the following conv's S-form input (x its style), in one pass
+                    Ln = self.next_conv[L.name]
+                    Hi = out.shape[2]
+                    pending = ops.sform_scratch(B, L.cout, 2 * Hi, 2 * Hi, self.device, tag=2)
+                    out = ops.blur_act_sform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True, ys=pending,
+                                             ys_scale=_Cols(s_all, Ln.row, Ln.cin))
                 else:
                     out = ops.blur_bias_act(z, self.k4x4, (1, 1), L.bias, nz, L.noise_w, act=True, in_hw=(H2, H2),
                                             in_pitch=z.shape[3])
@@ -328,12 +340,13 @@ class WPlusInverter:
         cuts = [(i * B) // streams for i in range(streams + 1)]
         parts = []
         for i, st in enumerate(side):
-            st.wait_stream(cur)
             sl = slice(cuts[i], cuts[i + 1])
             parts.append(dict(target=target[sl].contiguous(), w=w0[sl].detach().clone().contiguous(),
                               noises=[n[sl].contiguous() if n.shape[0] == B else n for n in noises], losses=[]))
             parts[-1]['m'] = torch.zeros_like(parts[-1]['w'])
             parts[-1]['v'] = torch.zeros_like(parts[-1]['w'])
+        for st in side:
+            st.wait_stream(cur)                 # AFTER the slices / clones above were enqueued on the caller's stream
         gmul = ops.loss_scale_for(target.numel() // B)
         engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
         for eng in engines:
@@ -349,8 +362,9 @@ class WPlusInverter:
 
         for i, st in enumerate(side):
             pr = parts[i]
-            pr['t'] = torch.zeros(1, dtype=torch.int32, device=dev)
-            pr['lbuf'] = torch.empty(steps, pr['w'].shape[0], device=dev, dtype=torch.float32)
+            with torch.cuda.stream(st):         # initialised on the stream that uses them
+                pr['t'] = torch.zeros(1, dtype=torch.int32, device=dev)
+                pr['lbuf'] = torch.empty(steps, pr['w'].shape[0], device=dev, dtype=torch.float32)
         # step 1 eagerly (also warms allocator pools / scratch buffers of every stream) ...
         for i, st in enumerate(side):
             with torch.cuda.stream(st):

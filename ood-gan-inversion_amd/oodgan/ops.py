@@ -286,6 +286,20 @@ def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
     return out
 
 
+def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys=None, ys_scale=None):
+    """Tail of the up-sampling StyledConv in one pass (include/oodgan.h, oodgan_blur_act_sform): z (B,C,2H+1,pitch) from
+    conv3x3(mode T2) -> y (B,C,2H,2W) and, into ``ys`` (an SForm), y*ys_scale for the next conv."""
+    z = _dev(z)
+    B, C = z.shape[0], z.shape[1]
+    y = torch.empty(B, C, 2 * H, 2 * W, device=z.device, dtype=torch.float32)
+    nz = _opt(noise, 'noise')
+    check(_lib.lib().oodgan_blur_act_sform(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
+                                           0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
+                                           1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
+                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _stream()), 'blur_act_sform')
+    return y
+
+
 def _reduce_parts(part, rows, npart):
     out = torch.empty(part.shape[0], part.shape[1], device=part.device, dtype=torch.float32)
     check(_lib.lib().oodgan_reduce_parts(_p(part), _p(out), rows, npart, 0, _stream()), 'reduce')

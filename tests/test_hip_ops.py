@@ -283,3 +283,34 @@ def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
         wpk2 = ops.pack_conv3x3(w2.to(dev), precision='f16s')
         z = ops.conv3x3(ys, wpk2, Co, ops.CONV_S1)
         close(z, F.conv2d(ref * s2[:, :, None, None], w2, padding=1), 2e-4)
+
+
+@pytest.mark.parametrize('B,C,H,W,act', [(2, 32, 8, 8, True), (1, 40, 9, 20, True), (1, 16, 4, 36, False)])
+def test_blur_act_sform_vs_two_pass_and_oracle(dev, B, C, H, W, act):
+    """Fused up-conv tail: y equals the oracle's blur + noise + bias + lrelu, and the S-form output equals
+    to_sform(y, next style)."""
+    from oodgan import ops
+    seed = 23 + C
+    Hz, Wz = 2 * H + 1, 2 * W + 1
+    pitch = (Wz + 3) // 4 * 4
+    z = synth.normal('z', (B, C, Hz, Wz), seed)
+    zp = torch.full((B, C, Hz, pitch), float('nan'))          # the pitch padding must never be read as data
+    zp[..., :Wz] = z
+    noise = synth.normal('nz', (B, 1, 2 * H, 2 * W), seed)
+    bias = synth.normal('b', (C,), seed, 0.2)
+    nw = torch.tensor([0.3])
+    s_next = synth.normal('s', (B, C), seed, 0.3, 1.0)
+    k = R.make_kernel([1, 3, 3, 1]) * 4.0
+    ref = R.upfirdn2d(z, k, pad=(1, 1)) + nw * noise
+    ref = R.fused_leaky_relu(ref, bias) if act else ref + bias.reshape(1, -1, 1, 1)
+    ys = ops.SForm(B, C, 2 * H, 2 * W, dev)
+    y = ops.blur_act_sform(zp.to(dev), k.to(dev), H, W, bias.to(dev), noise.to(dev), nw.to(dev), act=act, ys=ys,
+                           ys_scale=s_next.to(dev))
+    close(y, ref)
+    ref_s = ops.to_sform(y, s_next.to(dev))
+    assert torch.equal(ys.data, ref_s.data)
+    # non-separable kernel -> generic 16-tap path
+    k2 = k.clone()
+    k2[1, 2] += 0.37
+    y2 = ops.blur_act_sform(zp.to(dev), k2.to(dev), H, W, None, None, None, act=False)
+    close(y2, R.upfirdn2d(z, k2, pad=(1, 1)))
