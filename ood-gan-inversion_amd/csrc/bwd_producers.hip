@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
 // the up-conv's INPUT; all tensors of ActArgs are at (2H)x(2W).
 constexpr int BT_R = 11, BT_C = 72;
 
+template <bool RGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void act_bwd_blurT_sp_kernel(const ActArgs a, const float* __restrict__ kern,
                                                                uint4* __restrict__ outp, int H, int W, SPDims sp, int tiles_x,
                                                                int tiles_y) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool sep_ok = ksep[8] != 0.f;
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
-    const float* gr = a.g_rgb ? a.g_rgb + (long)b * 3 * HW : nullptr;
+    const float* gr = (RGB && a.g_rgb) ? a.g_rgb + (long)b * 3 * HW : nullptr;
     // ---- A: thread -> fixed channel ch = tid>>4, 16 threads sweep its 11 x 18 float4 tile
     const int gy0 = 2 * i0 - 2, gx0 = 2 * j0 - 4;
     float amax = 0.f;
@@ -220,42 +221,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float w0 = cst[0][ch], w1 = cst[1][ch], w2 = cst[2][ch], sr = cst[3][ch], bv = cst[4][ch];
         const long cbase = ((long)b * a.C + c) * HW;
         float acc_r = 0.f, acc_t = 0.f;
-        for (int e = tid & 15; e < BT_R * (BT_C / 4); e += 16) {
-            const int c4 = e % (BT_C / 4), r = e / (BT_C / 4);
-            const int gy = gy0 + r, gx = gx0 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < a.C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg) {
-                const long p = (long)gy * Wg + gx;
-                const float4 o4 = *reinterpret_cast<const float4*>(a.out + cbase + p);
-                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), nz = g4, r0 = g4, r1 = g4, r2 = g4;
-                if (a.g_feat) g4 = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
-                if (np) nz = *reinterpret_cast<const float4*>(np + p);
-                if (gr) {
-                    r0 = *reinterpret_cast<const float4*>(gr + p);
-                    r1 = *reinterpret_cast<const float4*>(gr + HW + p);
-                    r2 = *reinterpret_cast<const float4*>(gr + 2 * HW + p);
-                }
-                const float ov[4] = {o4.x, o4.y, o4.z, o4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, nzv[4] = {nz.x, nz.y, nz.z, nz.w};
-                const float r0v[4] = {r0.x, r0.y, r0.z, r0.w}, r1v[4] = {r1.x, r1.y, r1.z, r1.w}, r2v[4] = {r2.x, r2.y, r2.z, r2.w};
-                // every g pixel is reduced by exactly one block: the one whose 8x64 interior contains it
-                const bool own = gy >= 2 * i0 && gy < 2 * i0 + 8 && gx >= 2 * j0 && gx < 2 * j0 + 64;
-                float gp[4];
+        // loads are issued in two batches of 7 / 6 tile elements before anything depends on them (a load per iteration
+        // would serialise the fill into 13 HBM latencies)
+        constexpr int NE = (BT_R * (BT_C / 4) + 15) / 16;       // 13
+        constexpr int NB = RGB ? 3 : 5;                           // batch: NB elements x (3 or 6) float4 loads in flight
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float o = ov[j];
-                    const float t = w0 * r0v[j] + w1 * r1v[j] + w2 * r2v[j];
-                    const float g = gv[j] + sr * t;
-                    gp[j] = g * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
-                    if (own) {
-                        const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nzv[j] - bv;
-                        acc_r += gp[j] * ycv;
-                        acc_t += o * t;
-                        amax = fmaxf(amax, fabsf(gp[j]));
+        for (int k0 = 0; k0 < NE; k0 += NB) {
+            float4 o4[NB], g4[NB], nz4[NB], r04[RGB ? NB : 1], r14[RGB ? NB : 1], r24[RGB ? NB : 1];
+            bool okv[NB];
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) {
+                const int e = (tid & 15) + 16 * (k0 + kk);
+                const int c4 = e % (BT_C / 4), r = e / (BT_C / 4);
+                const int gy = gy0 + r, gx = gx0 + 4 * c4;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                o4[kk] = g4[kk] = nz4[kk] = z4;
+                if (RGB) r04[kk] = r14[kk] = r24[kk] = z4;
+                okv[kk] = k0 + kk < NE && e < BT_R * (BT_C / 4) && c < a.C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg;
+                if (okv[kk]) {
+                    const long p = (long)gy * Wg + gx;
+                    o4[kk] = *reinterpret_cast<const float4*>(a.out + cbase + p);
+                    if (a.g_feat) g4[kk] = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
+                    if (np) nz4[kk] = *reinterpret_cast<const float4*>(np + p);
+                    if (RGB && gr) {
+                        r04[kk] = *reinterpret_cast<const float4*>(gr + p);
+                        r14[kk] = *reinterpret_cast<const float4*>(gr + HW + p);
+                        r24[kk] = *reinterpret_cast<const float4*>(gr + 2 * HW + p);
                     }
                 }
-                v = make_float4(gp[0], gp[1], gp[2], gp[3]);
             }
-            *reinterpret_cast<float4*>(lin + (ch * BT_R + r) * BT_C + 4 * c4) = v;
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk) {
+                const int e = (tid & 15) + 16 * (k0 + kk);
+                if (k0 + kk >= NE || e >= BT_R * (BT_C / 4)) continue;
+                const int c4 = e % (BT_C / 4), r = e / (BT_C / 4);
+                const int gy = gy0 + r, gx = gx0 + 4 * c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (okv[kk]) {
+                    const float ov[4] = {o4[kk].x, o4[kk].y, o4[kk].z, o4[kk].w}, gv[4] = {g4[kk].x, g4[kk].y, g4[kk].z, g4[kk].w};
+                    const float nzv[4] = {nz4[kk].x, nz4[kk].y, nz4[kk].z, nz4[kk].w};
+                    constexpr int ri = RGB ? 1 : 0;
+                    const float4 q0 = RGB ? r04[kk * ri] : make_float4(0.f, 0.f, 0.f, 0.f), q1 = RGB ? r14[kk * ri] : q0, q2 = RGB ? r24[kk * ri] : q0;
+                    const float r0v[4] = {q0.x, q0.y, q0.z, q0.w}, r1v[4] = {q1.x, q1.y, q1.z, q1.w}, r2v[4] = {q2.x, q2.y, q2.z, q2.w};
+                    // every g pixel is reduced by exactly one block: the one whose 8x64 interior contains it
+                    const bool own = gy >= 2 * i0 && gy < 2 * i0 + 8 && gx >= 2 * j0 && gx < 2 * j0 + 64;
+                    float gp[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float o = ov[j];
+                        const float t = w0 * r0v[j] + w1 * r1v[j] + w2 * r2v[j];
+                        const float g = gv[j] + sr * t;
+                        gp[j] = g * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                        if (own) {
+                            const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nzv[j] - bv;
+                            acc_r += gp[j] * ycv;
+                            acc_t += o * t;
+                            amax = fmaxf(amax, fabsf(gp[j]));
+                        }
+                    }
+                    v = make_float4(gp[0], gp[1], gp[2], gp[3]);
+                }
+                *reinterpret_cast<float4*>(lin + (ch * BT_R + r) * BT_C + 4 * c4) = v;
+            }
         }
         // reduce over the 16 threads of the channel
 #pragma unroll
@@ -440,8 +467,12 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
     a.nparts = tiles_x * tiles_y;
     const long nb = (long)tiles_x * tiles_y * d.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "act_bwd_blurT: grid too large");
-    hipLaunchKernelGGL(act_bwd_blurT_sp_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, kernel,
-                       reinterpret_cast<uint4*>(out_phases), H, W, d, tiles_x, tiles_y);
+    if (g_rgb)
+        hipLaunchKernelGGL(act_bwd_blurT_sp_kernel<true>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, kernel,
+                           reinterpret_cast<uint4*>(out_phases), H, W, d, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(act_bwd_blurT_sp_kernel<false>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, kernel,
+                           reinterpret_cast<uint4*>(out_phases), H, W, d, tiles_x, tiles_y);
     return check_launch("act_bwd_blurT_sform_phases");
 }
 

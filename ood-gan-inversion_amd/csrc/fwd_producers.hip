@@ -34,7 +34,7 @@ struct BlurArgs {
     SDims yd;
 };
 
-__global__ __launch_bounds__(256) void blur_act_sform_kernel(const BlurArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur_act_sform_kernel(const BlurArgs a) {
     __shared__ __attribute__((aligned(16))) float lin[16 * FT_R * FT_C];     // reused as lst[16][512]
     __shared__ float kf[16];
     __shared__ float ksep[9];
@@ -68,20 +68,32 @@ __global__ __launch_bounds__(256) void blur_act_sform_kernel(const BlurArgs a) {
     {
         const int ch = tid >> 4, c = kc * 16 + ch;
         const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
-        for (int e = tid & 15; e < FT_R * (FT_C / 4); e += 16) {
+        // all loads of the sweep are issued before the first LDS store: one dependent load per iteration would make
+        // the tile fill a chain of 13 HBM latencies
+        constexpr int NE = (FT_R * (FT_C / 4) + 15) / 16;       // 13
+        float4 v[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = (tid & 15) + 16 * k;
             const int c4 = e % (FT_C / 4), r = e / (FT_C / 4);
             const int gy = Y0 - 1 + r, gx = X0 - 4 + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < a.C && gy >= 0 && gy < Hz && gx >= 0 && gx + 3 < a.pitch) {
-                v = *reinterpret_cast<const float4*>(zp + (long)gy * a.pitch + gx);
-                if (gx + 3 >= Wz) {          // columns between the valid width and the pitch are not defined
-                    if (gx + 0 >= Wz) v.x = 0.f;
-                    if (gx + 1 >= Wz) v.y = 0.f;
-                    if (gx + 2 >= Wz) v.z = 0.f;
-                    v.w = 0.f;
-                }
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < FT_R * (FT_C / 4) && c < a.C && gy >= 0 && gy < Hz && gx >= 0 && gx + 3 < a.pitch)
+                v[k] = *reinterpret_cast<const float4*>(zp + (long)gy * a.pitch + gx);
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = (tid & 15) + 16 * k;
+            if (e >= FT_R * (FT_C / 4)) continue;
+            const int c4 = e % (FT_C / 4), r = e / (FT_C / 4);
+            const int gx = X0 - 4 + 4 * c4;
+            if (gx + 3 >= Wz) {          // columns between the valid width and the pitch are not defined
+                if (gx + 0 >= Wz) v[k].x = 0.f;
+                if (gx + 1 >= Wz) v[k].y = 0.f;
+                if (gx + 2 >= Wz) v[k].z = 0.f;
+                v[k].w = 0.f;
             }
-            *reinterpret_cast<float4*>(lin + (ch * FT_R + r) * FT_C + 4 * c4) = v;
+            *reinterpret_cast<float4*>(lin + (ch * FT_R + r) * FT_C + 4 * c4) = v[k];
         }
     }
     __syncthreads();
@@ -90,24 +102,28 @@ __global__ __launch_bounds__(256) void blur_act_sform_kernel(const BlurArgs a) {
     const int yrow = tq >> 1, xh = tq & 1;
     float o[32];
     if (ksep[8] != 0.f) {
-        float tmp[36];
+        // two halves of 16 outputs: a 20-wide vertical pass each (keeps the live set at 32 + 20 registers)
 #pragma unroll
-        for (int j = 0; j < 36; ++j) tmp[j] = 0.f;
+        for (int hf = 0; hf < 2; ++hf) {
+            float tmp[20];
 #pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            // tile column of X-1 is (X - X0) + 3; read the aligned pairs from column 32*xh + 2 and skip one
-            const float2* row = reinterpret_cast<const float2*>(lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 2);
-            const float kv = ksep[aa];
+            for (int j = 0; j < 20; ++j) tmp[j] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const float2 v = row[j];
-                tmp[2 * j] += kv * v.x;
-                tmp[2 * j + 1] += kv * v.y;
+            for (int aa = 0; aa < 4; ++aa) {
+                // tile column of X-1 is (X - X0) + 3; read the aligned pairs from column 32*xh + 16*hf + 2 and skip one
+                const float2* row = reinterpret_cast<const float2*>(lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 16 * hf + 2);
+                const float kv = ksep[aa];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const float2 v = row[j];
+                    tmp[2 * j] += kv * v.x;
+                    tmp[2 * j + 1] += kv * v.y;
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
-            o[j] = ksep[4] * tmp[j + 1] + ksep[5] * tmp[j + 2] + ksep[6] * tmp[j + 3] + ksep[7] * tmp[j + 4];
+            for (int j = 0; j < 16; ++j)
+                o[16 * hf + j] = ksep[4] * tmp[j + 1] + ksep[5] * tmp[j + 2] + ksep[6] * tmp[j + 3] + ksep[7] * tmp[j + 4];
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 32; ++j) o[j] = 0.f;
