@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // loads are issued in two batches of 7 / 6 tile elements before anything depends on them (a load per iteration
         // would serialise the fill into 13 HBM latencies)
         constexpr int NE = (BT_R * (BT_C / 4) + 15) / 16;       // 13
-        constexpr int NB = RGB ? 3 : 5;                           // batch: NB elements x (3 or 6) float4 loads in flight
+        constexpr int NB = RGB ? 4 : 7;                           // batch: NB elements x (3 or 6) float4 loads in flight
 #pragma unroll
         for (int k0 = 0; k0 < NE; k0 += NB) {
             float4 o4[NB], g4[NB], nz4[NB], r04[RGB ? NB : 1], r14[RGB ? NB : 1], r24[RGB ? NB : 1];
@@ -310,21 +310,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float kv[4], kh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { kv[i] = ksep[3 - i]; kh[i] = ksep[4 + 3 - i]; }
-        float tmp[36];
+        // two halves of 16 outputs, a 20-wide vertical pass each (keeps the live set at 32 + 20 registers)
 #pragma unroll
-        for (int j = 0; j < 36; ++j) tmp[j] = 0.f;
+        for (int hf = 0; hf < 2; ++hf) {
+            float tmp[20];
 #pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const float2* row = reinterpret_cast<const float2*>(lin + (ch * BT_R + yrow + aa) * BT_C + 32 * xh + 2);
+            for (int j = 0; j < 20; ++j) tmp[j] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const float2 v = row[j];
-                tmp[2 * j] += kv[aa] * v.x;
-                tmp[2 * j + 1] += kv[aa] * v.y;
+            for (int aa = 0; aa < 4; ++aa) {
+                const float2* row = reinterpret_cast<const float2*>(lin + (ch * BT_R + yrow + aa) * BT_C + 32 * xh + 16 * hf + 2);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const float2 v = row[j];
+                    tmp[2 * j] += kv[aa] * v.x;
+                    tmp[2 * j + 1] += kv[aa] * v.y;
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) o[j] = kh[0] * tmp[j] + kh[1] * tmp[j + 1] + kh[2] * tmp[j + 2] + kh[3] * tmp[j + 3];
+            for (int j = 0; j < 16; ++j)
+                o[16 * hf + j] = kh[0] * tmp[j] + kh[1] * tmp[j + 1] + kh[2] * tmp[j + 2] + kh[3] * tmp[j + 3];
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 32; ++j) o[j] = 0.f;

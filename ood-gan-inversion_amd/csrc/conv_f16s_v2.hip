@@ -158,13 +158,16 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, const SConv& sc, f
     }
 }
 
-template <int MT, int NG>
+// CPS = K chunks fetched per stage.  Layers with few tiles (4x4 ... 16x16 images) put at most one workgroup on a CU, so
+// every stage costs a full DMA latency; they run as NG = 1, CPS = 2: half the stages, twice the bytes in flight.
+template <int MT, int NG, int CPS = 1>
 __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
                                                              const SConv sc) {
     constexpr int MB = 32 * MT;
     constexpr int WROWS = 36;
     constexpr int WPIECES = WROWS * MB * 16 / 1024;
-    constexpr int GB = group_bytes<MT>();
+    constexpr int STAGE = XBYTES + WROWS * MB * 16;
+    constexpr int GB = (STAGE * CPS > group_bytes<MT>()) ? STAGE * CPS : group_bytes<MT>();
     constexpr int XPW = (XPIECES + 3) / 4;          // x pieces per wave
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,17 +212,17 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
     const int nchunk = (a.K + CK - 1) / CK;
     const long wchunk = (long)WROWS * p.Mp;
 
-    auto dma_x = [&](int t) {
+    auto dma_x = [&](int t, int sub) {
         const uint4* base = xplane0 + (long)t * sc.xd.plane;
 #pragma unroll
         for (int i = 0; i < XPW; ++i) {
             const int pc = wave + 4 * i;
             if (pc < XPIECES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
-                                                 (lds_void*)(lx + pc * 1024), 16, 0, 0);
+                                                 (lds_void*)(lx + sub * STAGE + pc * 1024), 16, 0, 0);
         }
     };
-    auto dma_w = [&](int t) {
+    auto dma_w = [&](int t, int sub) {
 #pragma unroll
         for (int i = 0; i < (WPIECES + 3) / 4; ++i) {
             const int pc = wave + i * 4;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
                 const int row = u / MB, j = u % MB;
                 const uint4* src = wpk16 + (long)t * wchunk + (long)row * p.Mp + m0 + j;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (lds_void*)(lw + pc * 1024), 16, 0, 0);
+                                                 (lds_void*)(lw + sub * STAGE + pc * 1024), 16, 0, 0);
             }
         }
     };
@@ -243,25 +246,35 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
 
     const unsigned char* lwh = lw + (half * MB + l31) * 16;
     const unsigned char* lxh = lx + ((wave * NT) * IN_C + l31) * REC + half * 16;
-#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
-#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
 #define MFMA3(accv, ah, al, bh, bl)                                              \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
 
-    const int nsteps = 2 * nchunk + 1;
+    const int nstage = (nchunk + CPS - 1) / CPS;
+    const int nsteps = 2 * nstage + 1;
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();
         const int s = step - grp;
-        if (!active || s < 0 || s >= 2 * nchunk) continue;
+        if (!active || s < 0 || s >= 2 * nstage) continue;
         const int t = s >> 1;
         if ((s & 1) == 0) {
             // stage segment: both operands by LDS-DMA; drained explicitly (a bare s_barrier does not wait for it)
-            dma_x(t);
-            dma_w(t);
+#pragma unroll
+            for (int sub = 0; sub < CPS; ++sub)
+                if (t * CPS + sub < nchunk) {
+                    dma_x(t * CPS + sub, sub);
+                    dma_w(t * CPS + sub, sub);
+                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
+#pragma unroll
+            for (int sub = 0; sub < CPS; ++sub) {
+            if (t * CPS + sub >= nchunk) break;
+            const unsigned char* lxs = lxh + sub * STAGE;
+            const unsigned char* lws = lwh + sub * STAGE;
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxs + (posoff) * REC + (lo_) * 32))
+#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lws + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
             half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #define LOADF(buf, tp_)                                                                               \
     {                                                                                                 \
@@ -287,10 +300,11 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef LOADF
-        }
-    }
 #undef XFRAG
 #undef WFRAG
+            }
+        }
+    }
 #undef MFMA3
     __syncthreads();
 
@@ -777,7 +791,13 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_y = (p.Hn + TR - 1) / TR;
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
-    const bool mt2 = a.M > 32;
+    // few work items and a long K loop (the 4x4 ... 32x32 layers): at most one workgroup per CU, every stage is a bare
+    // DMA latency and the tile's MFMAs all sit on one CU -> 32-channel M tiles (twice the workgroups) and two K chunks
+    // per stage
+    static const int force_cps = getenv("OODGAN_V2_CPS") ? atoi(getenv("OODGAN_V2_CPS")) : 0;
+    const long items64 = (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64);
+    const bool deep = force_cps ? force_cps == 2 : (items64 <= 256 && a.K >= 64);
+    const bool mt2 = a.M > 32 && !deep;
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {
@@ -803,17 +823,19 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     static const int force_ng = getenv("OODGAN_V2_GROUPS") ? atoi(getenv("OODGAN_V2_GROUPS")) : 0;
     const int ng = force_ng ? force_ng : (a.K >= 128 ? 2 : 1);
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-#define OODGAN_LAUNCH(MT_, NG_)                                                                                          \
+#define OODGAN_LAUNCH(MT_, NG_, CPS_)                                                                                    \
     {                                                                                                                    \
-        constexpr int sm = NG_ * group_bytes<MT_>();                                                                     \
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1v2_kernel<MT_, NG_>),   \
+        constexpr int stage_ = XBYTES + 36 * 32 * MT_ * 16;                                                              \
+        constexpr int sm = NG_ * (stage_ * CPS_ > group_bytes<MT_>() ? stage_ * CPS_ : group_bytes<MT_>());              \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1v2_kernel<MT_, NG_, CPS_>), \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);            \
         (void)once;                                                                                                      \
         dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                                \
-        hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_>), grid, block, sm, st, p, w16, items, sc);                   \
+        hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_, CPS_>), grid, block, sm, st, p, w16, items, sc);             \
     }
-    if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(2, 1) }
-    else { if (ng == 2) OODGAN_LAUNCH(1, 2) else OODGAN_LAUNCH(1, 1) }
+    if (deep) OODGAN_LAUNCH(1, 1, 2)
+    else if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2, 1) else OODGAN_LAUNCH(2, 1, 1) }
+    else { if (ng == 2) OODGAN_LAUNCH(1, 2, 1) else OODGAN_LAUNCH(1, 1, 1) }
 #undef OODGAN_LAUNCH
     return check_launch("conv3x3_f16s_s1v2");
 }
@@ -834,7 +856,8 @@ int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_y = (p.Hn + 3) / 4;
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
-    const bool mt2 = a.M > 32;
+    // few tiles (low-resolution layers): 32-channel M tiles put twice as many CUs to work on the same K loop
+    const bool mt2 = a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     SConv sc;
@@ -869,7 +892,7 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_y = (p.Hn + 7) / 8;
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
-    const bool mt2 = a.M > 32;
+    const bool mt2 = a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;    // as in launch_t2v2
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {

@@ -123,4 +123,7 @@ def test_wplus_streams_and_graph_match_single_stream(dev):
         assert l2.shape == l1.shape
         assert maxdiff(l2, l1.cpu()) <= 1e-4 * l1.abs().max().item(), (streams, graph)
         dw = (w2 - w1).abs()
-        assert (dw < 1e-4).float().mean().item() > 0.999, (streams, graph, dw.max().item())
+        # sub-batches carry their own power-of-two gradient range scales (max over fewer images), so the split-f16 `lo`
+        # parts round differently at the 1e-7 level; Adam's sign-like first steps turn that into <= lr-sized moves of a
+        # few near-zero-gradient coordinates
+        assert (dw < 5e-4).float().mean().item() > 0.999, (streams, graph, dw.max().item())
