@@ -238,7 +238,7 @@ def main():
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'modconv2d': modconv,
-            'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(size),
+            'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size),     # rank 0 at N=1 only
         }
         print(json.dumps(line, ensure_ascii=False))
     if dist_on:
