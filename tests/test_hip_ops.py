@@ -314,3 +314,40 @@ def test_blur_act_sform_vs_two_pass_and_oracle(dev, B, C, H, W, act):
     k2[1, 2] += 0.37
     y2 = ops.blur_act_sform(zp.to(dev), k2.to(dev), H, W, None, None, None, act=False)
     close(y2, R.upfirdn2d(z, k2, pad=(1, 1)))
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 32, 32, 16, 32), (1, 32, 32, 40, 64), (2, 24, 20, 13, 45), (1, 32, 32, 7, 100), (1, 30, 32, 72, 33)])
+def test_conv3x3_strip_kernel_low_channel_layers(dev, B, Ci, Co, H, W):
+    """17..32 -> 17..32 channel stride-1 convs on an S-form input take the strip-walking kernel (conv_f16s_strip.hip):
+    forward epilogue (demod, noise, bias, lrelu), plain output, and the input-gradient instance with the dot epilogue
+    and a power-of-two input range scale."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    x = synth.normal('st.x', (B, Ci, H, W), 1)
+    w = synth.normal('st.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('st.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('st.d', (B, Co), 4, 0.3, 1.0)
+    nz = synth.normal('st.nz', (B, 1, H, W), 5)
+    nw = torch.tensor([0.37])
+    bias = synth.normal('st.b', (Co,), 6)
+    xs = ops.to_sform(x.to(dev), s.to(dev))
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    raw = F.conv2d(x * s[:, :, None, None], w, padding=1)
+    ref = R.fused_leaky_relu(raw * d[:, :, None, None] + nw * nz, bias)
+    y = ops.conv3x3(xs, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), bias=bias.to(dev), noise=nz.to(dev), noise_weight=nw.to(dev),
+                    act=ops.ACT_LRELU)
+    close(y, ref)
+    close(ops.conv3x3(xs, wpk, Co, ops.CONV_S1, out_scale=d.to(dev)), raw * d[:, :, None, None])
+    # shared noise (batch 1)
+    y1 = ops.conv3x3(xs, wpk, Co, ops.CONV_S1, noise=nz[:1].to(dev), noise_weight=nw.to(dev))
+    close(y1, raw + nw * nz[:1])
+    # backward instance: input pre-scaled by 2^7 (mul2 = {2^-7, 2^7}), dot with the saved forward input
+    mul2 = torch.tensor([2.0 ** -7, 2.0 ** 7], device=dev)
+    xs2 = ops.to_sform(x.to(dev), s.to(dev), mul2)
+    dotx = synth.normal('st.dx', (B, Co, H, W), 8)
+    y2, dot = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
+    close(y2, raw * d[:, :, None, None])
+    close(dot, (raw * dotx).sum(dim=(2, 3)), 2e-4)
+    # run-to-run identical (deterministic reductions)
+    y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
+    assert torch.equal(y2, y3) and torch.equal(dot, dot3)
