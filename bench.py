@@ -43,7 +43,6 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
     ap.add_argument('--no-modconv', action='store_true', help='skip the fp16 modulated-conv roofline leg (BASELINE configs[4])')
-    ap.add_argument('--no-multistream-leg', action='store_true', help='skip the extra 4-stream + hipGraph measurement of the same workload')
     ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
@@ -227,19 +226,6 @@ def main():
         modconv = None
         if not a.no_modconv and world == 1:
             modconv = modconv_roofline()
-        multi = None
-        if not a.no_multistream_leg and world == 1 and a.streams == 1 and not a.graph and a.precision == 'f16s':
-            # the same workload with the batch advanced as 4 sub-batches on 4 HIP streams, each W+ step replayed from a
-            # captured hipGraph (fills the CUs the low-resolution layers leave idle).  Reported beside `value`, which
-            # stays the single-stream eager run whose kernels the roofline events can bracket one by one.
-            def ms_step():
-                return model.invert(x, steps=a.wsteps, noise=noises, streams=4, use_graph=True, enc_lats=enc_lats, enc_feats=enc_feats)
-            ms_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            ms_step()
-            torch.cuda.synchronize()
-            multi = dict(value=round(gB / (time.perf_counter() - t1), 4), unit='images/s', streams=4, hipgraph_replay=True)
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
@@ -252,7 +238,6 @@ def main():
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'modconv2d': modconv,
-            'value_multistream': multi,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size),     # rank 0 at N=1 only
         }
         print(json.dumps(line, ensure_ascii=False))

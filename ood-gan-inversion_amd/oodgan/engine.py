@@ -318,6 +318,10 @@ class GeneratorEngine:
         return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent, grad_div=grad_scale)
 
 
+import os as _os
+_DBG_SERIAL = _os.environ.get('OODGAN_GRAPH_SERIAL', '0') == '1'
+
+
 class WPlusInverter:
     """Build-defined W+ optimisation loop: ``steps`` x {G(w) with fixed noise,
     per-image MSE, backward to w, Adam(lr, betas, eps)} — anchors: reference Generator.forward with
@@ -384,6 +388,8 @@ class WPlusInverter:
                 with torch.cuda.stream(st):
                     if graphs[i] is not None:
                         graphs[i].replay()
+                        if _DBG_SERIAL:
+                            st.synchronize()
                         parts[i]['lbuf'][t - 1].copy_(parts[i]['lstat'])
                     else:
                         parts[i]['lbuf'][t - 1].copy_(one_step(parts[i], engines[i]))
