@@ -797,7 +797,10 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     static const int force_cps = getenv("OODGAN_V2_CPS") ? atoi(getenv("OODGAN_V2_CPS")) : 0;
     const long items64 = (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64);
     const bool deep = force_cps ? force_cps == 2 : (items64 <= 256 && a.K >= 64);
-    const bool mt2 = a.M > 32 && !deep;
+    // < 128 input channels (the 512² layer): the single-group 64-channel instance needs 256 registers (two workgroups per
+    // CU); 32-channel M tiles fit three and are 7 % faster although the x tile is fetched once per M block
+    static const int s1_mt2 = getenv("OODGAN_S1_MT2") ? atoi(getenv("OODGAN_S1_MT2")) : 0;
+    const bool mt2 = a.M > 32 && !deep && (a.K >= 128 || s1_mt2);
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {
@@ -857,7 +860,10 @@ int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
     // few tiles (low-resolution layers): 32-channel M tiles put twice as many CUs to work on the same K loop
-    const bool mt2 = a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;
+    // 32-channel M tiles: the 64-channel instance needs 276 registers (accumulators of 4 output phases x 2 M tiles), i.e.
+    // one workgroup per CU; the 32-channel one fits three (140 registers, 32 KB of LDS) and is 30-35 % faster
+    static const int t2_mt2 = getenv("OODGAN_T2_MT2") ? atoi(getenv("OODGAN_T2_MT2")) : 0;
+    const bool mt2 = t2_mt2 && a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     SConv sc;
