@@ -800,7 +800,8 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     // < 128 input channels (the 512² layer): the single-group 64-channel instance needs 256 registers (two workgroups per
     // CU); 32-channel M tiles fit three and are 7 % faster although the x tile is fetched once per M block
     static const int s1_mt2 = getenv("OODGAN_S1_MT2") ? atoi(getenv("OODGAN_S1_MT2")) : 0;
-    const bool mt2 = a.M > 32 && !deep && (a.K >= 128 || s1_mt2);
+    static const int s1_mt1 = getenv("OODGAN_S1_MT1") ? atoi(getenv("OODGAN_S1_MT1")) : 0;
+    const bool mt2 = a.M > 32 && !deep && (a.K >= 128 || s1_mt2) && !s1_mt1;
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {

@@ -133,3 +133,28 @@ def test_wplus_streams_and_graph_match_single_stream(dev):
         assert l2.shape == l1.shape and torch.isfinite(w2).all()
         assert maxdiff(l2, l1.cpu()) <= 1e-2 * l1.abs().max().item(), (streams, graph)
         assert (l2[-1] < l2[0]).all()
+
+
+def test_full_size_inversion_properties(dev):
+    """BASELINE configs[2] geometry (1024², every production kernel instance incl. the strip kernel of the 32-channel
+    layers and the fused producers) through size-independent properties: (a) images are independent — inverting a
+    sub-batch alone reproduces its part of the batch run; (b) the carried-scale fused backward follows the exact
+    per-step scales; (c) the loss decreases."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, B, steps = 1024, 4, 3
+    P = synth.generator_state(size, seed=0)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    target = torch.cat([synth.make_images(size, 1, seed=1000 + g) for g in range(B)]).to(dev)
+    noises = [torch.cat([synth.make_noises(size, 1, seed=2000 + g)[i] for g in range(B)]).to(dev) for i in range(17)]
+    w0 = torch.cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in range(B)]).to(dev)
+    inv = WPlusInverter(eng)
+    w, l = inv.invert(target, w0, noises, steps=steps)
+    assert torch.isfinite(w).all() and (l[-1] < l[0]).all() and not eng.bwd_scale_violated()
+    ws, ls = inv.invert(target[:2].contiguous(), w0[:2].contiguous(), [n[:2].contiguous() for n in noises], steps=steps)
+    assert maxdiff(ls, l[:, :2].cpu()) <= 1e-4 * l.abs().max().item()
+    assert ((ws - w[:2]).abs() < 5e-4).float().mean().item() > 0.999
+    eng.fused_bwd = False
+    w2, l2 = inv.invert(target, w0, noises, steps=steps)
+    eng.fused_bwd = True
+    assert maxdiff(l2, l.cpu()) <= 2e-5 * l.abs().max().item()
+    assert ((w2 - w).abs() < 1e-4).float().mean().item() > 0.999
