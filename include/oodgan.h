@@ -323,6 +323,10 @@ int oodgan_mask_blend(const float* const* fields, const int* sizes, int nfields,
 int oodgan_resize_nearest(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout,
                           int out_pitch, int out_xoff, void* stream);
 /* F.interpolate(x, size, mode='bilinear', align_corners=False) */
+/* F.interpolate(mode='bicubic', align_corners=True) to (Hout,Wout), optionally + add (same shape as the result):
+ * `_upsample_add` of the e4e encoder's FPN (src/ops/e4e/encoders/helpers.py:504-521). */
+int oodgan_resize_bicubic_ac(const float* x, const float* add, float* y, int planes, int Hin, int Win, int Hout, int Wout,
+                             void* stream);
 int oodgan_resize_bilinear(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
 
 #ifdef __cplusplus

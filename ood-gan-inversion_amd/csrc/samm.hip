@@ -339,7 +339,29 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     }
 }
 
+// y = bicubic(x -> Hout x Wout, align_corners=True) (+ add): the FPN step of the e4e encoder
+// (reference src/ops/e4e/encoders/helpers.py:504-521 `_upsample_add`)
+__global__ __launch_bounds__(256) void resize_bicubic_ac_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                                float* __restrict__ y, int planes, int Hin, int Win, int Hout,
+                                                                int Wout) {
+    const long total = (long)planes * Hout * Wout;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+        const long pl = e / ((long)Wout * Hout);
+        const float v = bicubic_ac(x + pl * Hin * Win, Hin, Win, oy, ox, Hout, Wout);
+        y[e] = add ? v + add[e] : v;
+    }
+}
+
 }  // namespace
+
+extern "C" int oodgan_resize_bicubic_ac(const float* x, const float* add, float* y, int planes, int Hin, int Win, int Hout, int Wout,
+                                        void* stream) {
+    OODGAN_REQUIRE(x && y && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "resize_bicubic_ac: bad args");
+    hipLaunchKernelGGL(resize_bicubic_ac_kernel, dim3(stream_grid((long)planes * Hout * Wout, 256)), dim3(256), 0,
+                       as_stream(stream), x, add, y, planes, Hin, Win, Hout, Wout);
+    return check_launch("resize_bicubic_ac");
+}
 
 extern "C" int oodgan_instnorm_stats(const float* x, float* stats, int B, int C, long HW, float eps, void* stream) {
     OODGAN_REQUIRE(x && stats && B > 0 && C > 0 && HW > 0, "instnorm_stats: bad args");

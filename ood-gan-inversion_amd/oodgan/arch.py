@@ -91,7 +91,11 @@ class ood_faceGAN_e4e(nn.Module):
         self.style_dim = style_dim
         self.channels = generator_channels(channel_multiplier, narrow)
         if kwargs.get('build_encoder', True):
-            from .encoder import Encoder4Editing, ProgressiveStage
+            from .encoder import ProgressiveStage
+            if kwargs.get('encoder_impl', 'hip') == 'hip':      # the e4e encoder on the HIP kernels
+                from .encoder_hip import Encoder4EditingHIP as Encoder4Editing
+            else:                                               # 'torch': the plain torch-ROCm mirror (oodgan/encoder.py)
+                from .encoder import Encoder4Editing
             self.encoder = Encoder4Editing(num_layers=50, mode='ir_se', opts={'stylegan_size': out_size}, bn=True)
             self.encoder.progressive_stage = ProgressiveStage[stage]
         else:

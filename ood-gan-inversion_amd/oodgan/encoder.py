@@ -5,10 +5,11 @@ src/ops/e4e/encoders/psp_encoders.py:125-216; IR-SE-50 backbone helpers.py:33-57
 ``_upsample_add`` :504-521; ``GradualStyleBlock`` psp_encoders.py:35-57) with the same state-dict keys
 (621 entries for num_layers=50), forward signature and ``channels`` / ``progressive_stage`` attributes.
 
-STATUS: interim implementation on plain torch-ROCm ops (MIOpen / rocBLAS through ``torch.nn.functional``), as
-SURVEY.md §8f N1 allows until the HIP version exists; it runs once per image at 256² under ``no_grad`` and is
-not part of the measured inversion loop.  It is NOT a fallback for the hot path — generator, SAMM and the W+
-loop have none."""
+This module is the parameter container + a plain-torch forward (MIOpen / rocBLAS through ``torch.nn.functional``);
+``oodgan.encoder_hip.Encoder4EditingHIP`` subclasses it and runs the same graph on the HIP kernels — that is what
+``ood_faceGAN_e4e`` instantiates (``encoder_impl='torch'`` selects this one).  The plain-torch forward is kept as the
+CPU-checkable restatement of the graph (tests/test_encoder.py); it is NOT a fallback for the hot path — generator,
+SAMM and the W+ loop have none."""
 import math
 from collections import namedtuple
 from enum import Enum

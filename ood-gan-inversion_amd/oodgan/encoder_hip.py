@@ -1,0 +1,159 @@
+"""e4e encoder on the HIP kernels — the same parameters, state-dict keys and forward signature as
+``oodgan.encoder.Encoder4Editing`` (mirror of reference src/ops/e4e/encoders/psp_encoders.py:125-216), but every
+convolution, normalisation, gate application and resize runs through ``liboodgan_hip.so``:
+
+  BatchNorm (eval) before a conv   -> per-channel in_scale / in_shift of ``oodgan_conv3x3`` (shift applied to in-bounds
+                                      samples only = BN followed by zero padding)
+  BatchNorm (eval) after a conv    -> out_scale + bias of the conv epilogue
+  PReLU / LeakyReLU(0.01)          -> per-channel slope in the conv epilogue
+  conv3x3 stride 2, pad 1          -> the stride-2 kernel (mode S2) on the input shifted by one zero row / column
+  SE gate + residual               -> ``oodgan_instnorm_stats`` (mean), ``oodgan_conv1x1`` x2, ``oodgan_affine_apply``
+  FPN ``_upsample_add``            -> ``oodgan_resize_bicubic_ac`` (helpers.py:504-521)
+  GradualStyleBlock                -> stride-2 convs + ``oodgan_equal_linear``
+
+torch is used for plumbing only (zero-padding copy, strided slice of the shortcut, ReLU / sigmoid on (B,C) vectors).
+The encoder runs once per image at 256² and is not part of the measured loop."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib, ops, samm
+from ._lib import ACT_NONE, ACT_PRELU, CONV_S1, CONV_S2, check
+from .encoder import Encoder4Editing
+
+
+def _bn_affine(bn):
+    """eval-mode BatchNorm2d as y = x*sc + sh."""
+    sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return sc, bn.bias - bn.running_mean * sc
+
+
+def _rows(v, B):
+    return v.detach().float().reshape(1, -1).expand(B, -1).contiguous()
+
+
+def _pad_tl(x):
+    """(B,C,H,W) -> (B,C,H+1,pitch>=W+1) with a zero first row / column; pitch is a multiple of 4 floats."""
+    B, C, H, W = x.shape
+    pitch = (W + 1 + 3) // 4 * 4
+    y = torch.zeros(B, C, H + 1, pitch, device=x.device, dtype=torch.float32)
+    y[:, :, 1:, 1:W + 1] = x
+    return y, pitch
+
+
+def _resize_bicubic_ac(x, size, add=None):
+    B, C, H, W = x.shape
+    y = torch.empty(B, C, size[0], size[1], device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_resize_bicubic_ac(ops._p(x.contiguous()), ops._p(None if add is None else add.contiguous()), ops._p(y),
+                                              B * C, H, W, size[0], size[1], ops._stream()), 'resize_bicubic_ac')
+    return y
+
+
+class _Packed:
+    """packed conv weights, re-packed when the parameter changes"""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            self.key, self.val = key, ops.pack_conv3x3(w.detach().float().contiguous(), precision='f16s')
+        return self.val
+
+
+def _conv3x3(x, pk, M, stride=1, **kw):
+    if stride == 1:
+        return ops.conv3x3(x, pk, M, CONV_S1, **kw)
+    assert stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+    xp, pitch = _pad_tl(x)
+    return ops.conv3x3(xp, pk, M, CONV_S2, in_hw=(x.shape[2] + 1, x.shape[3] + 1), in_pitch=pitch, **kw)
+
+
+class Encoder4EditingHIP(Encoder4Editing):
+    def __init__(self, num_layers, mode='ir', opts=None, bn=True):
+        super().__init__(num_layers, mode, opts, bn)
+        self._mode = mode
+        self._pk = {}
+
+    def _packed(self, name, w):
+        p = self._pk.get(name)
+        if p is None:
+            p = self._pk[name] = _Packed()
+        return p.get(w)
+
+    # ---- one bottleneck_IR(_SE) unit (helpers.py:439-501)
+    def _unit(self, idx, u, x):
+        B = x.shape[0]
+        rl = u.res_layer
+        depth = rl[1].weight.shape[0]
+        stride = rl[3].stride[0]
+        sc1, sh1 = _bn_affine(rl[0])
+        r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=_rows(sc1, B), in_shift=_rows(sh1, B),
+                     act=ACT_PRELU, slope=rl[2].weight.detach())
+        sc2, sh2 = _bn_affine(rl[4])
+        r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=_rows(sc2, B), bias=sh2.detach().contiguous())
+        if isinstance(u.shortcut_layer, torch.nn.MaxPool2d):
+            sc = x if stride == 1 else x[:, :, ::stride, ::stride].contiguous()
+        else:
+            xs = x if stride == 1 else x[:, :, ::stride, ::stride].contiguous()
+            s = samm.conv1x1(xs, u.shortcut_layer[0].weight.detach())
+            a, b = _bn_affine(u.shortcut_layer[1])
+            sc = samm.affine_apply(s, _rows(a, B), _rows(b, B))
+        if self._mode == 'ir_se':
+            se = rl[5]
+            g = samm.instnorm_stats(r)[..., 0].reshape(B, depth, 1, 1).contiguous()            # per-(b,c) mean
+            g = torch.relu(samm.conv1x1(g, se.fc1.weight.detach()))
+            g = torch.sigmoid(samm.conv1x1(g, se.fc2.weight.detach())).reshape(B, depth)
+            return samm.affine_apply(r, g.contiguous(), torch.zeros_like(g), res=sc)
+        return samm.affine_apply(r, torch.ones(B, depth, device=x.device), torch.zeros(B, depth, device=x.device), res=sc)
+
+    def _style(self, i, feat):
+        blk = self.styles[i]
+        x = feat
+        convs = [m for m in blk.convs if isinstance(m, torch.nn.Conv2d)]
+        slope = torch.full((blk.out_c,), 0.01, device=feat.device)
+        for j, c in enumerate(convs):
+            x = _conv3x3(x, self._packed(f's{i}.{j}', c.weight), blk.out_c, 2, bias=c.bias.detach(), act=ACT_PRELU, slope=slope)
+        return ops.equal_linear(x.reshape(-1, blk.out_c), blk.linear.weight.detach(), blk.linear.bias.detach(), lr_mul=blk.linear.lr_mul)
+
+    @torch.no_grad()
+    def forward(self, x, **kwargs):
+        if not x.is_cuda:
+            raise RuntimeError('Encoder4EditingHIP needs a ROCm tensor (no CPU fallback)')
+        x = x.float().contiguous()
+        B = x.shape[0]
+        il = self.input_layer
+        a, b = _bn_affine(il[1])
+        x = _conv3x3(x, self._packed('in', il[0].weight), 64, 1, out_scale=_rows(a, B), bias=b.detach().contiguous(), act=ACT_PRELU,
+                     slope=il[2].weight.detach())
+        feats = [x]
+        c1 = c2 = c3 = None
+        for i, layer in enumerate(self.body):
+            x = self._unit(i, layer, x)
+            if i == 2:
+                feats.append(x)
+            if i == 6:
+                c1 = x
+                feats.append(x)
+            elif i == 20:
+                c2 = x
+                feats.append(x)
+            elif i == 23:
+                c3 = x
+                feats.append(x)
+        w0 = self._style(0, c3)
+        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
+        stage = self.progressive_stage.value
+        features, p2 = c3, None
+        for i in range(1, min(stage + 1, self.style_count)):
+            if i == self.coarse_ind:
+                p2 = _resize_bicubic_ac(c3, c2.shape[-2:], add=samm.conv1x1(c2, self.latlayer1.weight.detach(), self.latlayer1.bias.detach()))
+                features = p2
+            elif i == self.middle_ind:
+                features = _resize_bicubic_ac(p2, c1.shape[-2:], add=samm.conv1x1(c1, self.latlayer2.weight.detach(), self.latlayer2.bias.detach()))
+            w[:, i] += self._style(i, features)
+        if kwargs.get('return_feats', False):
+            return w, feats
+        return w

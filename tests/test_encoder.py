@@ -81,3 +81,23 @@ def test_arch_forward_from_image_end_to_end():
     assert sorted(m.aligns.keys()) == [1, 2, 3, 4, 1024]
     out3, lats3, losses = m.invert(x, steps=3, noise=noises)
     assert losses.shape == (3, 1) and losses[-1].item() < losses[0].item() and torch.isfinite(out3).all()
+
+
+@pytest.mark.gpu
+def test_hip_encoder_vs_reference_golden_and_torch_mirror(golden):
+    """The encoder on the HIP kernels (oodgan/encoder_hip.py): same state dict, same outputs as the reference."""
+    from oodgan.encoder_hip import Encoder4EditingHIP
+    g = golden('encoder_256.npz')
+    dev = torch.device('cuda:0')
+    ref_mod = _build()
+    enc = Encoder4EditingHIP(50, 'ir_se', {'stylegan_size': 1024}, bn=True).eval()
+    assert list(enc.state_dict().keys()) == list(ref_mod.state_dict().keys())
+    enc.load_state_dict(ref_mod.state_dict(), strict=True)
+    enc = enc.to(dev)
+    x = synth.make_images(256, 1, seed=42).to(dev)
+    w, feats = enc(x, return_feats=True)
+    _check(w, feats, g, 2e-4)
+    # batch of 2 (second image different): rows independent
+    x2 = torch.cat([x, synth.make_images(256, 1, seed=43).to(dev)])
+    w2 = enc(x2)
+    assert w2.shape == (2, 18, 512) and (w2[:1] - w).abs().max().item() <= 1e-4 * w.abs().max().item()
