@@ -82,6 +82,69 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     }
 }
 
+// Low resolutions (HW <= 4096): the per-thread loop over 512 input channels is a chain of dependent loads with only a
+// handful of threads alive, so here ONE WAVE owns 4 consecutive pixels and its 64 lanes split the channels; the 12
+// partial sums (3 colours x 4 pixels) are combined with a wave reduction.  grid = (HW/4 / 4 waves, B).
+__global__ __launch_bounds__(256) void torgb_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ s, int s_stride,
+                                                              const float* __restrict__ bias, const float* __restrict__ skip,
+                                                              const float* __restrict__ kern, float* __restrict__ y, int Ci, int H,
+                                                              int W, float scale) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long HW = (long)H * W;
+    const long p = ((long)blockIdx.x * 4 + wave) * 4;
+    if (p >= HW) return;
+    const float* xp = x + (long)b * Ci * HW + p;
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int ci = lane; ci < Ci; ci += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + (long)ci * HW);
+        const float sv = scale * s[(long)b * s_stride + ci];
+        const float w0 = sv * w[ci], w1 = sv * w[Ci + ci], w2 = sv * w[2 * Ci + ci];
+        a0[0] += w0 * v.x; a0[1] += w0 * v.y; a0[2] += w0 * v.z; a0[3] += w0 * v.w;
+        a1[0] += w1 * v.x; a1[1] += w1 * v.y; a1[2] += w1 * v.z; a1[3] += w1 * v.w;
+        a2[0] += w2 * v.x; a2[1] += w2 * v.y; a2[2] += w2 * v.z; a2[3] += w2 * v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a0[j] = wave_sum(a0[j]);
+        a1[j] = wave_sum(a1[j]);
+        a2[j] = wave_sum(a2[j]);
+    }
+    if (lane >= 4) return;
+    const int j = lane;                       // lane j finishes pixel p + j
+    float o0 = a0[0], o1 = a1[0], o2 = a2[0];
+    if (j == 1) { o0 = a0[1]; o1 = a1[1]; o2 = a2[1]; }
+    if (j == 2) { o0 = a0[2]; o1 = a1[2]; o2 = a2[2]; }
+    if (j == 3) { o0 = a0[3]; o1 = a1[3]; o2 = a2[3]; }
+    o0 += bias ? bias[0] : 0.f;
+    o1 += bias ? bias[1] : 0.f;
+    o2 += bias ? bias[2] : 0.f;
+    if (skip) {
+        const int h2 = H >> 1, w2_ = W >> 1;
+        const int Y = (int)((p + j) / W), X = (int)((p + j) % W);
+        const float* sp = skip + (long)b * 3 * h2 * w2_;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ky = (Y & 1) + 2 * t;
+            const int iy = (Y + ky - 2) >> 1;
+            if (Y + ky - 2 < 0 || iy >= h2) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kx = (X & 1) + 2 * u;
+                const int ix = (X + kx - 2) >> 1;
+                if (X + kx - 2 < 0 || ix >= w2_) continue;
+                const float kv = kern[(3 - ky) * 4 + (3 - kx)];       // flipped
+                const long q = (long)iy * w2_ + ix;
+                o0 += kv * sp[q];
+                o1 += kv * sp[(long)h2 * w2_ + q];
+                o2 += kv * sp[2L * h2 * w2_ + q];
+            }
+        }
+    }
+    float* yp = y + (long)b * 3 * HW + p + j;
+    yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
+}
+
 }  // namespace
 
 extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
@@ -91,6 +154,12 @@ extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, 
     OODGAN_REQUIRE(Ci <= kMaxCi, "torgb_fwd: Ci %d > %d", Ci, kMaxCi);
     OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "torgb_fwd: skip needs kernel and even H,W");
     const long HW = (long)H * W;
+    if (HW <= 4096 && (HW & 3) == 0) {
+        dim3 grid((unsigned)((HW / 4 + 3) / 4), B);
+        hipLaunchKernelGGL(torgb_fwd_small_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y,
+                           Ci, H, W, scale);
+        return check_launch("torgb_fwd");
+    }
     dim3 grid((unsigned)((HW + 1023) / 1024), B);
     hipLaunchKernelGGL(torgb_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y, Ci, H,
                        W, scale);
