@@ -29,6 +29,8 @@ namespace oodgan {
 int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 bool s1_strip_eligible(const oodgan_conv_args& a);
+bool s1_big_eligible(const oodgan_conv_args& a);
+int launch_s1_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1_strip(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
@@ -408,6 +410,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     switch (a.mode) {
         case OODGAN_CONV_S1:
             if (a.x_sform && s1_strip_eligible(a)) return launch_s1_strip(a, a.wpk, unscale2, st);
+            if (a.x_sform && s1_big_eligible(a)) return launch_s1_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_s1v2(a, a.wpk, unscale2, st);
             OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");
             if (legacy_s1) return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);

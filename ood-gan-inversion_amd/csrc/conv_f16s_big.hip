@@ -1,0 +1,299 @@
+// Split-f16 3x3 stride-1 conv for the >= 128-channel layers (64² ... 256² images): the matrix-bound middle of the
+// generator (reference src/ops/StyleGAN/model.py:233-274, forward and input gradient).  Same arithmetic as
+// conv_f16s_s1v2_kernel; different pipeline.  The v2 kernel keeps two 64 KB stages in LDS as two anti-phase groups and
+// is bound by the LDS-DMA latency of one stage per step (each step moves 64 KB for 108 MFMAs per wave).  Here ONE
+// 4-wave group owns a 16 x 32 pixel tile (twice the pixels per weight byte): a K stage is 39 KB of x + 36 KB of
+// weights feeding 216 MFMAs per wave, two stages live in LDS, and the fetch of stage t+2 runs under the MFMAs of
+// stage t+1 — compute per stage (~3.4 us) now covers the DMA latency.
+//   * x tile 18 x 34 records of 64 B, slots rotated by (c>>2)&3 through the DMA source address (conflict-free reads,
+//     no padding);  weights in the packed order [tap][hi|lo][k-half][64][8] (36 KB per 16 input channels);
+//   * accumulators 2 M-tiles x 4 rows = 8 tiles per wave, MFMAs issued product-type-major so a tile is revisited
+//     after 8 instructions;
+//   * register epilogue: fp32 rows of 128 contiguous bytes per half wave, fused out-scale / noise / bias / lrelu, or
+//     the style-gradient dot (backward) reduced through DPP + LDS.
+#include "conv_common.hpp"
+#include "sform.hpp"
+#include <cstdint>
+#include <cstdlib>
+
+using namespace oodgan;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int BG_R = 18, BG_C = 34;                        // halo'd 16 x 32 tile
+constexpr int BG_XSLOTS = BG_R * BG_C * 4;                 // 2448 16-byte slots
+constexpr int BG_XPIECES = (BG_XSLOTS + 63) / 64;          // 39
+constexpr int BG_XBYTES = BG_XPIECES * 1024;               // 39936
+constexpr int BG_WPIECES = 36;                             // 36 rows x 64 channels x 16 B
+constexpr int BG_STAGE = BG_XBYTES + BG_WPIECES * 1024;    // 76800
+constexpr int BG_PIECES = BG_XPIECES + BG_WPIECES;         // 75
+constexpr int BG_RED = 2 * BG_STAGE;                       // 4 waves x 64 floats
+constexpr int BG_SMEM = BG_RED + 4 * 64 * 4;
+
+struct BigConv {
+    oodgan_conv_args a;
+    const uint4* xs;
+    SDims xd;
+    const float* w_unscale;
+    int tiles_x, tiles_y, mblocks, Mp;
+    long out_plane;
+    int ablate;      // debug: 1 skip MFMAs, 2 skip the per-stage DMA
+};
+
+template <bool DOT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_s1big_kernel(
+    const BigConv p, const uint4* __restrict__ wpk16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int mblk = w % p.mblocks;
+    w /= p.mblocks;
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int tile = w % ntile, b = w / ntile;
+    const int ty = tile / p.tiles_x, tx = tile % p.tiles_x;
+    const int r0 = ty * 16, c0 = tx * 32, m0 = mblk * 64;
+    const int H = a.Hin, W = a.Win, M = a.M;
+
+    // ---- per-lane DMA source offsets (bytes): x pieces relative to (plane of chunk 0, row r0, col c0), rotation applied;
+    // weight pieces relative to the chunk's block.  Piece pc = wave + 4*i, i < 19 (pc < 75).
+    constexpr int NPW = (BG_PIECES + 3) / 4;                // 19
+    unsigned off[NPW];
+    const int KC = p.xd.KC;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int pc = wave + 4 * i;
+        if (pc < BG_XPIECES) {
+            int P = pc * 64 + lane;
+            if (P >= BG_XSLOTS) P = BG_XSLOTS - 1;
+            const int row = P / (BG_C * 4), q = P % (BG_C * 4);
+            const int c = q >> 2, s = ((q & 3) - ((c >> 2) & 3)) & 3;
+            const int rr = min(r0 + row, p.xd.Hp - 1);      // tiles of 16 rows may reach below the 8-row padding
+            off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + s) * 16);
+        } else {
+            const int u = (pc - BG_XPIECES) * 64 + lane;    // 16-byte unit inside the 36 x 64 weight block
+            const int row = u >> 6, j = u & 63;
+            off[i] = (unsigned)((((long)row * p.Mp) + m0 + j) * 16);
+        }
+    }
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + (long)b * KC * p.xd.plane * 16;
+    const long xplane_bytes = p.xd.plane * 16;
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16);
+    const long wchunk_bytes = (long)36 * p.Mp * 16;
+    const int nchunk = (a.K + 15) / 16;
+    const int npc = wave < (BG_PIECES - 4 * (NPW - 1)) ? NPW : NPW - 1;      // 19,19,19,18
+
+    auto dma_stage = [&](int t, int buf) {
+        unsigned char* dst = smem + buf * BG_STAGE;
+        const unsigned char* xsrc = xb + (long)t * xplane_bytes;
+        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = wave + 4 * i;
+            if (pc >= BG_PIECES) break;
+            const unsigned char* src = (pc < BG_XPIECES ? xsrc : wsrc) + off[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // lane-constant fragment offsets
+    unsigned lrd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = kx + l31;
+            lrd[kx][lo] = c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
+        }
+    const unsigned lwf = (half * 64 + l31) * 16;
+
+    constexpr int kVm0 = 0x0F70;
+    dma_stage(0, 0);
+    if (nchunk > 1) dma_stage(1, 1);
+    for (int t = 0; t < nchunk; ++t) {
+        // stage t has landed when at most the pieces of stage t+1 are outstanding (in-order retirement)
+        if (t + 1 < nchunk) {
+            if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x4F73);      // vmcnt(19)
+            else __builtin_amdgcn_s_waitcnt(0x4F72);                 // vmcnt(18)
+        } else {
+            __builtin_amdgcn_s_waitcnt(kVm0);
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * 4) * (BG_C * 64);
+        const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES + lwf;
+        if (!(p.ablate & 1))
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int ky = tp / 3, kx = tp % 3;
+            half8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ah[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 0) * 2) * 64 + mt * 32) * 16);
+                al[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 1) * 2) * 64 + mt * 32) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bh[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][0]);
+                bl[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();            // every wave is done with buffer t&1
+        if (t + 2 < nchunk && !(p.ablate & 2)) dma_stage(t + 2, t & 1);
+    }
+
+    // ---- epilogue from the accumulators
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    const int px = c0 + l31;
+    const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W : nullptr;
+    float dsum[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[mt][r] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float osc[16], bia[16];
+        unsigned moff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool mok = m < M;
+            osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
+            bia[r] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
+            moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int py = r0 + wave * 4 + nt;
+            const bool ok = py < H && px < W;
+            float nz = 0.f;
+            if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
+            unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + px) * 4;
+            const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py * W + px) * 4 : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[mt][nt][r];
+                float o = v * osc[r];
+                if (DOT) {
+                    if (ok && moff[r] != 0xFFFFFFFFu) {
+                        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        dsum[mt][r] += (v * us) * *reinterpret_cast<const float*>(dr + (long)m * H * W * 4);
+                    }
+                } else {
+                    o += nz + bia[r];
+                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                }
+                if (ok && moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = o;
+            }
+        }
+    }
+    if (DOT) {
+        float* red = reinterpret_cast<float*>(smem + BG_RED);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = dsum[mt][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (l31 == 0) red[wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+            }
+        __syncthreads();
+        if (tid < 64 && m0 + tid < M) {
+            // the host sizes dot_part for 8-row tiles: this 16-row tile owns two of its slots
+            const float v = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+            float* dp = a.dot_part + ((long)b * M + m0 + tid) * a.dot_nparts;
+            const int tx8 = (W + 31) / 32;
+            dp[(long)(2 * ty) * tx8 + tx] = v;
+            if (2 * ty + 1 < (H + 7) / 8) dp[(long)(2 * ty + 1) * tx8 + tx] = 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+namespace oodgan {
+
+bool s1_big_eligible(const oodgan_conv_args& a) {
+    static const int off = getenv("OODGAN_S1_BIG") ? atoi(getenv("OODGAN_S1_BIG")) == 0 : 0;
+    if (off) return false;
+    // Measured (tools/bench_conv.py, B=8): 8 % faster than the two-group tile kernel at 512 -> 512 channels @64², 3-9 %
+    // slower at 256 / 128 channels, no visible change of the end-to-end step.  Ablation: without its DMA the kernel
+    // takes the same time — it is bound by the MFMA + fragment-read stream of ONE wave per SIMD (31 ns per MFMA against
+    // 17-20 ns for a bare MFMA loop), not by the staging the v2 kernel suffers from.  Kept as an opt-in alternative
+    // (OODGAN_S1_BIG_MIN_K=512 enables it for the 512-channel layers); off by default so that the dominant-kernel
+    // measurements refer to a single instance.
+    const char* ek = getenv("OODGAN_S1_BIG_MIN_K");
+    const int min_k = ek ? atoi(ek) : (1 << 30);
+    if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
+          (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr && a.in_shift == nullptr &&
+          !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))
+        return false;
+    // enough 16x32 tiles to fill the chip; smaller layers keep the latency-oriented instances
+    const long items = (long)((a.Hin + 15) / 16) * ((a.Win + 31) / 32) * a.B * ((a.M + 63) / 64);
+    const char* e = getenv("OODGAN_S1_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
+    return items >= (e ? atol(e) : 256);
+}
+
+int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {
+    BigConv p;
+    p.a = a_in;
+    oodgan_conv_args& a = p.a;
+    if (a.out_pitch == 0) a.out_pitch = a.Win;
+    p.out_plane = (long)a.Hin * a.out_pitch;
+    p.xs = reinterpret_cast<const uint4*>(a.x);
+    p.xd = sform_dims(a.K, a.Hin, a.Win);
+    p.w_unscale = unscale;
+    p.tiles_y = (a.Hin + 15) / 16;
+    p.tiles_x = (a.Win + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    p.mblocks = (a.M + 63) / 64;
+    if (a.dotx) {
+        OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
+        OODGAN_REQUIRE(a.dot_nparts == ((a.Hin + 7) / 8) * p.tiles_x, "conv3x3 f16s S1: dot_nparts %d != %d", a.dot_nparts,
+                       ((a.Hin + 7) / 8) * p.tiles_x);
+    }
+    OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32), "conv3x3 big: plane too large");
+    static const int abl = getenv("OODGAN_BIG_ABLATE") ? atoi(getenv("OODGAN_BIG_ABLATE")) : 0;
+    p.ablate = abl;
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
+    (void)once;
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
+    return check_launch("conv3x3_f16s_s1big");
+}
+
+}  // namespace oodgan

@@ -351,3 +351,35 @@ def test_conv3x3_strip_kernel_low_channel_layers(dev, B, Ci, Co, H, W):
     # run-to-run identical (deterministic reductions)
     y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
     assert torch.equal(y2, y3) and torch.equal(dot, dot3)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 128, 128, 32, 64), (1, 144, 192, 40, 33), (2, 256, 64, 17, 32)])
+def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
+    """>= 128 -> >= 64 channel stride-1 convs with enough tiles take the 16x32-tile two-stage kernel
+    (conv_f16s_big.hip); the item threshold is lowered so that small tensors reach it."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1')
+    monkeypatch.setenv('OODGAN_S1_BIG_MIN_K', '128')
+    x = synth.normal('bg.x', (B, Ci, H, W), 1)
+    w = synth.normal('bg.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('bg.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('bg.d', (B, Co), 4, 0.3, 1.0)
+    nz = synth.normal('bg.nz', (B, 1, H, W), 5)
+    nw = torch.tensor([0.37])
+    bias = synth.normal('bg.b', (Co,), 6)
+    xs = ops.to_sform(x.to(dev), s.to(dev))
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    raw = F.conv2d(x * s[:, :, None, None], w, padding=1)
+    y = ops.conv3x3(xs, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), bias=bias.to(dev), noise=nz.to(dev), noise_weight=nw.to(dev),
+                    act=ops.ACT_LRELU)
+    close(y, R.fused_leaky_relu(raw * d[:, :, None, None] + nw * nz, bias))
+    mul2 = torch.tensor([2.0 ** -5, 2.0 ** 5], device=dev)
+    xs2 = ops.to_sform(x.to(dev), s.to(dev), mul2)
+    dotx = synth.normal('bg.dx', (B, Co, H, W), 8)
+    y2, dot = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
+    close(y2, raw * d[:, :, None, None])
+    close(dot, (raw * dotx).sum(dim=(2, 3)), 2e-4)
+    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1000000000')         # same call through the tile kernel
+    y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
+    assert (y3 - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
