@@ -2,9 +2,9 @@
 // generator (reference src/ops/StyleGAN/model.py:233-274, forward and input gradient).  Same arithmetic as
 // conv_f16s_s1v2_kernel; different pipeline.  The v2 kernel keeps two 64 KB stages in LDS as two anti-phase groups and
 // is bound by the LDS-DMA latency of one stage per step (each step moves 64 KB for 108 MFMAs per wave).  Here ONE
-// 4-wave group owns a 16 x 32 pixel tile (twice the pixels per weight byte): a K stage is 39 KB of x + 36 KB of
-// weights feeding 216 MFMAs per wave, two stages live in LDS, and the fetch of stage t+2 runs under the MFMAs of
-// stage t+1 — compute per stage (~3.4 us) now covers the DMA latency.
+// workgroup of 8 waves owns a 16 x 32 pixel tile (twice the pixels per weight byte): a K stage is 39 KB of x + 36 KB
+// of weights feeding 108 MFMAs in each of the 8 waves, two stages live in LDS, and the fetch of stage t+2 runs under
+// the MFMAs of stage t+1; both waves of a SIMD issue MFMAs, so one covers the other's fragment-read latency.
 //   * x tile 18 x 34 records of 64 B, slots rotated by (c>>2)&3 through the DMA source address (conflict-free reads,
 //     no padding);  weights in the packed order [tap][hi|lo][k-half][64][8] (36 KB per 16 input channels);
 //   * accumulators 2 M-tiles x 4 rows = 8 tiles per wave, MFMAs issued product-type-major so a tile is revisited
@@ -31,7 +31,7 @@ constexpr int BG_WPIECES = 36;                             // 36 rows x 64 chann
 constexpr int BG_STAGE = BG_XBYTES + BG_WPIECES * 1024;    // 76800
 constexpr int BG_PIECES = BG_XPIECES + BG_WPIECES;         // 75
 constexpr int BG_RED = 2 * BG_STAGE;                       // 4 waves x 64 floats
-constexpr int BG_SMEM = BG_RED + 4 * 64 * 4;
+constexpr int BG_SMEM = BG_RED + 8 * 64 * 4;
 
 struct BigConv {
     oodgan_conv_args a;
@@ -43,8 +43,8 @@ struct BigConv {
     int ablate;      // debug: 1 skip MFMAs, 2 skip the per-stage DMA
 };
 
-template <bool DOT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_s1big_kernel(
+template <bool DOT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const BigConv p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const oodgan_conv_args& a = p.a;
@@ -63,12 +63,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- per-lane DMA source offsets (bytes): x pieces relative to (plane of chunk 0, row r0, col c0), rotation applied;
     // weight pieces relative to the chunk's block.  Piece pc = wave + 4*i, i < 19 (pc < 75).
-    constexpr int NPW = (BG_PIECES + 3) / 4;                // 19
+    constexpr int NT = 16 / NW;                              // rows per wave
+    constexpr int NPW = (BG_PIECES + NW - 1) / NW;          // 19 (4 waves) / 10 (8 waves)
     unsigned off[NPW];
     const int KC = p.xd.KC;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-        const int pc = wave + 4 * i;
+        const int pc = wave + NW * i;
         if (pc < BG_XPIECES) {
             int P = pc * 64 + lane;
             if (P >= BG_XSLOTS) P = BG_XSLOTS - 1;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16);
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
-    const int npc = wave < (BG_PIECES - 4 * (NPW - 1)) ? NPW : NPW - 1;      // 19,19,19,18
+    const int npc = wave < (BG_PIECES - NW * (NPW - 1)) ? NPW : NPW - 1;
 
     auto dma_stage = [&](int t, int buf) {
         unsigned char* dst = smem + buf * BG_STAGE;
@@ -95,18 +96,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int pc = wave + 4 * i;
+            const int pc = wave + NW * i;
             if (pc >= BG_PIECES) break;
             const unsigned char* src = (pc < BG_XPIECES ? xsrc : wsrc) + off[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
@@ -127,41 +128,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int t = 0; t < nchunk; ++t) {
         // stage t has landed when at most the pieces of stage t+1 are outstanding (in-order retirement)
         if (t + 1 < nchunk) {
-            if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x4F73);      // vmcnt(19)
-            else __builtin_amdgcn_s_waitcnt(0x4F72);                 // vmcnt(18)
+            if (NW == 4) {
+                if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x4F73);      // vmcnt(19)
+                else __builtin_amdgcn_s_waitcnt(0x4F72);                 // vmcnt(18)
+            } else {
+                if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x0F7A);      // vmcnt(10)
+                else __builtin_amdgcn_s_waitcnt(0x0F79);                 // vmcnt(9)
+            }
         } else {
             __builtin_amdgcn_s_waitcnt(kVm0);
         }
         __builtin_amdgcn_s_barrier();
-        const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * 4) * (BG_C * 64);
+        const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * NT) * (BG_C * 64);
         const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES + lwf;
         if (!(p.ablate & 1))
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int ky = tp / 3, kx = tp % 3;
-            half8 ah[2], al[2], bh[4], bl[4];
+            half8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 ah[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 0) * 2) * 64 + mt * 32) * 16);
                 al[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 1) * 2) * 64 + mt * 32) * 16);
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 bh[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][0]);
                 bl[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][1]);
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_s_barrier();            // every wave is done with buffer t&1
         if (t + 2 < nchunk && !(p.ablate & 2)) dma_stage(t + 2, t & 1);
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int py = r0 + wave * 4 + nt;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int py = r0 + wave * NT + nt;
             const bool ok = py < H && px < W;
             float nz = 0.f;
             if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
@@ -228,7 +234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         if (tid < 64 && m0 + tid < M) {
             // the host sizes dot_part for 8-row tiles: this 16-row tile owns two of its slots
-            const float v = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) v += red[wv * 64 + tid];
             float* dp = a.dot_part + ((long)b * M + m0 + tid) * a.dot_nparts;
             const int tx8 = (W + 31) / 32;
             dp[(long)(2 * ty) * tx8 + tx] = v;
@@ -244,13 +252,15 @@ namespace oodgan {
 bool s1_big_eligible(const oodgan_conv_args& a) {
     static const int off = getenv("OODGAN_S1_BIG") ? atoi(getenv("OODGAN_S1_BIG")) == 0 : 0;
     if (off) return false;
-    // Measured (tools/bench_conv.py, B=8): 8 % faster than the two-group tile kernel at 512 -> 512 channels @64², 3-9 %
-    // slower at 256 / 128 channels, no visible change of the end-to-end step.  Ablation: without its DMA the kernel
-    // takes the same time — it is bound by the MFMA + fragment-read stream of ONE wave per SIMD (31 ns per MFMA against
-    // 17-20 ns for a bare MFMA loop), not by the staging the v2 kernel suffers from.  Kept as an opt-in alternative
-    // (OODGAN_S1_BIG_MIN_K=512 enables it for the 512-channel layers); off by default so that the dominant-kernel
-    // measurements refer to a single instance.
+    // Measured (tools/bench_conv.py, B=8, us per launch; v2 two-group tile kernel -> this kernel with 8 waves):
+    // 512->512 @64²: 455 -> 393 (394 TF/s), 256->256 @128²: 435 -> 407, 128->128 @256²: 484 -> 464.  With 4 waves (one
+    // per SIMD) it is slower than v2 (474 / 475 / 552): ablating its DMA does not change the time — the MFMA +
+    // fragment-read stream of a single wave per SIMD runs at 31 ns per MFMA (a bare MFMA loop: 17-20 ns), two waves per
+    // SIMD overlap each other's LDS waits.
     const char* ek = getenv("OODGAN_S1_BIG_MIN_K");
+    // In the inversion loop half of the launches are the input-gradient instance, whose register-side dot epilogue
+    // (64 strided loads + 32 lane reductions per lane, nothing left to overlap them with) costs more than the forward
+    // gains: 561 us vs 414 us forward, against ~460 us for either v2 instance — end to end a loss.  Opt-in only.
     const int min_k = ek ? atoi(ek) : (1 << 30);
     if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr && a.in_shift == nullptr &&
@@ -285,14 +295,21 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     p.ablate = abl;
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
+    const char* ew = getenv("OODGAN_S1_BIG_WAVES");
+    const int nw = ew ? atoi(ew) : 8;          // two waves per SIMD keep the MFMA pipe fed while the partner waits on LDS
+    if (nw == 8) {
+        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    } else {
+        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 4>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 4>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
+    }
     return check_launch("conv3x3_f16s_s1big");
 }
 
