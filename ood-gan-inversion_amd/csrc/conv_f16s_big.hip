@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         float osc[16], bia[16];
-        unsigned moff[16];
+        unsigned moff[16], doff[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
             osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
             bia[r] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
             moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
+            doff[r] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
         }
+        const bool mfull = m0 + mt * 32 + 32 <= M;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int py = r0 + wave * NT + nt;
@@ -203,20 +205,43 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
             if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
             unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + px) * 4;
             const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py * W + px) * 4 : nullptr;
+            float o[16], dv[16];
+            if (DOT) {
+                // all 16 loads of the row are issued before the first use (one conditional load per value would serialise
+                // them into 16 memory latencies)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+                if (ok) {
+                    if (mfull) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (moff[r] != 0xFFFFFFFFu) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[mt][nt][r];
-                float o = v * osc[r];
+                o[r] = v * osc[r];
                 if (DOT) {
-                    if (ok && moff[r] != 0xFFFFFFFFu) {
-                        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        dsum[mt][r] += (v * us) * *reinterpret_cast<const float*>(dr + (long)m * H * W * 4);
-                    }
+                    dsum[mt][r] += (v * us) * dv[r];
                 } else {
-                    o += nz + bia[r];
-                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                    o[r] += nz + bia[r];
+                    if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
                 }
-                if (ok && moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = o;
+            }
+            if (ok) {
+                if (mfull) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
+                }
             }
         }
     }
@@ -258,10 +283,10 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
     // fragment-read stream of a single wave per SIMD runs at 31 ns per MFMA (a bare MFMA loop: 17-20 ns), two waves per
     // SIMD overlap each other's LDS waits.
     const char* ek = getenv("OODGAN_S1_BIG_MIN_K");
-    // In the inversion loop half of the launches are the input-gradient instance, whose register-side dot epilogue
-    // (64 strided loads + 32 lane reductions per lane, nothing left to overlap them with) costs more than the forward
-    // gains: 561 us vs 414 us forward, against ~460 us for either v2 instance — end to end a loss.  Opt-in only.
-    const int min_k = ek ? atoi(ek) : (1 << 30);
+    // In the inversion loop (rocprof, per launch): forward 397 us, input gradient with the dot epilogue 443 us, against
+    // ~458 us for either v2 instance.  (The dot epilogue first cost 561 us: one conditional load per value serialised
+    // 64 memory latencies; the loads of a row are now issued together.)
+    const int min_k = ek ? atoi(ek) : 128;
     if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr && a.in_shift == nullptr &&
           !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))
@@ -290,7 +315,7 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
         OODGAN_REQUIRE(a.dot_nparts == ((a.Hin + 7) / 8) * p.tiles_x, "conv3x3 f16s S1: dot_nparts %d != %d", a.dot_nparts,
                        ((a.Hin + 7) / 8) * p.tiles_x);
     }
-    OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32), "conv3x3 big: plane too large");
+    OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 big: plane too large");
     static const int abl = getenv("OODGAN_BIG_ABLATE") ? atoi(getenv("OODGAN_BIG_ABLATE")) : 0;
     p.ablate = abl;
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
