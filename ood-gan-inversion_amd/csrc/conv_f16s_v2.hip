@@ -455,8 +455,8 @@ __host__ __device__ inline SPDims sp_dims(int C, int H, int W) {    // H,W = S2 
     return d;
 }
 
-template <int MT>
-__global__ __launch_bounds__(512) void conv_f16s_s2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
+template <int MT, int NG = 2>
+__global__ __launch_bounds__(256 * NG) void conv_f16s_s2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
                                                              const SConv sc, const SPDims sp) {
     constexpr int MB = 32 * MT;
     constexpr int GB = s2_group_bytes<MT>();
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2v2_kernel(const KArgs p, cons
     const int l31 = lane & 31, half = lane >> 5;
     unsigned char* lx = smem + grp * GB;
     unsigned char* lw = lx + S2_XBYTES;
-    const int wi = 2 * xcd_remap(blockIdx.x, gridDim.x) + grp;
+    const int wi = NG * xcd_remap(blockIdx.x, gridDim.x) + grp;
     const bool active = wi < total_items;
     BlockCtx ctx;
     {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2v2_kernel(const KArgs p, cons
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
 
     const int nstage = 2 * nchunk;                 // (chunk, py)
-    const int nsteps = 2 * nstage + 1;
+    const int nsteps = 2 * nstage + (NG - 1);
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();
         const int sidx = step - grp;
@@ -899,7 +899,8 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_y = (p.Hn + 7) / 8;
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
-    const bool mt2 = a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;    // as in launch_t2v2
+    static const int s2_mt1 = getenv("OODGAN_S2_MT1") ? atoi(getenv("OODGAN_S2_MT1")) : 0;
+    const bool mt2 = !s2_mt1 && a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;    // as in launch_t2v2
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {
@@ -915,17 +916,19 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     const int items = (int)total;
-    dim3 grid((unsigned)((total + 1) / 2)), block(512);
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-#define OODGAN_LAUNCH(MT_)                                                                                         \
+    static const int s2_ng = getenv("OODGAN_S2_GROUPS") ? atoi(getenv("OODGAN_S2_GROUPS")) : 2;
+#define OODGAN_LAUNCH(MT_, NG_)                                                                                    \
     {                                                                                                              \
-        constexpr int sm = 2 * s2_group_bytes<MT_>();                                                              \
-        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2v2_kernel<MT_>),  \
+        constexpr int sm = NG_ * s2_group_bytes<MT_>();                                                            \
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2v2_kernel<MT_, NG_>),  \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);      \
         (void)once;                                                                                                \
-        hipLaunchKernelGGL((conv_f16s_s2v2_kernel<MT_>), grid, block, sm, st, p, w16, items, sc, sp);              \
+        dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                          \
+        hipLaunchKernelGGL((conv_f16s_s2v2_kernel<MT_, NG_>), grid, block, sm, st, p, w16, items, sc, sp);         \
     }
-    if (mt2) OODGAN_LAUNCH(2) else OODGAN_LAUNCH(1)
+    if (s2_ng == 1) { if (mt2) OODGAN_LAUNCH(2, 1) else OODGAN_LAUNCH(1, 1) }
+    else { if (mt2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(1, 2) }
 #undef OODGAN_LAUNCH
     return check_launch("conv3x3_f16s_s2v2");
 }
