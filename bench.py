@@ -51,7 +51,7 @@ def parse():
 
 class ConvProbe:
     """HIP-event timing of every launch of the dominant kernel inside the timed region.  Dominant kernel (largest
-    share of GPU time in profiles/): the plain 3x3 stride-1 implicit-GEMM conv with S-form input and >= 128 input
+    share of GPU time in profiles/): the plain 3x3 stride-1 implicit-GEMM conv with S-form input and >= 64 input
     channels — template instances ``conv_f16s_s1big_kernel<false, 8>`` (forward) and ``<true, 8>`` (input gradient + style-gradient dot) (split-f16) / ``conv_mfma_kernel<0, 2>`` (fp32):
     forward of the plain ModulatedConv2d layers, their input gradients, and the dense AlignNet convs.
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
@@ -67,7 +67,7 @@ class ConvProbe:
             # work items (16x32-pixel tiles x 64-channel blocks) of the dominant kernel; layers with fewer than 256 of them
             # (4x4 ... 32x32 images) are dispatched to the latency-oriented instance conv_f16s_s1v2_kernel<1, 1, 2>
             items = ((H + 15) // 16) * ((W + 31) // 32) * B * ((M + 63) // 64)
-            if torch.cuda.is_current_stream_capturing() or not (probe.on and mode == probe.ops.CONV_S1 and M >= 64 and K >= 128 and
+            if torch.cuda.is_current_stream_capturing() or not (probe.on and mode == probe.ops.CONV_S1 and M >= 64 and K >= 64 and
                     (wpk.precision == 'f32' or (isinstance(x, probe.ops.SForm) and items >= 256))):
                 return probe.orig(x, wpk, M, mode, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -217,7 +217,7 @@ def main():
             roof = dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
                         frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a),
                         kernel=('conv_f16s_s1big_kernel<false|true, 8>' if f16s else 'conv_mfma_kernel<0, 2>') +
-                               ' (plain 3x3 stride-1 implicit GEMM, >=128 input channels: forward + input gradient)',
+                               ' (plain 3x3 stride-1 implicit GEMM, >=64 input channels: forward + input gradient)',
                         alg_bytes_per_launch=ps['bytes_per_launch'],
                         note=('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product, so its own ceiling is '
                               'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
