@@ -320,7 +320,7 @@ constexpr int T2_XPIECES = (T2_NPOS * 5 + 63) / 64;          // 13
 constexpr int T2_XBYTES = T2_XPIECES * 1024;
 
 template <int MT>
-__global__ __launch_bounds__(256) void conv_f16s_t2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, const SConv sc) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 1 ? 4 : 1, MT == 1 ? 4 : 1))) void conv_f16s_t2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, const SConv sc) {
     constexpr int MB = 32 * MT;
     constexpr int WROWS = 36;
     constexpr int WPIECES = WROWS * MB * 16 / 1024;
