@@ -455,11 +455,14 @@ __host__ __device__ inline SPDims sp_dims(int C, int H, int W) {    // H,W = S2 
     return d;
 }
 
-template <int MT, int NG = 2>
+// PYM: both row parities (all 9 taps) of a channel chunk in ONE stage — half the stages for layers with so few tiles
+// that every stage is a bare DMA latency (single group: the merged stage needs 112 KB of LDS at MT = 1).
+template <int MT, int NG = 2, bool PYM = false>
 __global__ __launch_bounds__(256 * NG) void conv_f16s_s2v2_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
                                                              const SConv sc, const SPDims sp) {
     constexpr int MB = 32 * MT;
-    constexpr int GB = s2_group_bytes<MT>();
+    constexpr int PYMB = 2 * S2_XBYTES + 9 * 4 * MB * 16;
+    constexpr int GB = PYM ? (PYMB > s2_group_bytes<MT>() ? PYMB : s2_group_bytes<MT>()) : s2_group_bytes<MT>();
     constexpr int XPW = (S2_XPIECES + 3) / 4;       // 12
     constexpr int TPP = 4 * MB * 16 / 1024;         // DMA pieces per tap (hi|lo x h x MB x 16 B)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s2v2_kernel(const KArgs p,
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     unsigned char* lx = smem + grp * GB;
-    unsigned char* lw = lx + S2_XBYTES;
+    unsigned char* lw = lx + (PYM ? 2 : 1) * S2_XBYTES;
     const int wi = NG * xcd_remap(blockIdx.x, gridDim.x) + grp;
     const bool active = wi < total_items;
     BlockCtx ctx;
@@ -510,60 +513,80 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s2v2_kernel(const KArgs p,
             for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
     const unsigned char* lwh = lw + (half * MB + l31) * 16;
     const unsigned char* lxh = lx + ((wave * 2) * 2 * S2_C + l31) * REC + half * 16;
-#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * REC + (lo_) * 32))
+#define XFRAGB(buf, posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (buf) * S2_XBYTES + (posoff) * REC + (lo_) * 32))
 #define WSLOT(slot, lo_, mt) (*reinterpret_cast<const half8*>(lwh + ((((slot) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
 #define MFMA3(accv, ah, al, bh, bl)                                              \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+    // taps (a, kx): LDS slot; x position: row nt + a, plane px = kx&1, col shift kx>>1, x buffer buf
+#define S2_TAP(slot_, a_, kx_, buf_)                                                                             \
+    {                                                                                                            \
+        half8 ahv[MT], alv[MT];                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { ahv[mt] = WSLOT(slot_, 0, mt); alv[mt] = WSLOT(slot_, 1, mt); } \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                       \
+            const half8 bhv = XFRAGB(buf_, ((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 0);            \
+            const half8 blv = XFRAGB(buf_, ((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 1);            \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { MFMA3(acc[mt][nt], ahv[mt], alv[mt], bhv, blv); } \
+        }                                                                                                        \
+    }
 
-    const int nstage = 2 * nchunk;                 // (chunk, py)
+    auto dma_x = [&](int t, int py, int buf) {
+        const uint4* base = xb0 + ((long)t * 4 + py * 2) * sp.plane;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int pc = wave + 4 * i;
+            if (pc < S2_XPIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
+                                                 (lds_void*)(lx + buf * S2_XBYTES + pc * 1024), 16, 0, 0);
+        }
+    };
+    // weights: LDS slot order = py-0 taps (ky in {0,2}: slot (ky>>1)*3 + kx, 6 taps), then (PYM) py-1 taps (ky = 1, slots 6..8)
+    auto dma_w = [&](int t, int slot0, int nslot, bool py1) {
+        for (int pc = wave; pc < nslot * TPP; pc += 4) {
+            const int sl = pc / TPP;
+            const int tap = py1 ? (3 + sl) : ((sl / 3) * 6 + sl % 3);
+            const int u = (pc % TPP) * 64 + lane;                 // 16-byte unit inside the tap block [hl][h][MB]
+            const int row = u / MB, j = u % MB;
+            const uint4* src = wpk16 + (long)t * wchunk + (long)(tap * 4 + row) * p.Mp + m0 + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (lds_void*)(lw + (slot0 * TPP + pc) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int nstage = PYM ? nchunk : 2 * nchunk;  // (chunk) or (chunk, py)
     const int nsteps = 2 * nstage + (NG - 1);
     for (int step = 0; step < nsteps; ++step) {
         __syncthreads();
         const int sidx = step - grp;
         if (!active || sidx < 0 || sidx >= 2 * nstage) continue;
-        const int q = sidx >> 1, t = q >> 1, py = q & 1;
-        if ((sidx & 1) == 0) {
-            const uint4* base = xb0 + ((long)t * 4 + py * 2) * sp.plane;
-#pragma unroll
-            for (int i = 0; i < XPW; ++i) {
-                const int pc = wave + 4 * i;
-                if (pc < S2_XPIECES)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + xsrc[i]),
-                                                     (lds_void*)(lx + pc * 1024), 16, 0, 0);
+        const int q = sidx >> 1;
+        if constexpr (PYM) {
+            if ((sidx & 1) == 0) {
+                dma_x(q, 0, 0);
+                dma_x(q, 1, 1);
+                dma_w(q, 0, 6, false);
+                dma_w(q, 6, 3, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                S2_TAP(0, 0, 0, 0) S2_TAP(1, 0, 1, 0) S2_TAP(2, 0, 2, 0)
+                S2_TAP(3, 1, 0, 0) S2_TAP(4, 1, 1, 0) S2_TAP(5, 1, 2, 0)
+                S2_TAP(6, 0, 0, 1) S2_TAP(7, 0, 1, 1) S2_TAP(8, 0, 2, 1)
             }
-            // weights of the taps with ky parity py: py=0 -> ky in {0,2} (6 taps), py=1 -> ky = 1 (3 taps);
-            // LDS slot order: slot = (ky>>1)*3 + kx
-            const int ntap = py ? 3 : 6;
-            for (int pc = wave; pc < ntap * TPP; pc += 4) {
-                const int slot = pc / TPP;
-                const int tap = py ? (3 + slot) : ((slot / 3) * 6 + slot % 3);
-                const int u = (pc % TPP) * 64 + lane;                 // 16-byte unit inside the tap block [hl][h][MB]
-                const int row = u / MB, j = u % MB;
-                const uint4* src = wpk16 + (long)t * wchunk + (long)(tap * 4 + row) * p.Mp + m0 + j;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (lds_void*)(lw + pc * 1024), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            // taps (a, kx): LDS slot = a*3 + kx; x position: row nt + a, plane px = kx&1, col shift kx>>1
-#define S2_TAP(slot_, a_, kx_)                                                                                   \
-    {                                                                                                            \
-        half8 ahv[MT], alv[MT];                                                                                  \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { ahv[mt] = WSLOT(slot_, 0, mt); alv[mt] = WSLOT(slot_, 1, mt); } \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                       \
-            const half8 bhv = XFRAG(((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 0);                   \
-            const half8 blv = XFRAG(((nt + (a_)) * 2 + ((kx_) & 1)) * S2_C + ((kx_) >> 1), 1);                   \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { MFMA3(acc[mt][nt], ahv[mt], alv[mt], bhv, blv); } \
-        }                                                                                                        \
-    }
-            S2_TAP(0, 0, 0) S2_TAP(1, 0, 1) S2_TAP(2, 0, 2)
-            if (py == 0) { S2_TAP(3, 1, 0) S2_TAP(4, 1, 1) S2_TAP(5, 1, 2) }
-#undef S2_TAP
+            const int t = q >> 1, py = q & 1;
+            if ((sidx & 1) == 0) {
+                dma_x(t, py, 0);
+                dma_w(t, 0, py ? 3 : 6, py != 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                S2_TAP(0, 0, 0, 0) S2_TAP(1, 0, 1, 0) S2_TAP(2, 0, 2, 0)
+                if (py == 0) { S2_TAP(3, 1, 0, 0) S2_TAP(4, 1, 1, 0) S2_TAP(5, 1, 2, 0) }
+            }
         }
     }
-#undef XFRAG
+#undef S2_TAP
+#undef XFRAGB
 #undef WSLOT
 #undef MFMA3
     __syncthreads();
@@ -926,6 +949,16 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         (void)once;                                                                                                \
         dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                          \
         hipLaunchKernelGGL((conv_f16s_s2v2_kernel<MT_, NG_>), grid, block, sm, st, p, w16, items, sc, sp);         \
+    }
+    // few tiles (low-resolution layers, already on 32-channel M tiles): one stage per channel chunk instead of two
+    static const int s2_pym = getenv("OODGAN_S2_PYM") ? atoi(getenv("OODGAN_S2_PYM")) : 1;
+    if (!mt2 && s2_pym && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) <= 256 && a.K >= 64) {
+        constexpr int sm = 2 * S2_XBYTES + 9 * 4 * 32 * 16;
+        static bool once1 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2v2_kernel<1, 1, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
+        (void)once1;
+        hipLaunchKernelGGL((conv_f16s_s2v2_kernel<1, 1, true>), dim3((unsigned)total), dim3(256), sm, st, p, w16, items, sc, sp);
+        return check_launch("conv3x3_f16s_s2v2");
     }
     if (s2_ng == 1) { if (mt2) OODGAN_LAUNCH(2, 1) else OODGAN_LAUNCH(1, 1) }
     else { if (mt2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(1, 2) }
