@@ -860,7 +860,9 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                                \
         hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_, CPS_>), grid, block, sm, st, p, w16, items, sc);             \
     }
-    if (deep) OODGAN_LAUNCH(1, 1, 2)
+    static const int deep_cps = getenv("OODGAN_V2_DEEP_CPS") ? atoi(getenv("OODGAN_V2_DEEP_CPS")) : 2;   // 3 chunks per stage measured equal: these layers are MFMA-bound on their padded tiles
+    if (deep && deep_cps == 3) OODGAN_LAUNCH(1, 1, 3)
+    else if (deep) OODGAN_LAUNCH(1, 1, 2)
     else if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2, 1) else OODGAN_LAUNCH(2, 1, 1) }
     else { if (ng == 2) OODGAN_LAUNCH(1, 2, 1) else OODGAN_LAUNCH(1, 1, 1) }
 #undef OODGAN_LAUNCH
