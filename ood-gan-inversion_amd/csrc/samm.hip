@@ -353,7 +353,31 @@ __global__ __launch_bounds__(256) void resize_bicubic_ac_kernel(const float* __r
     }
 }
 
+// y = AdaptiveAvgPool2d((Hin/f, Win/f))(x) for an integer factor f: ReStyle's `face_pool`
+// (reference src/archs/OOD_faceGAN_restyle_arch.py:89, 1024 -> 256)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Hin, int Win,
+                                                      int f) {
+    const int Hout = Hin / f, Wout = Win / f;
+    const long total = (long)planes * Hout * Wout;
+    const float inv = 1.0f / (float)(f * f);
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+        const float* src = x + (e / ((long)Wout * Hout)) * Hin * Win + (long)oy * f * Win + ox * f;
+        float acc = 0.f;
+        for (int i = 0; i < f; ++i)
+            for (int j = 0; j < f; ++j) acc += src[(long)i * Win + j];
+        y[e] = acc * inv;
+    }
+}
+
 }  // namespace
+
+extern "C" int oodgan_avgpool(const float* x, float* y, int planes, int Hin, int Win, int f, void* stream) {
+    OODGAN_REQUIRE(x && y && planes > 0 && f > 0 && Hin > 0 && Win > 0 && Hin % f == 0 && Win % f == 0, "avgpool: bad args");
+    hipLaunchKernelGGL(avgpool_kernel, dim3(stream_grid((long)planes * (Hin / f) * (Win / f), 256)), dim3(256), 0, as_stream(stream), x,
+                       y, planes, Hin, Win, f);
+    return check_launch("avgpool");
+}
 
 extern "C" int oodgan_resize_bicubic_ac(const float* x, const float* add, float* y, int planes, int Hin, int Win, int Hout, int Wout,
                                         void* stream) {

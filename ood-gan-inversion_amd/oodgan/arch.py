@@ -207,6 +207,10 @@ class ood_faceGAN_e4e(nn.Module):
         if kwargs.get('random_gen', False):
             return self.random_gen(batch_size=kwargs.get('batch_size', 1), gen=kwargs.get('gen', True))
         lats, enc_feats = self.encode(x, **kwargs)
+        return self._ood_forward(x, lats, enc_feats, **kwargs)
+
+    def _ood_forward(self, x, lats, enc_feats, **kwargs):
+        """generate() of the reference (e4e :268-313 / restyle :246-283): feats_conv -> hooked generator -> mask blend."""
         if 'lats' in kwargs and kwargs['lats'] is not None:      # W+ refined latents replace the encoder's
             lats = kwargs['lats']
         self.ori_lats = lats
@@ -262,7 +266,97 @@ class ood_faceGAN_e4e(nn.Module):
             noise = [n.expand(B, -1, -1, -1).contiguous() for n in self.generator.make_noise()]
         inv = WPlusInverter(self.generator.engine(), lr=lr)
         w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams, use_graph=use_graph)
-        kw = dict(kwargs)
-        kw.update({'enc_lats': lats0, 'enc_feats': enc_feats, 'lats': w, 'noise': noise})
-        out, lats = self.forward(x, **kw)
+        kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats')}
+        kw.update({'lats': w, 'noise': noise})
+        out, lats = self._ood_forward(x, lats0, enc_feats, **kw)
         return out, lats, losses
+
+
+@ARCH_REGISTRY.register()
+class ood_faceGAN_restyle(ood_faceGAN_e4e):
+    """The ReStyle variant (reference src/archs/OOD_faceGAN_restyle_arch.py:29-375): the latent code is
+    predicted iteratively — ``enc_cycle`` passes of a 6-channel encoder over [pool256(x), pool256(current reconstruction)],
+    starting from the average image — and the OOD forward (SAMM hooks, mask, blend) then runs exactly as in
+    ``ood_faceGAN_e4e``.  Same constructor surface, ``forward(x, **kw) -> (out, lats)`` and side channels.
+
+    ``ReStyle_pth``: a checkpoint with ``state_dict`` (``encoder.*`` keys), ``latent_avg`` (style_cnt, style_dim) and
+    ``opts`` (``encoder_type``, ``input_nc``), as the reference loads it (:67-83).  Only ``ProgressiveBackboneEncoder``
+    is supported (the ResNet-34 variant needs torchvision).
+
+    The reference draws fresh noise in every generator pass (it never forwards ``noise=``).  For reproducible runs
+    ``forward`` takes ``noise_passes=[avg-image pass (batch 1), cycle pass 1, ..., final pass]``, each a list of the 17
+    per-layer maps; ``noise=`` sets the final pass only."""
+
+    def __init__(self, out_size=1024, style_dim=512, encoder='ReStyle', ReStyle_pth=None, enc_cycle=2, avg_latent_pth=None, **kwargs):
+        if encoder != 'ReStyle':
+            raise NotImplementedError("ood_faceGAN_restyle: encoder must be 'ReStyle'")
+        if ReStyle_pth is None:
+            raise AssertionError('ReStyle_pth is required (reference :66)')
+        stage = kwargs.pop('stage', 'Inference')
+        impl = kwargs.pop('encoder_impl', 'hip')
+        kwargs.pop('build_encoder', None)
+        kwargs.pop('E4E_pth', None)
+        super().__init__(out_size=out_size, style_dim=style_dim, encoder='E4E', stage=stage, build_encoder=False, **kwargs)
+        self.encoder_type = encoder
+        from collections import OrderedDict
+        from .encoder import ProgressiveStage
+        enc_ckpt = torch.load(ReStyle_pth, map_location='cpu') if isinstance(ReStyle_pth, (str, bytes)) or hasattr(ReStyle_pth, '__fspath__') else ReStyle_pth
+        opts = dict(enc_ckpt['opts'])
+        if opts.get('encoder_type') != 'ProgressiveBackboneEncoder':
+            raise NotImplementedError(f"ReStyle encoder_type {opts.get('encoder_type')!r}: only ProgressiveBackboneEncoder")
+        if impl == 'hip':
+            from .encoder_hip import ProgressiveBackboneEncoderHIP as Enc
+        else:
+            from .encoder import ProgressiveBackboneEncoder as Enc
+        self.encoder = Enc(num_layers=50, mode='ir_se', n_styles=self.style_cnt, opts=opts)
+        enc_dict = OrderedDict((k[len('encoder.'):], v) for k, v in enc_ckpt['state_dict'].items() if k.startswith('encoder.'))
+        self.encoder.load_state_dict(enc_dict, strict=True)
+        self.encoder.progressive_stage = ProgressiveStage[stage]
+        self.avg_latent = nn.Parameter(enc_ckpt['latent_avg'].detach().clone().float().reshape(self.style_cnt, style_dim), requires_grad=False)
+        self.enc_cycle = enc_cycle
+        self.avg_img = None
+
+    def face_pool(self, x):
+        return samm.avgpool(x, 256)
+
+    def random_gen_center(self, scale=0.1, gen=True, noise=None):
+        lats = (self.avg_latent + (torch.randn_like(self.avg_latent) * scale)).unsqueeze(0)
+        out = self.generator(lats, input_is_tensor=True, input_is_latent=True, noise=noise)[0] if gen else None
+        return out, lats
+
+    def encode(self, x, **kwargs):
+        """:288-318 — iterative latent prediction; returns (lats, encoder feats of the last cycle)."""
+        passes = list(kwargs.get('noise_passes', None) or [])
+        take = lambda: passes.pop(0) if passes else None          # noqa: E731
+        with torch.no_grad():
+            if self.avg_img is None:
+                avg_img, _ = self.random_gen_center(scale=0, noise=take())
+                self.avg_img = self.face_pool(avg_img)
+            elif len(passes) > self.enc_cycle:                    # avg image cached: its noise entry is not needed
+                passes.pop(0)
+            self.encoder.eval()
+            x256 = self.face_pool(x)
+            lats, feats = self.encoder(torch.cat([x256, self.avg_img.repeat(x.shape[0], 1, 1, 1)], dim=1), return_feats=True)
+            lats = lats + self.avg_latent.unsqueeze(0)
+            for _ in range(self.enc_cycle - 1):
+                # both reference branches (:308-311) end in the plain, hook-free generator pass
+                new_x = self.generator(lats.contiguous(), input_is_tensor=True, input_is_latent=True, noise=take())[0]
+                delta, feats = self.encoder(torch.cat([x256, self.face_pool(new_x)], dim=1), return_feats=True)
+                lats = lats + delta
+        lats = lats + self.delta_latent
+        truncation = kwargs.get('truncation', 1.0)
+        if truncation < 1.0:
+            lats = self.avg_latent.unsqueeze(0) * (1. - truncation) + (lats * truncation)
+        self._final_noise = take()
+        return lats.contiguous(), feats
+
+    def forward(self, x, **kwargs):
+        if kwargs.get('random_gen', False):
+            return self.random_gen(batch_size=kwargs.get('batch_size', 1), gen=kwargs.get('gen', True))
+        if kwargs.get('enc_lats', None) is not None:
+            raise NotImplementedError('enc_lats= is the e4e entry; the ReStyle encoder is iterative')
+        lats, feats = self.encode(x, **kwargs)
+        kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation')}
+        if kw.get('noise', None) is None:
+            kw['noise'] = self._final_noise
+        return self._ood_forward(x, lats, feats, **kw)

@@ -202,3 +202,50 @@ class Encoder4Editing(nn.Module):
         if kwargs.get('return_feats', False):
             return w, feats
         return w
+
+
+class ProgressiveBackboneEncoder(nn.Module):
+    """ReStyle's encoder (reference src/ops/restyle/restyle_e4e_encoder.py:37-112): the same IR-SE-50 trunk on
+    ``opts.input_nc`` input channels (6: image + current reconstruction); all ``n_styles`` codes come from
+    ``GradualStyleBlock(512, 512, 16)`` heads on the final 16x16 map (no FPN).  Same state-dict keys, ``channels`` and
+    ``progressive_stage`` as the reference; plain-torch forward (``encoder_hip.ProgressiveBackboneEncoderHIP`` runs it on
+    the HIP kernels)."""
+
+    def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
+        super().__init__()
+        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE
+        input_nc = opts.input_nc if hasattr(opts, 'input_nc') else opts['input_nc']
+        self.input_layer = nn.Sequential(nn.Conv2d(input_nc, 64, (3, 3), 1, 1, bias=False), nn.BatchNorm2d(64), nn.PReLU(64))
+        self.channels = [64]
+        mods = []
+        for block in get_blocks(num_layers):
+            for u in block:
+                mods.append(unit(u.in_channel, u.depth, u.stride))
+            self.channels.append(block[-1].depth)
+        self.body = nn.Sequential(*mods)
+        self.style_count = n_styles
+        self.styles = nn.ModuleList([GradualStyleBlock(512, 512, 16) for _ in range(n_styles)])
+        self.progressive_stage = ProgressiveStage.Inference
+
+    def get_deltas_starting_dimensions(self):
+        return list(range(self.style_count))
+
+    def set_progressive_stage(self, new_stage):
+        self.progressive_stage = new_stage
+
+    def forward(self, x, **kwargs):
+        x = self.input_layer(x)
+        feats = [x]
+        for i, layer in enumerate(self.body):
+            x = layer(x)
+            if i in (2, 6, 20, 23):
+                feats.append(x)
+        w0 = self.styles[0](x)
+        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2)
+        for i in range(1, min(self.progressive_stage.value + 1, self.style_count)):
+            w[:, i] += self.styles[i](x)
+        if kwargs.get('return_feats', False):
+            return w, feats
+        return w

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib, ops, samm
 from ._lib import ACT_NONE, ACT_PRELU, CONV_S1, CONV_S2, check
-from .encoder import Encoder4Editing
+from .encoder import Encoder4Editing, ProgressiveBackboneEncoder
 
 
 def _bn_affine(bn):
@@ -71,11 +71,8 @@ def _conv3x3(x, pk, M, stride=1, **kw):
     return ops.conv3x3(xp, pk, M, CONV_S2, in_hw=(x.shape[2] + 1, x.shape[3] + 1), in_pitch=pitch, **kw)
 
 
-class Encoder4EditingHIP(Encoder4Editing):
-    def __init__(self, num_layers, mode='ir', opts=None, bn=True):
-        super().__init__(num_layers, mode, opts, bn)
-        self._mode = mode
-        self._pk = {}
+class _HipTrunk:
+    """shared HIP implementation of the IR-SE trunk and the GradualStyleBlock heads"""
 
     def _packed(self, name, w):
         p = self._pk.get(name)
@@ -118,16 +115,25 @@ class Encoder4EditingHIP(Encoder4Editing):
             x = _conv3x3(x, self._packed(f's{i}.{j}', c.weight), blk.out_c, 2, bias=c.bias.detach(), act=ACT_PRELU, slope=slope)
         return ops.equal_linear(x.reshape(-1, blk.out_c), blk.linear.weight.detach(), blk.linear.bias.detach(), lr_mul=blk.linear.lr_mul)
 
+    def _input(self, x):
+        B = x.shape[0]
+        il = self.input_layer
+        a, b = _bn_affine(il[1])
+        return _conv3x3(x, self._packed('in', il[0].weight), 64, 1, out_scale=_rows(a, B), bias=b.detach().contiguous(), act=ACT_PRELU,
+                        slope=il[2].weight.detach())
+
+
+class Encoder4EditingHIP(_HipTrunk, Encoder4Editing):
+    def __init__(self, num_layers, mode='ir', opts=None, bn=True):
+        Encoder4Editing.__init__(self, num_layers, mode, opts, bn)
+        self._mode = mode
+        self._pk = {}
+
     @torch.no_grad()
     def forward(self, x, **kwargs):
         if not x.is_cuda:
             raise RuntimeError('Encoder4EditingHIP needs a ROCm tensor (no CPU fallback)')
-        x = x.float().contiguous()
-        B = x.shape[0]
-        il = self.input_layer
-        a, b = _bn_affine(il[1])
-        x = _conv3x3(x, self._packed('in', il[0].weight), 64, 1, out_scale=_rows(a, B), bias=b.detach().contiguous(), act=ACT_PRELU,
-                     slope=il[2].weight.detach())
+        x = self._input(x.float().contiguous())
         feats = [x]
         c1 = c2 = c3 = None
         for i, layer in enumerate(self.body):
@@ -154,6 +160,33 @@ class Encoder4EditingHIP(Encoder4Editing):
             elif i == self.middle_ind:
                 features = _resize_bicubic_ac(p2, c1.shape[-2:], add=samm.conv1x1(c1, self.latlayer2.weight.detach(), self.latlayer2.bias.detach()))
             w[:, i] += self._style(i, features)
+        if kwargs.get('return_feats', False):
+            return w, feats
+        return w
+
+
+class ProgressiveBackboneEncoderHIP(_HipTrunk, ProgressiveBackboneEncoder):
+    """ReStyle's encoder (restyle_e4e_encoder.py:37-112) on the HIP kernels."""
+
+    def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
+        ProgressiveBackboneEncoder.__init__(self, num_layers, mode, n_styles, opts)
+        self._mode = mode
+        self._pk = {}
+
+    @torch.no_grad()
+    def forward(self, x, **kwargs):
+        if not x.is_cuda:
+            raise RuntimeError('ProgressiveBackboneEncoderHIP needs a ROCm tensor (no CPU fallback)')
+        x = self._input(x.float().contiguous())
+        feats = [x]
+        for i, layer in enumerate(self.body):
+            x = self._unit(i, layer, x)
+            if i in (2, 6, 20, 23):
+                feats.append(x)
+        w0 = self._style(0, x)
+        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
+        for i in range(1, min(self.progressive_stage.value + 1, self.style_count)):
+            w[:, i] += self._style(i, x)
         if kwargs.get('return_feats', False):
             return w, feats
         return w

@@ -228,3 +228,17 @@ def encoder_state(shapes, seed=0, prefix=''):
         else:
             sd[k] = normal(name, shp, seed, 0.1, 1.0)             # BatchNorm weight
     return sd
+
+
+def restyle_checkpoint(seed=0, style_cnt=18, style_dim=512):
+    """A ReStyle-e4e checkpoint in the layout the reference loads (OOD_faceGAN_restyle_arch.py:67-83): ``state_dict``
+    with ``encoder.*`` keys (ProgressiveBackboneEncoder, 6 input channels), ``latent_avg`` (style_cnt, style_dim), ``opts``."""
+    from .encoder import ProgressiveBackboneEncoder
+    opts = {'encoder_type': 'ProgressiveBackboneEncoder', 'input_nc': 6}
+    shapes = {k: tuple(v.shape) for k, v in ProgressiveBackboneEncoder(50, 'ir_se', style_cnt, opts).state_dict().items()}
+    enc = encoder_state(shapes, seed=seed, prefix='restyle.')
+    for k in enc:
+        if k.endswith('.linear.weight'):
+            enc[k] = enc[k] / 256.0          # recipe trunk features are O(10): keep the predicted codes O(1) like trained ones
+    return {'state_dict': OrderedDict(('encoder.' + k, v) for k, v in enc.items()),
+            'latent_avg': normal('restyle.latent_avg', (style_cnt, style_dim), seed, 0.5), 'opts': opts}

@@ -37,6 +37,7 @@ def install_stubs():
     tv = _stub('torchvision')
     tv.ops = _stub('torchvision.ops', deform_conv2d=None)
     tv.transforms = _stub('torchvision.transforms')
+    tv.models = _stub('torchvision.models', resnet34=None)
 
     class EasyDict(dict):
         __getattr__ = dict.__getitem__
@@ -328,6 +329,8 @@ def main():
         gold_ood(1)
     if 'enc' in which:
         gold_encoder()
+    if 'restyle' in which:
+        gold_restyle()
 
 
 
@@ -350,6 +353,42 @@ def gold_encoder():
         g[f'feat{i}_sub'] = f[:, ::8, ::step, ::step]
         g[f'feat{i}_mean'] = f.mean(dim=(2, 3))
     save('encoder_256.npz', **g)
+
+
+def gold_restyle(B=1):
+    """ReStyle variant: full forward of ood_faceGAN_restyle at 1024², enc_cycle=2 — average image,
+    two encoder passes, one plain reconstruction, then the OOD forward.  Recipe weights; preset noise for the three
+    generator passes (avg image at batch 1, cycle reconstruction, final)."""
+    import tempfile
+    from src.archs.OOD_faceGAN_restyle_arch import ood_faceGAN_restyle
+    ck = synth.restyle_checkpoint(seed=51)
+    with tempfile.TemporaryDirectory() as d:
+        pth = os.path.join(d, 'restyle.pth')
+        torch.save(ck, pth)
+        m = ood_faceGAN_restyle(out_size=1024, style_dim=512, encoder='ReStyle', ReStyle_pth=pth, enc_cycle=2,
+                                enable_modulation=True, warp_scale=0.08, cycle_align=2, blend_with_gen=True, ModSize=256).eval()
+    sd = synth.ood_state(1024, seed=31)
+    sd.pop('avg_latent')
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith('encoder.') or k == 'avg_latent' for k in res.missing_keys), res.missing_keys[:5]
+    x = synth.make_images(1024, B, seed=52)
+    passes = [synth.make_noises(1024, 1, seed=53), synth.make_noises(1024, B, seed=54), synth.make_noises(1024, B, seed=55)]
+    feed = _NoiseFeed([n for p in passes for n in p])
+    feed.install()
+    with torch.no_grad():
+        out, lats = m(x)
+    feed.remove()
+    assert feed.calls == 51, feed.calls
+    g = dict(out_sub=out[:, :, ::16, ::16], out_crop=out[:, :, 480:544, 480:544], lats=lats, avg_img_sub=m.avg_img[:, :, ::4, ::4],
+             out_mean=out.mean(dim=(2, 3)), out_std=out.std(dim=(2, 3)))
+    for k in (1, 2, 3, 4):
+        a = m.aligns[k]
+        step = max(1, a.shape[-1] // 32)
+        g[f'align{k}_sub'] = a[:, :, ::step, ::step]
+        g[f'align{k}_mean'] = a.mean(dim=(2, 3))
+    g['align1024_sub'] = m.aligns[1024][:, :1, ::16, ::16]
+    save('restyle_1024.npz', **g)
 
 
 if __name__ == '__main__':
