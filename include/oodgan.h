@@ -327,9 +327,10 @@ int oodgan_resize_nearest(const float* x, float* y, int planes, int Hin, int Win
  * `_upsample_add` of the e4e encoder's FPN (src/ops/e4e/encoders/helpers.py:504-521). */
 int oodgan_resize_bicubic_ac(const float* x, const float* add, float* y, int planes, int Hin, int Win, int Hout, int Wout,
                              void* stream);
-/* AdaptiveAvgPool2d((Hin/f, Win/f)) for an integer factor f: `face_pool` of the ReStyle variant
- * (src/archs/OOD_faceGAN_restyle_arch.py:89, 292-303), 1024 -> 256. */
-int oodgan_avgpool(const float* x, float* y, int planes, int Hin, int Win, int f, void* stream);
+/* AdaptiveAvgPool2d((Hout, Wout)): `face_pool` of the ReStyle / FeatureStyle variants
+ * (src/archs/OOD_faceGAN_restyle_arch.py:89, 292-303; 1024 -> 256) and the 3x3 pooled descriptors of `fs_encoder_v2`
+ * (src/ops/FeatureStyle/feature_style_encoder.py:42,55-66). */
+int oodgan_avgpool(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
 int oodgan_resize_bilinear(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream);
 
 #ifdef __cplusplus

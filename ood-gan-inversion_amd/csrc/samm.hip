@@ -353,29 +353,54 @@ __global__ __launch_bounds__(256) void resize_bicubic_ac_kernel(const float* __r
     }
 }
 
-// y = AdaptiveAvgPool2d((Hin/f, Win/f))(x) for an integer factor f: ReStyle's `face_pool`
-// (reference src/archs/OOD_faceGAN_restyle_arch.py:89, 1024 -> 256)
+// y = AdaptiveAvgPool2d((Hout, Wout))(x): window [floor(o*In/Out), ceil((o+1)*In/Out)) per axis.  ReStyle's `face_pool`
+// (reference src/archs/OOD_faceGAN_restyle_arch.py:89, 1024 -> 256, 4x4 windows: one thread per output) and the 3x3 pooled
+// descriptors of the FeatureStyle encoder (src/ops/FeatureStyle/feature_style_encoder.py:42, windows up to 43x43: one wave
+// per output, lanes stride the window, DPP-free shuffle reduction).
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Hin, int Win,
-                                                      int f) {
-    const int Hout = Hin / f, Wout = Win / f;
+                                                      int Hout, int Wout) {
     const long total = (long)planes * Hout * Wout;
-    const float inv = 1.0f / (float)(f * f);
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
-        const float* src = x + (e / ((long)Wout * Hout)) * Hin * Win + (long)oy * f * Win + ox * f;
+        const int y0 = (int)((long)oy * Hin / Hout), y1 = (int)(((long)(oy + 1) * Hin + Hout - 1) / Hout);
+        const int x0 = (int)((long)ox * Win / Wout), x1 = (int)(((long)(ox + 1) * Win + Wout - 1) / Wout);
+        const float* src = x + (e / ((long)Wout * Hout)) * Hin * Win;
         float acc = 0.f;
-        for (int i = 0; i < f; ++i)
-            for (int j = 0; j < f; ++j) acc += src[(long)i * Win + j];
-        y[e] = acc * inv;
+        for (int i = y0; i < y1; ++i)
+            for (int j = x0; j < x1; ++j) acc += src[(long)i * Win + j];
+        y[e] = acc / (float)((y1 - y0) * (x1 - x0));
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_wave_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Hin,
+                                                           int Win, int Hout, int Wout) {
+    const long total = (long)planes * Hout * Wout;
+    const int lane = threadIdx.x & 63;
+    for (long e = blockIdx.x * 4L + (threadIdx.x >> 6); e < total; e += (long)gridDim.x * 4) {
+        const int ox = (int)(e % Wout), oy = (int)((e / Wout) % Hout);
+        const int y0 = (int)((long)oy * Hin / Hout), y1 = (int)(((long)(oy + 1) * Hin + Hout - 1) / Hout);
+        const int x0 = (int)((long)ox * Win / Wout), x1 = (int)(((long)(ox + 1) * Win + Wout - 1) / Wout);
+        const float* src = x + (e / ((long)Wout * Hout)) * Hin * Win;
+        const int ww = x1 - x0, n = (y1 - y0) * ww;
+        float acc = 0.f;
+        for (int t = lane; t < n; t += 64) acc += src[(long)(y0 + t / ww) * Win + x0 + t % ww];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) y[e] = acc / (float)n;
     }
 }
 
 }  // namespace
 
-extern "C" int oodgan_avgpool(const float* x, float* y, int planes, int Hin, int Win, int f, void* stream) {
-    OODGAN_REQUIRE(x && y && planes > 0 && f > 0 && Hin > 0 && Win > 0 && Hin % f == 0 && Win % f == 0, "avgpool: bad args");
-    hipLaunchKernelGGL(avgpool_kernel, dim3(stream_grid((long)planes * (Hin / f) * (Win / f), 256)), dim3(256), 0, as_stream(stream), x,
-                       y, planes, Hin, Win, f);
+extern "C" int oodgan_avgpool(const float* x, float* y, int planes, int Hin, int Win, int Hout, int Wout, void* stream) {
+    OODGAN_REQUIRE(x && y && planes > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Hout <= Hin && Wout <= Win, "avgpool: bad args");
+    const long total = (long)planes * Hout * Wout;
+    const long window = (long)((Hin + Hout - 1) / Hout + 1) * ((Win + Wout - 1) / Wout + 1);
+    if (window >= 128)
+        hipLaunchKernelGGL(avgpool_wave_kernel, dim3(stream_grid(total, 4)), dim3(256), 0, as_stream(stream), x, y, planes, Hin, Win, Hout,
+                           Wout);
+    else
+        hipLaunchKernelGGL(avgpool_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, y, planes, Hin, Win, Hout,
+                           Wout);
     return check_launch("avgpool");
 }
 

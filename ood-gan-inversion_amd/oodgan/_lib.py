@@ -56,7 +56,7 @@ _SIGS = {
     'oodgan_to_sform_phases': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_resize_bicubic_ac': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'oodgan_avgpool': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_avgpool': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_blur_act_sform': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_sform_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

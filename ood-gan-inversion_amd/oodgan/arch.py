@@ -360,3 +360,57 @@ class ood_faceGAN_restyle(ood_faceGAN_e4e):
         if kw.get('noise', None) is None:
             kw['noise'] = self._final_noise
         return self._ood_forward(x, lats, feats, **kw)
+
+
+@ARCH_REGISTRY.register()
+class ood_faceGAN_FeatureStyle(ood_faceGAN_e4e):
+    """The Feature-Style variant (reference src/archs/OOD_faceGAN_featureStyle_arch.py:28-334): latents from
+    ``fs_encoder_v2`` (IResNet-50 trunk, pooled descriptors, 18 linear heads) on the 256² average-pooled input, SAMM taps
+    = stem + first three stages, then the shared OOD forward.  ``FeatureStyle_pth`` is the encoder's state dict (loaded
+    strictly, :74-79).  ``arcface_model_path`` is accepted and not read: the reference only uses it to initialise the trunk
+    before ``FeatureStyle_pth`` overwrites every parameter.  Like the reference (:277-291) the encoder's ``content`` feature
+    is computed and NOT injected — ``generate(lats, feats, x)`` leaves ``contents=None``."""
+
+    def __init__(self, out_size=1024, style_dim=512, StyleGAN_pth_key='g_ema', encoder='FeatureStyle', FeatureStyle_pth=None,
+                 arcface_model_path=None, avg_latent_pth=None, **kwargs):
+        if encoder != 'FeatureStyle':
+            raise NotImplementedError("ood_faceGAN_FeatureStyle: encoder must be 'FeatureStyle'")
+        if FeatureStyle_pth is None:
+            raise AssertionError('FeatureStyle_pth is required (reference :73)')
+        impl = kwargs.pop('encoder_impl', 'hip')
+        kwargs.pop('build_encoder', None)
+        kwargs.pop('E4E_pth', None)
+        super().__init__(out_size=out_size, style_dim=style_dim, StyleGAN_pth_key=StyleGAN_pth_key, encoder='E4E', build_encoder=False, **kwargs)
+        self.encoder_type = encoder
+        if impl == 'hip':
+            from .encoder_hip import fs_encoder_v2HIP as Enc
+        else:
+            from .encoder import fs_encoder_v2 as Enc
+        self.encoder = Enc(n_styles=self.style_cnt, stride=(2, 2))
+        enc_ckpt = torch.load(FeatureStyle_pth, map_location='cpu') if isinstance(FeatureStyle_pth, (str, bytes)) or hasattr(FeatureStyle_pth, '__fspath__') else FeatureStyle_pth
+        self.encoder.load_state_dict(enc_ckpt, strict=True)
+        self.avg_latent = nn.Parameter(torch.zeros((self.style_cnt, style_dim)), requires_grad=False)
+        if avg_latent_pth is not None:
+            self.avg_latent.data = torch.load(avg_latent_pth, map_location='cpu')
+
+    def face_pool(self, x):
+        return samm.avgpool(x, 256)
+
+    def encode(self, x, **kwargs):
+        """:268-285"""
+        with torch.no_grad():
+            self.encoder.eval()
+            lats, self.content, feats = self.encoder(self.face_pool(x), return_feats=True)
+        lats = lats + self.avg_latent.unsqueeze(0) + self.delta_latent
+        truncation = kwargs.get('truncation', 1.0)
+        if truncation < 1.0:
+            lats = self.avg_latent.unsqueeze(0) * (1. - truncation) + (lats * truncation)
+        return lats.contiguous(), feats
+
+    def forward(self, x, **kwargs):
+        if kwargs.get('random_gen', False):
+            return self.random_gen(batch_size=kwargs.get('batch_size', 1), gen=kwargs.get('gen', True))
+        if kwargs.get('enc_lats', None) is not None:
+            raise NotImplementedError('enc_lats= is the e4e entry')
+        lats, feats = self.encode(x, **kwargs)
+        return self._ood_forward(x, lats, feats, **{k: v for k, v in kwargs.items() if k != 'truncation'})

@@ -249,3 +249,69 @@ class ProgressiveBackboneEncoder(nn.Module):
         if kwargs.get('return_feats', False):
             return w, feats
         return w
+
+
+class IBasicBlock(nn.Module):
+    """Pre-activation basic block of the ArcFace IResNet (reference src/ops/FeatureStyle/arcface/iresnet.py:30-61):
+    bn1 -> conv3x3 -> bn2 -> PReLU -> conv3x3(stride) -> bn3, + identity (1x1 conv stride + bn when the shape changes)."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(cin, eps=1e-5)
+        self.conv1 = nn.Conv2d(cin, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout, eps=1e-5)
+        self.prelu = nn.PReLU(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, stride, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout, eps=1e-5)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout, eps=1e-5))
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.bn3(self.conv2(self.prelu(self.bn2(self.conv1(self.bn1(x))))))
+        return out + (x if self.downsample is None else self.downsample(x))
+
+
+def _iresnet_stage(cin, cout, n):
+    return nn.Sequential(IBasicBlock(cin, cout, 2), *[IBasicBlock(cout, cout, 1) for _ in range(n - 1)])
+
+
+class fs_encoder_v2(nn.Module):
+    """Feature-Style encoder (reference src/ops/FeatureStyle/feature_style_encoder.py:12-74): IResNet-50 trunk (stem +
+    stages of 3/4/14/3 blocks), 3x3 adaptive-average-pooled descriptors of the four stages (64+128+256+512 channels x 9)
+    -> ``n_styles`` Linear(8640, 512) heads; ``content_layer`` on the 256-channel stage; the stem and the first three
+    stages are the SAMM taps.  Same state-dict keys.  The reference builds the trunk from an ArcFace checkpoint
+    (``opts.arcface_model_path``) and then overwrites every parameter from ``FeatureStyle_pth``; the mirror only needs the
+    latter."""
+
+    def __init__(self, n_styles=18, opts=None, stride=(1, 1), **kwargs):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(3, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64, eps=1e-5), nn.PReLU(64))
+        self.block_1 = _iresnet_stage(64, 64, 3)
+        self.block_2 = _iresnet_stage(64, 128, 4)
+        self.block_3 = _iresnet_stage(128, 256, 14)
+        self.block_4 = _iresnet_stage(256, 512, 3)
+        self.content_layer = nn.Sequential(nn.BatchNorm2d(256), nn.Conv2d(256, 512, 3, 1, 1, bias=False), nn.BatchNorm2d(512),
+                                           nn.PReLU(512), nn.Conv2d(512, 512, 3, stride, 1, bias=False), nn.BatchNorm2d(512))
+        self.avg_pool = nn.AdaptiveAvgPool2d((3, 3))
+        self.styles = nn.ModuleList([nn.Linear(960 * 9, 512) for _ in range(n_styles)])
+
+    def forward(self, x, return_feats=False):
+        x = self.conv(x)
+        taps, pooled = [x], []
+        x = self.block_1(x)
+        taps.append(x)
+        pooled.append(self.avg_pool(x))
+        x = self.block_2(x)
+        taps.append(x)
+        pooled.append(self.avg_pool(x))
+        x = self.block_3(x)
+        taps.append(x)
+        content = self.content_layer(x)
+        pooled.append(self.avg_pool(x))
+        x = self.block_4(x)
+        pooled.append(self.avg_pool(x))
+        d = torch.cat(pooled, dim=1).flatten(1)
+        out = torch.stack([s(d) for s in self.styles], dim=1)
+        return (out, content, taps) if return_feats else (out, content)

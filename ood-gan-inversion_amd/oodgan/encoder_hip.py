@@ -20,7 +20,7 @@ import torch
 
 from . import _lib, ops, samm
 from ._lib import ACT_NONE, ACT_PRELU, CONV_S1, CONV_S2, check
-from .encoder import Encoder4Editing, ProgressiveBackboneEncoder
+from .encoder import Encoder4Editing, ProgressiveBackboneEncoder, fs_encoder_v2
 
 
 def _bn_affine(bn):
@@ -190,3 +190,81 @@ class ProgressiveBackboneEncoderHIP(_HipTrunk, ProgressiveBackboneEncoder):
         if kwargs.get('return_feats', False):
             return w, feats
         return w
+
+
+class fs_encoder_v2HIP(_HipTrunk, fs_encoder_v2):
+    """Feature-Style encoder (feature_style_encoder.py:12-74) on the HIP kernels: every IBasicBlock is two ``oodgan_conv3x3``
+    launches with the three BatchNorms and the PReLU folded in, the shortcut an ``oodgan_conv1x1`` + affine, the pooled
+    descriptors ``oodgan_avgpool`` and the ``n_styles`` heads ONE ``oodgan_equal_linear`` (scale 1) over the stacked
+    (n_styles*512, 8640) weight."""
+
+    def __init__(self, n_styles=18, opts=None, stride=(1, 1), **kwargs):
+        fs_encoder_v2.__init__(self, n_styles, opts, stride, **kwargs)
+        self._pk = {}
+        self._heads = None
+
+    def _block(self, name, blk, x):
+        B = x.shape[0]
+        cout = blk.conv1.weight.shape[0]
+        a1, b1 = _bn_affine(blk.bn1)
+        a2, b2 = _bn_affine(blk.bn2)
+        r = _conv3x3(x, self._packed(name + '.c1', blk.conv1.weight), cout, 1, in_scale=_rows(a1, B), in_shift=_rows(b1, B),
+                     out_scale=_rows(a2, B), bias=b2.detach().contiguous(), act=ACT_PRELU, slope=blk.prelu.weight.detach())
+        a3, b3 = _bn_affine(blk.bn3)
+        r = _conv3x3(r, self._packed(name + '.c2', blk.conv2.weight), cout, blk.stride, out_scale=_rows(a3, B), bias=b3.detach().contiguous())
+        if blk.downsample is None:
+            idt = x
+        else:
+            xs = x if blk.stride == 1 else x[:, :, ::blk.stride, ::blk.stride].contiguous()
+            a, b = _bn_affine(blk.downsample[1])
+            idt = samm.affine_apply(samm.conv1x1(xs, blk.downsample[0].weight.detach()), _rows(a, B), _rows(b, B))
+        return samm.affine_apply(r, torch.ones(B, cout, device=x.device), torch.zeros(B, cout, device=x.device), res=idt)
+
+    def _stage(self, name, stage, x):
+        for i, blk in enumerate(stage):
+            x = self._block(f'{name}.{i}', blk, x)
+        return x
+
+    def _content(self, x):
+        B = x.shape[0]
+        cl = self.content_layer
+        a0, b0 = _bn_affine(cl[0])
+        a2, b2 = _bn_affine(cl[2])
+        r = _conv3x3(x, self._packed('cl.1', cl[1].weight), 512, 1, in_scale=_rows(a0, B), in_shift=_rows(b0, B), out_scale=_rows(a2, B),
+                     bias=b2.detach().contiguous(), act=ACT_PRELU, slope=cl[3].weight.detach())
+        a5, b5 = _bn_affine(cl[5])
+        return _conv3x3(r, self._packed('cl.4', cl[4].weight), 512, cl[4].stride[0], out_scale=_rows(a5, B), bias=b5.detach().contiguous())
+
+    def _head_weights(self):
+        key = tuple((s.weight.data_ptr(), s.weight._version, s.bias._version) for s in self.styles)
+        if self._heads is None or self._heads[0] != key:
+            self._heads = (key, torch.cat([s.weight.detach() for s in self.styles], 0).contiguous(),
+                           torch.cat([s.bias.detach() for s in self.styles], 0).contiguous())
+        return self._heads[1], self._heads[2]
+
+    @torch.no_grad()
+    def forward(self, x, return_feats=False):
+        if not x.is_cuda:
+            raise RuntimeError('fs_encoder_v2HIP needs a ROCm tensor (no CPU fallback)')
+        x = x.float().contiguous()
+        B = x.shape[0]
+        a, b = _bn_affine(self.conv[1])
+        x = _conv3x3(x, self._packed('stem', self.conv[0].weight), 64, 1, out_scale=_rows(a, B), bias=b.detach().contiguous(), act=ACT_PRELU,
+                     slope=self.conv[2].weight.detach())
+        taps, pooled = [x], []
+        x = self._stage('b1', self.block_1, x)
+        taps.append(x)
+        pooled.append(samm.avgpool(x, 3))
+        x = self._stage('b2', self.block_2, x)
+        taps.append(x)
+        pooled.append(samm.avgpool(x, 3))
+        x = self._stage('b3', self.block_3, x)
+        taps.append(x)
+        content = self._content(x)
+        pooled.append(samm.avgpool(x, 3))
+        x = self._stage('b4', self.block_4, x)
+        pooled.append(samm.avgpool(x, 3))
+        d = torch.cat(pooled, dim=1).flatten(1).contiguous()
+        w, bias = self._head_weights()
+        out = ops.linear(d, w, bias).reshape(B, len(self.styles), -1)
+        return (out, content, taps) if return_feats else (out, content)

@@ -169,6 +169,17 @@ def equal_linear(x, weight, bias=None, lr_mul=1.0, activation=False):
     return y
 
 
+def linear(x, weight, bias=None):
+    """nn.Linear (feature_style_encoder.py:45,67-68) through the EqualLinear kernel with scale 1."""
+    x = _dev(x)
+    w = _dev(weight, 'weight')
+    B, I = x.shape
+    O = w.shape[0]
+    y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_equal_linear(_p(x), _p(w), _p(_opt(bias, 'bias')), _p(y), B, I, O, 1.0, 1.0, 0, _stream()), 'linear')
+    return y
+
+
 def pixel_norm(x):
     x = _dev(x)
     y = torch.empty_like(x)

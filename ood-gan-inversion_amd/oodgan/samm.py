@@ -153,12 +153,12 @@ def resize_nearest(x, size, out=None, xoff=0):
 
 
 def avgpool(x, size):
-    """AdaptiveAvgPool2d((size,size)) for H, W multiples of size (restyle arch :89)."""
+    """AdaptiveAvgPool2d(size) (restyle arch :89; feature_style_encoder.py:42)."""
     x = _dev(x)
     B, C, H, W = x.shape
-    assert H % size == 0 and W % size == 0 and H // size == W // size
-    y = torch.empty(B, C, size, size, device=x.device, dtype=torch.float32)
-    check(_lib.lib().oodgan_avgpool(_p(x.contiguous()), _p(y), B * C, H, W, H // size, _stream()), 'avgpool')
+    Ho, Wo = (size, size) if isinstance(size, int) else size
+    y = torch.empty(B, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_avgpool(_p(x.contiguous()), _p(y), B * C, H, W, Ho, Wo, _stream()), 'avgpool')
     return y
 
 

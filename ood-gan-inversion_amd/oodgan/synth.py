@@ -242,3 +242,31 @@ def restyle_checkpoint(seed=0, style_cnt=18, style_dim=512):
             enc[k] = enc[k] / 256.0          # recipe trunk features are O(10): keep the predicted codes O(1) like trained ones
     return {'state_dict': OrderedDict(('encoder.' + k, v) for k, v in enc.items()),
             'latent_avg': normal('restyle.latent_avg', (style_cnt, style_dim), seed, 0.5), 'opts': opts}
+
+
+def featurestyle_state(seed=0, style_cnt=18):
+    """State dict of ``fs_encoder_v2`` (the content of ``FeatureStyle_pth``, OOD_faceGAN_featureStyle_arch.py:74-79)."""
+    from .encoder import fs_encoder_v2
+    shapes = {k: tuple(v.shape) for k, v in fs_encoder_v2(style_cnt, stride=(2, 2)).state_dict().items()}
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        name = 'fs.' + k
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith('running_mean'):
+            sd[k] = normal(name, shp, seed, 0.1)
+        elif k.endswith('running_var'):
+            sd[k] = uniform(name, shp, seed, 0.5, 1.5)
+        elif len(shp) == 4:
+            sd[k] = normal(name, shp, seed, math.sqrt(2.0 / (shp[1] * shp[2] * shp[3])))
+        elif len(shp) == 2:
+            sd[k] = normal(name, shp, seed, 0.1 / math.sqrt(shp[1]))      # Linear heads: recipe descriptors are O(10), codes O(1)
+        elif 'prelu' in k or k in ('conv.2.weight', 'content_layer.3.weight'):
+            sd[k] = normal(name, shp, seed, 0.05, 0.25)                     # PReLU slopes
+        elif k.endswith('.bias'):
+            sd[k] = normal(name, shp, seed, 0.1)
+        elif '.bn3.weight' in k:
+            sd[k] = normal(name, shp, seed, 0.03, 0.25)                     # damp the residual branch (see encoder_state)
+        else:
+            sd[k] = normal(name, shp, seed, 0.1, 1.0)
+    return sd

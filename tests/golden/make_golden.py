@@ -38,6 +38,7 @@ def install_stubs():
     tv.ops = _stub('torchvision.ops', deform_conv2d=None)
     tv.transforms = _stub('torchvision.transforms')
     tv.models = _stub('torchvision.models', resnet34=None)
+    tv.utils = _stub('torchvision.utils')
 
     class EasyDict(dict):
         __getattr__ = dict.__getitem__
@@ -331,6 +332,8 @@ def main():
         gold_encoder()
     if 'restyle' in which:
         gold_restyle()
+    if 'fs' in which:
+        gold_featurestyle()
 
 
 
@@ -389,6 +392,46 @@ def gold_restyle(B=1):
         g[f'align{k}_mean'] = a.mean(dim=(2, 3))
     g['align1024_sub'] = m.aligns[1024][:, :1, ::16, ::16]
     save('restyle_1024.npz', **g)
+
+
+def gold_featurestyle(B=1):
+    """Feature-Style variant: full forward of ood_faceGAN_FeatureStyle at 1024², recipe weights, preset
+    noise.  The reference builds its trunk from an ArcFace IResNet-50 checkpoint before FeatureStyle_pth overwrites it:
+    a freshly initialised iresnet50 state stands in for that file."""
+    import tempfile
+    from src.archs.OOD_faceGAN_featureStyle_arch import ood_faceGAN_FeatureStyle
+    from src.ops.FeatureStyle.arcface.iresnet import iresnet50
+    with tempfile.TemporaryDirectory() as d:
+        arc, pth, avg = (os.path.join(d, n) for n in ('arc.pth', 'fs.pth', 'avg.pth'))
+        torch.save(iresnet50().state_dict(), arc)
+        torch.save(synth.featurestyle_state(seed=61), pth)
+        torch.save(synth.normal('fs.latent_avg', (18, 512), 61, 0.5), avg)
+        m = ood_faceGAN_FeatureStyle(out_size=1024, style_dim=512, encoder='FeatureStyle', FeatureStyle_pth=pth, arcface_model_path=arc,
+                                     avg_latent_pth=avg, enable_modulation=True, warp_scale=0.08, cycle_align=2, blend_with_gen=True,
+                                     ModSize=256).eval()
+    sd = synth.ood_state(1024, seed=31)
+    sd.pop('avg_latent')
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith('encoder.') or k == 'avg_latent' for k in res.missing_keys), res.missing_keys[:5]
+    x = synth.make_images(1024, B, seed=62)
+    feed = _NoiseFeed(synth.make_noises(1024, B, seed=63))
+    feed.install()
+    with torch.no_grad():
+        out, lats = m(x)
+        _, content, taps = m.encoder(m.face_pool(x), return_feats=True)
+    feed.remove()
+    assert feed.calls == 17, feed.calls
+    g = dict(out_sub=out[:, :, ::16, ::16], out_crop=out[:, :, 480:544, 480:544], lats=lats, content_sub=content[:, ::8],
+             out_mean=out.mean(dim=(2, 3)), out_std=out.std(dim=(2, 3)))
+    for i, f in enumerate(taps):
+        g[f'tap{i}_mean'] = f.mean(dim=(2, 3))
+    for k in (1, 2, 3, 4):
+        a = m.aligns[k]
+        step = max(1, a.shape[-1] // 32)
+        g[f'align{k}_sub'] = a[:, :, ::step, ::step]
+    g['align1024_sub'] = m.aligns[1024][:, :1, ::16, ::16]
+    save('featurestyle_1024.npz', **g)
 
 
 if __name__ == '__main__':

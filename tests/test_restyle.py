@@ -90,3 +90,58 @@ def test_restyle_forward_1024_vs_golden(dev, golden, tmp_path):
     # second call reuses the cached average image; same noise for the remaining passes -> same result
     out2, lats2 = m(x, noise_passes=passes)
     assert torch.equal(lats2, lats)
+
+
+# ------------------------------------------------------------------ Feature-Style variant
+def test_fs_encoder_keys_and_cpu_forward_shapes():
+    """Mirror of fs_encoder_v2 (feature_style_encoder.py:12-74): the state the reference loaded strictly loads strictly
+    here; output contract (latents, content, 4 SAMM taps) on a small input."""
+    from oodgan.encoder import fs_encoder_v2
+    enc = fs_encoder_v2(18, stride=(2, 2)).eval()
+    enc.load_state_dict(synth.featurestyle_state(seed=61), strict=True)
+    with torch.no_grad():
+        lats, content, taps = enc(synth.make_images(64, 1, seed=5), return_feats=True)
+    assert lats.shape == (1, 18, 512) and content.shape == (1, 512, 4, 4)
+    assert [tuple(t.shape[1:]) for t in taps] == [(64, 64, 64), (64, 32, 32), (128, 16, 16), (256, 8, 8)]
+    assert enc.styles[0].weight.shape == (512, 960 * 9)
+
+
+@pytest.mark.gpu
+def test_adaptive_avgpool_3x3(dev):
+    from oodgan import samm
+    for s in (128, 64, 32, 16, 7):
+        x = synth.normal(f'ap.{s}', (2, 5, s, s), 3)
+        _close(samm.avgpool(x.to(dev), 3), torch.nn.functional.adaptive_avg_pool2d(x, (3, 3)), 2e-6)
+
+
+@pytest.mark.gpu
+def test_featurestyle_forward_1024_vs_golden(dev, golden, tmp_path):
+    from oodgan.arch import build_network
+    g = golden('featurestyle_1024.npz')
+    pth, avg = tmp_path / 'fs.pth', tmp_path / 'avg.pth'
+    torch.save(synth.featurestyle_state(seed=61), pth)
+    torch.save(synth.normal('fs.latent_avg', (18, 512), 61, 0.5), avg)
+    m = build_network(dict(type='ood_faceGAN_FeatureStyle', out_size=1024, style_dim=512, encoder='FeatureStyle', FeatureStyle_pth=str(pth),
+                           arcface_model_path=None, avg_latent_pth=str(avg), enable_modulation=True, warp_scale=0.08, cycle_align=2,
+                           blend_with_gen=True, ModSize=256))
+    sd = synth.ood_state(1024, seed=31)
+    sd.pop('avg_latent')
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith('encoder.') or k == 'avg_latent' for k in res.missing_keys)
+    m = m.to(dev).eval()
+    x = synth.make_images(1024, 1, seed=62).to(dev)
+    noise = [n.to(dev) for n in synth.make_noises(1024, 1, seed=63)]
+    out, lats = m(x, noise=noise)
+    _, content, taps = m.encoder(m.face_pool(x), return_feats=True)
+    for i, f in enumerate(taps):
+        _close(f.mean(dim=(2, 3)), g[f'tap{i}_mean'], 2e-4)
+    _close(content[:, ::8], g['content_sub'], 1e-3)
+    _close(lats, g['lats'], 2e-4)
+    tol = 1e-3
+    _close(out[:, :, ::16, ::16], g['out_sub'], tol)
+    _close(out[:, :, 480:544, 480:544], g['out_crop'], tol)
+    for k in (1, 2, 3, 4):
+        a = m.aligns[k]
+        step = max(1, a.shape[-1] // 32)
+        _close(a[:, :, ::step, ::step], g[f'align{k}_sub'], tol)
+    _close(m.aligns[1024][:, :1, ::16, ::16], g['align1024_sub'], tol)
