@@ -169,12 +169,17 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
 // (b, 16-channel block) x a tile of 4x32 (i,j) positions = g2 rows 2*i0..2*i0+7, cols 2*j0..2*j0+63.  H,W = size of
 // the up-conv's INPUT; all tensors of ActArgs are at (2H)x(2W).
 constexpr int BT_R = 11, BT_C = 72;
+// LDS pitches (floats): row 74, channel plane 816 — with the FIR's lane mapping (4 channels x 8 rows x 2 half rows per wave)
+// every ds_read_b64 of a half wave covers the 64 banks once (72 / 792 was a 4-way conflict).  Exchange buffer:
+// [16 ch x 521][4 phases x 130][4 rows x 32, column ^ (row >= 2 ? 8 : 0)] — conflict-free for the FIR's scalar writes and the
+// pixel-major reads.
+constexpr int BT_P = 74, BT_Q = 816, BX_CH = 521, BX_PH = 130;
 
 template <bool RGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void act_bwd_blurT_sp_kernel(const ActArgs a, const float* __restrict__ kern,
                                                                uint4* __restrict__ outp, int H, int W, SPDims sp, int tiles_x,
                                                                int tiles_y) {
-    __shared__ __attribute__((aligned(16))) float lin[16 * BT_R * BT_C];
+    __shared__ __attribute__((aligned(16))) float lin[16 * BT_Q];
     __shared__ float kf[16];
     __shared__ float ksep[9];
     __shared__ float cst[6][16];
@@ -281,7 +286,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                     v = make_float4(gp[0], gp[1], gp[2], gp[3]);
                 }
-                *reinterpret_cast<float4*>(lin + (ch * BT_R + r) * BT_C + 4 * c4) = v;
+                float2* dst = reinterpret_cast<float2*>(lin + ch * BT_Q + r * BT_P + 4 * c4);
+                dst[0] = make_float2(v.x, v.y);
+                dst[1] = make_float2(v.z, v.w);
             }
         }
         // reduce over the 16 threads of the channel
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int j = 0; j < 20; ++j) tmp[j] = 0.f;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
-                const float2* row = reinterpret_cast<const float2*>(lin + (ch * BT_R + yrow + aa) * BT_C + 32 * xh + 16 * hf + 2);
+                const float2* row = reinterpret_cast<const float2*>(lin + ch * BT_Q + (yrow + aa) * BT_P + 32 * xh + 16 * hf + 2);
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
                     const float2 v = row[j];
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < 32; ++j) o[j] = 0.f;
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
-            const float* row = lin + (ch * BT_R + yrow + aa) * BT_C + 32 * xh + 2;
+            const float* row = lin + ch * BT_Q + (yrow + aa) * BT_P + 32 * xh + 2;
             float win[35];
 #pragma unroll
             for (int j = 0; j < 35; ++j) win[j] = row[j];
@@ -354,8 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 32; ++j) {
         const int Xl = 32 * xh + j;
         const int ph = (yrow & 1) * 2 + (Xl & 1);
-        const int pos = (ph * 4 + (yrow >> 1)) * 32 + (Xl >> 1);
-        lst[ch * 512 + pos] = o[j] * sc_;
+        lst[ch * BX_CH + ph * BX_PH + (yrow >> 1) * 32 + ((Xl >> 1) ^ ((yrow & 4) << 1))] = o[j] * sc_;
     }
     __syncthreads();
     // ---- C
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         half8 h0, h1, l0, l1;
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
-            float v = lst[cc * 512 + pos];
+            float v = lst[cc * BX_CH + ph * BX_PH + il * 32 + (jl ^ ((il & 2) << 2))];
             const int Y = 2 * i + (ph >> 1), X = 2 * j + (ph & 1);
             if (Y > 2 * H || X > 2 * W) v = 0.f;
             const _Float16 hh = (_Float16)v;
@@ -384,15 +390,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // state[0..1] = {unscale, scale} (in: used by the pass that produced `part`, out: for the next step);
 // flag[0] |= 1 when max*scale_used left [2^-8, 2^15] (the window in which hi+lo is exact to fp32 and cannot overflow
 // after the demodulation factor), |= 2 when a non-finite value was seen.
-__global__ __launch_bounds__(256) void absmax_scale_check_kernel(const float* __restrict__ part, long n, float* __restrict__ state,
-                                                                 int* __restrict__ flag) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void absmax_scale_check_kernel(const float* __restrict__ part, long n, float* __restrict__ state,
+                                                                  int* __restrict__ flag) {
+    __shared__ float red[16];
     float m = 0.f;
     bool bad = false;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        const float v = part[i];
-        if (!isfinite(v)) bad = true;
-        m = fmaxf(m, fabsf(v));
+    // 4 independent loads in flight per thread: the list has up to ~130k entries and one block reads it
+    for (long i = threadIdx.x; i < n; i += 4096) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + 1024 * u < n ? part[i + 1024 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!isfinite(v[u])) bad = true;
+            m = fmaxf(m, fabsf(v[u]));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -400,7 +412,9 @@ __global__ __launch_bounds__(256) void absmax_scale_check_kernel(const float* __
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        m = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
         const float used = state[1];
         if (m > 0.f && isfinite(m)) {
             const float scaled = m * used;
@@ -483,6 +497,6 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
 
 extern "C" int oodgan_absmax_scale_check(const float* part, long n, float* state, int* flag, void* stream) {
     OODGAN_REQUIRE(part && state && flag && n > 0, "absmax_scale_check: bad args");
-    hipLaunchKernelGGL(absmax_scale_check_kernel, dim3(1), dim3(256), 0, as_stream(stream), part, n, state, flag);
+    hipLaunchKernelGGL(absmax_scale_check_kernel, dim3(1), dim3(1024), 0, as_stream(stream), part, n, state, flag);
     return check_launch("absmax_scale_check");
 }

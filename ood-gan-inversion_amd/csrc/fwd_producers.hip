@@ -18,6 +18,10 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int FT_R = 11, FT_C = 72;      // input tile: rows Y0-1..Y0+9, cols X0-4..X0+67
+// LDS pitches (floats): row 74, channel plane 816 — with the FIR's lane mapping (4 channels x 8 rows x 2 half rows per wave)
+// every ds_read_b64 of a half wave then covers the 64 banks once (72 / 792 was a 4-way conflict); rows stay 8-byte aligned.
+constexpr int FT_P = 74, FT_Q = 816;
+constexpr int LS_ROW = 65, LS_CH = 520;  // exchange buffer [16 ch][8 rows x 65]: conflict-free scalar writes and row reads
 
 struct BlurArgs {
     const float* z;          // (B,C,Hz,pitch), Hz = 2H+1, valid width Wz = 2W+1
@@ -35,7 +39,7 @@ struct BlurArgs {
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur_act_sform_kernel(const BlurArgs a) {
-    __shared__ __attribute__((aligned(16))) float lin[16 * FT_R * FT_C];     // reused as lst[16][512]
+    __shared__ __attribute__((aligned(16))) float lin[16 * FT_Q];     // reused as lst[16][LS_CH]
     __shared__ float kf[16];
     __shared__ float ksep[9];
     __shared__ float cb[2][16];          // bias, ys_scale of the block's channels
@@ -93,7 +97,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (gx + 2 >= Wz) v[k].z = 0.f;
                 v[k].w = 0.f;
             }
-            *reinterpret_cast<float4*>(lin + (ch * FT_R + r) * FT_C + 4 * c4) = v[k];
+            float2* dst = reinterpret_cast<float2*>(lin + ch * FT_Q + r * FT_P + 4 * c4);
+            dst[0] = make_float2(v[k].x, v[k].y);
+            dst[1] = make_float2(v[k].z, v[k].w);
         }
     }
     __syncthreads();
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
                 // tile column of X-1 is (X - X0) + 3; read the aligned pairs from column 32*xh + 16*hf + 2 and skip one
-                const float2* row = reinterpret_cast<const float2*>(lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 16 * hf + 2);
+                const float2* row = reinterpret_cast<const float2*>(lin + ch * FT_Q + (yrow + aa) * FT_P + 32 * xh + 16 * hf + 2);
                 const float kv = ksep[aa];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int j = 0; j < 32; ++j) o[j] = 0.f;
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
-            const float* row = lin + (ch * FT_R + yrow + aa) * FT_C + 32 * xh + 3;
+            const float* row = lin + ch * FT_Q + (yrow + aa) * FT_P + 32 * xh + 3;
             float win[35];
 #pragma unroll
             for (int j = 0; j < 35; ++j) win[j] = row[j];
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     float* lst = lin;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) lst[ch * 512 + yrow * 64 + 32 * xh + j] = o[j];
+    for (int j = 0; j < 32; ++j) lst[ch * LS_CH + yrow * LS_ROW + 32 * xh + j] = o[j];
     __syncthreads();
     // ---- C: thread = pixel: noise + bias + activation for its 16 channels, fp32 store per channel plane, one record
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int cc = 2 * cp + e;
-                float t = lst[cc * 512 + pos] + nz + cb[0][cc];
+                float t = lst[cc * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)] + nz + cb[0][cc];
                 if (a.act == OODGAN_ACT_LRELU) t = (t > 0.f ? t : 0.2f * t) * kSqrt2;
                 if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
                 v[e] = t * cb[1][cc];

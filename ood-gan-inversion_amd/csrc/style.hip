@@ -68,12 +68,15 @@ __global__ __launch_bounds__(256) void style_affine_wave_kernel(const float* __r
 }
 
 // glat[b,l,k] = scale * sum_{r in [lat_start[l], lat_start[l+1])} gs[b,r] * W[r,k]
-// grid (ceil(S/64), L, ceil(B/8)); block = 64 k-columns x 4 row groups (rows of the latent split 4 ways, reduced
-// through LDS); W row reads are 256-B coalesced, the 8 batch accumulators share every W element.
-__global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ w,
-                                                               const int* __restrict__ lat_start, float* __restrict__ glat,
-                                                               int B, int L, int S, int R, float scale) {
-    __shared__ float red[4][8][64];
+// grid (ceil(S/64), L, ceil(B/8)); block = 64 k-columns x 16 row groups (rows of the latent split 16 ways, reduced
+// through LDS in a fixed order); W row reads are 256-B coalesced, the 8 batch accumulators share every W element.
+// (With 4 row groups the ~500 rows of a latent were a chain of 125 dependent-latency iterations per thread: 325 us.)
+constexpr int SAB_RG = 16, SAB_CHUNK = 1024;
+__global__ __launch_bounds__(64 * SAB_RG) void style_affine_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ w,
+                                                                      const int* __restrict__ lat_start, float* __restrict__ glat,
+                                                                      int B, int L, int S, int R, float scale) {
+    __shared__ float red[SAB_RG][8][64];
+    __shared__ float gsl[8][SAB_CHUNK];
     const int kl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kl;
     const int l = blockIdx.y;
@@ -82,25 +85,34 @@ __global__ __launch_bounds__(256) void style_affine_bwd_kernel(const float* __re
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    if (k < S) {
+    // the latent's slice of gs (8 batch rows) is staged in LDS: read from global it is 8 broadcast loads per W element
+    for (int c0 = ra; c0 < rb; c0 += SAB_CHUNK) {
+        const int cn = rb - c0 < SAB_CHUNK ? rb - c0 : SAB_CHUNK;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 8 * cn; e += 64 * SAB_RG) {
+            const int j = e / cn, r = e - j * cn;
+            gsl[j][r] = b0 + j < B ? gs[(long)(b0 + j) * R + c0 + r] : 0.f;
+        }
+        __syncthreads();
+        if (k < S) {
 #pragma unroll 4
-        for (int r = ra + rg; r < rb; r += 4) {
-            const float wv = w[(long)r * S + k];
+            for (int r = rg; r < cn; r += SAB_RG) {
+                const float wv = w[(long)(c0 + r) * S + k];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int b = b0 + j;
-                if (b < B) acc[j] += gs[(long)b * R + r] * wv;
+                for (int j = 0; j < 8; ++j) acc[j] += gsl[j][r] * wv;
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[rg][j][kl] = acc[j];
     __syncthreads();
-    if (rg == 0 && k < S) {
+    if (rg < 8 && k < S) {          // wave j sums batch row j over the row groups, in a fixed order
+        const int b = b0 + rg;
+        if (b < B) {
+            float v = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int b = b0 + j;
-            if (b < B) glat[((long)b * L + l) * S + k] = (red[0][j][kl] + red[1][j][kl] + red[2][j][kl] + red[3][j][kl]) * scale;
+            for (int g = 0; g < SAB_RG; ++g) v += red[g][rg][kl];
+            glat[((long)b * L + l) * S + k] = v * scale;
         }
     }
 }
@@ -202,7 +214,7 @@ extern "C" int oodgan_style_affine_fwd(const float* latent, const float* wcat, c
 extern "C" int oodgan_style_affine_bwd(const float* gs, const float* wcat, const int* lat_start, float* glat, int B, int L,
                                        int S, int R, float scale, void* stream) {
     OODGAN_REQUIRE(gs && wcat && lat_start && glat && B > 0 && L > 0 && S > 0 && R > 0, "style_affine_bwd: bad args");
-    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3((S + 63) / 64, L, (B + 7) / 8), dim3(256), 0, as_stream(stream), gs,
+    hipLaunchKernelGGL(style_affine_bwd_kernel, dim3((S + 63) / 64, L, (B + 7) / 8), dim3(64 * SAB_RG), 0, as_stream(stream), gs,
                        wcat, lat_start, glat, B, L, S, R, scale);
     return check_launch("style_affine_bwd");
 }

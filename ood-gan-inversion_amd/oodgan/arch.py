@@ -207,12 +207,12 @@ class ood_faceGAN_e4e(nn.Module):
         if kwargs.get('random_gen', False):
             return self.random_gen(batch_size=kwargs.get('batch_size', 1), gen=kwargs.get('gen', True))
         lats, enc_feats = self.encode(x, **kwargs)
-        return self._ood_forward(x, lats, enc_feats, **kwargs)
+        if kwargs.get('lats', None) is not None:                 # W+ refined latents replace the encoder's
+            lats = kwargs['lats']
+        return self._ood_forward(x, lats, enc_feats, **{k: v for k, v in kwargs.items() if k not in ('lats', 'enc_lats', 'enc_feats')})
 
     def _ood_forward(self, x, lats, enc_feats, **kwargs):
         """generate() of the reference (e4e :268-313 / restyle :246-283): feats_conv -> hooked generator -> mask blend."""
-        if 'lats' in kwargs and kwargs['lats'] is not None:      # W+ refined latents replace the encoder's
-            lats = kwargs['lats']
         self.ori_lats = lats
         noise = kwargs.get('noise', None)
         if self.modulation is None:
@@ -266,9 +266,8 @@ class ood_faceGAN_e4e(nn.Module):
             noise = [n.expand(B, -1, -1, -1).contiguous() for n in self.generator.make_noise()]
         inv = WPlusInverter(self.generator.engine(), lr=lr)
         w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams, use_graph=use_graph)
-        kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats')}
-        kw.update({'lats': w, 'noise': noise})
-        out, lats = self._ood_forward(x, lats0, enc_feats, **kw)
+        kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats', 'lats', 'noise')}
+        out, lats = self._ood_forward(x, w, enc_feats, noise=noise, **kw)
         return out, lats, losses
 
 
