@@ -175,6 +175,15 @@ constexpr int BT_R = 11, BT_C = 72;
 // pixel-major reads.
 constexpr int BT_P = 74, BT_Q = 816, BX_CH = 521, BX_PH = 130;
 
+// element k (0..12) of thread i (0..15 within its channel) of the 11-row x 18-float4 input tile: the thread walks down
+// column group i (k = row), then rows 0..10 of the two halo column groups 16 and 17 go to threads 0..10.  Row offsets are
+// compile-time and the column is fixed per thread, so the sweep needs no per-element division or bounds arithmetic.
+__device__ __forceinline__ bool tile_elem(int k, int i, int& r, int& c4) {
+    if (k < BT_R) { r = k; c4 = i; return true; }
+    r = i; c4 = 16 + (k - BT_R);
+    return i < BT_R;
+}
+
 template <bool RGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void act_bwd_blurT_sp_kernel(const ActArgs a, const float* __restrict__ kern,
                                                                uint4* __restrict__ outp, int H, int W, SPDims sp, int tiles_x,
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         float acc_r = 0.f, acc_t = 0.f;
         // loads are issued in two batches of 7 / 6 tile elements before anything depends on them (a load per iteration
         // would serialise the fill into 13 HBM latencies)
-        constexpr int NE = (BT_R * (BT_C / 4) + 15) / 16;       // 13
+        constexpr int NE = BT_R + 2;                              // 13 (tile_elem)
         constexpr int NB = RGB ? 4 : 7;                           // batch: NB elements x (3 or 6) float4 loads in flight
 #pragma unroll
         for (int k0 = 0; k0 < NE; k0 += NB) {
@@ -236,13 +245,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             bool okv[NB];
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) {
-                const int e = (tid & 15) + 16 * (k0 + kk);
-                const int c4 = e % (BT_C / 4), r = e / (BT_C / 4);
+                int r, c4;
+                const bool act = tile_elem(k0 + kk, tid & 15, r, c4);
                 const int gy = gy0 + r, gx = gx0 + 4 * c4;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 o4[kk] = g4[kk] = nz4[kk] = z4;
                 if (RGB) r04[kk] = r14[kk] = r24[kk] = z4;
-                okv[kk] = k0 + kk < NE && e < BT_R * (BT_C / 4) && c < a.C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg;
+                okv[kk] = k0 + kk < NE && act && c < a.C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg;
                 if (okv[kk]) {
                     const long p = (long)gy * Wg + gx;
                     o4[kk] = *reinterpret_cast<const float4*>(a.out + cbase + p);
@@ -257,9 +266,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk) {
-                const int e = (tid & 15) + 16 * (k0 + kk);
-                if (k0 + kk >= NE || e >= BT_R * (BT_C / 4)) continue;
-                const int c4 = e % (BT_C / 4), r = e / (BT_C / 4);
+                int r, c4;
+                if (k0 + kk >= NE || !tile_elem(k0 + kk, tid & 15, r, c4)) continue;
                 const int gy = gy0 + r, gx = gx0 + 4 * c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (okv[kk]) {
@@ -274,13 +282,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float o = ov[j];
-                        const float t = w0 * r0v[j] + w1 * r1v[j] + w2 * r2v[j];
-                        const float g = gv[j] + sr * t;
+                        float t = 0.f, g = gv[j];
+                        if (RGB) {          // without a ToRGB branch the three products are not even issued
+                            t = w0 * r0v[j] + w1 * r1v[j] + w2 * r2v[j];
+                            g += sr * t;
+                        }
                         gp[j] = g * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
                         if (own) {
                             const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nzv[j] - bv;
                             acc_r += gp[j] * ycv;
-                            acc_t += o * t;
+                            if (RGB) acc_t += o * t;
                             amax = fmaxf(amax, fabsf(gp[j]));
                         }
                     }

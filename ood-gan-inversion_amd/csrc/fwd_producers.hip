@@ -23,6 +23,15 @@ constexpr int FT_R = 11, FT_C = 72;      // input tile: rows Y0-1..Y0+9, cols X0
 constexpr int FT_P = 74, FT_Q = 816;
 constexpr int LS_ROW = 65, LS_CH = 520;  // exchange buffer [16 ch][8 rows x 65]: conflict-free scalar writes and row reads
 
+// element k (0..12) of thread i (0..15 within its channel) of the 11-row x 18-float4 input tile: the thread walks down
+// column group i (k = row), then rows 0..10 of the two halo column groups 16 and 17 go to threads 0..10 — compile-time
+// row offsets and a fixed column per thread instead of a division per element.
+__device__ __forceinline__ bool tile_elem(int k, int i, int& r, int& c4) {
+    if (k < FT_R) { r = k; c4 = i; return true; }
+    r = i; c4 = 16 + (k - FT_R);
+    return i < FT_R;
+}
+
 struct BlurArgs {
     const float* z;          // (B,C,Hz,pitch), Hz = 2H+1, valid width Wz = 2W+1
     const float* kern;       // 4x4 (the op flips it, as upfirdn2d does)
@@ -74,22 +83,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
         // all loads of the sweep are issued before the first LDS store: one dependent load per iteration would make
         // the tile fill a chain of 13 HBM latencies
-        constexpr int NE = (FT_R * (FT_C / 4) + 15) / 16;       // 13
+        constexpr int NE = FT_R + 2;       // 13 (tile_elem)
         float4 v[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (tid & 15) + 16 * k;
-            const int c4 = e % (FT_C / 4), r = e / (FT_C / 4);
+            int r, c4;
+            const bool act = tile_elem(k, tid & 15, r, c4);
             const int gy = Y0 - 1 + r, gx = X0 - 4 + 4 * c4;
             v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < FT_R * (FT_C / 4) && c < a.C && gy >= 0 && gy < Hz && gx >= 0 && gx + 3 < a.pitch)
+            if (act && c < a.C && gy >= 0 && gy < Hz && gx >= 0 && gx + 3 < a.pitch)
                 v[k] = *reinterpret_cast<const float4*>(zp + (long)gy * a.pitch + gx);
         }
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = (tid & 15) + 16 * k;
-            if (e >= FT_R * (FT_C / 4)) continue;
-            const int c4 = e % (FT_C / 4), r = e / (FT_C / 4);
+            int r, c4;
+            if (!tile_elem(k, tid & 15, r, c4)) continue;
             const int gx = X0 - 4 + 4 * c4;
             if (gx + 3 >= Wz) {          // columns between the valid width and the pitch are not defined
                 if (gx + 0 >= Wz) v[k].x = 0.f;
