@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-roofline-events', action='store_true')
     ap.add_argument('--no-modconv', action='store_true', help='skip the fp16 modulated-conv roofline leg (BASELINE configs[4])')
     ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
+    ap.add_argument('--no-multistream', action='store_true', help='skip the extra leg that times the same job on 3 concurrent HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
     return ap.parse_args()
@@ -226,6 +227,21 @@ def main():
         modconv = None
         if not a.no_modconv and world == 1:
             modconv = modconv_roofline()
+        multi = None
+        if not a.no_multistream and world == 1 and a.streams == 1:
+            # the same job with the batch advanced as 3 sub-batches on concurrent HIP streams (bit-reproducible since the
+            # library is built without packed-fp32 instructions); reported beside `value`, not as `value`:
+            # the roofline events above need kernels that do not share the GPU
+            ms_run = lambda: model.invert(x, steps=a.wsteps, noise=noises, streams=3, enc_lats=enc_lats, enc_feats=enc_feats)
+            ms_run()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, _, ml = ms_run()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            multi = dict(streams=3, value=round(B / (t2 - t1), 4), unit='images/s',
+                         final_loss_mean=float(ml[-1].mean().item()),
+                         note='same workload, 3 sub-batches on concurrent HIP streams (opt-in: --streams 3)')
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
@@ -238,6 +254,7 @@ def main():
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'modconv2d': modconv,
+            'multistream': multi,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size),     # rank 0 at N=1 only
         }
         print(json.dumps(line, ensure_ascii=False))

@@ -322,6 +322,18 @@ import os as _os
 _DBG_SERIAL = _os.environ.get('OODGAN_GRAPH_SERIAL', '0') == '1'
 
 
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    """The same n side streams on every call: the caching allocator's pools and the S-form scratch buffers are keyed by
+    stream, so fresh streams per inversion would mean fresh (synchronising) device allocations inside every inversion."""
+    pool = _SIDE.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 class WPlusInverter:
     """Build-defined W+ optimisation loop: ``steps`` x {G(w) with fixed noise,
     per-image MSE, backward to w, Adam(lr, betas, eps)} — anchors: reference Generator.forward with
@@ -340,7 +352,7 @@ class WPlusInverter:
         if (streams == 1 and not use_graph) or return_trajectory:
             return self._invert_one(target, w0, noises, steps, return_trajectory)
         cur = torch.cuda.current_stream()
-        side = [torch.cuda.Stream(device=w0.device) for _ in range(streams)]
+        side = _side_streams(w0.device, streams)
         cuts = [(i * B) // streams for i in range(streams + 1)]
         parts = []
         for i, st in enumerate(side):
