@@ -184,3 +184,51 @@ def test_full_size_inversion_properties(dev):
     eng.fused_bwd = True
     assert maxdiff(l2, l.cpu()) <= 2e-5 * l.abs().max().item()
     assert ((w2 - w).abs() < 1e-4).float().mean().item() > 0.999
+
+
+def test_torgb_reproducible_beside_matrix_kernels_of_another_stream(dev):
+    """Guard for DESIGN.md §10: a ToRGB launch that shares the GPU with the stride-2 / transposed matrix kernels of
+    another HIP stream must give the same bits as alone (with packed-fp32 instructions in the kernels 70–85 % of such
+    launches came out with a few wrong elements)."""
+    import math
+    from oodgan import ops
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(0)
+    B = 4
+    k = (R.make_kernel([1, 3, 3, 1]) * 4.0).to(dev)
+
+    def conv_case(C, M, H, mode):
+        x = torch.randn(B, C, H, H, generator=g).to(dev)
+        s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+        d = (1 + 0.3 * torch.randn(B, M, generator=g)).to(dev)
+        w = (torch.randn(M, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+        wpk = ops.pack_conv3x3(w, precision='f16s')
+        if mode == ops.CONV_S2:
+            Hin = 2 * H + 1
+            P2 = (Hin + 3) // 4 * 4
+            g2 = torch.randn(B, C, Hin, P2, generator=g).to(dev)
+            xs = ops.to_sform_phases(g2, H, H, s, in_pitch=P2)
+        else:
+            xs = ops.to_sform(x, s)
+        return lambda: ops.conv3x3(xs, wpk, M, mode, out_scale=d)
+
+    neighbours = [conv_case(512, 512, 8, ops.CONV_S2), conv_case(512, 256, 64, ops.CONV_T2), conv_case(32, 32, 512, ops.CONV_S1)]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for C0, H0 in ((512, 16), (64, 128)):                 # torgb_fwd_small_kernel / torgb_fwd_kernel
+        x0 = torch.randn(B, C0, H0, H0, generator=g).to(dev)
+        s0 = (1 + 0.3 * torch.randn(B, C0, generator=g)).to(dev)
+        wr = torch.randn(3, C0, generator=g).to(dev)
+        bias = torch.randn(3, generator=g).to(dev)
+        skip = torch.randn(B, 3, H0 // 2, H0 // 2, generator=g).to(dev)
+        torch.cuda.synchronize()
+        ref = ops.torgb(x0, wr, s0, bias, skip, k).clone()
+        torch.cuda.synchronize()
+        for fn in neighbours:
+            for _ in range(3):
+                with torch.cuda.stream(sb):
+                    for _ in range(12):
+                        fn()
+                with torch.cuda.stream(sa):
+                    outs = [ops.torgb(x0, wr, s0, bias, skip, k) for _ in range(40)]
+                torch.cuda.synchronize()
+                assert all(torch.equal(o, ref) for o in outs)
