@@ -138,10 +138,15 @@ class GeneratorEngine:
         """(B, n_latent, S) -> all style vectors (B, R) in one contraction."""
         return ops.style_affine(latent, self.wcat, self.bcat, self.row_lat)
 
-    def forward(self, latent, noises, save=False, cond_hook=None, cond_layers=None, return_features=False):
+    def forward(self, latent, noises, save=False, cond_hook=None, cond_layers=None, return_features=False, features_in=None,
+                feature_scale=1.0):
         """latent (B,n_latent,S); noises list[num_layers] of (B|1,1,r,r).
         cond_hook(k, raw, latent_i, noise, noise_w) -> cond tensor replacing the raw up-conv output
-        (the algebra of OOD_faceGAN_e4e_arch.py:239-242 + model.py:292: layer = cond + w*noise)."""
+        (the algebra of OOD_faceGAN_e4e_arch.py:239-242 + model.py:292: layer = cond + w*noise).
+        features_in[i] (or None), feature_scale: `insert_feature` of the Feature-Style variant (model.py:541-546,557,572):
+        the input of the styled conv that reads latent i becomes (1-fs)*x + fs*features_in[i]."""
+        if save and features_in is not None:
+            raise NotImplementedError('backward through an injected feature is not part of the path')
         B = latent.shape[0]
         s_all = self.styles(latent)
         d_all = torch.empty(B, self.DR, device=self.device, dtype=torch.float32)
@@ -161,6 +166,15 @@ class GeneratorEngine:
                 continue
             d = _Cols(d_all, L.drow, L.cout)
             nz = noises[L.noise_idx]
+            if features_in is not None and L.lat >= 1 and L.lat < len(features_in) and features_in[L.lat] is not None:
+                from . import samm as _samm
+                f = features_in[L.lat].to(out.dtype).contiguous()
+                C = out.shape[1]
+                ones = torch.ones(B, C, device=self.device)
+                zeros = torch.zeros(B, C, device=self.device)
+                t = _samm.affine_apply(f, ones * float(feature_scale), zeros)
+                out = _samm.affine_apply(out, ones * float(1.0 - feature_scale), zeros, res=t)
+                pending = None              # an S-form written for the un-mixed tensor is stale
             if L.kind == 'conv':
                 if self.sform:
                     # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA

@@ -293,8 +293,6 @@ class Generator(nn.Module):
                                     styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         else:
             latent = styles
-        if kwargs.get('features_in', None) is not None:
-            raise NotImplementedError('features_in injection belongs to the FeatureStyle variant (SURVEY.md §8f N4)')
         latent = latent.contiguous().float()
         B = latent.shape[0]
         hook = None
@@ -318,7 +316,8 @@ class Generator(nn.Module):
                 if conditions[k] is not None and len(conditions[k]) > 1 and conditions[k][1] is not None:
                     noise[i] = conditions[k][1]
         noises = self._draw_noises(B, noise, randomize_noise)
-        image, feat = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=True)
+        image, feat = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=True,
+                                            features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
         if return_latents:
             return image, latent
         if return_features:

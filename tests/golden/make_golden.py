@@ -334,6 +334,8 @@ def main():
         gold_restyle()
     if 'fs' in which:
         gold_featurestyle()
+    if 'featin' in which:
+        gold_features_in()
 
 
 
@@ -432,6 +434,29 @@ def gold_featurestyle(B=1):
         g[f'align{k}_sub'] = a[:, :, ::step, ::step]
     g['align1024_sub'] = m.aligns[1024][:, :1, ::16, ::16]
     save('featurestyle_1024.npz', **g)
+
+
+def gold_features_in(size=32):
+    """`insert_feature` of Generator.forward (model.py:541-546,557,572): features mixed into the inputs of the styled
+    convs reading latents 4 (plain conv at 16²) and 5 (up-conv 16² -> 32²), feature_scale 0.3 and 1.0."""
+    from src.ops.StyleGAN.model import Generator
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(synth.generator_state(size, seed=5), strict=True)
+    B = 2
+    lat = synth.make_latents(size, B, seed=6)
+    noises = synth.make_noises(size, B, seed=7)
+    f4 = synth.normal('featin.4', (B, 512, 16, 16), 9)
+    f5 = synth.normal('featin.5', (B, 512, 16, 16), 10)
+    feats = [None] * 8
+    feats[4], feats[5] = f4, f5
+    g = {}
+    with torch.no_grad():
+        for fs in (0.3, 1.0):
+            img, feat = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True, features_in=feats,
+                          feature_scale=fs)
+            g[f'image_fs{fs}'] = img
+            g[f'feat_fs{fs}_sub'] = feat[:, ::16]
+    save(f'features_in_s{size}.npz', **g)
 
 
 if __name__ == '__main__':

@@ -232,3 +232,24 @@ def test_torgb_reproducible_beside_matrix_kernels_of_another_stream(dev):
                     outs = [ops.torgb(x0, wr, s0, bias, skip, k) for _ in range(40)]
                 torch.cuda.synchronize()
                 assert all(torch.equal(o, ref) for o in outs)
+
+
+def test_features_in_injection_vs_golden(dev, golden):
+    """`insert_feature` (model.py:541-546): vectors produced by the reference Generator with features_in / feature_scale."""
+    from oodgan.modules import Generator
+    size, B = 32, 2
+    g = golden('features_in_s32.npz')
+    G = Generator(size, 512, 8)
+    G.load_state_dict(synth.generator_state(size, seed=5), strict=True)
+    G = G.to(dev).eval()
+    lat = synth.make_latents(size, B, seed=6).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    feats = [None] * 8
+    feats[4] = synth.normal('featin.4', (B, 512, 16, 16), 9).to(dev)
+    feats[5] = synth.normal('featin.5', (B, 512, 16, 16), 10).to(dev)
+    for fs in (0.3, 1.0):
+        img, feat = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True, features_in=feats,
+                      feature_scale=fs)
+        ref = g[f'image_fs{fs}']
+        assert maxdiff(img, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), fs
+        assert maxdiff(feat[:, ::16], g[f'feat_fs{fs}_sub']) <= 1e-4 * max(1.0, g[f'feat_fs{fs}_sub'].abs().max().item())
