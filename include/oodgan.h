@@ -237,6 +237,12 @@ int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, in
 int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                      const float* skip, const float* kernel, float* y, int B, int Ci, int H, int W,
                      float scale, void* stream);
+/* The same ToRGB, additionally writing the S-form (split-f16 layout of oodgan_to_sform) of x*ys_scale[b,ci] for the
+ * up-sampling ModulatedConv2d that reads the same feature map next (model.py:557-576: to_rgb and the next conv1 share
+ * `out`).  ys: S-form buffer of (B,Ci,H,W); ys_scale (B,*) stride ys_scale_stride or NULL.  Ci % 16 == 0, W % 4 == 0. */
+int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                           const float* skip, const float* kernel, float* y, void* ys, const float* ys_scale,
+                           int ys_scale_stride, int B, int Ci, int H, int W, float scale, void* stream);
 
 /* Backward through (bias + noise + lrelu*sqrt2) of one StyledConv, merged with the ToRGB branch that
  * reads the same feature (build-defined W+ loop):

@@ -3,6 +3,7 @@
 // HBM-bound (AI ~1.4 flop/B): every feature element is read exactly once with 16-B loads; the three
 // modulated weight rows live in LDS; the skip (3 channels at half resolution) is gathered from L2.
 #include "common.hpp"
+#include "sform.hpp"
 
 using namespace oodgan;
 
@@ -145,6 +146,90 @@ __global__ __launch_bounds__(256) void torgb_fwd_small_kernel(const float* __res
     yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
 }
 
+// ToRGB that ALSO emits the S-form input of the following up-sampling conv (x * its style, hi/lo split): the feature map
+// is read once for both consumers instead of once by ToRGB and once by to_sform_kernel.  Same arithmetic as
+// torgb_fwd_kernel for y.  Needs Ci % 16 == 0 and W % 4 == 0 (a thread's 4 pixels share a row).
+__global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ s, int s_stride, const float* __restrict__ bias,
+                                                              const float* __restrict__ skip, const float* __restrict__ kern,
+                                                              float* __restrict__ y, uint4* __restrict__ ys,
+                                                              const float* __restrict__ ys_scale, int ys_scale_stride, SDims yd, int Ci,
+                                                              int H, int W, float scale) {
+    __shared__ float ws[3 * kMaxCi];
+    __shared__ float sc[kMaxCi];
+    __shared__ float kf[16];
+    const int b = blockIdx.y;
+    const long HW = (long)H * W;
+    for (int e = threadIdx.x; e < 3 * Ci; e += 256) {
+        const int c = e / Ci, ci = e % Ci;
+        ws[e] = scale * w[c * Ci + ci] * s[(long)b * s_stride + ci];
+    }
+    for (int e = threadIdx.x; e < Ci; e += 256) sc[e] = ys_scale ? ys_scale[(long)b * ys_scale_stride + e] : 1.f;
+    if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
+    __syncthreads();
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const float* xp = x + (long)b * Ci * HW + p;
+    const int Y0 = (int)(p / W), X0 = (int)(p % W);
+    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int kc = 0; kc < Ci / 16; ++kc) {
+        unsigned hp[4][8], lp[4][8];
+#pragma unroll
+        for (int cp = 0; cp < 8; ++cp) {
+            const int ci = kc * 16 + 2 * cp;
+            const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)ci * HW);
+            const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(ci + 1) * HW);
+            const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
+            const float w00 = ws[ci], w01 = ws[Ci + ci], w02 = ws[2 * Ci + ci];
+            const float w10 = ws[ci + 1], w11 = ws[Ci + ci + 1], w12 = ws[2 * Ci + ci + 1];
+            const float s0 = sc[ci], s1 = sc[ci + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a0[j] += w00 * e0[j]; a1[j] += w01 * e0[j]; a2[j] += w02 * e0[j];
+                a0[j] += w10 * e1[j]; a1[j] += w11 * e1[j]; a2[j] += w12 * e1[j];
+                split_pair(e0[j] * s0, e1[j] * s1, hp[j][cp], lp[j][cp]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4* rec = ys + sform_unit(yd, b, kc, Y0, X0 + j, 0);
+            rec[0] = make_uint4(hp[j][0], hp[j][1], hp[j][2], hp[j][3]);
+            rec[1] = make_uint4(hp[j][4], hp[j][5], hp[j][6], hp[j][7]);
+            rec[2] = make_uint4(lp[j][0], lp[j][1], lp[j][2], lp[j][3]);
+            rec[3] = make_uint4(lp[j][4], lp[j][5], lp[j][6], lp[j][7]);
+        }
+    }
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    const int h2 = H >> 1, w2_ = W >> 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
+        if (skip) {
+            const int Y = Y0, X = X0 + j;
+            const float* sp = skip + (long)b * 3 * h2 * w2_;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ky = (Y & 1) + 2 * t;
+                const int iy = (Y + ky - 2) >> 1;
+                if (Y + ky - 2 < 0 || iy >= h2) continue;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kx = (X & 1) + 2 * u;
+                    const int ix = (X + kx - 2) >> 1;
+                    if (X + kx - 2 < 0 || ix >= w2_) continue;
+                    const float kv = kf[ky * 4 + kx];
+                    const long q = (long)iy * w2_ + ix;
+                    o0 += kv * sp[q];
+                    o1 += kv * sp[(long)h2 * w2_ + q];
+                    o2 += kv * sp[2L * h2 * w2_ + q];
+                }
+            }
+        }
+        float* yp = y + (long)b * 3 * HW + p + j;
+        yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
+    }
+}
+
 }  // namespace
 
 extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
@@ -164,4 +249,17 @@ extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, 
     hipLaunchKernelGGL(torgb_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y, Ci, H,
                        W, scale);
     return check_launch("torgb_fwd");
+}
+
+extern "C" int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                                      const float* skip, const float* kernel, float* y, void* ys, const float* ys_scale,
+                                      int ys_scale_stride, int B, int Ci, int H, int W, float scale, void* stream) {
+    OODGAN_REQUIRE(x && w && s && y && ys && B > 0 && Ci > 0 && H > 0 && W > 0, "torgb_fwd_sform: bad args");
+    OODGAN_REQUIRE(Ci <= kMaxCi && (Ci % 16) == 0 && (W % 4) == 0, "torgb_fwd_sform: needs Ci %% 16 == 0, Ci <= %d, W %% 4 == 0", kMaxCi);
+    OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "torgb_fwd_sform: skip needs kernel and even H,W");
+    const long HW = (long)H * W;
+    dim3 grid((unsigned)((HW + 1023) / 1024), B);
+    hipLaunchKernelGGL(torgb_fwd_sform_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y,
+                       reinterpret_cast<uint4*>(ys), ys_scale, ys_scale_stride, sform_dims(Ci, H, W), Ci, H, W, scale);
+    return check_launch("torgb_fwd_sform");
 }

@@ -87,6 +87,9 @@ class GeneratorEngine:
         self.fused_fwd = os.environ.get('OODGAN_FUSED_FWD', '1') != '0'
         self.next_conv = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b.kind == 'conv'}
         self.next_styled = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'conv' and b.kind == 'up'}
+        # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
+        self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
+        self.fused_rgb = os.environ.get('OODGAN_FUSED_RGB', '1') != '0'
         src = 'input'
         for L in layers:            # producer of every layer's input feature
             L.src = src
@@ -162,7 +165,15 @@ class GeneratorEngine:
         for L in self.layers:
             s = _Cols(s_all, L.row, L.cin)
             if L.kind == 'rgb':
-                skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None)
+                Lu = self.rgb_next_up.get(L.name) if (self.sform and self.fused_rgb and features_in is None) else None
+                if (Lu is not None and pending is None and out.shape[2] * out.shape[3] > 4096 and L.cin % 16 == 0
+                        and out.shape[3] % 4 == 0):
+                    # one pass over the feature map: RGB contribution AND the next up-conv's S-form input (x its style)
+                    pending = ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device)
+                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None, ys=pending,
+                                     ys_scale=_Cols(s_all, Lu.row, Lu.cin))
+                else:
+                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None)
                 continue
             d = _Cols(d_all, L.drow, L.cout)
             nz = noises[L.noise_idx]

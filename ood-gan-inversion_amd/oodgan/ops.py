@@ -503,12 +503,19 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     return out
 
 
-def torgb(x, weight, s, bias=None, skip=None, kernel=None):
-    """ToRGB.forward (src/ops/StyleGAN/model.py:363-372): weight (3,Ci), s (B,Ci) style, skip (B,3,H/2,W/2)."""
+def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=None):
+    """ToRGB.forward (src/ops/StyleGAN/model.py:363-372): weight (3,Ci), s (B,Ci) style, skip (B,3,H/2,W/2).
+    ``ys`` (an SForm of x's shape): additionally receives x*ys_scale in S-form for the up-sampling conv that follows."""
     x = _dev(x)
     B, Ci, H, W = x.shape
     y = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
     w = _dev(weight, 'weight').reshape(3, Ci)
+    if ys is not None:
+        check(_lib.lib().oodgan_torgb_fwd_sform(_p(x), _p(w), _p(_dev(s, 's')), s.shape[1], _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')),
+                                                _p(_opt(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
+                                                0 if ys_scale is None else ys_scale.shape[1], B, Ci, H, W, 1.0 / math.sqrt(Ci),
+                                                _stream()), 'torgb_fwd_sform')
+        return y
     check(_lib.lib().oodgan_torgb_fwd(_p(x), _p(w), _p(_dev(s, 's')), s.shape[1], _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')),
                                       _p(_opt(kernel, 'kernel')), _p(y), B, Ci, H, W, 1.0 / math.sqrt(Ci), _stream()), 'torgb_fwd')
     return y

@@ -383,3 +383,34 @@ def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
     monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1000000000')         # same call through the tile kernel
     y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
     assert (y3 - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 16, 32), (1, 64, 72, 128), (2, 16, 6, 4)])
+def test_torgb_with_sform_output_matches_separate_passes(dev, B, C, H, W):
+    """ToRGB that also emits the next up-conv's S-form input: y as the plain ToRGB (and the oracle), S-form as to_sform."""
+    from oodgan import ops
+    seed = 31 + C
+    x = synth.normal('x', (B, C, H, W), seed)
+    w = synth.normal('w', (3, C), seed)
+    s = synth.normal('s', (B, C), seed, 0.3, 1.0)
+    s_next = synth.normal('s2', (B, C), seed, 0.3, 1.0)
+    bias = synth.normal('b', (3,), seed, 0.2)
+    skip = synth.normal('skip', (B, 3, H // 2, W // 2), seed)
+    k = R.make_kernel([1, 3, 3, 1]) * 4.0
+    for sk in (skip, None):
+        ys = ops.SForm(B, C, H, W, dev)
+        y = ops.torgb(x.to(dev), w.to(dev), s.to(dev), bias.to(dev), None if sk is None else sk.to(dev), k.to(dev) if sk is not None else None,
+                      ys=ys, ys_scale=s_next.to(dev))
+        y_plain = ops.torgb(x.to(dev), w.to(dev), s.to(dev), bias.to(dev), None if sk is None else sk.to(dev), k.to(dev) if sk is not None else None)
+        close(y, y_plain.cpu(), 1e-6)
+        ref = torch.einsum('kc,bc,bchw->bkhw', w, s, x) / math.sqrt(C) + bias.view(1, 3, 1, 1)
+        if sk is not None:
+            ref = ref + R.upfirdn2d(sk, k, up=2, pad=(2, 1))
+        close(y, ref)
+        # same split-f16 representation as to_sform: identical hi halves, hi+lo equal to fp32 rounding (the lo half may
+        # differ in its last bit: packed vs scalar conversion on exact ties)
+        a = ys.data.reshape(-1, 4, 8).float()
+        b_ = ops.to_sform(x.to(dev), s_next.to(dev)).data.reshape(-1, 4, 8).float()
+        assert torch.equal(a[:, :2], b_[:, :2])
+        va, vb = a[:, :2] + a[:, 2:], b_[:, :2] + b_[:, 2:]
+        assert (va - vb).abs().max().item() <= 2.0 ** -21 * max(1.0, vb.abs().max().item())
