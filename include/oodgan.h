@@ -228,6 +228,10 @@ int oodgan_modconv_f16(const void* x, const void* wpk, const float* noise, int n
                        const float* bias, int act, void* y, int B, int K, int M, int H, int W, void* stream);
 /* out[i] (+)= sum_j part[i,j]  (deterministic two-stage reductions) */
 int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream);
+/* the same for a (B,C,nparts) array, written to (accumulate=0) or added to (1) out[b*out_stride + c]: the style gradient
+ * of a layer lands directly in its column block of the (B, sum Ci) accumulator (autograd's += of model.py:236-241's s) */
+int oodgan_reduce_parts_cols(const float* part, float* out, int B, int C, int nparts, int out_stride, int accumulate,
+                             void* stream);
 
 /* ------------------------------------------------------------------ A5 ToRGB -------------- */
 

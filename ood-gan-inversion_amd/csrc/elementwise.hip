@@ -181,6 +181,23 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     if (lane == 0) out[row] = accumulate ? out[row] + s : s;
 }
 
+// out[b*out_stride + c] (+)= sum_j part[(b*C + c), j]: the reduction lands directly in a column block of a wider matrix
+// (the style-gradient accumulator), so no separate copy / add pass is needed; one wave per (b,c)
+__global__ __launch_bounds__(256) void reduce_parts_cols_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int C,
+                                                                int nparts, int out_stride, int accumulate) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * C) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = part + row * nparts;
+    float s = 0.f;
+    for (int j = lane; j < nparts; j += 64) s += p[j];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float* o = out + (row / C) * out_stride + (row % C);
+        *o = accumulate ? *o + s : s;
+    }
+}
+
 constexpr int kMseChunk = 16384;
 
 // grid: (nparts, B)
@@ -334,6 +351,14 @@ extern "C" int oodgan_reduce_parts(const float* part, float* out, long rows, int
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), part, out, rows,
                        nparts, accumulate);
     return check_launch("reduce_parts");
+}
+
+extern "C" int oodgan_reduce_parts_cols(const float* part, float* out, int B, int C, int nparts, int out_stride, int accumulate,
+                                        void* stream) {
+    OODGAN_REQUIRE(part && out && B > 0 && C > 0 && nparts > 0 && out_stride >= C, "reduce_parts_cols: bad args");
+    hipLaunchKernelGGL(reduce_parts_cols_kernel, dim3((unsigned)(((long)B * C + 3) / 4)), dim3(256), 0, as_stream(stream), part, out, B,
+                       C, nparts, out_stride, accumulate);
+    return check_launch("reduce_parts_cols");
 }
 
 extern "C" int oodgan_mse_nparts(long CHW) { return (int)((CHW + kMseChunk - 1) / kMseChunk); }

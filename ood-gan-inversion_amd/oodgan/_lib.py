@@ -70,6 +70,7 @@ _SIGS = {
     'oodgan_modconv_f16_pack': (c_int, [P, P, c_int, c_float, c_int, c_int, P, c_int, c_int, c_int, P]),
     'oodgan_modconv_f16': (c_int, [P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
+    'oodgan_reduce_parts_cols': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),

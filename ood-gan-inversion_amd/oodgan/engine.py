@@ -285,13 +285,14 @@ class GeneratorEngine:
             if st is not None:
                 # fused producer: g_pre goes straight into the next matrix kernel's input layout, scaled with the
                 # range scale measured on the previous step (verified below, after the conv has consumed it)
+                t_into = None if Rg is None else _Cols(gs_all, Rg.row, Rg.cin)
                 if L.kind == 'conv':
                     gin = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device)
-                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, **rgb_kw)
+                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, t_into=t_into, **rgb_kw)
                 else:
                     gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin,
-                                                              blur_kernel=self.k4x4_flip, **rgb_kw)
+                                                              blur_kernel=self.k4x4_flip, t_into=t_into, **rgb_kw)
                 mul2, g_pre = st, None
             else:
                 if Rg is not None:
@@ -303,7 +304,7 @@ class GeneratorEngine:
                     self.bwd_state[L.name] = mul2            # exact this step; carried to the next one
                     if self.bwd_flag is None:
                         self.bwd_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-            if Rg is not None:
+            if Rg is not None and tsum is not None:
                 gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
             # demodulation gradient
             check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
@@ -312,7 +313,7 @@ class GeneratorEngine:
                                          ops._stream()), 'demod_bwd')
             if st is not None:
                 dx, dot = ops.conv3x3(gin, L.wpk_bwd, L.cin, CONV_S1 if L.kind == 'conv' else CONV_S2, out_scale=s, dotx=x_in,
-                                      in_mul2=mul2)
+                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin))
                 del gin
                 ops.absmax_scale_check(part_m, st, self.bwd_flag)
             elif L.kind == 'conv':
@@ -336,7 +337,8 @@ class GeneratorEngine:
                     dx, dot = ops.conv3x3(g2, L.wpk_bwd, L.cin, CONV_S2, in_scale=d, out_scale=s, dotx=x_in, in_hw=(H2, H2),
                                           in_pitch=P2, in_mul2=mul2)
                     del g2
-            gs_all[:, L.row:L.row + L.cin] += dot
+            if dot is not None:
+                gs_all[:, L.row:L.row + L.cin] += dot
             g_feat = dx
             del g_pre
         self.last_gs = gs_all

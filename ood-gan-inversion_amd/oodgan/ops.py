@@ -311,6 +311,12 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     return y
 
 
+def _reduce_into(part, B, C, npart, into, accumulate):
+    """sum the partials straight into the column block ``into`` (a Cols of the style-gradient accumulator)."""
+    check(_lib.lib().oodgan_reduce_parts_cols(_p(part), _p(into), B, C, npart, into.shape[1], 1 if accumulate else 0, _stream()),
+          'reduce_parts_cols')
+
+
 def _reduce_parts(part, rows, npart):
     out = torch.empty(part.shape[0], part.shape[1], device=part.device, dtype=torch.float32)
     check(_lib.lib().oodgan_reduce_parts(_p(part), _p(out), rows, npart, 0, _stream()), 'reduce')
@@ -318,7 +324,7 @@ def _reduce_parts(part, rows, npart):
 
 
 def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, g_rgb=None, w_rgb=None, s_rgb=None,
-                     blur_kernel=None):
+                     blur_kernel=None, t_into=None):
     """Fused backward producer (include/oodgan.h): the gradient of bias+noise+lrelu*sqrt2 (+ToRGB branch) of ``out``
     written straight into ``dst`` — an ``SForm`` (plain conv layer) or, with ``blur_kernel``, an ``SFormPhases``
     (up-conv layer: blur^T and phase split fused) — scaled by ``dscale[b,c] * mul2[1]``.
@@ -344,7 +350,12 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
         check(L.oodgan_act_bwd_sform(*common, _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()),
               'act_bwd_sform')
     r = _reduce_parts(part_r, B * C, npart)
-    t = _reduce_parts(part_t, B * C, npart) if part_t is not None else None
+    t = None
+    if part_t is not None:
+        if t_into is not None:          # ToRGB style gradient straight into its columns of the accumulator
+            _reduce_into(part_t, B, C, npart, t_into, False)
+        else:
+            t = _reduce_parts(part_t, B * C, npart)
     return r, t, part_m
 
 
@@ -449,7 +460,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
@@ -497,6 +508,9 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     else:
         check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
     if dotx is not None:
+        if dot_into is not None:        # += into the layer's columns of the style-gradient accumulator
+            _reduce_into(part, B, M, a.dot_nparts, dot_into, True)
+            return out, None
         dot = torch.empty(B, M, device=dx_.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
         return out, dot
