@@ -567,7 +567,11 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
     p.xd = hform_dims(K, H, W);
     p.yd = hform_dims(M, H, W);
     static const int no_vm4 = getenv("OODGAN_F16_NO_VM4") ? atoi(getenv("OODGAN_F16_NO_VM4")) : 0;
-    static const int ablate = getenv("OODGAN_F16_ABLATE") ? atoi(getenv("OODGAN_F16_ABLATE")) : 0;   // debug: 2 no stores, 4 no loads
+#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: 2 no stores, 4 no loads (wrong results)
+    static const int ablate = getenv("OODGAN_F16_ABLATE") ? atoi(getenv("OODGAN_F16_ABLATE")) : 0;
+#else
+    const int ablate = 0;
+#endif
     p.flags = (no_vm4 ? 0 : 1) | ablate;
     const long T = (long)p.tiles_x * p.tiles_y * B;
     OODGAN_REQUIRE(T < (1L << 31), "modconv_f16: too many tiles");

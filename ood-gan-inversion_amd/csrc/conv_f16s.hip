@@ -272,7 +272,11 @@ int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     KArgs p;
     p.a = a;
     p.w_unscale = unscale;
+#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: the ablation bits make the kernel skip work (wrong results)
     { static int abl = getenv("OODGAN_ABLATE") ? atoi(getenv("OODGAN_ABLATE")) : 0; p.ablate = abl; }
+#else
+    p.ablate = 0;
+#endif
     if (MODE == OODGAN_CONV_S1) { p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == OODGAN_CONV_T2) { p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1; }
     else { p.Hn = (a.Hin - 1) / 2; p.Wn = (a.Win - 1) / 2; p.Hout = p.Hn; p.Wout = p.Wn; }

@@ -316,8 +316,12 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
                        ((a.Hin + 7) / 8) * p.tiles_x);
     }
     OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 big: plane too large");
+#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: the ablation bits make the kernel skip work (wrong results)
     static const int abl = getenv("OODGAN_BIG_ABLATE") ? atoi(getenv("OODGAN_BIG_ABLATE")) : 0;
     p.ablate = abl;
+#else
+    p.ablate = 0;
+#endif
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),

@@ -315,7 +315,11 @@ int launch_s1pp(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     KArgs p;
     p.a = a;
     p.w_unscale = unscale;
+#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: the ablation bits make the kernel skip work (wrong results)
     { static int abl = getenv("OODGAN_ABLATE") ? atoi(getenv("OODGAN_ABLATE")) : 0; p.ablate = abl; }
+#else
+    p.ablate = 0;
+#endif
     p.Hn = a.Hin; p.Wn = a.Win; p.Hout = a.Hin; p.Wout = a.Win;
     if (p.a.in_pitch == 0) p.a.in_pitch = a.Win;
     if (p.a.out_pitch == 0) p.a.out_pitch = p.Wout;
