@@ -140,6 +140,14 @@ typedef struct oodgan_conv_args {
     void* ys;                /* optional S-form output of (activated y) * ys_scale[b,m] for the next conv, or NULL */
     const float* ys_scale;   /* (B,M) stride ys_scale_stride, or NULL */
     int ys_scale_stride;
+    /* optional fused ToRGB partial (split-f16 strip kernel only: mode S1, 16 < K,M <= 32): rgb_y[b,k,p] =
+     * rgb_scale * sum_m rgb_w[k,m] * rgb_s[b,m] * act(y)[b,m,p]  (ToRGB.forward without bias / skip, model.py:363-372;
+     * finish with oodgan_rgb_finish).  rgb_y NULL = off. */
+    const float* rgb_w;      /* (3,M) */
+    const float* rgb_s;      /* (B,*) stride rgb_s_stride */
+    float* rgb_y;            /* (B,3,Hout,Wout) dense */
+    int rgb_s_stride;
+    float rgb_scale;
 } oodgan_conv_args;
 
 /* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -247,6 +255,10 @@ int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_strid
 int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                            const float* skip, const float* kernel, float* y, void* ys, const float* ys_scale,
                            int ys_scale_stride, int B, int Ci, int H, int W, float scale, void* stream);
+/* y[b,k,p] = partial[b,k,p] + bias[k] + upfirdn2d(skip, k4*4, up=2, pad=(2,1))[b,k,p]: second half of ToRGB.forward when the
+ * three colour sums came out of the conv kernel's epilogue (oodgan_conv_args.rgb_y).  y may alias partial. */
+int oodgan_rgb_finish(const float* partial, const float* bias, const float* skip, const float* kernel, float* y, int B, int H,
+                      int W, void* stream);
 
 /* Backward through (bias + noise + lrelu*sqrt2) of one StyledConv, merged with the ToRGB branch that
  * reads the same feature (build-defined W+ loop):

@@ -409,11 +409,13 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
+    OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
     hipStream_t st = as_stream(stream);
     static const bool legacy_s1 = getenv("OODGAN_S1_LEGACY") != nullptr;   // A/B switch: single-pipeline S1 kernel
     switch (a.mode) {
         case OODGAN_CONV_S1:
             if (a.x_sform && s1_strip_eligible(a)) return launch_s1_strip(a, a.wpk, unscale2, st);
+            OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32)");
             if (a.x_sform && s1_big_eligible(a)) return launch_s1_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_s1v2(a, a.wpk, unscale2, st);
             OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");

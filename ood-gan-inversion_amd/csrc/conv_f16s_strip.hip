@@ -42,7 +42,7 @@ struct StripConv {
     int counted_wait;
 };
 
-template <bool DOT>
+template <bool DOT, bool RGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_strip_kernel(
     const StripConv p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -84,6 +84,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
         osc[r] = (m < M ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f) * us;
         bia[r] = (!DOT && a.bias && m < M) ? a.bias[m] : 0.f;
+    }
+    // fused ToRGB: this lane's 16 channels of the three modulated 1x1 rows (rgb_scale * w[k,m] * s_rgb[b,m])
+    float wr[RGB ? 3 : 1][16];
+    if (RGB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sv = m < M ? a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wr[RGB ? k : 0][r] = m < M ? sv * a.rgb_w[k * M + m] : 0.f;
+        }
     }
     const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     // byte offsets of this lane's 16 channel planes (32-bit: M*plane*4 < 4 GiB is checked by the host) + its column
@@ -176,7 +187,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else if (ragged & 1) {
                 __builtin_amdgcn_s_waitcnt(kVm0);
             } else {
-                if (wave < 2) __builtin_amdgcn_s_waitcnt(0x8F7A); else __builtin_amdgcn_s_waitcnt(0x8F79);       // 42 / 41
+                if (RGB) {      // 6 more stores per tile (three colour rows x two pixel rows)
+                    if (wave < 2) __builtin_amdgcn_s_waitcnt(0xCF70); else __builtin_amdgcn_s_waitcnt(0x8F7F);   // 48 / 47
+                } else {
+                    if (wave < 2) __builtin_amdgcn_s_waitcnt(0x8F7A); else __builtin_amdgcn_s_waitcnt(0x8F79);   // 42 / 41
+                }
             }
         } else if (t == 0) {
             if (wave < 2) __builtin_amdgcn_s_waitcnt(0x0F79); else __builtin_amdgcn_s_waitcnt(0x0F78);           // 9 / 8
@@ -276,6 +291,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
                 }
             }
+            if (RGB) {
+                // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
+                float c0s = 0.f, c1s = 0.f, c2s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    c0s += wr[0][r] * o[r];
+                    c1s += wr[RGB ? 1 : 0][r] * o[r];
+                    c2s += wr[RGB ? 2 : 0][r] * o[r];
+                }
+                c0s += __shfl_xor(c0s, 32, 64);
+                c1s += __shfl_xor(c1s, 32, 64);
+                c2s += __shfl_xor(c2s, 32, 64);
+                if (ok && half == 0) {
+                    float* rp = a.rgb_y + (long)b * 3 * H * W + (long)py * W + px;
+                    rp[0] = c0s;
+                    rp[(long)H * W] = c1s;
+                    rp[2L * H * W] = c2s;
+                }
+            }
             if (ok) {
                 unsigned char* yr = ybt + (long)nt * a.out_pitch * 4;
                 if (mfull) {
@@ -367,14 +401,19 @@ int launch_s1_strip(const oodgan_conv_args& a_in, const void* wpk16, const float
     const long nblk = strips * p.nseg;
     OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 strip: grid too large");
     OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 strip: plane too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<true>),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<true, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false>),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (a.dotx) hipLaunchKernelGGL((conv_f16s_strip_kernel<true>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_strip_kernel<false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    if (a.rgb_y) {
+        OODGAN_REQUIRE(!a.dotx && a.rgb_w && a.rgb_s, "conv3x3 strip: the fused ToRGB needs rgb_w, rgb_s and no dotx");
+        hipLaunchKernelGGL((conv_f16s_strip_kernel<false, true>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    } else if (a.dotx) hipLaunchKernelGGL((conv_f16s_strip_kernel<true, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_strip_kernel<false, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_strip");
 }
 

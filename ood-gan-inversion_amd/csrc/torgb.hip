@@ -230,6 +230,48 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     }
 }
 
+// second half of ToRGB when the colour sums were formed in the conv kernel's epilogue: + bias + 2x FIR-upsampled skip
+__global__ __launch_bounds__(256) void rgb_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                         const float* __restrict__ skip, const float* __restrict__ kern,
+                                                         float* __restrict__ y, int B, int H, int W) {
+    __shared__ float kf[16];
+    if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
+    __syncthreads();
+    const long HW = (long)H * W, total = (long)B * HW;
+    const int h2 = H >> 1, w2_ = W >> 1;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int b = (int)(e / HW);
+        const long p = e % HW;
+        const int Y = (int)(p / W), X = (int)(p % W);
+        float o0 = part[(long)b * 3 * HW + p] + (bias ? bias[0] : 0.f);
+        float o1 = part[(long)b * 3 * HW + HW + p] + (bias ? bias[1] : 0.f);
+        float o2 = part[(long)b * 3 * HW + 2 * HW + p] + (bias ? bias[2] : 0.f);
+        if (skip) {
+            const float* sp = skip + (long)b * 3 * h2 * w2_;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ky = (Y & 1) + 2 * t;
+                const int iy = (Y + ky - 2) >> 1;
+                if (Y + ky - 2 < 0 || iy >= h2) continue;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kx = (X & 1) + 2 * u;
+                    const int ix = (X + kx - 2) >> 1;
+                    if (X + kx - 2 < 0 || ix >= w2_) continue;
+                    const float kv = kf[ky * 4 + kx];
+                    const long q = (long)iy * w2_ + ix;
+                    o0 += kv * sp[q];
+                    o1 += kv * sp[(long)h2 * w2_ + q];
+                    o2 += kv * sp[2L * h2 * w2_ + q];
+                }
+            }
+        }
+        y[(long)b * 3 * HW + p] = o0;
+        y[(long)b * 3 * HW + HW + p] = o1;
+        y[(long)b * 3 * HW + 2 * HW + p] = o2;
+    }
+}
+
 }  // namespace
 
 extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_stride, const float* bias,
@@ -262,4 +304,13 @@ extern "C" int oodgan_torgb_fwd_sform(const float* x, const float* w, const floa
     hipLaunchKernelGGL(torgb_fwd_sform_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y,
                        reinterpret_cast<uint4*>(ys), ys_scale, ys_scale_stride, sform_dims(Ci, H, W), Ci, H, W, scale);
     return check_launch("torgb_fwd_sform");
+}
+
+extern "C" int oodgan_rgb_finish(const float* partial, const float* bias, const float* skip, const float* kernel, float* y, int B,
+                                 int H, int W, void* stream) {
+    OODGAN_REQUIRE(partial && y && B > 0 && H > 0 && W > 0, "rgb_finish: bad args");
+    OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "rgb_finish: skip needs kernel and even H,W");
+    hipLaunchKernelGGL(rgb_finish_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, as_stream(stream), partial, bias, skip,
+                       kernel, y, B, H, W);
+    return check_launch("rgb_finish");
 }

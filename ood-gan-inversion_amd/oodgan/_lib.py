@@ -24,6 +24,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float),
     ]
 
 
@@ -72,6 +73,7 @@ _SIGS = {
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_reduce_parts_cols': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_rgb_finish': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),

@@ -89,6 +89,7 @@ class GeneratorEngine:
         self.next_styled = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'conv' and b.kind == 'up'}
         # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
         self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
+        self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
         self.fused_rgb = os.environ.get('OODGAN_FUSED_RGB', '1') != '0'
         src = 'input'
         for L in layers:            # producer of every layer's input feature
@@ -161,9 +162,14 @@ class GeneratorEngine:
         acts['input'] = x
         skip, out = None, x
         pending = None
+        rgb_partial = None
         i = 1
         for L in self.layers:
             s = _Cols(s_all, L.row, L.cin)
+            if L.kind == 'rgb' and rgb_partial is not None:
+                skip = ops.rgb_finish(rgb_partial, L.bias, skip, self.k4x4 if skip is not None else None)
+                rgb_partial = None
+                continue
             if L.kind == 'rgb':
                 Lu = self.rgb_next_up.get(L.name) if (self.sform and self.fused_rgb and features_in is None) else None
                 if (Lu is not None and pending is None and out.shape[2] * out.shape[3] > 4096 and L.cin % 16 == 0
@@ -198,8 +204,14 @@ class GeneratorEngine:
                     if Ln is not None:      # the epilogue also emits the next up-conv's input (x * its style) in S-form
                         ys = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device, tag=1)
                         ys_scale = _Cols(s_all, Ln.row, Ln.cin)
-                    out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
-                                      noise_weight=L.noise_w, act=ACT_LRELU, ys=ys, ys_scale=ys_scale)
+                    Lr = self.conv_next_rgb.get(L.name) if (self.fused_rgb and ys is None) else None
+                    if Lr is not None and 16 < L.cin <= 32 and 16 < L.cout <= 32:
+                        # 32-channel 1024² layer (strip kernel): the ToRGB colour sums come out of the same epilogue
+                        out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
+                                                       noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)))
+                    else:
+                        out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
+                                          noise_weight=L.noise_w, act=ACT_LRELU, ys=ys, ys_scale=ys_scale)
                     pending = ys
                     del xs
                 else:

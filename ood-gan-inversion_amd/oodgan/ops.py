@@ -460,7 +460,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
@@ -493,6 +493,12 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.in_mul2 = _p(in_mul2)
     a.x_sform = 1 if sform_in else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
+    rgb_y = None
+    if rgb is not None:         # (w_rgb (3,M), s_rgb Cols/(B,M)): also emit the ToRGB colour sums of the activated output
+        w_rgb, s_rgb = rgb
+        rgb_y = torch.empty(B, 3, oh, ow, device=out.device, dtype=torch.float32)
+        a.rgb_w, a.rgb_s, a.rgb_y = _p(_dev(w_rgb, 'w_rgb').reshape(3, M)), _p(_dev(s_rgb, 's_rgb')), _p(rgb_y)
+        a.rgb_s_stride, a.rgb_scale = s_rgb.shape[1], 1.0 / math.sqrt(M)
     a.ys_scale_stride = ys_scale.shape[1] if ys_scale is not None else 0
     part = None
     if dotx is not None:
@@ -514,7 +520,18 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         dot = torch.empty(B, M, device=dx_.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
         return out, dot
+    if rgb is not None:
+        return out, rgb_y
     return out
+
+
+def rgb_finish(partial, bias=None, skip=None, kernel=None):
+    """second half of ToRGB.forward (model.py:363-372) for colour sums produced by conv3x3(rgb=...): + bias + upsampled skip
+    (in place)."""
+    B, _, H, W = partial.shape
+    check(_lib.lib().oodgan_rgb_finish(_p(partial), _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')), _p(_opt(kernel, 'kernel')),
+                                       _p(partial), B, H, W, _stream()), 'rgb_finish')
+    return partial
 
 
 def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=None):

@@ -414,3 +414,35 @@ def test_torgb_with_sform_output_matches_separate_passes(dev, B, C, H, W):
         assert torch.equal(a[:, :2], b_[:, :2])
         va, vb = a[:, :2] + a[:, 2:], b_[:, :2] + b_[:, 2:]
         assert (va - vb).abs().max().item() <= 2.0 ** -21 * max(1.0, vb.abs().max().item())
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 16, 64), (1, 32, 40, 96), (1, 24, 13, 45)])
+def test_strip_conv_with_fused_torgb_matches_separate_torgb(dev, B, C, H, W):
+    """The 32-channel strip kernel also forms the three ToRGB colour sums of its activated output (full and ragged tiles);
+    oodgan_rgb_finish adds bias and the up-sampled skip: same result as the conv followed by the ToRGB kernel."""
+    from oodgan import ops
+    seed = 41 + C + H
+    x = synth.normal('x', (B, C, H, W), seed)
+    w = synth.normal('w', (C, C, 3, 3), seed, 1.0 / math.sqrt(9 * C))
+    s = synth.normal('s', (B, C), seed, 0.3, 1.0)
+    d = synth.normal('d', (B, C), seed, 0.2, 1.0)
+    bias = synth.normal('b', (C,), seed, 0.2)
+    noise = synth.normal('nz', (B, 1, H, W), seed)
+    nw = torch.tensor([0.3])
+    w_rgb = synth.normal('wr', (3, C), seed)
+    s_rgb = synth.normal('sr', (B, C), seed, 0.3, 1.0)
+    b_rgb = synth.normal('br', (3,), seed, 0.2)
+    k = (R.make_kernel([1, 3, 3, 1]) * 4.0).to(dev)
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    xs = ops.to_sform(x.to(dev), s.to(dev))
+    kw = dict(out_scale=d.to(dev), bias=bias.to(dev), noise=noise.to(dev), noise_weight=nw.to(dev), act=ops.ACT_LRELU)
+    y_ref = ops.conv3x3(xs, wpk, C, ops.CONV_S1, **kw)
+    y, part = ops.conv3x3(xs, wpk, C, ops.CONV_S1, rgb=(w_rgb.to(dev), s_rgb.to(dev)), **kw)
+    assert torch.equal(y, y_ref)
+    skips = [None]
+    if H % 2 == 0 and W % 2 == 0:
+        skips.append(synth.normal('skip', (B, 3, H // 2, W // 2), seed).to(dev))
+    for sk in skips:
+        ref = ops.torgb(y_ref, w_rgb.to(dev), s_rgb.to(dev), b_rgb.to(dev), sk, k if sk is not None else None)
+        got = ops.rgb_finish(part.clone(), b_rgb.to(dev), sk, k if sk is not None else None)
+        close(got, ref.cpu(), 2e-6)
