@@ -446,3 +446,13 @@ def test_strip_conv_with_fused_torgb_matches_separate_torgb(dev, B, C, H, W):
         ref = ops.torgb(y_ref, w_rgb.to(dev), s_rgb.to(dev), b_rgb.to(dev), sk, k if sk is not None else None)
         got = ops.rgb_finish(part.clone(), b_rgb.to(dev), sk, k if sk is not None else None)
         close(got, ref.cpu(), 2e-6)
+
+
+def test_upfirdn2d_down2_4x4_kernel_vs_oracle(dev):
+    """the specialised down-2 / 4x4 path (gradient of the ToRGB skip up-sampling), odd and even sizes, asymmetric pads"""
+    from oodgan import ops
+    k = R.make_kernel([1, 3, 3, 1]) * 4.0
+    k[1, 2] += 0.25                                  # non-symmetric: the flip matters
+    for (H, W), pad in (((64, 64), (1, 1)), ((37, 50), (1, 1)), ((16, 24), (2, 1)), ((9, 9), (0, 3))):
+        x = synth.normal(f'd2.{H}', (2, 3, H, W), 7)
+        close(ops.upfirdn2d(x.to(dev), k.to(dev), 1, 2, pad), R.upfirdn2d(x, k, 1, 2, pad))
