@@ -217,6 +217,26 @@ int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, con
                                       float* part_r, float* part_t, float* part_max, int B, int C, int H, int W, void* stream);
 int oodgan_absmax_scale_check(const float* part, long n, float* state, int* flag, void* stream);
 
+/* ---- batched tail of the W+ backward (csrc/bwd_tail.hip): per-layer jobs that only feed the style-gradient accumulator,
+ * one launch per kind; `jobs` is a HOST array (copied into the kernel arguments).  Same arithmetic and per-output
+ * summation order as oodgan_reduce_parts[_cols] / oodgan_demod_bwd / oodgan_absmax_scale_check. */
+typedef struct oodgan_reduce_job {
+    const float* part;       /* (B,C,nparts) */
+    float* out;              /* out[b*out_stride + c] (+)= sum_j part[b,c,j] */
+    int B, C, nparts, out_stride, accumulate;
+} oodgan_reduce_job;
+typedef struct oodgan_demod_bwd_job {
+    const float* s; const float* wsq; const float* d; const float* r; float* gs;
+    int s_stride, d_stride, gs_stride, B, Ci, Co;
+    float scale;
+} oodgan_demod_bwd_job;
+typedef struct oodgan_scale_check_job {
+    const float* part; long n; float* state;
+} oodgan_scale_check_job;
+int oodgan_reduce_batch(const oodgan_reduce_job* jobs, int njobs, void* stream);
+int oodgan_demod_bwd_batch(const oodgan_demod_bwd_job* jobs, int njobs, void* stream);
+int oodgan_absmax_scale_check_batch(const oodgan_scale_check_job* jobs, int njobs, int* flag, void* stream);
+
 /* ---- fp16 modulated conv for the high-resolution, low-channel layers (BASELINE.json configs[4] / SURVEY §8 C5) ----
  * ModulatedConv2d.forward, plain 3x3 (src/ops/StyleGAN/model.py:233-245,268-274) + NoiseInjection + FusedLeakyReLU
  * (model.py:283-292,343-350) in f16 operands / fp32 accumulate / f16 result.  Activations live in "H-form":

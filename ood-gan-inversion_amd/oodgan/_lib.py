@@ -28,6 +28,19 @@ class ConvArgs(Structure):
     ]
 
 
+class ReduceJob(Structure):
+    _fields_ = [('part', P), ('out', P), ('B', c_int), ('C', c_int), ('nparts', c_int), ('out_stride', c_int), ('accumulate', c_int)]
+
+
+class DemodBwdJob(Structure):
+    _fields_ = [('s', P), ('wsq', P), ('d', P), ('r', P), ('gs', P), ('s_stride', c_int), ('d_stride', c_int), ('gs_stride', c_int),
+                ('B', c_int), ('Ci', c_int), ('Co', c_int), ('scale', c_float)]
+
+
+class ScaleCheckJob(Structure):
+    _fields_ = [('part', P), ('n', c_long), ('state', P)]
+
+
 _SIGS = {
     'oodgan_version': (c_int, []),
     'oodgan_last_error': (c_char_p, []),
@@ -64,6 +77,9 @@ _SIGS = {
     'oodgan_act_bwd_blurT_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_absmax_scale_check': (c_int, [P, c_long, P, P, P]),
+    'oodgan_reduce_batch': (c_int, [P, c_int, P]),
+    'oodgan_demod_bwd_batch': (c_int, [P, c_int, P]),
+    'oodgan_absmax_scale_check_batch': (c_int, [P, c_int, P, P]),
     'oodgan_hform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_to_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_from_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -91,6 +91,7 @@ class GeneratorEngine:
         self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
         self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
         self.fused_rgb = os.environ.get('OODGAN_FUSED_RGB', '1') != '0'
+        self.batched_tail = os.environ.get('OODGAN_BATCHED_TAIL', '1') != '0'
         src = 'input'
         for L in layers:            # producer of every layer's input feature
             L.src = src
@@ -282,6 +283,7 @@ class GeneratorEngine:
             r //= 2
         g_feat = None
         prev_rgb = None
+        jobs = ops.BwdJobs() if (carry_scale and self.fused_bwd and self.sform and self.batched_tail) else None
         for L in reversed(self.layers):
             if L.kind == 'rgb':          # fused into the backward of the styled conv that feeds it
                 prev_rgb = L
@@ -300,11 +302,11 @@ class GeneratorEngine:
                 t_into = None if Rg is None else _Cols(gs_all, Rg.row, Rg.cin)
                 if L.kind == 'conv':
                     gin = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device)
-                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, t_into=t_into, **rgb_kw)
+                    rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, t_into=t_into, jobs=jobs, **rgb_kw)
                 else:
                     gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin,
-                                                              blur_kernel=self.k4x4_flip, t_into=t_into, **rgb_kw)
+                                                              blur_kernel=self.k4x4_flip, t_into=t_into, jobs=jobs, **rgb_kw)
                 mul2, g_pre = st, None
             else:
                 if Rg is not None:
@@ -319,15 +321,23 @@ class GeneratorEngine:
             if Rg is not None and tsum is not None:
                 gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
             # demodulation gradient
-            check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
-                                         ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
-                                         ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
-                                         ops._stream()), 'demod_bwd')
+            deferred = st is not None and jobs is not None
+            if deferred:        # rsum is filled by the batched reduction at the end of the pass; so is this job's input
+                jobs.add_demod(_Cols(s_all, L.row, L.cin), L.wsq, _Cols(d_all, L.drow, L.cout), rsum, _Cols(gs_all, L.row, L.cin), B, L.cin,
+                               L.cout, L.scale)
+            else:
+                check(lib().oodgan_demod_bwd(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), self.R, ctypes.c_void_p(L.wsq.data_ptr()),
+                                             ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
+                                             ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
+                                             ops._stream()), 'demod_bwd')
             if st is not None:
                 dx, dot = ops.conv3x3(gin, L.wpk_bwd, L.cin, CONV_S1 if L.kind == 'conv' else CONV_S2, out_scale=s, dotx=x_in,
-                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin))
+                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs)
                 del gin
-                ops.absmax_scale_check(part_m, st, self.bwd_flag)
+                if deferred:
+                    jobs.add_check(part_m, st)
+                else:
+                    ops.absmax_scale_check(part_m, st, self.bwd_flag)
             elif L.kind == 'conv':
                 if self.sform:
                     gs_ = ops.to_sform(g_pre, d, mul2, out=ops.sform_scratch(B, L.cout, g_pre.shape[2], g_pre.shape[3], self.device))
@@ -353,6 +363,8 @@ class GeneratorEngine:
                 gs_all[:, L.row:L.row + L.cin] += dot
             g_feat = dx
             del g_pre
+        if jobs is not None:
+            jobs.run(self.bwd_flag)         # four launches: partial sums, demodulation gradient, dot products, scale checks
         self.last_gs = gs_all
         return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent, grad_div=grad_scale)
 

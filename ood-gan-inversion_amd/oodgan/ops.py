@@ -311,6 +311,48 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     return y
 
 
+class BwdJobs:
+    """Deferred per-layer tail work of one backward pass (reductions of partial sums, demodulation gradient, range-scale
+    checks): collected while the gradient chain is enqueued, run as three batched launches at its end.  Keeps the
+    tensors alive until then."""
+
+    def __init__(self):
+        self.reduce, self.reduce_acc, self.demod, self.check, self.keep = [], [], [], [], []
+
+    def add_reduce(self, part, out_ptr_obj, B, C, nparts, out_stride, accumulate):
+        # accumulating jobs (the dot products) run AFTER the demodulation gradient, as in the per-layer order: the
+        # demodulation kernel's `gs += a*b` is one fused multiply-add, so the order of the two contributions is visible
+        # in the last bit
+        (self.reduce_acc if accumulate else self.reduce).append(
+            _lib.ReduceJob(_p(part), _p(out_ptr_obj), B, C, nparts, out_stride, 1 if accumulate else 0))
+        self.keep += [part, out_ptr_obj]
+
+    def add_demod(self, s, wsq, d, r, gs, B, Ci, Co, scale):
+        self.demod.append(_lib.DemodBwdJob(_p(s), _p(wsq), _p(d), _p(r), _p(gs), s.shape[1], d.shape[1], gs.shape[1], B, Ci, Co,
+                                           float(scale)))
+        self.keep += [s, wsq, d, r, gs]
+
+    def add_check(self, part, state):
+        self.check.append(_lib.ScaleCheckJob(_p(part), part.numel(), _p(state)))
+        self.keep += [part, state]
+
+    def run(self, flag):
+        L = _lib.lib()
+        if self.reduce:
+            arr = (_lib.ReduceJob * len(self.reduce))(*self.reduce)
+            check(L.oodgan_reduce_batch(arr, len(self.reduce), _stream()), 'reduce_batch')
+        if self.demod:
+            arr = (_lib.DemodBwdJob * len(self.demod))(*self.demod)
+            check(L.oodgan_demod_bwd_batch(arr, len(self.demod), _stream()), 'demod_bwd_batch')
+        if self.reduce_acc:
+            arr = (_lib.ReduceJob * len(self.reduce_acc))(*self.reduce_acc)
+            check(L.oodgan_reduce_batch(arr, len(self.reduce_acc), _stream()), 'reduce_batch')
+        if self.check:
+            arr = (_lib.ScaleCheckJob * len(self.check))(*self.check)
+            check(L.oodgan_absmax_scale_check_batch(arr, len(self.check), _p(flag), _stream()), 'absmax_scale_check_batch')
+        self.reduce, self.reduce_acc, self.demod, self.check, self.keep = [], [], [], [], []
+
+
 def _reduce_into(part, B, C, npart, into, accumulate):
     """sum the partials straight into the column block ``into`` (a Cols of the style-gradient accumulator)."""
     check(_lib.lib().oodgan_reduce_parts_cols(_p(part), _p(into), B, C, npart, into.shape[1], 1 if accumulate else 0, _stream()),
@@ -324,7 +366,7 @@ def _reduce_parts(part, rows, npart):
 
 
 def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, g_rgb=None, w_rgb=None, s_rgb=None,
-                     blur_kernel=None, t_into=None):
+                     blur_kernel=None, t_into=None, jobs=None):
     """Fused backward producer (include/oodgan.h): the gradient of bias+noise+lrelu*sqrt2 (+ToRGB branch) of ``out``
     written straight into ``dst`` — an ``SForm`` (plain conv layer) or, with ``blur_kernel``, an ``SFormPhases``
     (up-conv layer: blur^T and phase split fused) — scaled by ``dscale[b,c] * mul2[1]``.
@@ -349,6 +391,12 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
     else:
         check(L.oodgan_act_bwd_sform(*common, _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()),
               'act_bwd_sform')
+    if jobs is not None:            # deferred: the sums are only needed by the batched tail of the backward
+        r = torch.empty(B, C, device=o.device, dtype=torch.float32)
+        jobs.add_reduce(part_r, r, B, C, npart, C, False)
+        if part_t is not None:
+            jobs.add_reduce(part_t, t_into, B, C, npart, t_into.shape[1], False)
+        return r, None, part_m
     r = _reduce_parts(part_r, B * C, npart)
     t = None
     if part_t is not None:
@@ -460,7 +508,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
@@ -515,7 +563,10 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
     if dotx is not None:
         if dot_into is not None:        # += into the layer's columns of the style-gradient accumulator
-            _reduce_into(part, B, M, a.dot_nparts, dot_into, True)
+            if jobs is not None:
+                jobs.add_reduce(part, dot_into, B, M, a.dot_nparts, dot_into.shape[1], True)
+            else:
+                _reduce_into(part, B, M, a.dot_nparts, dot_into, True)
             return out, None
         dot = torch.empty(B, M, device=dx_.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')

@@ -253,3 +253,23 @@ def test_features_in_injection_vs_golden(dev, golden):
         ref = g[f'image_fs{fs}']
         assert maxdiff(img, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), fs
         assert maxdiff(feat[:, ::16], g[f'feat_fs{fs}_sub']) <= 1e-4 * max(1.0, g[f'feat_fs{fs}_sub'].abs().max().item())
+
+
+def test_batched_backward_tail_is_bit_identical(dev):
+    """The batched tail of the backward (partial-sum reductions, demodulation gradient, dot products, scale checks in four
+    launches) must reproduce the per-layer launches bit for bit: same per-output summation order, same order of the two
+    contributions to every accumulator entry (the demodulation kernel's += is a fused multiply-add)."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, B = 64, 3
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=5).items()}, size)
+    target = synth.make_images(size, B, seed=9).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    w0 = synth.make_latents(size, B, seed=14).to(dev)
+    res = []
+    for flag in (False, True):
+        eng.batched_tail = flag
+        w, l = WPlusInverter(eng).invert(target, w0, noises, steps=5)
+        torch.cuda.synchronize()
+        res.append((w.clone(), l.clone()))
+    eng.batched_tail = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
