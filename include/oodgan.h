@@ -230,11 +230,17 @@ typedef struct oodgan_demod_bwd_job {
     int s_stride, d_stride, gs_stride, B, Ci, Co;
     float scale;
 } oodgan_demod_bwd_job;
+typedef struct oodgan_demod_fwd_job {
+    const float* s; const float* wsq; float* d;
+    int s_stride, d_stride, B, Ci, Co;
+    float scale;
+} oodgan_demod_fwd_job;
 typedef struct oodgan_scale_check_job {
     const float* part; long n; float* state;
 } oodgan_scale_check_job;
 int oodgan_reduce_batch(const oodgan_reduce_job* jobs, int njobs, void* stream);
 int oodgan_demod_bwd_batch(const oodgan_demod_bwd_job* jobs, int njobs, void* stream);
+int oodgan_demod_fwd_batch(const oodgan_demod_fwd_job* jobs, int njobs, void* stream);   /* oodgan_demod_fwd for all layers */
 int oodgan_absmax_scale_check_batch(const oodgan_scale_check_job* jobs, int njobs, int* flag, void* stream);
 
 /* ---- fp16 modulated conv for the high-resolution, low-channel layers (BASELINE.json configs[4] / SURVEY §8 C5) ----

@@ -74,6 +74,28 @@ __global__ __launch_bounds__(256) void demod_bwd_batch_kernel(const DemodTable t
                                             (red[0][cil] + red[1][cil] + red[2][cil] + red[3][cil]);
 }
 
+struct DemodFwdTable {
+    oodgan_demod_fwd_job j[kMaxDemod];
+    int first_wave[kMaxDemod + 1];
+    int n;
+};
+
+// demod_fwd_kernel for every styled conv of the generator in one launch (all of them only need the style vector)
+__global__ __launch_bounds__(256) void demod_fwd_batch_kernel(const DemodFwdTable t) {
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= t.first_wave[t.n]) return;
+    int k = 0;
+    while (k + 1 < t.n && wv >= t.first_wave[k + 1]) ++k;
+    const oodgan_demod_fwd_job& q = t.j[k];
+    const long idx = wv - t.first_wave[k];
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(idx / q.Co), co = (int)(idx % q.Co);
+    float acc = 0.f;
+    for (int ci = lane; ci < q.Ci; ci += 64) { const float sv = q.s[(long)b * q.s_stride + ci]; acc += sv * sv * q.wsq[(long)co * q.Ci + ci]; }
+    acc = wave_sum(acc);
+    if (lane == 0) q.d[(long)b * q.d_stride + co] = rsqrtf(acc * (q.scale * q.scale) + 1e-8f);
+}
+
 struct CheckTable {
     oodgan_scale_check_job j[kMaxCheck];
     int n;
@@ -172,6 +194,27 @@ extern "C" int oodgan_absmax_scale_check_batch(const oodgan_scale_check_job* job
         }
         hipLaunchKernelGGL(scale_check_batch_kernel, dim3(t.n), dim3(1024), 0, as_stream(stream), t, flag);
         int rc = check_launch("absmax_scale_check_batch");
+        if (rc != OODGAN_OK) return rc;
+    }
+    return OODGAN_OK;
+}
+
+extern "C" int oodgan_demod_fwd_batch(const oodgan_demod_fwd_job* jobs, int njobs, void* stream) {
+    OODGAN_REQUIRE(jobs && njobs > 0, "demod_fwd_batch: bad args");
+    for (int base = 0; base < njobs; base += kMaxDemod) {
+        DemodFwdTable t;
+        t.n = njobs - base < kMaxDemod ? njobs - base : kMaxDemod;
+        long waves = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const oodgan_demod_fwd_job& q = jobs[base + i];
+            OODGAN_REQUIRE(q.s && q.wsq && q.d && q.B > 0 && q.Ci > 0 && q.Co > 0, "demod_fwd_batch: bad job %d", base + i);
+            t.j[i] = q;
+            t.first_wave[i] = (int)waves;
+            waves += (long)q.B * q.Co;
+        }
+        t.first_wave[t.n] = (int)waves;
+        hipLaunchKernelGGL(demod_fwd_batch_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), t);
+        int rc = check_launch("demod_fwd_batch");
         if (rc != OODGAN_OK) return rc;
     }
     return OODGAN_OK;

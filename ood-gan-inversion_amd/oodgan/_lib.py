@@ -37,6 +37,11 @@ class DemodBwdJob(Structure):
                 ('B', c_int), ('Ci', c_int), ('Co', c_int), ('scale', c_float)]
 
 
+class DemodFwdJob(Structure):
+    _fields_ = [('s', P), ('wsq', P), ('d', P), ('s_stride', c_int), ('d_stride', c_int), ('B', c_int), ('Ci', c_int), ('Co', c_int),
+                ('scale', c_float)]
+
+
 class ScaleCheckJob(Structure):
     _fields_ = [('part', P), ('n', c_long), ('state', P)]
 
@@ -79,6 +84,7 @@ _SIGS = {
     'oodgan_absmax_scale_check': (c_int, [P, c_long, P, P, P]),
     'oodgan_reduce_batch': (c_int, [P, c_int, P]),
     'oodgan_demod_bwd_batch': (c_int, [P, c_int, P]),
+    'oodgan_demod_fwd_batch': (c_int, [P, c_int, P]),
     'oodgan_absmax_scale_check_batch': (c_int, [P, c_int, P, P]),
     'oodgan_hform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_to_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

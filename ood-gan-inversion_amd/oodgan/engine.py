@@ -155,9 +155,18 @@ class GeneratorEngine:
         B = latent.shape[0]
         s_all = self.styles(latent)
         d_all = torch.empty(B, self.DR, device=self.device, dtype=torch.float32)
-        for L in self.layers:
-            if L.kind != 'rgb':
-                self._demod(L, s_all, d_all)
+        if self.batched_tail:       # the demodulation factors of all styled convs in one launch
+            from ._lib import DemodFwdJob, lib, check
+            import ctypes
+            styled = [L for L in self.layers if L.kind != 'rgb']
+            arr = (DemodFwdJob * len(styled))(*[DemodFwdJob(ctypes.c_void_p(s_all.data_ptr() + 4 * L.row), ctypes.c_void_p(L.wsq.data_ptr()),
+                                                            ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.R, self.DR, B, L.cin, L.cout,
+                                                            float(L.scale)) for L in styled])
+            check(lib().oodgan_demod_fwd_batch(arr, len(styled), ops._stream()), 'demod_fwd_batch')
+        else:
+            for L in self.layers:
+                if L.kind != 'rgb':
+                    self._demod(L, s_all, d_all)
         acts = {}
         x = self.const_input.expand(B, -1, -1, -1).contiguous()
         acts['input'] = x
