@@ -322,23 +322,31 @@ int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unsca
 }
 
 // ------------------------------------------------------------------ weight packing
+// max |w*scale| over the tensor -> out2[0] (as the bit pattern of a non-negative float: integer order = float order);
+// out2[0] must be zero on entry
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, long n, float scale, float* __restrict__ out2) {
     __shared__ float red[4];
     float m = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i] * scale));
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i] * scale));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        // power of two s.t. max|w|*2^e in [512, 1024)
-        int e = 0;
-        if (m > 0.f && isfinite(m)) e = 9 - (int)floorf(log2f(m));
-        e = e < -60 ? -60 : (e > 60 ? 60 : e);
-        out2[0] = ldexpf(1.f, -e);    // unscale
-        out2[1] = ldexpf(1.f, e);     // scale
+        if (!(m >= 0.f)) m = __builtin_inff();        // NaN: make it visible to the finishing kernel
+        atomicMax(reinterpret_cast<unsigned*>(out2), __float_as_uint(m));
     }
+}
+
+// out2[0] = max -> {2^-e, 2^e} with max*2^e in [512, 1024)
+__global__ void absmax_finish_kernel(float* __restrict__ out2) {
+    const float m = out2[0];
+    int e = 0;
+    if (m > 0.f && isfinite(m)) e = 9 - (int)floorf(log2f(m));
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    out2[0] = ldexpf(1.f, -e);    // unscale
+    out2[1] = ldexpf(1.f, e);     // scale
 }
 
 // wpk16[kchunk][tap][hi|lo][h][Mp][8] f16
@@ -395,7 +403,12 @@ extern "C" int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unsc
     const int M = transpose ? Ci : Co, K = transpose ? Co : Ci;
     const int Mp = (M + 63) / 64 * 64;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(256), 0, st, w, (long)Co * Ci * 9, scale, unscale2);
+    if (hipMemsetAsync(unscale2, 0, 2 * sizeof(float), st) != hipSuccess) {
+        set_error("pack_conv3x3_f16s: memset failed");
+        return OODGAN_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(absmax_kernel, dim3(stream_grid((long)Co * Ci * 9, 256 * 16)), dim3(256), 0, st, w, (long)Co * Ci * 9, scale, unscale2);
+    hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(1), 0, st, unscale2);
     const long total = (long)((K + CK - 1) / CK) * 9 * 2 * Mp * 8;
     hipLaunchKernelGGL(pack_f16s_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, w, reinterpret_cast<_Float16*>(wpk16),
                        Co, Ci, Mp, scale, transpose, flip, unscale2);
