@@ -172,10 +172,13 @@ int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* s
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
  * fetch their halo'd tiles as contiguous runs by LDS-DMA.  Buffers must be zero-initialised once (border).
- * oodgan_to_sform converts an fp32 NCHW tensor: value = x*scale[b,c]*mul2[1]. */
+ * oodgan_to_sform converts an fp32 NCHW tensor: value = x*scale[b,c]*mul2[1].
+ * Every forward producer of an S-form (oodgan_to_sform, oodgan_blur_act_sform, oodgan_torgb_fwd_sform) takes an optional
+ * `vmax` (B unsigned, float bit patterns, atomically maxed): the largest |value| it wrote for each sample — the input of
+ * the forward range control below. */
 long oodgan_sform_bytes(int B, int C, int H, int W);
 int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
-                    int H, int W, int in_pitch, void* stream);
+                    int H, int W, int in_pitch, unsigned* vmax, void* stream);
 /* Phase-split S-form for the stride-2 conv (mode S2 with x_sform): the (2H+1)x(2W+1) input is stored as its four
  * parity images G[py][px][i][j] = x[2i+py][2j+px], each in S-form without border, so that the stride-2 conv
  * becomes stride-1 taps on contiguous runs.  H,W = OUTPUT size of the S2 conv. */
@@ -187,13 +190,29 @@ int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const floa
 int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
                            int C, int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
+/* ---- forward range control of the split-f16 path (csrc/fwd_range.hip).  ModulatedConv2d.forward in fp32
+ * (src/ops/StyleGAN/model.py:233-274) has no range limit; an S-form record (hi+lo f16) holds |v| < 65504.  Every styled
+ * conv l therefore carries one power-of-two scale per sample q[l][b] with max|x*s|*q in [512,1024): the producers get the
+ * style block s_sc = s*q, the conv epilogue the demodulation block d_sc = d/q (both exact).
+ *   oodgan_absmax_scaled:    vmax[b] = max_{c,p} |x[b,c,p]*s[b,c]| (atomic max into a zeroed array; non-finite -> inf)
+ *   oodgan_fwd_range_update: n entries (layer-major [l][b]); flag != NULL (carry mode): vmax was measured on values scaled
+ *                            by q -> flag |= 1 if it left [2^-8, 2^15), |= 2 if non-finite; next q from vmax/q.
+ *                            flag == NULL (exact mode): vmax is the true max, q is set from it.  vmax is zeroed.
+ *   oodgan_fwd_range_plan:   s_sc[b,r] = s_all[b,r]*q[row_layer[r]][b] for rows [row0,row0+nrows) (row_layer < 0: copy),
+ *                            d_sc[b,r] = d_all[b,r]/q[drow_layer[r]][b] for rows [drow0,drow0+ndrows). */
+int oodgan_absmax_scaled(const float* x, const float* s, int s_stride, unsigned* vmax, int B, int C, long HW, void* stream);
+int oodgan_fwd_range_update(unsigned* vmax, float* q, int* flag, int n, void* stream);
+int oodgan_fwd_range_plan(const float* s_all, const float* d_all, const int* row_layer, const int* drow_layer, const float* q,
+                          float* s_sc, float* d_sc, int B, int R, int DR, int row0, int nrows, int drow0, int ndrows,
+                          void* stream);
+
 /* ---- fused forward producer (csrc/fwd_producers.hip): the tail of the up-sampling StyledConv in one pass —
  * Blur(pad=(1,1)) of the transposed-conv output z (B,C,2H+1,in_pitch) (model.py:72-88,199-205), + noise_w*noise + bias,
  * leaky-ReLU*sqrt2 (model.py:283-292,343-350) -> y (B,C,2H,2W) fp32 AND, if ys != NULL, the S-form of y*ys_scale[b,c]
  * (the next conv's input).  in_pitch %% 4 == 0 (what oodgan_conv3x3 mode T2 produces). */
 int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale, int ys_scale_stride,
                           const float* bias, const float* noise, int noise_batch, const float* noise_w, int act, int B, int C,
-                          int H, int W, int in_pitch, void* stream);
+                          int H, int W, int in_pitch, unsigned* vmax, void* stream);
 
 /* ---- fused backward producers (csrc/bwd_producers.hip): oodgan_act_bwd_fused's arithmetic (autograd of NoiseInjection +
  * FusedLeakyReLU merged with the ToRGB branch, src/ops/StyleGAN/model.py:283-292,343-372) written directly as the
@@ -280,7 +299,7 @@ int oodgan_torgb_fwd(const float* x, const float* w, const float* s, int s_strid
  * `out`).  ys: S-form buffer of (B,Ci,H,W); ys_scale (B,*) stride ys_scale_stride or NULL.  Ci % 16 == 0, W % 4 == 0. */
 int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                            const float* skip, const float* kernel, float* y, void* ys, const float* ys_scale,
-                           int ys_scale_stride, int B, int Ci, int H, int W, float scale, void* stream);
+                           int ys_scale_stride, int B, int Ci, int H, int W, float scale, unsigned* vmax, void* stream);
 /* y[b,k,p] = partial[b,k,p] + bias[k] + upfirdn2d(skip, k4*4, up=2, pad=(2,1))[b,k,p]: second half of ToRGB.forward when the
  * three colour sums came out of the conv kernel's epilogue (oodgan_conv_args.rgb_y).  y may alias partial. */
 int oodgan_rgb_finish(const float* partial, const float* bias, const float* skip, const float* kernel, float* y, int B, int H,
@@ -300,11 +319,13 @@ int oodgan_act_bwd_fused(const float* g_feat, const float* out, const float* noi
                          const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre,
                          float* part_r, float* part_rgb, int B, int C, long HW, void* stream);
 int oodgan_act_bwd_nparts(long HW);
-/* same, additionally part_max[b,c,j] = partial max |g_pre| (feeds oodgan_absmax_scale) */
+/* same, additionally part_max[b,c,j] = partial max |g_pre| * |dscale[b,c]| (dscale = the layer's demodulation block, stride
+ * dscale_stride, NULL = 1): the largest value the consumer's S-form will hold before its range scale (feeds oodgan_absmax_scale) */
 int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float* noise, int noise_batch,
                              const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
                              const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre,
-                             float* part_r, float* part_rgb, float* part_max, int B, int C, long HW, void* stream);
+                             float* part_r, float* part_rgb, float* part_max, const float* dscale, int dscale_stride, int B,
+                             int C, long HW, void* stream);
 /* out2 = {2^-e, 2^e} with e chosen so that max_i |part[i]| * 2^e lies in [512,1024) (e = 0 for an all-zero or
  * non-finite input): the power-of-two scale that keeps a tensor inside the f16 range of the split-f16 kernels. */
 int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream);

@@ -53,17 +53,18 @@ struct ActArgs {
 
 constexpr float kInvPos = 1.f / kSqrt2, kInvNeg = 1.f / (0.2f * kSqrt2);
 
-// per-block channel constants in LDS: [0] w0 [1] w1 [2] w2 (already x rgb_scale) [3] s_rgb [4] bias [5] d*scale
+// per-block channel constants in LDS: [0] w0 [1] w1 [2] w2 (already x rgb_scale) [3] s_rgb [4] bias [5] d*scale [6] |d|
 __device__ __forceinline__ void load_consts(const ActArgs& a, int b, int kc, float (*cst)[16]) {
     const int t = threadIdx.x;
-    if (t < 96) {
+    if (t < 112) {
         const int which = t >> 4, j = t & 15, c = kc * 16 + j;
         float v = 0.f;
         if (c < a.C) {
             if (which < 3) v = a.g_rgb ? a.w_rgb[which * a.C + c] * a.rgb_scale : 0.f;
             else if (which == 3) v = a.g_rgb ? a.s_rgb[(long)b * a.s_rgb_stride + c] : 0.f;
             else if (which == 4) v = a.bias ? a.bias[c] : 0.f;
-            else v = (a.dscale ? a.dscale[(long)b * a.dscale_stride + c] : 1.f) * (a.mul2 ? a.mul2[1] : 1.f);
+            else if (which == 5) v = (a.dscale ? a.dscale[(long)b * a.dscale_stride + c] : 1.f) * (a.mul2 ? a.mul2[1] : 1.f);
+            else v = a.dscale ? fabsf(a.dscale[(long)b * a.dscale_stride + c]) : 1.f;
         }
         cst[which][j] = v;
     }
@@ -77,7 +78,7 @@ constexpr int kP1Pitch = kP1Chunk + 4;
 // pixel, gathers its 16 channels, splits hi/lo and writes the 64-byte record (consecutive lanes, consecutive records).
 __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uint4* __restrict__ ys, const SDims yd) {
     __shared__ __attribute__((aligned(16))) float lst[16 * kP1Pitch];
-    __shared__ float cst[6][16];
+    __shared__ float cst[7][16];
     __shared__ float redm[4];
     const int KC = yd.KC;
     const int bk = blockIdx.y, b = bk / KC, kc = bk % KC;
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
             if (a.part_t) a.part_t[o] = acc_t;
         }
     }
+    amax *= cst[6][tid >> 4];        // the value written is g_pre*d*scale: the range scale must cover the demodulation factor
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((tid & 63) == 0) redm[tid >> 6] = amax;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ __attribute__((aligned(16))) float lin[16 * BT_Q];
     __shared__ float kf[16];
     __shared__ float ksep[9];
-    __shared__ float cst[6][16];
+    __shared__ float cst[7][16];
     __shared__ float redm[4];
     const int tid = threadIdx.x;
     // contiguous chunk of the tile list per XCD: a tile's halo rows/columns are its neighbours' interiors, which the
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (a.part_t) a.part_t[o] = acc_t;
         }
     }
+    amax *= cst[6][tid >> 4];        // the value written is g_pre*d*scale: the range scale must cover the demodulation factor
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((tid & 63) == 0) redm[tid >> 6] = amax;

@@ -724,21 +724,28 @@ __global__ __launch_bounds__(256) void blurT_sp_kernel(const float* __restrict__
 // F-form (B,C,H,W) fp32 -> S-form, value = x*scale[b,c]*mul2[1]; one thread per (b,kc,y,x) record
 __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        int scale_stride, const float* __restrict__ mul2, uint4* __restrict__ out,
-                                                       int B, SDims d, int in_pitch) {
+                                                       int B, SDims d, int in_pitch, unsigned* __restrict__ vmax) {
     const long total = (long)B * d.KC * d.H * d.W;
     const float gm = mul2 ? mul2[1] : 1.f;
     const long in_plane = (long)d.H * in_pitch;
+    float vm = 0.f;
+    int vb = -1;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int xx = (int)(e % d.W);
         const int yy = (int)((e / d.W) % d.H);
         const int kc = (int)((e / ((long)d.W * d.H)) % d.KC);
         const int b = (int)(e / ((long)d.W * d.H * d.KC));
+        if (vmax && b != vb) {          // forward range control: max |v| per sample (rarely more than one sample per thread)
+            if (vb >= 0 && vm > 0.f) atomicMax(vmax + vb, __float_as_uint(vm));
+            vb = b; vm = 0.f;
+        }
         half8 h0, h1, l0, l1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int c = kc * 16 + j;
             float v = 0.f;
             if (c < d.C) v = x[((long)b * d.C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) * gm;
+            vm = fmaxf(vm, fabsf(v));
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
             if (j < 8) { h0[j] = h; l0[j] = l; } else { h1[j - 8] = h; l1[j - 8] = l; }
@@ -747,6 +754,7 @@ __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__
         half8* o = reinterpret_cast<half8*>(out + u);
         o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
     }
+    if (vmax && vb >= 0 && vm > 0.f) atomicMax(vmax + vb, __float_as_uint(vm));
 }
 
 }  // namespace
@@ -757,13 +765,13 @@ extern "C" long oodgan_sform_bytes(int B, int C, int H, int W) {
 }
 
 extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
-                               int H, int W, int in_pitch, void* stream) {
+                               int H, int W, int in_pitch, unsigned* vmax, void* stream) {
     OODGAN_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "to_sform: bad args");
     const SDims d = sform_dims(C, H, W);
     if (in_pitch == 0) in_pitch = W;
     const long total = (long)B * d.KC * H * W;
     hipLaunchKernelGGL(to_sform_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale, scale_stride,
-                       mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch);
+                       mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch, vmax);
     return check_launch("to_sform");
 }
 

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
     const float* __restrict__ g_feat, const float* __restrict__ out, const float* __restrict__ noise, int noise_batch,
     const float* __restrict__ noise_w, const float* __restrict__ bias, const float* __restrict__ g_rgb,
     const float* __restrict__ w_rgb, const float* __restrict__ s_rgb, int s_rgb_stride, float rgb_scale,
-    float* __restrict__ g_pre, float* __restrict__ part_r, float* __restrict__ part_rgb, float* __restrict__ part_max, int C,
-    long HW, int nparts) {
+    float* __restrict__ g_pre, float* __restrict__ part_r, float* __restrict__ part_rgb, float* __restrict__ part_max,
+    const float* __restrict__ dscale, int dscale_stride, int C, long HW, int nparts) {
     __shared__ float red[4];
     const int bc = blockIdx.y, b = bc / C, c = bc % C;
     const long base = (long)bc * HW;
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
         __syncthreads();
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
         __syncthreads();
-        if (threadIdx.x == 0) part_max[(long)bc * nparts + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (threadIdx.x == 0)
+            part_max[(long)bc * nparts + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) *
+                                                        (dscale ? fabsf(dscale[(long)b * dscale_stride + c]) : 1.f);
     }
 }
 
@@ -318,7 +320,8 @@ extern "C" int oodgan_act_bwd_nparts(long HW) { return (int)((HW + kActChunk - 1
 extern "C" int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float* noise, int noise_batch,
                                         const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
                                         const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre, float* part_r,
-                                        float* part_rgb, float* part_max, int B, int C, long HW, void* stream) {
+                                        float* part_rgb, float* part_max, const float* dscale, int dscale_stride, int B, int C,
+                                        long HW, void* stream) {
     OODGAN_REQUIRE(out && g_pre && B > 0 && C > 0 && HW > 0, "act_bwd_fused: bad args");
     OODGAN_REQUIRE(g_feat || g_rgb, "act_bwd_fused: no incoming gradient");
     OODGAN_REQUIRE(!g_rgb || (w_rgb && s_rgb), "act_bwd_fused: rgb branch needs w_rgb and s_rgb");
@@ -328,7 +331,7 @@ extern "C" int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, c
     dim3 grid(nparts, B * C);
     hipLaunchKernelGGL(act_bwd_fused_kernel, grid, dim3(256), 0, as_stream(stream), g_feat, out, noise, noise_batch, noise_w,
                        bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, g_pre, part_r, g_rgb ? part_rgb : nullptr, part_max,
-                       C, HW, nparts);
+                       dscale, dscale_stride, C, HW, nparts);
     return check_launch("act_bwd_fused");
 }
 
@@ -337,7 +340,7 @@ extern "C" int oodgan_act_bwd_fused(const float* g_feat, const float* out, const
                                     const float* s_rgb, int s_rgb_stride, float rgb_scale, float* g_pre, float* part_r,
                                     float* part_rgb, int B, int C, long HW, void* stream) {
     return oodgan_act_bwd_fused_max(g_feat, out, noise, noise_batch, noise_w, bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale,
-                                    g_pre, part_r, part_rgb, nullptr, B, C, HW, stream);
+                                    g_pre, part_r, part_rgb, nullptr, nullptr, 0, B, C, HW, stream);
 }
 
 extern "C" int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream) {

@@ -45,6 +45,7 @@ struct BlurArgs {
     int B, C, H, W, pitch;
     int tiles_x, tiles_y;
     SDims yd;
+    unsigned* vmax;          // (B) or null: max |value written to ys| per sample (fwd_range.hip)
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur_act_sform_kernel(const BlurArgs a) {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---- C: thread = pixel: noise + bias + activation for its 16 channels, fp32 store per channel plane, one record
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const long HWo = (long)Ho * Wo;
+    float vm = 0.f;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         const int pos = tid + rep * 256;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
                 v[e] = t * cb[1][cc];
             }
+            vm = fmaxf(vm, fmaxf(fabsf(v[0]), fabsf(v[1])));
             split_pair(v[0], v[1], hp[cp], lp[cp]);
         }
         if (a.ys) {
@@ -192,13 +195,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             rec[3] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
         }
     }
+    if (a.vmax) record_vmax(a.vmax, b, vm);
 }
 
 }  // namespace
 
 extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
                                      int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
-                                     const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, void* stream) {
+                                     const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
+                                     void* stream) {
     OODGAN_REQUIRE(z && kernel && y && B > 0 && C > 0 && H > 0 && W > 0, "blur_act_sform: bad args");
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "blur_act_sform: noise_batch");
     OODGAN_REQUIRE(act == OODGAN_ACT_NONE || act == OODGAN_ACT_LRELU, "blur_act_sform: act must be none or lrelu");
@@ -212,6 +217,7 @@ extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float*
     a.tiles_x = (2 * W + 63) / 64;
     a.tiles_y = (2 * H + 7) / 8;
     a.yd = sform_dims(C, 2 * H, 2 * W);
+    a.vmax = ys ? vmax : nullptr;
     const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "blur_act_sform: grid too large");
     hipLaunchKernelGGL(blur_act_sform_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);

@@ -52,4 +52,12 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// forward range control (fwd_range.hip): a producer records the max |v| of the values it wrote for sample b.
+// Every lane of the wave must call, with the same b.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void record_vmax(unsigned* vmax, int b, float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(vmax + b, __float_as_uint(m));
+}
+
 }  // namespace oodgan

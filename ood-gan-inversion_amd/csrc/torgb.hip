@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
                                                               const float* __restrict__ skip, const float* __restrict__ kern,
                                                               float* __restrict__ y, uint4* __restrict__ ys,
                                                               const float* __restrict__ ys_scale, int ys_scale_stride, SDims yd, int Ci,
-                                                              int H, int W, float scale) {
+                                                              int H, int W, float scale, unsigned* __restrict__ vmax) {
     __shared__ float ws[3 * kMaxCi];
     __shared__ float sc[kMaxCi];
     __shared__ float kf[16];
@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
     __syncthreads();
     const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool full_wave = __all(p < HW);        // evaluated before any lane leaves
     if (p >= HW) return;
     const float* xp = x + (long)b * Ci * HW + p;
     const int Y0 = (int)(p / W), X0 = (int)(p % W);
     float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    float vm = 0.f;
     for (int kc = 0; kc < Ci / 16; ++kc) {
         unsigned hp[4][8], lp[4][8];
 #pragma unroll
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
                 a0[j] += w00 * e0[j]; a1[j] += w01 * e0[j]; a2[j] += w02 * e0[j];
                 a0[j] += w10 * e1[j]; a1[j] += w11 * e1[j]; a2[j] += w12 * e1[j];
                 split_pair(e0[j] * s0, e1[j] * s1, hp[j][cp], lp[j][cp]);
+                vm = fmaxf(vm, fmaxf(fabsf(e0[j] * s0), fabsf(e1[j] * s1)));
             }
         }
 #pragma unroll
@@ -227,6 +230,10 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
         }
         float* yp = y + (long)b * 3 * HW + p + j;
         yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
+    }
+    if (vmax) {
+        if (full_wave) record_vmax(vmax, b, vm);
+        else if (vm > 0.f) atomicMax(vmax + b, __float_as_uint(vm));
     }
 }
 
@@ -295,14 +302,14 @@ extern "C" int oodgan_torgb_fwd(const float* x, const float* w, const float* s, 
 
 extern "C" int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                                       const float* skip, const float* kernel, float* y, void* ys, const float* ys_scale,
-                                      int ys_scale_stride, int B, int Ci, int H, int W, float scale, void* stream) {
+                                      int ys_scale_stride, int B, int Ci, int H, int W, float scale, unsigned* vmax, void* stream) {
     OODGAN_REQUIRE(x && w && s && y && ys && B > 0 && Ci > 0 && H > 0 && W > 0, "torgb_fwd_sform: bad args");
     OODGAN_REQUIRE(Ci <= kMaxCi && (Ci % 16) == 0 && (W % 4) == 0, "torgb_fwd_sform: needs Ci %% 16 == 0, Ci <= %d, W %% 4 == 0", kMaxCi);
     OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "torgb_fwd_sform: skip needs kernel and even H,W");
     const long HW = (long)H * W;
     dim3 grid((unsigned)((HW + 1023) / 1024), B);
     hipLaunchKernelGGL(torgb_fwd_sform_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y,
-                       reinterpret_cast<uint4*>(ys), ys_scale, ys_scale_stride, sform_dims(Ci, H, W), Ci, H, W, scale);
+                       reinterpret_cast<uint4*>(ys), ys_scale, ys_scale_stride, sform_dims(Ci, H, W), Ci, H, W, scale, vmax);
     return check_launch("torgb_fwd_sform");
 }
 

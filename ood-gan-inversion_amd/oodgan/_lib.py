@@ -73,10 +73,13 @@ _SIGS = {
     'oodgan_sform_phases_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform_phases': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_to_sform': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     'oodgan_resize_bicubic_ac': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_avgpool': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    'oodgan_blur_act_sform': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_blur_act_sform': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'oodgan_absmax_scaled': (c_int, [P, P, c_int, P, c_int, c_int, c_long, P]),
+    'oodgan_fwd_range_update': (c_int, [P, P, P, c_int, P]),
+    'oodgan_fwd_range_plan': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_sform_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_blurT_nparts': (c_int, [c_int, c_int]),
@@ -96,10 +99,10 @@ _SIGS = {
     'oodgan_reduce_parts_cols': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_rgb_finish': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
-    'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),
-    'oodgan_act_bwd_fused_max': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_act_bwd_fused_max': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_absmax_scale': (c_int, [P, c_long, P, P]),
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_nparts': (c_int, [c_long]),

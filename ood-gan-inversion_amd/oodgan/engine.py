@@ -22,7 +22,7 @@ _Cols = ops.Cols
 
 class _Layer:
     __slots__ = ('name', 'kind', 'cin', 'cout', 'res', 'lat', 'row', 'drow', 'wpk', 'wpk_bwd', 'wsq', 'w_rgb',
-                 'bias', 'noise_w', 'scale', 'noise_idx', 'src')
+                 'bias', 'noise_w', 'scale', 'noise_idx', 'src', 'sidx')
 
 
 class GeneratorEngine:
@@ -77,16 +77,13 @@ class GeneratorEngine:
             rgb(f'to_rgbs.{j}', cout, res, i + 2)
             cin, i = cout, i + 2
         self.layers = layers
-        # conv -> following up-conv pairs: the conv's epilogue can write the up-conv's S-form input directly
         import os
-        self.ys_handoff = os.environ.get('OODGAN_YS_HANDOFF', '0') != '0'
         # fused backward producers (csrc/bwd_producers.hip): per-layer range scale carried from one W+ step to the next
         self.fused_bwd = os.environ.get('OODGAN_FUSED_BWD', '1') != '0'
         self.bwd_state, self.bwd_flag = {}, None
         styled = [L for L in layers if L.kind != 'rgb']
         self.fused_fwd = os.environ.get('OODGAN_FUSED_FWD', '1') != '0'
         self.next_conv = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b.kind == 'conv'}
-        self.next_styled = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'conv' and b.kind == 'up'}
         # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
         self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
         self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
@@ -100,6 +97,7 @@ class GeneratorEngine:
         # concatenated modulation matrix, rows grouped by latent index (execution order already is)
         rows, drows, wl, bl, rl = 0, 0, [], [], []
         lat_start = [0] * (self.n_latent + 1)
+        row_layer, drow_layer, sidx = [], [], 0
         for L in layers:
             L.row = rows
             wl.append(g(f'{L.name}.conv.modulation.weight'))
@@ -110,6 +108,13 @@ class GeneratorEngine:
             if L.kind != 'rgb':
                 L.drow = drows
                 drows += L.cout
+                L.sidx = sidx                       # index of the styled conv: row of the forward range-scale table
+                row_layer += [sidx] * L.cin
+                drow_layer += [sidx] * L.cout
+                sidx += 1
+            else:
+                L.sidx = -1
+                row_layer += [-1] * L.cin           # ToRGB colour weights use the true style
         for l in range(1, self.n_latent + 1):
             lat_start[l] = max(lat_start[l], lat_start[l - 1])
         self.R, self.DR = rows, drows
@@ -117,6 +122,12 @@ class GeneratorEngine:
         self.bcat = torch.cat(bl, 0).contiguous()
         self.row_lat = torch.tensor(rl, dtype=torch.int32, device=dev)
         self.lat_start = torch.tensor(lat_start, dtype=torch.int32, device=dev)
+        self.row_layer = torch.tensor(row_layer, dtype=torch.int32, device=dev)
+        self.drow_layer = torch.tensor(drow_layer, dtype=torch.int32, device=dev)
+        self.n_styled = sidx
+        # forward range control of the split-f16 path (ops.FwdRange): per-step state, created for the batch size in use
+        self.fwd_range = None
+        self.carry_range = True      # False: every forward measures its scales exactly (the fallback after a violation)
         self.stored_noises = [g(f'noises.noise_{k}') for k in range(self.num_layers)] if (prefix + 'noises.noise_0') in state else None
         self.saved = None
 
@@ -126,7 +137,23 @@ class GeneratorEngine:
         e = copy.copy(self)
         e.saved = None
         e.bwd_state, e.bwd_flag = {}, None
+        e.fwd_range = None
         return e
+
+    def reset_fwd_state(self):
+        """Forget the carried forward range scales (new images / new batch): the next forward measures them exactly."""
+        if self.fwd_range is not None:
+            self.fwd_range.valid = False
+            self.fwd_range.flag.zero_()
+
+    def fwd_range_violated(self):
+        """True if a carried forward scale left the exact window in any forward since reset_fwd_state() (host sync)."""
+        return self.fwd_range is not None and self.fwd_range.violated()
+
+    def _range(self, B):
+        if self.fwd_range is None or self.fwd_range.B != B:
+            self.fwd_range = ops.FwdRange(self.n_styled, B, self.R, self.DR, self.row_layer, self.drow_layer, self.device)
+        return self.fwd_range
 
     def reset_bwd_state(self):
         """Forget the carried range scales (new images / new batch): the next backward measures them exactly."""
@@ -144,12 +171,14 @@ class GeneratorEngine:
         return ops.style_affine(latent, self.wcat, self.bcat, self.row_lat)
 
     def forward(self, latent, noises, save=False, cond_hook=None, cond_layers=None, return_features=False, features_in=None,
-                feature_scale=1.0):
+                feature_scale=1.0, range_mode='exact'):
         """latent (B,n_latent,S); noises list[num_layers] of (B|1,1,r,r).
         cond_hook(k, raw, latent_i, noise, noise_w) -> cond tensor replacing the raw up-conv output
         (the algebra of OOD_faceGAN_e4e_arch.py:239-242 + model.py:292: layer = cond + w*noise).
         features_in[i] (or None), feature_scale: `insert_feature` of the Feature-Style variant (model.py:541-546,557,572):
-        the input of the styled conv that reads latent i becomes (1-fs)*x + fs*features_in[i]."""
+        the input of the styled conv that reads latent i becomes (1-fs)*x + fs*features_in[i].
+        range_mode (split-f16 only, ops.FwdRange): 'exact' measures max|x*s| of every conv input before converting it;
+        'carry' (the W+ loop) uses the scales of the previous forward with the fused producers and verifies them."""
         if save and features_in is not None:
             raise NotImplementedError('backward through an injected feature is not part of the path')
         B = latent.shape[0]
@@ -167,6 +196,23 @@ class GeneratorEngine:
             for L in self.layers:
                 if L.kind != 'rgb':
                     self._demod(L, s_all, d_all)
+        rng, carry = None, False
+        s_use, d_use = s_all, d_all
+        if self.sform:
+            rng = self._range(B)
+            carry = range_mode == 'carry' and rng.valid and self.carry_range and cond_hook is None and features_in is None
+            if carry:
+                rng.plan(s_all, d_all)
+            s_use, d_use = rng.s_sc, rng.d_sc
+
+        def to_s(L, t):
+            # S-form input of styled conv L from the fp32 tensor t (x its style x the layer's range scale)
+            if not carry:
+                rng.measure(L.sidx, t, _Cols(s_all, L.row, L.cin))
+                rng.plan(s_all, d_all, L.row, L.cin, L.drow, L.cout)
+            return ops.to_sform(t, _Cols(s_use, L.row, L.cin), out=ops.sform_scratch(B, L.cin, t.shape[2], t.shape[3], self.device),
+                                vmax=rng.vm[L.sidx] if carry else None)
+
         acts = {}
         x = self.const_input.expand(B, -1, -1, -1).contiguous()
         acts['input'] = x
@@ -181,17 +227,17 @@ class GeneratorEngine:
                 rgb_partial = None
                 continue
             if L.kind == 'rgb':
-                Lu = self.rgb_next_up.get(L.name) if (self.sform and self.fused_rgb and features_in is None) else None
+                Lu = self.rgb_next_up.get(L.name) if (carry and self.fused_rgb) else None
                 if (Lu is not None and pending is None and out.shape[2] * out.shape[3] > 4096 and L.cin % 16 == 0
                         and out.shape[3] % 4 == 0):
                     # one pass over the feature map: RGB contribution AND the next up-conv's S-form input (x its style)
                     pending = ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device)
                     skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None, ys=pending,
-                                     ys_scale=_Cols(s_all, Lu.row, Lu.cin))
+                                     ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx])
                 else:
                     skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None)
                 continue
-            d = _Cols(d_all, L.drow, L.cout)
+            d = _Cols(d_use, L.drow, L.cout)
             nz = noises[L.noise_idx]
             if features_in is not None and L.lat >= 1 and L.lat < len(features_in) and features_in[L.lat] is not None:
                 from . import samm as _samm
@@ -208,21 +254,15 @@ class GeneratorEngine:
                     if pending is not None:     # written by the up-conv tail that produced `out`
                         xs, pending = pending, None
                     else:
-                        xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
-                    Ln = self.next_styled.get(L.name) if self.ys_handoff else None
-                    ys = ys_scale = None
-                    if Ln is not None:      # the epilogue also emits the next up-conv's input (x * its style) in S-form
-                        ys = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device, tag=1)
-                        ys_scale = _Cols(s_all, Ln.row, Ln.cin)
-                    Lr = self.conv_next_rgb.get(L.name) if (self.fused_rgb and ys is None) else None
+                        xs = to_s(L, out)
+                    Lr = self.conv_next_rgb.get(L.name) if self.fused_rgb else None
                     if Lr is not None and 16 < L.cin <= 32 and 16 < L.cout <= 32:
                         # 32-channel 1024² layer (strip kernel): the ToRGB colour sums come out of the same epilogue
                         out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                                        noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)))
                     else:
                         out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
-                                          noise_weight=L.noise_w, act=ACT_LRELU, ys=ys, ys_scale=ys_scale)
-                    pending = ys
+                                          noise_weight=L.noise_w, act=ACT_LRELU)
                     del xs
                 else:
                     out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
@@ -232,7 +272,7 @@ class GeneratorEngine:
                     if pending is not None:
                         xs, pending = pending, None
                     else:
-                        xs = ops.to_sform(out, s, out=ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device))
+                        xs = to_s(L, out)
                     z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
                     del xs
                 else:
@@ -243,18 +283,23 @@ class GeneratorEngine:
                     raw = ops.blur_bias_act(z, self.k4x4, (1, 1), act=False, in_hw=(H2, H2), in_pitch=z.shape[3])
                     cond = cond_hook(cond_layers.index(lat_idx), raw, latent[:, lat_idx], nz, L.noise_w)
                     out = ops.bias_noise_act(cond, L.bias, nz, L.noise_w)
-                elif self.sform and self.fused_fwd and L.name in self.next_conv:
+                elif carry and self.fused_fwd and L.name in self.next_conv:
                     # blur + noise + bias + activation, and the following conv's S-form input (x its style), in one pass
                     Ln = self.next_conv[L.name]
                     Hi = out.shape[2]
                     pending = ops.sform_scratch(B, L.cout, 2 * Hi, 2 * Hi, self.device, tag=2)
                     out = ops.blur_act_sform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True, ys=pending,
-                                             ys_scale=_Cols(s_all, Ln.row, Ln.cin))
+                                             ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
                 else:
                     out = ops.blur_bias_act(z, self.k4x4, (1, 1), L.bias, nz, L.noise_w, act=True, in_hw=(H2, H2),
                                             in_pitch=z.shape[3])
                 del z
             acts[L.name] = out
+        if rng is not None:
+            if carry:
+                rng.finish()            # verify the carried scales, publish the next ones
+            else:
+                rng.valid = True
         if save:
             self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B)
         if return_features:
@@ -320,9 +365,9 @@ class GeneratorEngine:
             else:
                 if Rg is not None:
                     g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, gskip[L.res], Rg.w_rgb,
-                                                                _Cols(s_all, Rg.row, Rg.cin), want_scale=True)
+                                                                _Cols(s_all, Rg.row, Rg.cin), want_scale=True, dscale=d)
                 else:
-                    g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, want_scale=True)
+                    g_pre, rsum, tsum, mul2 = ops.act_bwd_fused(out, g_feat, nz, L.noise_w, L.bias, want_scale=True, dscale=d)
                 if carry:
                     self.bwd_state[L.name] = mul2            # exact this step; carried to the next one
                     if self.bwd_flag is None:
@@ -427,10 +472,11 @@ class WPlusInverter:
         engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
         for eng in engines:
             eng.reset_bwd_state()
+            eng.reset_fwd_state()
         dev = w0.device
 
         def one_step(pr, eng):
-            img = eng.forward(pr['w'], pr['noises'], save=True)
+            img = eng.forward(pr['w'], pr['noises'], save=True, range_mode='carry')
             loss, gimg = ops.mse_loss_grad(img, pr['target'], gmul)
             g = eng.backward(gimg, gmul, carry_scale=True)
             ops.adam_step_dev(pr['w'], g, pr['m'], pr['v'], pr['t'], self.lr, self.betas, self.eps)
@@ -475,12 +521,12 @@ class WPlusInverter:
             pr['w'].record_stream(cur)
             pr['lbuf'].record_stream(cur)
         self._graphs = graphs               # keep the graphs (and their private pools) alive until the next call
-        if any(eng.bwd_scale_violated() for eng in engines):
-            self.engine.fused_bwd = False       # clones copy the flag
+        if any(eng.bwd_scale_violated() or eng.fwd_range_violated() for eng in engines):
+            self.engine.fused_bwd = self.engine.carry_range = False       # clones copy the flags
             try:
                 return self.invert(target, w0, noises, steps, False, streams, use_graph)
             finally:
-                self.engine.fused_bwd = True
+                self.engine.fused_bwd = self.engine.carry_range = True
         return w, losses
 
     def _invert_one(self, target, w0, noises, steps, return_trajectory):
@@ -490,8 +536,9 @@ class WPlusInverter:
         losses, traj = [], []
         gmul = ops.loss_scale_for(target.numel() // target.shape[0])
         self.engine.reset_bwd_state()
+        self.engine.reset_fwd_state()
         for t in range(1, steps + 1):
-            img = self.engine.forward(w, noises, save=True)
+            img = self.engine.forward(w, noises, save=True, range_mode='carry')
             loss, gimg = ops.mse_loss_grad(img, target, gmul)
             g = self.engine.backward(gimg, gmul, carry_scale=True)
             ops.adam_step(w, g, m, v, t, self.lr, self.betas, self.eps)
@@ -499,13 +546,14 @@ class WPlusInverter:
             if return_trajectory:
                 traj.append(w.clone())
         self.engine.saved = None
-        if self.engine.bwd_scale_violated():
-            # a gradient range moved by more than the format's head-room within one step: redo with per-step exact scales
-            self.engine.fused_bwd = False
+        if self.engine.bwd_scale_violated() or self.engine.fwd_range_violated():
+            # an activation or gradient range moved by more than the format's head-room within one step: redo with
+            # per-step exact scales (both directions)
+            self.engine.fused_bwd = self.engine.carry_range = False
             try:
                 return self._invert_one(target, w0, noises, steps, return_trajectory)
             finally:
-                self.engine.fused_bwd = True
+                self.engine.fused_bwd = self.engine.carry_range = True
         if return_trajectory:
             return w, torch.stack(losses), traj
         return w, torch.stack(losses)

@@ -285,19 +285,20 @@ def sform_scratch(B, C, H, W, device, tag=0):
     return buf
 
 
-def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0):
-    """fp32 NCHW -> S-form of x*scale[b,c]*mul2[1]."""
+def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0, vmax=None):
+    """fp32 NCHW -> S-form of x*scale[b,c]*mul2[1].  ``vmax`` (B int32, zero-initialised float bit patterns): per-sample
+    max |value written| for the forward range control (``FwdRange``)."""
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
     H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
     if out is None:
         out = SForm(B, C, H, W, x.device)
     check(_lib.lib().oodgan_to_sform(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2), _p(out),
-                                     B, C, H, W, in_pitch, _stream()), 'to_sform')
+                                     B, C, H, W, in_pitch, _p(vmax), _stream()), 'to_sform')
     return out
 
 
-def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys=None, ys_scale=None):
+def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys=None, ys_scale=None, vmax=None):
     """Tail of the up-sampling StyledConv in one pass (include/oodgan.h, oodgan_blur_act_sform): z (B,C,2H+1,pitch) from
     conv3x3(mode T2) -> y (B,C,2H,2W) and, into ``ys`` (an SForm), y*ys_scale for the next conv."""
     z = _dev(z)
@@ -307,8 +308,53 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     check(_lib.lib().oodgan_blur_act_sform(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
                                            0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
                                            1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
-                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _stream()), 'blur_act_sform')
+                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), _stream()), 'blur_act_sform')
     return y
+
+
+class FwdRange:
+    """Forward range control of the split-f16 path (csrc/fwd_range.hip): one power-of-two scale per styled
+    conv and sample, q[l][b], such that the S-form input of conv l holds max|x*s|*q in [512,1024) — an f16 pair cannot
+    represent |v| >= 65504 (ModulatedConv2d.forward in fp32, model.py:233-274, has no such limit; trained config-f
+    activations reach 1e3..1e4 before modulation).  The producers take the scaled style block ``s_sc`` and the conv
+    epilogue the inversely scaled demodulation block ``d_sc``; both are exact power-of-two multiples of the true ones.
+
+    * exact mode (default of a forward): every layer input is measured (``absmax_scaled``) before it is converted;
+    * carry mode (steps >= 2 of the W+ loop): the fused producers use the scale measured on the previous step and record
+      this step's max; ``finish`` sets ``flag`` when a scaled max left [2^-8, 2^15) or was non-finite (the caller re-runs
+      in exact mode) and publishes the next scales."""
+
+    def __init__(self, n_layers, B, R, DR, row_layer, drow_layer, device):
+        self.L, self.B, self.R, self.DR = n_layers, B, R, DR
+        self.q = torch.ones(n_layers, B, device=device, dtype=torch.float32)
+        self.vm = torch.zeros(n_layers, B, device=device, dtype=torch.int32)
+        self.flag = torch.zeros(1, device=device, dtype=torch.int32)
+        self.s_sc = torch.empty(B, R, device=device, dtype=torch.float32)
+        self.d_sc = torch.empty(B, DR, device=device, dtype=torch.float32)
+        self.row_layer, self.drow_layer = row_layer, drow_layer
+        self.valid = False          # q holds measured scales (set by an exact pass)
+
+    def plan(self, s_all, d_all, row0=0, nrows=None, drow0=0, ndrows=None):
+        nrows = self.R if nrows is None else nrows
+        ndrows = self.DR if ndrows is None else ndrows
+        check(_lib.lib().oodgan_fwd_range_plan(_p(s_all), _p(d_all), _p(self.row_layer), _p(self.drow_layer), _p(self.q), _p(self.s_sc),
+                                               _p(self.d_sc), self.B, self.R, self.DR, row0, nrows, drow0, ndrows, _stream()),
+              'fwd_range_plan')
+
+    def measure(self, l, x, s):
+        """exact mode: q[l][:] from max|x*s| (s = the layer's TRUE style block)."""
+        x = _dev(x)
+        B, C = x.shape[0], x.shape[1]
+        check(_lib.lib().oodgan_absmax_scaled(_p(x), _p(s), s.shape[1], _p(self.vm[l]), B, C, x.numel() // (B * C), _stream()),
+              'absmax_scaled')
+        check(_lib.lib().oodgan_fwd_range_update(_p(self.vm[l]), _p(self.q[l]), None, B, _stream()), 'fwd_range_update')
+
+    def finish(self):
+        """carry mode, after the last layer: verify the scales that were used, publish the next ones, clear the maxima."""
+        check(_lib.lib().oodgan_fwd_range_update(_p(self.vm), _p(self.q), _p(self.flag), self.L * self.B, _stream()), 'fwd_range_update')
+
+    def violated(self):
+        return int(self.flag.item()) != 0
 
 
 class BwdJobs:
@@ -585,7 +631,7 @@ def rgb_finish(partial, bias=None, skip=None, kernel=None):
     return partial
 
 
-def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=None):
+def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=None, vmax=None):
     """ToRGB.forward (src/ops/StyleGAN/model.py:363-372): weight (3,Ci), s (B,Ci) style, skip (B,3,H/2,W/2).
     ``ys`` (an SForm of x's shape): additionally receives x*ys_scale in S-form for the up-sampling conv that follows."""
     x = _dev(x)
@@ -596,7 +642,7 @@ def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=Non
         check(_lib.lib().oodgan_torgb_fwd_sform(_p(x), _p(w), _p(_dev(s, 's')), s.shape[1], _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')),
                                                 _p(_opt(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
                                                 0 if ys_scale is None else ys_scale.shape[1], B, Ci, H, W, 1.0 / math.sqrt(Ci),
-                                                _stream()), 'torgb_fwd_sform')
+                                                _p(vmax), _stream()), 'torgb_fwd_sform')
         return y
     check(_lib.lib().oodgan_torgb_fwd(_p(x), _p(w), _p(_dev(s, 's')), s.shape[1], _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')),
                                       _p(_opt(kernel, 'kernel')), _p(y), B, Ci, H, W, 1.0 / math.sqrt(Ci), _stream()), 'torgb_fwd')
@@ -604,10 +650,11 @@ def torgb(x, weight, s, bias=None, skip=None, kernel=None, ys=None, ys_scale=Non
 
 
 def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_rgb=None, w_rgb=None, s_rgb=None,
-                  want_scale=False):
+                  want_scale=False, dscale=None):
     """Backward through bias+noise+lrelu*sqrt2 merged with the ToRGB branch; returns
     (g_pre, r[B,C] = sum g_pre*y_cv, t[B,C] = sum out*t or None[, mul2]) where mul2 = device {2^-e, 2^e} with
-    max|g_pre|*2^e in [512,1024) (range control for the split-f16 convs)."""
+    max|g_pre*dscale|*2^e in [512,1024) (range control for the split-f16 convs; ``dscale`` = the demodulation block the
+    consumer multiplies g_pre with before the f16 split)."""
     o = _dev(out, 'out')
     B, C = o.shape[0], o.shape[1]
     HW = o.numel() // (B * C)
@@ -622,7 +669,8 @@ def act_bwd_fused(out, g_feat=None, noise=None, noise_weight=None, bias=None, g_
                                      _p(_opt(noise_weight, 'nw')), _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')),
                                      _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)), _p(_opt(s_rgb, 's_rgb')),
                                      0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(g_pre), _p(part_r),
-                                     _p(part_t), _p(part_m), B, C, HW, _stream()), 'act_bwd_fused')
+                                     _p(part_t), _p(part_m), _p(_opt(dscale, 'dscale')), 0 if dscale is None else dscale.shape[1],
+                                     B, C, HW, _stream()), 'act_bwd_fused')
     r = torch.empty(B, C, device=o.device, dtype=torch.float32)
     check(L.oodgan_reduce_parts(_p(part_r), _p(r), B * C, npart, 0, _stream()), 'reduce')
     t = None

@@ -194,6 +194,73 @@ def gold_wplus(size=32, steps=5):
     save(f'wplus_s{size}.npz', losses=torch.stack(losses), traj=torch.stack(traj), grads=torch.stack(grads))
 
 
+WPLUS_1024_IMAGE = 10     # global image index of the bench recipe (bench.py: weights seed 0, target 1000+g, noise 2000+g, latents 3000+g)
+
+
+def gold_wplus_1024():
+    """ONE W+ step at the benchmarked geometry (BASELINE configs[2]: 1024², the bench recipe's weights and the inputs of
+    its global image 10) through the REFERENCE Generator's autograd, evaluated in float64 (`G.double()`: same reference
+    code, no fp32 LeakyReLU-kink ambiguity) and in the reference's own float32.  Image 10 is the recipe image whose
+    low-resolution pre-activations keep the widest margin from the kink (scratch scan: >= 3e-6 in the 4²..16² layers).
+    Anchors: model.py:483-585, BasicSR/basicsr/losses/losses.py:58-83."""
+    from src.ops.StyleGAN.model import Generator
+    size, gi = 1024, WPLUS_1024_IMAGE
+    sd = synth.generator_state(size, seed=0)
+    target = synth.make_images(size, 1, seed=1000 + gi)
+    noises = synth.make_noises(size, 1, seed=2000 + gi)
+    lat = synth.make_latents(size, 1, seed=3000 + gi, std=0.3)
+    g = {}
+    for tag, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        G = Generator(size, 512, 8).eval()
+        G.load_state_dict(sd, strict=True)
+        G = G.to(dt)
+        for p in G.parameters():
+            p.requires_grad_(False)
+        w = lat.to(dt).clone().requires_grad_(True)
+        img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=[n.to(dt) for n in noises])
+        per = ((img - target.to(dt)) ** 2).mean(dim=(1, 2, 3))
+        per.sum().backward()
+        g[f'loss_{tag}'] = per.detach()
+        g[f'grad_{tag}'] = w.grad.detach()
+        if tag == 'f64':
+            im = img.detach()
+            g['image_sub'] = im[:, :, ::16, ::16].float()
+            g['image_crop'] = im[:, :, 480:544, 480:544].float()
+            g['image_mean'] = im.mean(dim=(2, 3))
+            g['image_std'] = im.std(dim=(2, 3))
+            g['image_absmax'] = im.abs().amax()
+        del G, img, per, w
+    rel = (g['grad_f32'].double() - g['grad_f64']).abs().max() / g['grad_f64'].abs().max()
+    print(f'wplus_1024: loss {g["loss_f64"].item():.6f}; reference fp32 vs fp64 gradient: rel {rel.item():.2e}')
+    g['image_index'] = np.int64(gi)
+    save('wplus_1024.npz', **g)
+
+
+def gold_wplus_256(steps=5):
+    """5-step W+ Adam trajectory at 256² (B=2) through the reference Generator autograd (fp32, as shipped)."""
+    from src.ops.StyleGAN.model import Generator
+    size, B = 256, 2
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(synth.generator_state(size, seed=0), strict=True)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    target = synth.make_images(size, B, seed=71)
+    noises = synth.make_noises(size, B, seed=72)
+    w = synth.make_latents(size, B, seed=73, std=0.3).clone().requires_grad_(True)
+    opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    losses, traj, grads = [], [], []
+    for _ in range(steps):
+        opt.zero_grad()
+        img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=noises)
+        per = ((img - target) ** 2).mean(dim=(1, 2, 3))
+        per.sum().backward()
+        losses.append(per.detach().clone())
+        grads.append(w.grad.detach().clone())
+        opt.step()
+        traj.append(w.detach().clone())
+    save('wplus_256.npz', losses=torch.stack(losses), traj=torch.stack(traj), grads=torch.stack(grads))
+
+
 def gold_samm():
     """AlignNet / SPM_Warp (2 cycles, with and without a coarser field) at C=8, H=16."""
     from src.ops.SAMM.helpers import SPM_Warp, new_PRM
@@ -324,6 +391,10 @@ def main():
         gold_generator(32)
     if 'wplus' in which:
         gold_wplus(32, 5)
+    if 'wplus1024' in which:
+        gold_wplus_1024()
+    if 'wplus256' in which:
+        gold_wplus_256()
     if 'samm' in which:
         gold_samm()
     if 'ood' in which:

@@ -118,16 +118,28 @@ def test_ood_forward_1024_vs_golden(dev, golden):
     x = synth.make_images(1024, 1, seed=34).to(dev)
     noises = [n.to(dev) for n in synth.make_noises(1024, 1, seed=35)]
     out, lats = m(x, enc_lats=enc_lats, enc_feats=enc_feats, noise=noises)
-    tol = 1e-3
-    close(lats, g['lats'], 1e-6)
-    close(out[:, :, ::16, ::16], g['out_sub'], tol)
-    close(out[:, :, 480:544, 480:544], g['out_crop'], tol)
+    # north_star bar: |Δpixel| < 1e-3 ABSOLUTE on the output (max |out| here is ~3)
+    def absclose(a, b, tol, what):
+        a = a.detach().cpu()
+        assert a.shape == b.shape, (what, a.shape, b.shape)
+        err = (a - b).abs().max().item()
+        print(f'ood_1024 {what}: max abs err {err:.3e} (ref absmax {b.abs().max().item():.3f})')
+        assert err < tol, (what, err)
+
+    absclose(lats, g['lats'], 1e-6, 'lats')
+    absclose(out[:, :, ::16, ::16], g['out_sub'], 1e-3, 'out ::16')
+    absclose(out[:, :, 480:544, 480:544], g['out_crop'], 1e-3, 'out centre crop')
+    absclose(out.double().mean(dim=(2, 3)).float(), g['out_mean'], 1e-5, 'per-channel mean')
+    absclose(out.double().std(dim=(2, 3)).float(), g['out_std'], 1e-5, 'per-channel std')
+    assert abs(out.abs().max().item() - g['out_absmax'].item()) < 1e-3
     for k in (1, 2, 3, 4):
         a = m.aligns[k]
         step = max(1, a.shape[-1] // 32)
-        close(a[:, :, ::step, ::step], g[f'align{k}_sub'], tol)
-    close(m.aligns[1024][:, :, ::16, ::16], g['align1024_sub'], tol)
+        absclose(a[:, :, ::step, ::step], g[f'align{k}_sub'], 1e-3, f'aligns[{k}]')
+        absclose(a.mean(dim=(2, 3)), g[f'align{k}_mean'], 1e-4, f'aligns[{k}] mean')
+    absclose(m.aligns[1024][:, :, ::16, ::16], g['align1024_sub'], 1e-3, 'aligns[1024]')
+    absclose(m.aligns[1024][:, :1, 480:544, 480:544], g['align1024_crop'], 1e-3, 'aligns[1024] crop')
     from oodgan import samm
     strip = samm.extract_masks(m.aligns)
-    close(strip[:, :, ::16, ::16], g['mask_strip_sub'], tol)
-    close(strip[:, :, 500:502, :], g['mask_strip_rows'], tol)
+    absclose(strip[:, :, ::16, ::16], g['mask_strip_sub'], 1e-3, 'mask strip')
+    absclose(strip[:, :, 500:502, :], g['mask_strip_rows'], 1e-3, 'mask strip rows')

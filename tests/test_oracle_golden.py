@@ -85,6 +85,34 @@ def test_wplus_trajectory_s32(golden):
     close(torch.stack(traj), g['traj'], 1e-4)
 
 
+def test_wplus_trajectory_256(golden):
+    """the oracle's W+ loop at 256² against the reference Generator + torch.optim.Adam trajectory."""
+    g = golden('wplus_256.npz')
+    size, B = 256, 2
+    P = synth.generator_state(size, seed=0)
+    w, losses, traj = R.wplus_invert(P, synth.make_images(size, B, seed=71), synth.make_latents(size, B, seed=73, std=0.3),
+                                     synth.make_noises(size, B, seed=72), size, steps=5, return_trajectory=True)
+    close(losses, g['losses'], 1e-4)
+    dw = (torch.stack(traj) - g['traj']).abs()
+    assert (dw < 2e-3).float().mean().item() > 0.999, dw.max().item()
+
+
+def test_wplus_step_1024_oracle_vs_reference(golden):
+    """the oracle at the benchmarked geometry (1024², bench recipe image 10): loss and dL/dW+ of one step in the oracle's
+    fp32 vs the reference Generator evaluated in float64 (the reference's own fp32 is 2.5e-5 from it)."""
+    g = golden('wplus_1024.npz')
+    size, gi = 1024, int(g['image_index'])
+    P = synth.generator_state(size, seed=0)
+    w = synth.make_latents(size, 1, seed=3000 + gi, std=0.3).requires_grad_(True)
+    img = R.generator_forward(P, w, synth.make_noises(size, 1, seed=2000 + gi), size)
+    loss = R.wplus_loss(img, synth.make_images(size, 1, seed=1000 + gi))
+    loss.backward()
+    assert abs(loss.item() - g['loss_f64'].item()) < 1e-5 * g['loss_f64'].item()
+    assert (img.detach()[:, :, ::16, ::16] - g['image_sub']).abs().max().item() < 1e-4
+    rel = (w.grad.double() - g['grad_f64']).abs().max().item() / g['grad_f64'].abs().max().item()
+    assert rel < 2e-4, rel
+
+
 def test_samm(golden):
     g = golden('samm.npz')
     P = synth.samm_state(8, 'm', seed=21)
