@@ -174,8 +174,9 @@ int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* s
  * fetch their halo'd tiles as contiguous runs by LDS-DMA.  Buffers must be zero-initialised once (border).
  * oodgan_to_sform converts an fp32 NCHW tensor: value = x*scale[b,c]*mul2[1].
  * Every forward producer of an S-form (oodgan_to_sform, oodgan_blur_act_sform, oodgan_torgb_fwd_sform) takes an optional
- * `vmax` (B unsigned, float bit patterns, atomically maxed): the largest |value| it wrote for each sample — the input of
- * the forward range control below. */
+ * `vmax` (B x OODGAN_VMAX_SLOTS unsigned, float bit patterns, atomically maxed into one of the sample's slots): the
+ * largest |value| it wrote for each sample — the input of the forward range control below. */
+#define OODGAN_VMAX_SLOTS 64
 long oodgan_sform_bytes(int B, int C, int H, int W);
 int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
                     int H, int W, int in_pitch, unsigned* vmax, void* stream);
@@ -194,8 +195,8 @@ int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
  * (src/ops/StyleGAN/model.py:233-274) has no range limit; an S-form record (hi+lo f16) holds |v| < 65504.  Every styled
  * conv l therefore carries one power-of-two scale per sample q[l][b] with max|x*s|*q in [512,1024): the producers get the
  * style block s_sc = s*q, the conv epilogue the demodulation block d_sc = d/q (both exact).
- *   oodgan_absmax_scaled:    vmax[b] = max_{c,p} |x[b,c,p]*s[b,c]| (atomic max into a zeroed array; non-finite -> inf)
- *   oodgan_fwd_range_update: n entries (layer-major [l][b]); flag != NULL (carry mode): vmax was measured on values scaled
+ *   oodgan_absmax_scaled:    max_k vmax[b][k] = max_{c,p} |x[b,c,p]*s[b,c]| (atomic max into a zeroed array; non-finite -> inf)
+ *   oodgan_fwd_range_update: n entries (layer-major [l][b], OODGAN_VMAX_SLOTS slots each); flag != NULL (carry mode): vmax was measured on values scaled
  *                            by q -> flag |= 1 if it left [2^-8, 2^15), |= 2 if non-finite; next q from vmax/q.
  *                            flag == NULL (exact mode): vmax is the true max, q is set from it.  vmax is zeroed.
  *   oodgan_fwd_range_plan:   s_sc[b,r] = s_all[b,r]*q[row_layer[r]][b] for rows [row0,row0+nrows) (row_layer < 0: copy),

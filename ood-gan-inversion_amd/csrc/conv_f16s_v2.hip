@@ -730,15 +730,19 @@ __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__
     const long in_plane = (long)d.H * in_pitch;
     float vm = 0.f;
     int vb = -1;
-    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    // uniform trip count per wave (the range-control flushes below use cross-lane operations)
+    for (long base = blockIdx.x * 256L; base < total; base += (long)gridDim.x * 256) {
+        const long e = base + threadIdx.x;
+        const bool live = e < total;
         const int xx = (int)(e % d.W);
         const int yy = (int)((e / d.W) % d.H);
         const int kc = (int)((e / ((long)d.W * d.H)) % d.KC);
-        const int b = (int)(e / ((long)d.W * d.H * d.KC));
-        if (vmax && b != vb) {          // forward range control: max |v| per sample (rarely more than one sample per thread)
-            if (vb >= 0 && vm > 0.f) atomicMax(vmax + vb, __float_as_uint(vm));
+        const int b = live ? (int)(e / ((long)d.W * d.H * d.KC)) : vb;
+        if (vmax && __any(b != vb)) {       // forward range control: max |v| per sample; a wave changes sample B-1 times
+            record_vmax_mixed(vmax, vb, vm);
             vb = b; vm = 0.f;
         }
+        if (!live) continue;
         half8 h0, h1, l0, l1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__
         half8* o = reinterpret_cast<half8*>(out + u);
         o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
     }
-    if (vmax && vb >= 0 && vm > 0.f) atomicMax(vmax + vb, __float_as_uint(vm));
+    if (vmax) record_vmax_mixed(vmax, vb, vm);
 }
 
 }  // namespace

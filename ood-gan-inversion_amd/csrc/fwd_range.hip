@@ -15,7 +15,7 @@ using namespace oodgan;
 
 namespace {
 
-// grid (nblk, C, B): block max of |x[b,c,:]| over its chunk, times |s[b,c]|, atomically maxed into vmax[b]
+// grid (nblk, C, B): block max of |x[b,c,:]| over its chunk, times |s[b,c]|, atomically maxed into a slot of vmax[b][:]
 // (non-negative floats order like their bit patterns, and max is order independent: deterministic)
 __global__ __launch_bounds__(256) void absmax_scaled_kernel(const float* __restrict__ x, const float* __restrict__ s, int s_stride,
                                                             unsigned* __restrict__ vmax, int C, long HW, long chunk) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void absmax_scaled_kernel(const float* __restr
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * fabsf(s ? s[(long)b * s_stride + c] : 1.f);
         if (!(m == m)) m = INFINITY;          // 0 * inf
-        if (m > 0.f) atomicMax(vmax + b, __float_as_uint(m));
+        if (m > 0.f) atomicMax(vmax + (long)b * OODGAN_VMAX_SLOTS + ((blockIdx.x + blockIdx.y) & (OODGAN_VMAX_SLOTS - 1)), __float_as_uint(m));
     }
 }
 
@@ -51,8 +51,11 @@ __global__ __launch_bounds__(256) void absmax_scaled_kernel(const float* __restr
 __global__ void fwd_range_update_kernel(unsigned* __restrict__ vmax, float* __restrict__ q, int* __restrict__ flag, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float m = __uint_as_float(vmax[i]);
-    vmax[i] = 0u;
+    float m = 0.f;
+    for (int k = 0; k < OODGAN_VMAX_SLOTS; ++k) {
+        m = fmaxf(m, __uint_as_float(vmax[(long)i * OODGAN_VMAX_SLOTS + k]));
+        vmax[(long)i * OODGAN_VMAX_SLOTS + k] = 0u;
+    }
     float t = m;                            // true max |x*s|
     if (flag) {                             // carry mode: m was measured on values scaled by q[i]
         if (!isfinite(m)) atomicOr(flag, 2);

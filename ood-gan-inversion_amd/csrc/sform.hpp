@@ -52,12 +52,31 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-// forward range control (fwd_range.hip): a producer records the max |v| of the values it wrote for sample b.
-// Every lane of the wave must call, with the same b.  Non-negative floats order like their bit patterns.
+// forward range control (fwd_range.hip): a producer records the max |v| of the values it wrote for sample b into one of
+// OODGAN_VMAX_SLOTS slots of that sample (same-address atomics serialise in L2: 130k waves on 8 addresses cost
+// milliseconds, spread over 512 addresses nothing).  Every lane of the wave must call, with the same b.
+// Non-negative floats order like their bit patterns, and max is order independent: deterministic.
 __device__ __forceinline__ void record_vmax(unsigned* vmax, int b, float m) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(vmax + b, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (OODGAN_VMAX_SLOTS - 1);
+        atomicMax(vmax + (long)b * OODGAN_VMAX_SLOTS + slot, __float_as_uint(m));
+    }
+}
+
+// the same when the lanes of a wave may hold different samples (vb < 0: nothing recorded)
+__device__ __forceinline__ void record_vmax_mixed(unsigned* vmax, int vb, float vm) {
+    int bmax = vb, bmin = vb < 0 ? 0x7fffffff : vb;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bmax = max(bmax, __shfl_xor(bmax, o, 64));
+        bmin = min(bmin, __shfl_xor(bmin, o, 64));
+    }
+    if (bmax < 0) return;
+    if (bmin == bmax) record_vmax(vmax, bmax, vm);
+    else if (vb >= 0 && vm > 0.f)
+        atomicMax(vmax + (long)vb * OODGAN_VMAX_SLOTS + (threadIdx.x & (OODGAN_VMAX_SLOTS - 1)), __float_as_uint(vm));
 }
 
 }  // namespace oodgan

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     }
     if (vmax) {
         if (full_wave) record_vmax(vmax, b, vm);
-        else if (vm > 0.f) atomicMax(vmax + b, __float_as_uint(vm));
+        else if (vm > 0.f) atomicMax(vmax + (long)b * OODGAN_VMAX_SLOTS + (threadIdx.x & (OODGAN_VMAX_SLOTS - 1)), __float_as_uint(vm));
     }
 }
 

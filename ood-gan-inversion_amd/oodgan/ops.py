@@ -312,6 +312,9 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     return y
 
 
+VMAX_SLOTS = 64      # OODGAN_VMAX_SLOTS (include/oodgan.h)
+
+
 class FwdRange:
     """Forward range control of the split-f16 path (csrc/fwd_range.hip): one power-of-two scale per styled
     conv and sample, q[l][b], such that the S-form input of conv l holds max|x*s|*q in [512,1024) — an f16 pair cannot
@@ -327,7 +330,7 @@ class FwdRange:
     def __init__(self, n_layers, B, R, DR, row_layer, drow_layer, device):
         self.L, self.B, self.R, self.DR = n_layers, B, R, DR
         self.q = torch.ones(n_layers, B, device=device, dtype=torch.float32)
-        self.vm = torch.zeros(n_layers, B, device=device, dtype=torch.int32)
+        self.vm = torch.zeros(n_layers, B, VMAX_SLOTS, device=device, dtype=torch.int32)
         self.flag = torch.zeros(1, device=device, dtype=torch.int32)
         self.s_sc = torch.empty(B, R, device=device, dtype=torch.float32)
         self.d_sc = torch.empty(B, DR, device=device, dtype=torch.float32)

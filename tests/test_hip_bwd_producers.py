@@ -40,9 +40,9 @@ def test_act_bwd_sform_matches_two_pass(B, C, H, W, rgb):
     dev = torch.device('cuda:0')
     out, g_feat, noise, nw, bias, d, kw = _inputs(B, C, H, W, 11 + C, rgb, dev)
     if rgb:
-        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True)
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True, dscale=d)
     else:
-        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True)
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True, dscale=d)
     ref = ops.to_sform(g_pre, d, mul2)
     dst = ops.SForm(B, C, H, W, dev)
     state = mul2.clone()
@@ -70,9 +70,9 @@ def test_act_bwd_blurT_phases_matches_two_pass(B, C, H, W, rgb):
     out, g_feat, noise, nw, bias, d, kw = _inputs(B, C, 2 * H, 2 * W, 5 + C, rgb, dev)
     k = torch.flip(R.make_kernel([1, 3, 3, 1]) * 4.0, [0, 1]).contiguous().to(dev)
     if rgb:
-        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True)
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, kw['g_rgb'], kw['w_rgb'], kw['s_rgb'], want_scale=True, dscale=d)
     else:
-        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True)
+        g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True, dscale=d)
     ref = ops.blurT_to_sform_phases(g_pre, k, d, mul2)
     dst = ops.SFormPhases(B, C, H, W, dev)
     r1, t1, part_m = ops.act_bwd_producer(out, g_feat, noise, nw, bias, d, mul2.clone(), dst, blur_kernel=k, **kw)
