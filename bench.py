@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-roofline-events', action='store_true')
     ap.add_argument('--no-modconv', action='store_true', help='skip the fp16 modulated-conv roofline leg (BASELINE configs[4])')
     ap.add_argument('--streams', type=int, default=1, help='independent sub-batches advanced on separate HIP streams')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the extra leg that times the inversion including the e4e encoder')
     ap.add_argument('--no-multistream', action='store_true', help='skip the extra leg that times the same job on 3 concurrent HIP streams')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
@@ -107,40 +108,134 @@ def pmc_traffic(a):
         return None
 
 
-def modconv_roofline():
-    """BASELINE.json's second metric ("modulated-conv2d GB/s", configs[4]): the fp16 modulated conv of the 1024² layer,
-    x (16,32,1024,1024) f16, 32 -> 32 channels, noise + bias + leaky ReLU fused; algorithmic bytes per SURVEY.md §8(d)
-    (2.147 GB) over the HIP-event time of the launch, against the 8 TB/s HBM peak.  Runs after the timed region."""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    import bench_modconv_f16
-    r = bench_modconv_f16.run(B=16, C=32, H=1024, iters=30, warmup=3)
+def modconv_roofline(iters=30, warmup=3):
+    """BASELINE.json's second metric ("modulated-conv2d GB/s", configs[4]): ModulatedConv2d.forward (model.py:233-274) of the
+    1024² layer in fp16 — x (16,32,1024,1024) f16, 32 -> 32 channels, + noise + bias + leaky ReLU.  ONE timed iteration =
+    the whole op as the reference defines it: style affine (EqualLinear 512 -> 32 on the latent, MFMA contraction),
+    weight modulation + demodulation + f16 packing, and the 3x3 conv kernel; algorithmic bytes per SURVEY.md §8(d)
+    (2.147 GB, the affine's and the weights' bytes included) over the HIP-event time of that sequence, against the 8 TB/s
+    HBM peak.  The activations live in the f16 channel-blocked layout of csrc/conv_f16.hip (H-form: what an fp16 pipeline
+    of this layer would keep between layers); `kernel_ms` is the conv kernel alone.  Runs after the timed region."""
+    from oodgan import ops
+    B, C, H = 16, 32, 1024
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xh = ops.HForm(B, C, H, H, dev)
+    per = xh.buf.numel() // B
+
+    class _Sample:                               # H-form view of one sample (fill without a (16,32,1024,1024) fp32 tensor)
+        def __init__(self, b):
+            self.buf, self.B, self.C, self.H, self.W = xh.buf[b * per:(b + 1) * per], 1, C, H, H
+
+        def data_ptr(self):
+            return self.buf.data_ptr()
+
+    for b in range(B):
+        ops.to_hform(torch.randn(1, C, H, H, generator=g).to(dev), out=_Sample(b))
+    wgt = torch.randn(1, C, C, 3, 3, generator=g).to(dev)
+    lat = torch.randn(B, 512, generator=g).to(dev)
+    mod_w = torch.randn(C, 512, generator=g).to(dev)
+    mod_b = torch.ones(C, device=dev)
+    noise = torch.randn(B, 1, H, H, generator=g).to(dev)
+    bias = (0.1 * torch.randn(C, generator=g)).to(dev)
+    nw = torch.tensor([0.1], device=dev)
+    out = ops.HForm(B, C, H, H, dev)
+
+    def op():
+        s = ops.style_affine(lat, mod_w, mod_b)                      # EqualLinear(512, Ci, bias_init=1)  model.py:223,236
+        packed = ops.modconv_f16_pack(wgt, s, act='lrelu')           # scale*W*s, demodulate            model.py:237-241
+        ops.modconv_f16(xh, packed, noise, nw, bias, out=out)        # grouped conv + noise + bias + act model.py:268-272,343-350
+        return packed
+
+    for _ in range(warmup):
+        packed = op()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        op()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    e0.record()
+    for _ in range(iters):
+        ops.modconv_f16(xh, packed, noise, nw, bias, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    kms = e0.elapsed_time(e1) / iters
+    alg = 2 * (B * C * H * H + B * C * H * H + C * C * 9) + 2 * B * (512 + C)
+    flops = 2.0 * B * C * C * 9 * H * H
     traffic = None
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             traffic = json.load(f).get('modconv_f16_b16_s1024', {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         pass
-    return dict(workload='fp16 ModulatedConv2d 3x3 32->32 @1024x1024, batch 16 (+noise, bias, lrelu)', kernel='modconv_f16_strip_kernel',
-                bound='hbm', achieved=round(r['GBps'], 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(r['hbm_frac'], 4),
-                ms=round(r['ms'], 4), alg_bytes=r['alg_bytes'], traffic=traffic, tflops=round(r['TFLOPs'], 1))
+    gbps = alg / ms / 1e6
+    return dict(workload='fp16 ModulatedConv2d 3x3 32->32 @1024x1024, batch 16: style affine + modulate/demodulate/pack + conv (+noise, bias, lrelu)',
+                kernel='modconv_f16_strip_kernel', bound='hbm', achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
+                frac=round(gbps / HBM_PEAK_GBPS, 4), ms=round(ms, 4), kernel_ms=round(kms, 4), alg_bytes=alg, traffic=traffic,
+                tflops=round(flops / ms / 1e9, 1))
 
 
 def cpu_baseline(size):
-    """Reported baseline: the CPU oracle (same ATen graph as the reference's PyTorch path) doing ONE W+ step
-    (forward + backward + Adam) for one image at the bench resolution, extrapolated to 100 steps."""
+    """Reported baseline: the CPU oracle (same ATen graph as the reference's PyTorch path) on this box's
+    host threads, B = 1: one W+ step (forward + backward + Adam) timed as 1 warm-up + median of 3, and the final OOD
+    forward (post-encoder: generator + SAMM 2 cycles x 4 levels + mask blend) timed once after it; one inversion =
+    100 steps + 1 OOD forward."""
+    import statistics
     from oracle import ref_cpu as R
     from oodgan import synth
     n = torch.get_num_threads()
-    P = synth.generator_state(size, seed=0)
-    lat = synth.make_latents(size, 1, seed=3)
-    noises = synth.make_noises(size, 1, seed=2)
-    target = synth.make_images(size, 1, seed=1)
+    P = synth.ood_state(size, seed=0)
+    G = {k[len('generator.'):]: v for k, v in P.items() if k.startswith('generator.')}
+    lat = synth.make_latents(size, 1, seed=3000, std=0.3)
+    noises = synth.make_noises(size, 1, seed=2000)
+    target = synth.make_images(size, 1, seed=1000)
+    ts = []
+    for _ in range(4):
+        t0 = time.time()
+        R.wplus_invert(G, target, lat, noises, size, steps=1)
+        ts.append(time.time() - t0)
+    step = statistics.median(ts[1:])
     t0 = time.time()
-    R.wplus_invert(P, target, lat, noises, size, steps=1)
-    dt = time.time() - t0
-    return dict(value=1.0 / (100.0 * dt), unit='images/s', cores=n, kind='port',
-                sample=f'1 W+ step (fwd+bwd+Adam) of 1 image at {size}x{size} in {dt:.1f}s on {n} threads, x100; '
-                       'final OOD forward not included')
+    with torch.no_grad():
+        R.ood_forward(P, target, lat, synth.make_encoder_feats(1, seed=4000), noises, size)
+    ood = time.time() - t0
+    return dict(value=1.0 / (100.0 * step + ood), unit='images/s', cores=n, kind='port', batch=1,
+                sample=f'B=1 at {size}x{size} on {n} threads: 1 W+ step (fwd+bwd+Adam) = {step:.2f}s (median of 3 after 1 warm-up: '
+                       f'{", ".join(f"{t:.2f}" for t in ts)}), final OOD forward = {ood:.2f}s (1 run); inversion = 100 steps + 1 OOD forward')
+
+
+def end_to_end(a, model, x, noises, dev):
+    """The same inversion INCLUDING the step before the path: the e4e encoder (IR-SE-50 + FPN + 18
+    GradualStyleBlocks, `Encoder4EditingHIP` on the HIP conv kernels, recipe weights) predicts the start latents and the
+    4-level feature pyramid from the 256x256-pooled input; then the timed workload of `value` runs unchanged.
+    1 warm-up + 1 timed inversion of the same batch; reported beside `value`."""
+    from oodgan import synth
+    from oodgan.arch import ood_faceGAN_e4e
+    B = x.shape[0]
+    m = ood_faceGAN_e4e(out_size=a.size, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08, cycle_align=2,
+                        blend_with_gen=True, ModSize=256)
+    sd = synth.ood_state(a.size, seed=0)
+    enc = synth.encoder_state({k: tuple(v.shape) for k, v in m.encoder.state_dict().items()}, seed=41)
+    sd.update({'encoder.' + k: (v * 0.1 if k.endswith('linear.weight') else v) for k, v in enc.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    run = lambda: m.invert(x, steps=a.wsteps, noise=noises)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.encode(x)
+    torch.cuda.synchronize()
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, _, losses = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=round(B / dt, 4), unit='images/s', ms_per_step=round(dt * 1e3, 2), encoder_ms=round(t_enc * 1e3, 2),
+                final_loss_mean=float(losses[-1].mean().item()),
+                note=f'encoder (Encoder4EditingHIP, batch {B} at 256x256) + {a.wsteps} W+ steps + OOD forward; recipe encoder weights')
 
 
 def main():
@@ -148,7 +243,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist_on = world > 1
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch N ranks with python -m torch.distributed.run --nproc-per-node N'
+    # launched by torch.distributed.run (also with ONE rank): the process group is RCCL ('nccl') and the barrier / MAX
+    # all_reduce / all_gather below run through it; a plain `python bench.py` has no process group
+    dist_on = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the hot path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -188,7 +286,7 @@ def main():
 
     def one_step():
         out, lats, losses = model.invert(x, steps=a.wsteps, noise=noises, streams=a.streams, use_graph=bool(a.graph), enc_lats=enc_lats, enc_feats=enc_feats)
-        return gather_latents(lats) if dist_on else lats, losses
+        return gather_latents(lats, gB) if dist_on else lats, losses
 
     for _ in range(a.warmup):
         one_step()
@@ -242,6 +340,9 @@ def main():
             multi = dict(streams=3, value=round(B / (t2 - t1), 4), unit='images/s',
                          final_loss_mean=float(ml[-1].mean().item()),
                          note='same workload, 3 sub-batches on concurrent HIP streams (opt-in: --streams 3)')
+        e2e = None
+        if not a.no_end_to_end and world == 1 and size == 1024:
+            e2e = end_to_end(a, model, x, noises, dev)
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
@@ -250,11 +351,13 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
                                    f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
-                       'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}', 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
+                       'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}',
+                       'collective_backend': (dist.get_backend() if dist_on else None), 'gathered_latents': list(all_lats.shape), 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'modconv2d': modconv,
             'multistream': multi,
+            'end_to_end': e2e,
             'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size),     # rank 0 at N=1 only
         }
         print(json.dumps(line, ensure_ascii=False))

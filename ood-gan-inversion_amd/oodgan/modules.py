@@ -230,20 +230,20 @@ class Generator(nn.Module):
             self.to_rgbs.append(ToRGB(cout, style_dim))
             cin = cout
         self.n_latent = self.log_size * 2 - 2
-        self._engine_obj = None
+        self._engine_obj, self._engine_key = None, None
 
-    # -- prepared-weights engine, rebuilt whenever parameters move or are reloaded
-    def _apply(self, fn, *a, **k):
-        self._engine_obj = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._engine_obj = None
-        return super().load_state_dict(*a, **k)
+    # -- prepared-weights engine (packed weights, demodulation tables, concatenated style matrix).  Keyed on the storage
+    # address and in-place version counter of every parameter and buffer, so that ANY way of changing the weights — .to(),
+    # load_state_dict on this module or on a parent (which recurses through _load_from_state_dict and never reaches an
+    # override here), optimiser steps, manual copy_ — rebuilds it; encoder_hip._Packed keys its cache the same way.
+    def _weights_key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def engine(self):
-        if self._engine_obj is None:
+        key = self._weights_key()
+        if self._engine_obj is None or key != self._engine_key:
             self._engine_obj = GeneratorEngine(self.state_dict(), self.size, self.style_dim, self.channel_multiplier)
+            self._engine_key = key
         return self._engine_obj
 
     def make_noise(self):

@@ -43,9 +43,14 @@ def gather_latents(local, global_batch=None, group=None):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
 
 
-def invert_sharded(invert_fn, inputs, global_batch, rank, world_size, group=None):
+def invert_sharded(invert_fn, inputs, global_batch, rank, world_size, group=None, empty_like=None):
     """Run ``invert_fn(**local_inputs) -> latents`` on this rank's slice of every tensor in
-    ``inputs`` (tensors or lists of tensors with the batch on dim 0) and gather the latents."""
+    ``inputs`` (tensors or lists of tensors with the batch on dim 0) and gather the latents.
+
+    A rank whose slice is empty (world_size > global_batch) does NOT call ``invert_fn`` (the HIP entry points require
+    B > 0): it joins the collective with an empty (0, L, S) tensor shaped like ``inputs[empty_like]`` (default: the
+    'w0' / 'lats' / 'enc_lats' entry).  A rank whose ``invert_fn`` raises still joins the collective — with NaN latents —
+    before re-raising, so that its peers are not left blocked in all_gather."""
     sl = shard_slice(global_batch, rank, world_size)
 
     def cut(v):
@@ -54,5 +59,21 @@ def invert_sharded(invert_fn, inputs, global_batch, rank, world_size, group=None
         return v[sl] if isinstance(v, torch.Tensor) and v.shape[0] == global_batch else v
 
     local = {k: cut(v) for k, v in inputs.items()}
-    lat = invert_fn(**local)
-    return gather_latents(lat, global_batch, group)
+    key = empty_like or next((k for k in ('w0', 'lats', 'enc_lats') if isinstance(inputs.get(k), torch.Tensor)), None)
+    err = None
+    if sl.stop == sl.start:
+        if key is None:
+            raise ValueError('invert_sharded: an empty shard needs a latent-shaped input (w0 / lats / enc_lats or empty_like=)')
+        lat = local[key][:0]
+    else:
+        try:
+            lat = invert_fn(**local)
+        except Exception as e:          # noqa: BLE001 — re-raised below, after the collective
+            if key is None:
+                raise
+            err = e
+            lat = torch.full_like(local[key], float('nan'))
+    out = gather_latents(lat, global_batch, group)
+    if err is not None:
+        raise err
+    return out

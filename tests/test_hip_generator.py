@@ -273,3 +273,37 @@ def test_batched_backward_tail_is_bit_identical(dev):
         res.append((w.clone(), l.clone()))
     eng.batched_tail = True
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_engine_cache_follows_weight_changes(dev):
+    """The prepared-weights engine must be rebuilt when the generator's weights change by ANY route: load_state_dict on a
+    PARENT module (recurses through _load_from_state_dict, never calls Generator.load_state_dict — what BasicSR's
+    load_network / resume does) and in-place writes."""
+    from oodgan.modules import Generator
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.generator = Generator(32, 512, 8)
+
+    m = Wrapper()
+    m.load_state_dict({'generator.' + k: v for k, v in synth.generator_state(32, seed=5).items()}, strict=True)
+    m = m.to(dev).eval()
+    lat = synth.make_latents(32, 2, seed=6).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(32, 2, seed=7)]
+    run = lambda: m.generator(lat, input_is_tensor=True, input_is_latent=True, noise=noises)[0].clone()
+    img_a = run()
+    eng_a = m.generator.engine()
+    assert m.generator.engine() is eng_a                      # unchanged weights: cached
+    m.load_state_dict({'generator.' + k: v for k, v in synth.generator_state(32, seed=6).items()}, strict=True)
+    img_b = run()
+    fresh = Generator(32, 512, 8)
+    fresh.load_state_dict(synth.generator_state(32, seed=6), strict=True)
+    fresh = fresh.to(dev).eval()
+    ref_b = fresh(lat, input_is_tensor=True, input_is_latent=True, noise=noises)[0]
+    assert (img_b - img_a).abs().max().item() > 1e-2 and torch.equal(img_b, ref_b)
+    with torch.no_grad():
+        m.generator.conv1.conv.weight.mul_(0.5)               # in-place write
+        m.generator.conv1.activate.bias.add_(0.25)
+    img_c = run()
+    assert (img_c - img_b).abs().max().item() > 1e-3

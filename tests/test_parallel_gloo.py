@@ -18,7 +18,10 @@ def _free_port():
 
 
 def _fake_invert(target, w0, noises):
-    # stands in for the GPU inversion: any per-image function of this rank's slice
+    # stands in for the GPU inversion: any per-image function of this rank's slice.  Like the HIP entry points it
+    # refuses an empty batch — invert_sharded must not call it for an empty shard
+    if w0.shape[0] == 0:
+        raise RuntimeError('liboodgan_hip: B must be > 0')
     return w0 * 2.0 + target.mean(dim=(1, 2, 3)).view(-1, 1, 1) + noises[0].sum(dim=(1, 2, 3)).view(-1, 1, 1)
 
 

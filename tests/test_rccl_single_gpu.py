@@ -1,0 +1,45 @@
+"""The RCCL code path on ONE GPU: bench.py launched by torch.distributed.run with a single rank initialises the 'nccl'
+(= RCCL) process group and runs its barrier, MAX all_reduce and the all_gather of the finished latents on device
+tensors — the code the 8-GPU scaling run (BASELINE configs[3]) executes, minus the peers.  The child is a fresh process
+(never an exec from this one)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_uses_rccl():
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--size', '256', '--batch', '2',
+           '--wsteps', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-modconv', '--no-multistream', '--no-end-to-end']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', NCCL_DEBUG='VERSION')
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['config']['parallelism'] == 'batch-shard x1' and rec['config']['collective_backend'] == 'nccl'
+    assert rec['config']['gathered_latents'] == [2, 14, 512] and rec['value'] > 0
+    assert 'RCCL' in (r.stdout + r.stderr) or 'NCCL' in (r.stdout + r.stderr)       # the library announced itself
+
+
+def test_bench_refuses_mismatched_world_size():
+    """--gpus must equal WORLD_SIZE (checked before anything touches a GPU)."""
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and '--gpus 1 but WORLD_SIZE=2' in r.stderr
