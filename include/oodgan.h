@@ -113,6 +113,7 @@ int oodgan_pack_conv3x3(const float* w, float* wpk, int Co, int Ci, float scale,
 #define OODGAN_ACT_LRELU 1   /* sqrt2 * leaky_relu(.,0.2) */
 #define OODGAN_ACT_PRELU 2   /* per-channel slope */
 
+struct oodgan_actbwd_fuse;
 typedef struct oodgan_conv_args {
     const float* x;          /* (B,K,Hin,Win), row pitch in_pitch */
     const float* wpk;        /* packed by oodgan_pack_conv3x3 */
@@ -148,7 +149,35 @@ typedef struct oodgan_conv_args {
     float* rgb_y;            /* (B,3,Hout,Wout) dense */
     int rgb_s_stride;
     float rgb_scale;
+    const struct oodgan_actbwd_fuse* fuse;   /* optional fused activation backward (mode S2, split-f16, S-form input), or NULL */
 } oodgan_conv_args;
+
+/* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
+ * g_feat w.r.t. the output `out` (= args->dotx) of the StyledConv below, so the kernel continues with that layer's
+ * oodgan_act_bwd_sform arithmetic (autograd of NoiseInjection + FusedLeakyReLU merged with the ToRGB branch,
+ * src/ops/StyleGAN/model.py:283-292,343-372) on its accumulators: neither g_feat nor g_pre goes to HBM.
+ *   t = rgb_scale * sum_k w_rgb[k,m]*g_rgb[b,k,p];  g = g_feat + s_rgb[b,m]*t;  g_pre = g * (out>0 ? sqrt2 : 0.2*sqrt2)
+ *   ys       <- S-form of g_pre * dscale[b,m] * mul2[1]                         (input of that layer's input-gradient conv)
+ *   part_r   <- partial sum_p g_pre*y_cv,  part_t <- partial sum_p out*t       (B,M,nparts), nparts = args->dot_nparts
+ *   part_max <- partial max |g_pre*dscale| (nmax floats, zero-initialised by the caller; feeds oodgan_absmax_scale_check)
+ * args->y may be NULL (g_feat is not stored); args->dotx / dot_part are mandatory; M %% 32 == 0. */
+typedef struct oodgan_actbwd_fuse {
+    const float* g_rgb;      /* (B,3,H,W) or NULL */
+    const float* w_rgb;      /* (3,M) */
+    const float* s_rgb;      /* (B,*) stride s_rgb_stride */
+    const float* noise;      /* (noise_batch,H,W) or NULL */
+    const float* noise_w;
+    const float* bias;       /* (M) or NULL */
+    const float* dscale;     /* (B,*) stride dscale_stride */
+    const float* mul2;       /* device {unscale, scale} carried from the previous optimisation step */
+    void* ys;
+    float* part_r;
+    float* part_t;           /* NULL when g_rgb is NULL */
+    float* part_max;
+    int s_rgb_stride, noise_batch, dscale_stride;
+    float rgb_scale;
+    long nmax;               /* entries of part_max: B * tiles * ceil(M/64) * 8 */
+} oodgan_actbwd_fuse;
 
 /* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
  * replaces: the grouped F.conv2d / F.conv_transpose2d of ModulatedConv2d.forward
@@ -168,6 +197,8 @@ int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unscale2, int C
 int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream);
 int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expected by oodgan_conv3x3_f16s */
 int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* same, for an S-form input */
+/* 1 when mode S2 with an S-form input of this shape accepts oodgan_conv_args.fuse (the 8-wave kernel of csrc/conv_f16s_s2big.hip) */
+int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, int Win);
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs

@@ -34,6 +34,8 @@ int launch_s1_big(const oodgan_conv_args& a, const void* wpk16, const float* uns
 int launch_s1_strip(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+bool s2_big_eligible(const oodgan_conv_args& a);
+int launch_s2_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -423,6 +425,8 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
     OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
+    OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
+                   "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
     hipStream_t st = as_stream(stream);
     static const bool legacy_s1 = getenv("OODGAN_S1_LEGACY") != nullptr;   // A/B switch: single-pipeline S1 kernel
     switch (a.mode) {
@@ -439,6 +443,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
             return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
+            if (a.x_sform && s2_big_eligible(a)) return launch_s2_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_s2v2(a, a.wpk, unscale2, st);
             return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);
         default: break;

@@ -1,0 +1,543 @@
+// Split-f16 3x3 STRIDE-2 conv on the phase-split S-form: the input gradient of the up-sampling ModulatedConv2d
+// (adjoint of conv_transpose2d(stride 2), reference src/ops/StyleGAN/model.py:247-258) for the mid- and high-resolution
+// layers, on the "all waves compute" structure of conv_f16s_big.hip.
+//
+//   dx[m,i,j] = sum_{k,ky,kx} g2[k, 2i+ky, 2j+kx] W[ky,kx]  =  stride-1 taps on the four parity images
+//   G_{py,px}[i,j] = g2[2i+py, 2j+px]:  G_{py,px}[i+a, j+b] W[2a+py, 2b+px]   (a = 1 only for py = 0, b = 1 only for px = 0)
+//
+// One workgroup of 8 waves owns an 8 x 32 output tile and 64*MH output channels (MH = 2: four row pairs x two channel
+// halves, every wave 2 rows x 2 M-tiles; MH = 1: eight rows, every wave 1 row x 2 M-tiles).  The K loop runs over stages
+// (16-channel chunk, row parity py):
+//   stage A (py = 0): x = 9 rows x {px 0,1} x 33 records (38 KB) + the 6 taps ky in {0,2} (4 KB * MH each)
+//   stage B (py = 1): x = the same footprint of G_{1,*}              + the 3 taps ky = 1
+// A and B stages alternate, so giving each its own LDS slot IS double buffering: the fetch of stage t+2 (LDS-DMA,
+// global_load_lds) runs under the MFMAs of stage t+1, counted vmcnt waits, two barriers per stage.  The previous kernel
+// (conv_f16s_s2v2_kernel<2,2>: two anti-phase 4-wave groups) had one group issuing MFMAs at a time and exposed one DMA
+// latency per stage: 19 % MFMA-busy (profiles/, round 1).  With 128 channels per workgroup the x tile — four times the
+// bytes of a stride-1 tile per output pixel — is fetched once per 128 instead of once per 64 output channels.
+//   * x records keep the slot rotation (c>>2)&3 of conv_f16s_big.hip (conflict-free ds_read_b128, applied through the DMA
+//     source address); weights arrive in their packed order [tap][hi|lo][k-half][channel][8].
+//   * register epilogue as conv_f16s_big.hip: out-scale and 128-byte row segments, style-gradient dot via DPP + LDS.
+#include "conv_common.hpp"
+#include "sform.hpp"
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+using namespace oodgan;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int SB_ROWS = 9, SB_C = 33;
+constexpr int SB_ROWSLOTS = 2 * SB_C * 4;                  // 264 16-byte slots per tile row (both column parities)
+constexpr int SB_XSLOTS = SB_ROWS * SB_ROWSLOTS;           // 2376
+constexpr int SB_XPIECES = 40;                             // 5 one-KiB pieces per wave; the tail pieces are harmless duplicates
+constexpr int SB_XBYTES = SB_XPIECES * 1024;
+
+struct SPDims2 { int KC, Hq, Wq; long plane; };            // as sp_dims() of conv_f16s_v2.hip
+
+__host__ __device__ inline SPDims2 sp_dims2(int C, int H, int W) {
+    SPDims2 d;
+    d.KC = (C + 15) / 16;
+    d.Hq = (H + 7) / 8 * 8 + 2;
+    d.Wq = (W + 31) / 32 * 32 + 2;
+    d.plane = (long)d.Hq * d.Wq * 4;
+    return d;
+}
+
+struct S2Big {
+    oodgan_conv_args a;
+    const uint4* xs;
+    SPDims2 sp;
+    const float* w_unscale;
+    int Hout, Wout, tiles_x, tiles_y, mblocks, Mp;
+    long out_plane;
+    int ablate;      // profiling builds (-DOODGAN_DEBUG_ABLATE): 1 skip MFMAs, 2 skip the per-stage DMA
+    oodgan_actbwd_fuse f;     // FUSE instances: the activation backward of the layer below (include/oodgan.h)
+    SDims yd;                 // S-form of (M, Hout, Wout)
+};
+
+template <int MH>
+struct S2Cfg {
+    static constexpr int RW = MH == 2 ? 2 : 1;             // output rows per wave
+    static constexpr int NRG = 8 / RW;                     // row groups
+    static constexpr int MBW = 64 * MH;                    // channels per workgroup
+    static constexpr int TAPB = 4 * MBW * 16;              // bytes per tap: [hi|lo][k-half][MBW][16 B]
+    static constexpr int PPT = TAPB / 1024;                // DMA pieces per tap (8 / 4)
+    static constexpr int WA = 6 * PPT / 8, WB = (3 * PPT + 7) / 8;      // weight pieces per wave and stage (6,3 / 3,2)
+    static constexpr int NA = 5 + WA, NB = 5 + WB;         // loads per wave in flight for a stage
+    static constexpr int OFF_XA = 0, OFF_WA = SB_XBYTES, OFF_XB = OFF_WA + 6 * TAPB, OFF_WB = OFF_XB + SB_XBYTES;
+    static constexpr int SMEM = OFF_WB + 3 * TAPB;         // 155648 (MH = 2) / 118784 (MH = 1)
+};
+
+constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15); }
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+constexpr float kInvPos = 1.f / kSqrt2, kInvNeg = 1.f / (0.2f * kSqrt2);
+
+template <bool DOT, int MH, bool FUSE = false>
+__global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, const uint4* __restrict__ wpk16) {
+    using C = S2Cfg<MH>;
+    constexpr int RW = C::RW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int rg = wave % C::NRG, mh = wave / C::NRG;      // row group, channel half
+
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int mblk = w % p.mblocks;
+    w /= p.mblocks;
+    const int ntile = p.tiles_x * p.tiles_y;
+    const int tile = w % ntile, b = w / ntile;
+    const int ty = tile / p.tiles_x, tx = tile % p.tiles_x;
+    const int r0 = ty * 8, c0 = tx * 32, m0 = mblk * C::MBW;
+    const int H = p.Hout, W = p.Wout, M = a.M;
+
+    // ---- per-lane DMA source offsets (bytes) of this wave's 5 x pieces, relative to the (b, chunk, py) base
+    unsigned offx[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int P = (wave + 8 * i) * 64 + lane;
+        if (P >= SB_XSLOTS) P = SB_XSLOTS - 1;
+        const int row = P / SB_ROWSLOTS, rem = P % SB_ROWSLOTS;
+        const int px = rem / (SB_C * 4), q = rem % (SB_C * 4);
+        const int c = q >> 2, s = ((q & 3) - ((c >> 2) & 3)) & 3;
+        offx[i] = (unsigned)(((long)px * p.sp.plane + ((long)(r0 + row) * p.sp.Wq + (c0 + c)) * 4 + s) * 16);
+    }
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + (long)b * p.sp.KC * 4 * p.sp.plane * 16;
+    const long plane_bytes = p.sp.plane * 16;
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16) + ((long)m0 + lane) * 16;
+    const long wchunk_bytes = (long)36 * p.Mp * 16;
+    const long wrow_bytes = (long)p.Mp * 16;
+    const int nchunk = (a.K + 15) / 16;
+    const int nstage = 2 * nchunk;
+
+    // stage st = (chunk t = st>>1, py = st&1); weights: py 0 -> taps ky in {0,2} (LDS slot (ky>>1)*3 + kx), py 1 -> ky = 1
+    auto dma_stage = [&](int st) {
+        const int t = st >> 1, py = st & 1;
+        unsigned char* dx_ = smem + (py ? C::OFF_XB : C::OFF_XA);
+        unsigned char* dw_ = smem + (py ? C::OFF_WB : C::OFF_WA);
+        const unsigned char* xsrc = xb + ((long)t * 4 + py * 2) * plane_bytes;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + offx[i]),
+                                             (lds_void*)(dx_ + (wave + 8 * i) * 1024), 16, 0, 0);
+        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
+        const int nw = py ? C::WB : C::WA, npieces = (py ? 3 : 6) * C::PPT;
+#pragma unroll
+        for (int i = 0; i < C::WA; ++i) {
+            if (i >= nw) break;
+            int pw = wave + 8 * i;
+            if (pw >= npieces) pw -= 8;                    // MH = 1, stage B: waves 4-7 repeat a piece (uniform load count)
+            const int sl = pw / C::PPT, q = pw % C::PPT;
+            const int tap = py ? 3 + sl : (sl / 3) * 6 + sl % 3;
+            const int row = (q * 64) / C::MBW, j0 = (q * 64) % C::MBW;      // [hi|lo][k-half] row and channel offset of the piece
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long)(tap * 4 + row) * wrow_bytes + j0 * 16),
+                                             (lds_void*)(dw_ + pw * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][RW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < RW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // lane-constant fragment offsets: x column shift dxs in {0,1}; weights: lane -> (k-half, channel)
+    unsigned lrd[2][2];
+#pragma unroll
+    for (int dxs = 0; dxs < 2; ++dxs)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = dxs + l31;
+            lrd[dxs][lo] = c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
+        }
+    const unsigned lwf = (half * C::MBW + mh * 64 + l31) * 16;
+
+    // One stage = 3 (py = 1) or 6 (py = 0) taps on the SAME accumulators.  The fragments of tap i+1 are fetched from LDS while
+    // the 12 MFMAs of tap i issue (two register sets, order pinned with sched_barrier): a wave's MFMA stream does not wait
+    // for LDS, and both waves of a SIMD can keep the matrix pipe busy.
+    struct Frag { half8 ah[2], al[2], bh[RW], bl[RW]; };
+    auto load_tap = [&](Frag& f, const unsigned char* lx, const unsigned char* lw, auto sl_c) {
+        constexpr int sl = decltype(sl_c)::value;
+        constexpr int arow = sl / 3, kx = sl % 3;          // x row shift (ky = 2*arow in stage A, ky = 1 in stage B), column tap
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f.ah[mt] = *reinterpret_cast<const half8*>(lw + sl * C::TAPB + (0 * 2) * C::MBW * 16 + mt * 32 * 16);
+            f.al[mt] = *reinterpret_cast<const half8*>(lw + sl * C::TAPB + (1 * 2) * C::MBW * 16 + mt * 32 * 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < RW; ++nt) {
+            const unsigned char* xr = lx + ((rg * RW + nt + arow) * 2 + (kx & 1)) * (SB_C * 64);
+            f.bh[nt] = *reinterpret_cast<const half8*>(xr + lrd[kx >> 1][0]);
+            f.bl[nt] = *reinterpret_cast<const half8*>(xr + lrd[kx >> 1][1]);
+        }
+    };
+    auto mfma_tap = [&](const Frag& f) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+    };
+#define S2B_IC(n) std::integral_constant<int, n>{}
+#define S2B_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // single barrier per stage: after it every wave has finished stage st-1 (its slot is free) and stage st has landed
+    // (each wave waited for its own loads); the fetch of stage st+1 is issued first and runs under this stage's MFMAs
+    dma_stage(0);
+    for (int st = 0; st < nstage; ++st) {
+        const int py = st & 1;
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+        __builtin_amdgcn_s_barrier();
+        if (st + 1 < nstage && !(p.ablate & 2)) dma_stage(st + 1);
+        if (p.ablate & 1) continue;
+        const unsigned char* lx = smem + (py ? C::OFF_XB : C::OFF_XA);
+        const unsigned char* lw = smem + (py ? C::OFF_WB : C::OFF_WA) + lwf;
+        Frag f0, f1;
+        load_tap(f0, lx, lw, S2B_IC(0));
+        S2B_SB();
+        load_tap(f1, lx, lw, S2B_IC(1)); S2B_SB(); mfma_tap(f0); S2B_SB();
+        load_tap(f0, lx, lw, S2B_IC(2)); S2B_SB(); mfma_tap(f1); S2B_SB();
+        if (py == 0) {
+            load_tap(f1, lx, lw, S2B_IC(3)); S2B_SB(); mfma_tap(f0); S2B_SB();
+            load_tap(f0, lx, lw, S2B_IC(4)); S2B_SB(); mfma_tap(f1); S2B_SB();
+            load_tap(f1, lx, lw, S2B_IC(5)); S2B_SB(); mfma_tap(f0); S2B_SB();
+            mfma_tap(f1);
+        } else {
+            mfma_tap(f0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();            // LDS is reused by the dot reduction below
+#undef S2B_IC
+#undef S2B_SB
+
+    if constexpr (FUSE) {
+        // ---- fused epilogue: style-gradient dot + activation backward of the layer below, written as its S-form gradient.
+        // Per-channel constants of the workgroup's channels go through LDS (a lane needs 16 channels x 7 values per M-tile).
+        static_assert(DOT, "the fused epilogue includes the dot");
+        const oodgan_actbwd_fuse& f = p.f;
+        float* red = reinterpret_cast<float*>(smem);                     // [row group][3][MBW]
+        float* cst = reinterpret_cast<float*>(smem + 8192);              // [7][MBW]: a*us->g_feat scale, w0, w1, w2, s_rgb, bias, d*scale
+        const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+        const float rscale = f.mul2[1];
+        if (tid < C::MBW) {
+            const int m = m0 + tid;
+            const bool mok = m < M;
+            cst[0 * C::MBW + tid] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f;
+            cst[1 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[0 * M + m] * f.rgb_scale : 0.f;
+            cst[2 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[1 * M + m] * f.rgb_scale : 0.f;
+            cst[3 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[2 * M + m] * f.rgb_scale : 0.f;
+            cst[4 * C::MBW + tid] = (mok && f.g_rgb) ? f.s_rgb[(long)b * f.s_rgb_stride + m] : 0.f;
+            cst[5 * C::MBW + tid] = (mok && f.bias) ? f.bias[m] : 0.f;
+            cst[6 * C::MBW + tid] = mok ? f.dscale[(long)b * f.dscale_stride + m] * rscale : 0.f;
+        }
+        __syncthreads();
+        const int px = c0 + l31;
+        const long HW = (long)H * W;
+        const float nw = f.noise ? (f.noise_w ? f.noise_w[0] : 1.f) : 0.f;
+        // pixel-level inputs of this wave's rows: ToRGB gradient (3 colours) and the noise map
+        float q0[RW], q1[RW], q2[RW], nzv[RW];
+        bool okr[RW];
+#pragma unroll
+        for (int nt = 0; nt < RW; ++nt) {
+            const int py_ = r0 + rg * RW + nt;
+            okr[nt] = py_ < H && px < W;
+            q0[nt] = q1[nt] = q2[nt] = nzv[nt] = 0.f;
+            if (okr[nt]) {
+                const long pix = (long)py_ * W + px;
+                if (f.g_rgb) {
+                    const float* gr = f.g_rgb + (long)b * 3 * HW + pix;
+                    q0[nt] = gr[0]; q1[nt] = gr[HW]; q2[nt] = gr[2 * HW];
+                }
+                if (f.noise) nzv[nt] = nw * f.noise[(long)(f.noise_batch > 1 ? b : 0) * HW + pix];
+            }
+        }
+        float vmaxv = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int chb = mh * 64 + mt * 32;                             // first channel of the M-tile inside the workgroup
+            // saved activations of the tile: all loads of the M-tile are issued before the first use
+            float dv[RW][16];
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) {
+                const int py_ = r0 + rg * RW + nt;
+                const float* dr = a.dotx + ((long)b * M + m0 + chb) * HW + (long)py_ * W + px;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    dv[nt][r] = (okr[nt] && m0 + chb + ch < M) ? dr[(long)ch * HW] : 0.f;
+                }
+            }
+            unsigned hi[RW][8], lo[RW][8];
+            float sd[16], sr_[16], st_[16];
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                float vv[RW][2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * r2 + e;
+                    const int ch = chb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float c_g = cst[0 * C::MBW + ch], w0 = cst[1 * C::MBW + ch], w1 = cst[2 * C::MBW + ch], w2 = cst[3 * C::MBW + ch];
+                    const float srg = cst[4 * C::MBW + ch], bv = cst[5 * C::MBW + ch], ds = cst[6 * C::MBW + ch];
+                    float ad = 0.f, ar = 0.f, at = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < RW; ++nt) {
+                        const float a0 = acc[mt][nt][r] * us;              // raw conv sum = d(loss)/d(x*s) of the up-conv
+                        const float o = dv[nt][r];
+                        ad += a0 * o;
+                        const float t = w0 * q0[nt] + w1 * q1[nt] + w2 * q2[nt];
+                        const float g = a0 * c_g + srg * t;
+                        const float gp = okr[nt] ? g * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2) : 0.f;
+                        const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nzv[nt] - bv;
+                        ar += gp * ycv;
+                        at += o * t;
+                        const float v = gp * ds;
+                        vmaxv = fmaxf(vmaxv, fabsf(v));
+                        vv[nt][e] = v;
+                    }
+                    sd[r] = ad; sr_[r] = ar; st_[r] = at;
+                }
+#pragma unroll
+                for (int nt = 0; nt < RW; ++nt) split_pair(vv[nt][0], vv[nt][1], hi[nt][r2], lo[nt][r2]);
+            }
+            // 64-byte records: lanes 0-31 hold channels {0-3, 8-11} of a 16-channel block, lanes 32-63 {4-7, 12-15};
+            // one v_permlane32_swap pair completes the 16-byte slots (half 0 -> slots 0 / 2, half 1 -> slots 1 / 3)
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) {
+                const int py_ = r0 + rg * RW + nt;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    auto h0 = __builtin_amdgcn_permlane32_swap(hi[nt][cb * 4 + 0], hi[nt][cb * 4 + 2], false, false);
+                    auto h1 = __builtin_amdgcn_permlane32_swap(hi[nt][cb * 4 + 1], hi[nt][cb * 4 + 3], false, false);
+                    auto l0 = __builtin_amdgcn_permlane32_swap(lo[nt][cb * 4 + 0], lo[nt][cb * 4 + 2], false, false);
+                    auto l1 = __builtin_amdgcn_permlane32_swap(lo[nt][cb * 4 + 1], lo[nt][cb * 4 + 3], false, false);
+                    const int kc = (m0 + chb) / 16 + cb;
+                    if (okr[nt] && kc < p.yd.KC) {
+                        uint4* rec = reinterpret_cast<uint4*>(f.ys) + sform_unit(p.yd, b, kc, py_, px, 0);
+                        rec[half] = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+                        rec[2 + half] = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+                    }
+                }
+            }
+            // the three per-channel sums of this M-tile: lanes -> row group -> LDS
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v0 = sd[r], v1 = sr_[r], v2 = st_[r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    v0 += __shfl_xor(v0, o, 64);
+                    v1 += __shfl_xor(v1, o, 64);
+                    v2 += __shfl_xor(v2, o, 64);
+                }
+                if (l31 == 0) {
+                    const int ch = chb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(rg * 3 + 0) * C::MBW + ch] = v0;
+                    red[(rg * 3 + 1) * C::MBW + ch] = v1;
+                    red[(rg * 3 + 2) * C::MBW + ch] = v2;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmaxv = fmaxf(vmaxv, __shfl_xor(vmaxv, o, 64));
+        if (lane == 0) f.part_max[(((long)b * ntile + tile) * p.mblocks + mblk) * 8 + wave] = vmaxv / rscale;   // max |g_pre*d|
+        __syncthreads();
+        if (tid < C::MBW && m0 + tid < M) {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < C::NRG; ++g) {
+                v0 += red[(g * 3 + 0) * C::MBW + tid];
+                v1 += red[(g * 3 + 1) * C::MBW + tid];
+                v2 += red[(g * 3 + 2) * C::MBW + tid];
+            }
+            const long o = ((long)b * M + m0 + tid) * a.dot_nparts + tile;
+            a.dot_part[o] = v0;
+            f.part_r[o] = v1;
+            if (f.part_t) f.part_t[o] = v2;
+        }
+        return;
+    }
+    // ---- epilogue from the accumulators (conv_f16s_big.hip's, NT = RW rows per wave)
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    const int px = c0 + l31;
+    float dsum[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[mt][r] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float osc[16];
+        unsigned moff[16], doff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool mok = m < M;
+            osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
+            moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
+            doff[r] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
+        }
+        const bool mfull = m0 + mh * 64 + mt * 32 + 32 <= M;
+#pragma unroll
+        for (int nt = 0; nt < RW; ++nt) {
+            const int py_ = r0 + rg * RW + nt;
+            const bool ok = py_ < H && px < W;
+            unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py_ * a.out_pitch + px) * 4;
+            const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py_ * W + px) * 4 : nullptr;
+            float dv[16];
+            if (DOT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+                if (ok) {
+                    if (mfull) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (moff[r] != 0xFFFFFFFFu) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsum[mt][r] += (acc[mt][nt][r] * us) * dv[r];
+            }
+            if (ok && a.y) {
+                if (mfull) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + moff[r]) = acc[mt][nt][r] * osc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = acc[mt][nt][r] * osc[r];
+                }
+            }
+        }
+    }
+    if (DOT) {
+        // per-wave sums over its rows -> LDS [row group][channel of the workgroup] -> one partial per (b, m, tile)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = dsum[mt][r];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (l31 == 0) red[rg * C::MBW + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+            }
+        __syncthreads();
+        if (tid < C::MBW && m0 + tid < M) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < C::NRG; ++g) v += red[g * C::MBW + tid];
+            a.dot_part[((long)b * M + m0 + tid) * a.dot_nparts + tile] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace oodgan {
+
+bool s2_big_eligible(const oodgan_conv_args& a) {
+    if (!(a.mode == OODGAN_CONV_S2 && a.x_sform && a.ys == nullptr && a.in_scale == nullptr && a.in_shift == nullptr &&
+          a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && (a.y != nullptr || a.dotx != nullptr) && a.M >= 64))
+        return false;
+    if (a.fuse) return true;                // the fused epilogue exists only here (the caller checked s2_fuse_supported)
+    // enough 8x32 tiles x 64-channel blocks to fill the chip; the low-resolution layers keep their latency-oriented instance
+    const int Hn = (a.Hin - 1) / 2, Wn = (a.Win - 1) / 2;
+    const long items = (long)((Hn + 7) / 8) * ((Wn + 31) / 32) * a.B * ((a.M + 63) / 64);
+    const char* e = getenv("OODGAN_S2_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
+    return items > (e ? atol(e) : 256);
+}
+
+}  // namespace oodgan
+
+// 1 when oodgan_conv3x3_f16s (mode S2, S-form input) of this shape runs the kernel that has the fused activation backward
+extern "C" int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, int Win) {
+    oodgan_conv_args a = {};
+    a.mode = OODGAN_CONV_S2; a.x_sform = 1; a.B = B; a.K = K; a.M = M; a.Hin = Hin; a.Win = Win;
+    a.y = reinterpret_cast<float*>(1);
+    return (M % 32) == 0 && oodgan::s2_big_eligible(a) ? 1 : 0;
+}
+
+namespace oodgan {
+
+int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {
+    S2Big p;
+    p.a = a_in;
+    oodgan_conv_args& a = p.a;
+    p.Hout = (a.Hin - 1) / 2;
+    p.Wout = (a.Win - 1) / 2;
+    if (a.out_pitch == 0) a.out_pitch = p.Wout;
+    p.out_plane = (long)p.Hout * a.out_pitch;
+    p.xs = reinterpret_cast<const uint4*>(a.x);
+    p.sp = sp_dims2(a.K, p.Hout, p.Wout);
+    p.w_unscale = unscale;
+    p.tiles_y = (p.Hout + 7) / 8;
+    p.tiles_x = (p.Wout + 31) / 32;
+    p.Mp = (a.M + 63) / 64 * 64;
+    // 128 channels per workgroup when the channel count allows it and the grid still covers the chip
+    const long items128 = (long)p.tiles_x * p.tiles_y * a.B * (a.M / 128);
+    const bool mh2 = (a.M % 128) == 0 && items128 >= 256;
+    p.mblocks = mh2 ? a.M / 128 : (a.M + 63) / 64;
+    if (a.dotx) {
+        OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
+        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 f16s S2: dot_nparts %d != %d", a.dot_nparts, p.tiles_x * p.tiles_y);
+    }
+    OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32), "conv3x3 S2 big: plane too large");
+    const bool fuse = a.fuse != nullptr;
+    p.yd = sform_dims(a.M, p.Hout, p.Wout);
+    if (fuse) {
+        p.f = *a.fuse;
+        OODGAN_REQUIRE(a.dotx && a.dot_part && p.f.ys && p.f.part_r && p.f.part_max && p.f.dscale && p.f.mul2 && (a.M % 32) == 0,
+                       "conv3x3 S2 fused activation backward: needs dotx, ys, part_r, part_max, dscale, mul2 and M %% 32 == 0");
+        OODGAN_REQUIRE(!p.f.g_rgb || (p.f.w_rgb && p.f.s_rgb && p.f.part_t), "conv3x3 S2 fused: rgb branch needs w_rgb, s_rgb and part_t");
+        OODGAN_REQUIRE(p.f.noise == nullptr || p.f.noise_batch == 1 || p.f.noise_batch == a.B, "conv3x3 S2 fused: noise_batch");
+        OODGAN_REQUIRE(p.f.nmax >= (long)a.B * p.tiles_x * p.tiles_y * p.mblocks * 8, "conv3x3 S2 fused: part_max too small");
+    }
+    OODGAN_REQUIRE(p.sp.plane * 32 < (1L << 32), "conv3x3 S2 big: input plane too large");
+#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: the ablation bits make the kernel skip work (wrong results)
+    static const int abl = getenv("OODGAN_S2BIG_ABLATE") ? atoi(getenv("OODGAN_S2BIG_ABLATE")) : 0;
+    p.ablate = abl;
+#else
+    p.ablate = 0;
+#endif
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM), true);
+    (void)once;
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    if (fuse) {
+        if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM, st, p, w16);
+    } else if (mh2) {
+        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<false, 2>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
+    } else {
+        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<false, 1>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM, st, p, w16);
+    }
+    return check_launch("conv3x3_f16s_s2big");
+}
+
+}  // namespace oodgan

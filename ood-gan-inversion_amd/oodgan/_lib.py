@@ -24,8 +24,15 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P),
     ]
+
+
+class ActBwdFuse(Structure):
+    """oodgan_actbwd_fuse (include/oodgan.h): fused activation backward of the stride-2 input-gradient conv."""
+    _fields_ = [('g_rgb', P), ('w_rgb', P), ('s_rgb', P), ('noise', P), ('noise_w', P), ('bias', P), ('dscale', P), ('mul2', P), ('ys', P),
+                ('part_r', P), ('part_t', P), ('part_max', P), ('s_rgb_stride', c_int), ('noise_batch', c_int), ('dscale_stride', c_int),
+                ('rgb_scale', c_float), ('nmax', c_long)]
 
 
 class ReduceJob(Structure):
@@ -69,6 +76,7 @@ _SIGS = {
     'oodgan_conv3x3_f16s': (c_int, [POINTER(ConvArgs), P, P]),
     'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
     'oodgan_conv3x3_f16s_nparts2': (c_int, [c_int, c_int, c_int, c_int]),
+    'oodgan_conv3x3_s2_fuse_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_sform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_sform_phases_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),

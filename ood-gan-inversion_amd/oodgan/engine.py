@@ -87,6 +87,8 @@ class GeneratorEngine:
         # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
         self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
         self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
+        self.by_name = {L.name: L for L in layers}
+        self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
         self.fused_rgb = os.environ.get('OODGAN_FUSED_RGB', '1') != '0'
         self.batched_tail = os.environ.get('OODGAN_BATCHED_TAIL', '1') != '0'
         src = 'input'
@@ -337,6 +339,7 @@ class GeneratorEngine:
             r //= 2
         g_feat = None
         prev_rgb = None
+        fused_in = None         # ops.ActBwdFusion produced by the stride-2 conv of the layer above
         jobs = ops.BwdJobs() if (carry_scale and self.fused_bwd and self.sform and self.batched_tail) else None
         for L in reversed(self.layers):
             if L.kind == 'rgb':          # fused into the backward of the styled conv that feeds it
@@ -350,7 +353,13 @@ class GeneratorEngine:
             st = self.bwd_state.get(L.name) if carry else None
             Rg, prev_rgb = prev_rgb, None
             rgb_kw = {} if Rg is None else dict(g_rgb=gskip[L.res], w_rgb=Rg.w_rgb, s_rgb=_Cols(s_all, Rg.row, Rg.cin))
-            if st is not None:
+            if st is not None and fused_in is not None:
+                # this layer's activation backward already ran in the epilogue of the stride-2 conv above (its S-form
+                # gradient, partial sums and maxima come from there; g_feat never went to HBM)
+                gin, rsum, tsum, part_m = fused_in.dst, fused_in.r, None, fused_in.part_m
+                fused_in = None
+                mul2, g_pre = st, None
+            elif st is not None:
                 # fused producer: g_pre goes straight into the next matrix kernel's input layout, scaled with the
                 # range scale measured on the previous step (verified below, after the conv has consumed it)
                 t_into = None if Rg is None else _Cols(gs_all, Rg.row, Rg.cin)
@@ -385,8 +394,19 @@ class GeneratorEngine:
                                              ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
                                              ops._stream()), 'demod_bwd')
             if st is not None:
+                fz = None
+                Lp = self.by_name.get(L.src)
+                stp = self.bwd_state.get(L.src) if (L.kind == 'up' and Lp is not None and self.fuse_act_bwd) else None
+                if stp is not None and ops.s2_fuse_supported(B, L.cout, L.cin, 2 * Hd + 1, 2 * Hd + 1):
+                    # the stride-2 conv's result is the gradient w.r.t. the output of the conv layer below (x_in): its
+                    # epilogue continues with that layer's activation backward (+ ToRGB branch) and writes the S-form
+                    Rp = self.conv_next_rgb[Lp.name]
+                    fz = ops.ActBwdFusion(ops.sform_scratch(B, Lp.cout, Hd, Hd, self.device), noises[Lp.noise_idx], Lp.noise_w, Lp.bias,
+                                          _Cols(d_all, Lp.drow, Lp.cout), stp, g_rgb=gskip[Lp.res], w_rgb=Rp.w_rgb,
+                                          s_rgb=_Cols(s_all, Rp.row, Rp.cin), t_into=_Cols(gs_all, Rp.row, Rp.cin))
                 dx, dot = ops.conv3x3(gin, L.wpk_bwd, L.cin, CONV_S1 if L.kind == 'conv' else CONV_S2, out_scale=s, dotx=x_in,
-                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs)
+                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs, fuse=fz, want_y=fz is None)
+                fused_in = fz
                 del gin
                 if deferred:
                     jobs.add_check(part_m, st)

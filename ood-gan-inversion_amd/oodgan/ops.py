@@ -557,7 +557,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
@@ -597,6 +597,10 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         a.rgb_w, a.rgb_s, a.rgb_y = _p(_dev(w_rgb, 'w_rgb').reshape(3, M)), _p(_dev(s_rgb, 's_rgb')), _p(rgb_y)
         a.rgb_s_stride, a.rgb_scale = s_rgb.shape[1], 1.0 / math.sqrt(M)
     a.ys_scale_stride = ys_scale.shape[1] if ys_scale is not None else 0
+    fz = None
+    if fuse is not None:        # ActBwdFusion: the activation backward of the layer below runs in this conv's epilogue
+        fz = fuse.struct(B, M, oh, ow)
+        a.fuse = ctypes.cast(ctypes.pointer(fz), ctypes.c_void_p)
     part = None
     if dotx is not None:
         dx_ = _dev(dotx, 'dotx')
@@ -610,6 +614,8 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         check(_lib.lib().oodgan_conv3x3_f16s(ctypes.byref(a), _p(wpk.unscale), _stream()), 'conv3x3_f16s')
     else:
         check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
+    if fuse is not None:
+        fuse.finish(part, a.dot_nparts, jobs)
     if dotx is not None:
         if dot_into is not None:        # += into the layer's columns of the style-gradient accumulator
             if jobs is not None:
@@ -623,6 +629,54 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     if rgb is not None:
         return out, rgb_y
     return out
+
+
+def s2_fuse_supported(B, K, M, Hin, Win):
+    return bool(_lib.lib().oodgan_conv3x3_s2_fuse_supported(B, K, M, Hin, Win))
+
+
+class ActBwdFusion:
+    """Arguments and results of the activation backward fused into the stride-2 input-gradient conv
+    (oodgan_actbwd_fuse, include/oodgan.h): the same quantities ``act_bwd_producer`` returns — (r, t, part_max) and the
+    S-form gradient ``dst`` — produced by ``conv3x3(..., mode=CONV_S2, fuse=this)`` for the layer whose output is ``dotx``."""
+
+    def __init__(self, dst, noise, noise_weight, bias, dscale, mul2, g_rgb=None, w_rgb=None, s_rgb=None, t_into=None):
+        self.dst, self.noise, self.noise_weight, self.bias, self.dscale, self.mul2 = dst, _opt(noise, 'noise'), _opt(noise_weight, 'nw'), _opt(bias, 'bias'), dscale, mul2
+        self.g_rgb, self.w_rgb, self.s_rgb, self.t_into = _opt(g_rgb, 'g_rgb'), w_rgb, s_rgb, t_into
+        self.r = self.t = self.part_m = None
+
+    def struct(self, B, M, H, W):
+        dev = self.dst.data.device
+        ntile = ((H + 7) // 8) * ((W + 31) // 32)
+        self.B, self.M = B, M
+        self.part_r = torch.empty(B, M, ntile, device=dev, dtype=torch.float32)
+        self.part_t = torch.empty(B, M, ntile, device=dev, dtype=torch.float32) if self.g_rgb is not None else None
+        self.part_m = torch.zeros(B * ntile * ((M + 63) // 64) * 8, device=dev, dtype=torch.float32)
+        z = _lib.ActBwdFuse()
+        z.g_rgb, z.noise, z.noise_w, z.bias = _p(self.g_rgb), _p(self.noise), _p(self.noise_weight), _p(self.bias)
+        self._w = None if self.w_rgb is None else _dev(self.w_rgb).reshape(3, M)
+        z.w_rgb, z.s_rgb = _p(self._w), _p(self.s_rgb)
+        z.s_rgb_stride = 0 if self.s_rgb is None else self.s_rgb.shape[1]
+        z.noise_batch = 1 if self.noise is None else self.noise.shape[0]
+        z.dscale, z.dscale_stride, z.mul2, z.ys = _p(self.dscale), self.dscale.shape[1], _p(self.mul2), _p(self.dst)
+        z.part_r, z.part_t, z.part_max = _p(self.part_r), _p(self.part_t), _p(self.part_m)
+        z.rgb_scale, z.nmax = 1.0 / math.sqrt(M), self.part_m.numel()
+        return z
+
+    def finish(self, dot_part, nparts, jobs):
+        B, M = self.B, self.M
+        if jobs is not None:            # deferred, as in act_bwd_producer
+            self.r = torch.empty(B, M, device=self.part_r.device, dtype=torch.float32)
+            jobs.add_reduce(self.part_r, self.r, B, M, nparts, M, False)
+            if self.part_t is not None:
+                jobs.add_reduce(self.part_t, self.t_into, B, M, nparts, self.t_into.shape[1], False)
+            return
+        self.r = _reduce_parts(self.part_r, B * M, nparts)
+        if self.part_t is not None:
+            if self.t_into is not None:
+                _reduce_into(self.part_t, B, M, nparts, self.t_into, False)
+            else:
+                self.t = _reduce_parts(self.part_t, B * M, nparts)
 
 
 def rgb_finish(partial, bias=None, skip=None, kernel=None):

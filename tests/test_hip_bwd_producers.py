@@ -131,3 +131,49 @@ def test_violated_scale_falls_back_to_exact_loop():
     del eng.backward
     assert calls['n'] == 8                                   # 4 flagged steps + the 4 steps of the exact re-run
     assert torch.isfinite(w).all() and (l - l_ref).abs().max().item() <= 1e-5 * l_ref.abs().max().item()
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W,rgb', [(2, 32, 128, 16, 32, True), (1, 48, 64, 9, 40, True), (1, 64, 256, 8, 36, False)])
+def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, monkeypatch):
+    """The stride-2 input-gradient conv whose epilogue continues with the activation backward of the layer below
+    (oodgan_actbwd_fuse) == the same conv followed by act_bwd_producer on its fp32 result: S-form gradient, the three
+    per-channel sums, and the maxima that drive the carried range scale."""
+    import math
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '0')
+    assert ops.s2_fuse_supported(B, Co, Ci, 2 * H + 1, 2 * W + 1)
+    t = lambda n, shp, std=1.0, mean=0.0: synth.normal('fz.' + n, shp, 40 + Ci, std, mean).to(dev)
+    out_below = t('out', (B, Ci, H, W))                      # saved activation of the conv layer below (= dotx)
+    w = t('w', (Co, Ci, 3, 3), 1.0 / math.sqrt(Ci * 9))
+    s_up = t('s', (B, Ci), 0.3, 1.0)
+    d_up = t('dup', (B, Co), 0.3, 1.0)
+    gz = t('gz', (B, Co, 2 * H + 1, 2 * W + 1), 3e-4)
+    noise, nw, bias = t('nz', (B, 1, H, W)), torch.tensor([0.1], device=dev), t('bias', (Ci,), 0.1)
+    d_below = t('d', (B, Ci), 0.2, 1.0).abs()
+    kw = dict(g_rgb=t('grgb', (B, 3, H, W), 1e-3), w_rgb=t('wrgb', (3, Ci)), s_rgb=t('srgb', (B, Ci), 0.3, 1.0)) if rgb else {}
+    wpk_t = ops.pack_conv3x3(w, 1.0, transpose=True, flip=False, precision='f16s')
+    mul_up = torch.tensor([2.0 ** -10, 2.0 ** 10], device=dev)
+    gp = ops.to_sform_phases(gz, H, W, d_up, mul_up)
+    # two passes: conv -> fp32 g_feat -> producer
+    g_feat, dot0 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s_up, dotx=out_below, in_mul2=mul_up)
+    _, _, _, state = ops.act_bwd_fused(out_below, g_feat, noise, nw, bias, kw.get('g_rgb'), kw.get('w_rgb'), kw.get('s_rgb'),
+                                       want_scale=True, dscale=d_below)
+    ref = ops.SForm(B, Ci, H, W, dev)
+    r0, t0, pm0 = ops.act_bwd_producer(out_below, g_feat, noise, nw, bias, d_below, state, ref, **kw)
+    # fused
+    dst = ops.SForm(B, Ci, H, W, dev)
+    fz = ops.ActBwdFusion(dst, noise, nw, bias, d_below, state, **kw)
+    y, dot1 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s_up, dotx=out_below, in_mul2=mul_up, fuse=fz, want_y=False)
+    assert y is None
+    a, b_ = dst.data.float().view(-1, 2, 16), ref.data.float().view(-1, 2, 16)
+    va, vb = a[:, 0] + a[:, 1], b_[:, 0] + b_[:, 1]              # hi + lo
+    assert (va - vb).abs().max().item() <= 2e-6 * vb.abs().max().item()
+    assert (dot1 - dot0).abs().max().item() <= 1e-5 * dot0.abs().max().item()
+    assert (fz.r - r0).abs().max().item() <= 1e-5 * max(1e-30, r0.abs().max().item())
+    if rgb:
+        assert (fz.t - t0).abs().max().item() <= 1e-5 * max(1e-30, t0.abs().max().item())
+    assert abs(fz.part_m.max().item() - pm0.max().item()) <= 1e-5 * pm0.max().item()
+    # the border of the S-form must stay zero (only the interior is written)
+    full = dst.data.float().abs().sum().item()
+    assert full > 0

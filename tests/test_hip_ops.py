@@ -456,3 +456,35 @@ def test_upfirdn2d_down2_4x4_kernel_vs_oracle(dev):
     for (H, W), pad in (((64, 64), (1, 1)), ((37, 50), (1, 1)), ((16, 24), (2, 1)), ((9, 9), (0, 3))):
         x = synth.normal(f'd2.{H}', (2, 3, H, W), 7)
         close(ops.upfirdn2d(x.to(dev), k.to(dev), 1, 2, pad), R.upfirdn2d(x, k, 1, 2, pad))
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 64, 128, 16, 32), (1, 48, 256, 9, 40), (2, 32, 64, 24, 33), (1, 80, 192, 8, 64)])
+def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, monkeypatch):
+    """Stride-2 conv (input gradient of the up-sampling conv: K = Co channels of the gradient, M = Ci) on the phase-split
+    S-form through conv_f16s_s2big.hip — both instances (128 / 64 channels per workgroup), ragged tiles, with the
+    style-gradient dot and a power-of-two input range scale — against autograd of conv_transpose2d and against the
+    two-group tile kernel it replaces."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '0')
+    x = synth.normal('s2b.x', (B, Ci, H, W), 1)
+    w = synth.normal('s2b.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('s2b.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('s2b.d', (B, Co), 4, 0.3, 1.0)
+    gz = synth.normal('s2b.gz', (B, Co, 2 * H + 1, 2 * W + 1), 5)
+    xs_ = (x * s[:, :, None, None]).clone().requires_grad_(True)
+    (F.conv_transpose2d(xs_, w.transpose(0, 1), stride=2) * d[:, :, None, None] * gz).sum().backward()
+    wpk_t = ops.pack_conv3x3(w.to(dev), 1.0, transpose=True, flip=False, precision='f16s')
+    mul2 = torch.tensor([2.0 ** -4, 2.0 ** 4], device=dev)
+    gp = ops.to_sform_phases(gz.to(dev), H, W, d.to(dev), mul2)
+    dx, dot = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
+    close(dx, xs_.grad * s[:, :, None, None], 2e-4)
+    close(dot, (xs_.grad * x).sum(dim=(2, 3)), 2e-4)
+    dx1 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), in_mul2=mul2)          # no dot epilogue
+    assert torch.equal(dx1, dx)
+    dx2, dot2 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
+    assert torch.equal(dx2, dx) and torch.equal(dot2, dot)                                      # deterministic
+    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '1000000000')                                 # the tile kernel
+    dx3, dot3 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
+    assert (dx3 - dx).abs().max().item() <= 1e-5 * dx.abs().max().item()
+    assert (dot3 - dot).abs().max().item() <= 1e-4 * dot.abs().max().item()
