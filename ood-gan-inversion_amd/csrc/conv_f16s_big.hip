@@ -15,6 +15,7 @@
 #include "sform.hpp"
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 using namespace oodgan;
 
@@ -88,7 +89,6 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16);
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
-    const int npc = wave < (BG_PIECES - NW * (NPW - 1)) ? NPW : NPW - 1;
 
     auto dma_stage = [&](int t, int buf) {
         unsigned char* dst = smem + buf * BG_STAGE;
@@ -122,56 +122,65 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
         }
     const unsigned lwf = (half * 64 + l31) * 16;
 
-    constexpr int kVm0 = 0x0F70;
-    dma_stage(0, 0);
-    if (nchunk > 1) dma_stage(1, 1);
-    for (int t = 0; t < nchunk; ++t) {
-        // stage t has landed when at most the pieces of stage t+1 are outstanding (in-order retirement)
-        if (t + 1 < nchunk) {
-            if (NW == 4) {
-                if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x4F73);      // vmcnt(19)
-                else __builtin_amdgcn_s_waitcnt(0x4F72);                 // vmcnt(18)
-            } else {
-                if (npc == NPW) __builtin_amdgcn_s_waitcnt(0x0F7A);      // vmcnt(10)
-                else __builtin_amdgcn_s_waitcnt(0x0F79);                 // vmcnt(9)
-            }
-        } else {
-            __builtin_amdgcn_s_waitcnt(kVm0);
+    // One stage = 9 taps on the same accumulators.  The fragments of tap i+1 are fetched from LDS while the MFMAs of tap i
+    // issue (two register sets, order pinned with sched_barrier); ONE barrier per stage: after it every wave has finished
+    // stage t-1 (its buffer is free: the fetch of stage t+1 is issued right there and runs under this stage's MFMAs) and
+    // stage t has landed (each wave waited for its own loads).  Measured equal to the earlier two-barrier / counted-vmcnt
+    // loop (A/B on one box, +-1 %): the kernel runs at the MFMA rate the chip sustains under load.
+    struct Frag { half8 ah[2], al[2], bh[NT], bl[NT]; };
+    auto load_tap = [&](Frag& f, const unsigned char* lx, const unsigned char* lw, auto tp_c) {
+        constexpr int tp = decltype(tp_c)::value;
+        constexpr int ky = tp / 3, kx = tp % 3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f.ah[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 0) * 2) * 64 + mt * 32) * 16);
+            f.al[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 1) * 2) * 64 + mt * 32) * 16);
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f.bh[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][0]);
+            f.bl[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][1]);
+        }
+    };
+    auto mfma_tap = [&](const Frag& f) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+    };
+#define BG_IC(n) std::integral_constant<int, n>{}
+#define BG_SB() __builtin_amdgcn_sched_barrier(0)
+    dma_stage(0, 0);
+    for (int t = 0; t < nchunk; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
+        if (t + 1 < nchunk && !(p.ablate & 2)) dma_stage(t + 1, (t + 1) & 1);
+        if (p.ablate & 1) continue;
         const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * NT) * (BG_C * 64);
         const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES + lwf;
-        if (!(p.ablate & 1))
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-            const int ky = tp / 3, kx = tp % 3;
-            half8 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                ah[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 0) * 2) * 64 + mt * 32) * 16);
-                al[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 1) * 2) * 64 + mt * 32) * 16);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bh[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][0]);
-                bl[nt] = *reinterpret_cast<const half8*>(lx + (nt + ky) * (BG_C * 64) + lrd[kx][1]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_barrier();            // every wave is done with buffer t&1
-        if (t + 2 < nchunk && !(p.ablate & 2)) dma_stage(t + 2, t & 1);
+        Frag f0, f1;
+        load_tap(f0, lx, lw, BG_IC(0));
+        BG_SB();
+        load_tap(f1, lx, lw, BG_IC(1)); BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(2)); BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(3)); BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(4)); BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(5)); BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(6)); BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(7)); BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(8)); BG_SB(); mfma_tap(f1); BG_SB();
+        mfma_tap(f0);
     }
+#undef BG_IC
+#undef BG_SB
 
     // ---- epilogue from the accumulators
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
@@ -275,8 +284,6 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
 namespace oodgan {
 
 bool s1_big_eligible(const oodgan_conv_args& a) {
-    static const int off = getenv("OODGAN_S1_BIG") ? atoi(getenv("OODGAN_S1_BIG")) == 0 : 0;
-    if (off) return false;
     // Measured (tools/bench_conv.py, B=8, us per launch; v2 two-group tile kernel -> this kernel with 8 waves):
     // 512->512 @64²: 455 -> 393 (394 TF/s), 256->256 @128²: 435 -> 407, 128->128 @256²: 484 -> 464.  With 4 waves (one
     // per SIMD) it is slower than v2 (474 / 475 / 552): ablating its DMA does not change the time — the MFMA +
@@ -324,21 +331,14 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
 #endif
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    const char* ew = getenv("OODGAN_S1_BIG_WAVES");
-    const int nw = ew ? atoi(ew) : 8;          // two waves per SIMD keep the MFMA pipe fed while the partner waits on LDS
-    if (nw == 8) {
-        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
-        else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
-    } else {
-        if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 4>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
-        else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 4>), dim3((unsigned)total), dim3(256), BG_SMEM, st, p, w16);
-    }
+    // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (the 4-wave variant was slower than the
+    // v2 tile kernel: 474 / 475 / 552 us against 393 / 407 / 464 on the 64² / 128² / 256² layers)
+    if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_s1big");
 }
 

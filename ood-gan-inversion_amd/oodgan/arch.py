@@ -92,10 +92,7 @@ class ood_faceGAN_e4e(nn.Module):
         self.channels = generator_channels(channel_multiplier, narrow)
         if kwargs.get('build_encoder', True):
             from .encoder import ProgressiveStage
-            if kwargs.get('encoder_impl', 'hip') == 'hip':      # the e4e encoder on the HIP kernels
-                from .encoder_hip import Encoder4EditingHIP as Encoder4Editing
-            else:                                               # 'torch': the plain torch-ROCm mirror (oodgan/encoder.py)
-                from .encoder import Encoder4Editing
+            from .encoder_hip import Encoder4EditingHIP as Encoder4Editing     # the e4e encoder on the HIP kernels
             self.encoder = Encoder4Editing(num_layers=50, mode='ir_se', opts={'stylegan_size': out_size}, bn=True)
             self.encoder.progressive_stage = ProgressiveStage[stage]
         else:
@@ -292,7 +289,6 @@ class ood_faceGAN_restyle(ood_faceGAN_e4e):
         if ReStyle_pth is None:
             raise AssertionError('ReStyle_pth is required (reference :66)')
         stage = kwargs.pop('stage', 'Inference')
-        impl = kwargs.pop('encoder_impl', 'hip')
         kwargs.pop('build_encoder', None)
         kwargs.pop('E4E_pth', None)
         super().__init__(out_size=out_size, style_dim=style_dim, encoder='E4E', stage=stage, build_encoder=False, **kwargs)
@@ -303,10 +299,7 @@ class ood_faceGAN_restyle(ood_faceGAN_e4e):
         opts = dict(enc_ckpt['opts'])
         if opts.get('encoder_type') != 'ProgressiveBackboneEncoder':
             raise NotImplementedError(f"ReStyle encoder_type {opts.get('encoder_type')!r}: only ProgressiveBackboneEncoder")
-        if impl == 'hip':
-            from .encoder_hip import ProgressiveBackboneEncoderHIP as Enc
-        else:
-            from .encoder import ProgressiveBackboneEncoder as Enc
+        from .encoder_hip import ProgressiveBackboneEncoderHIP as Enc
         self.encoder = Enc(num_layers=50, mode='ir_se', n_styles=self.style_cnt, opts=opts)
         enc_dict = OrderedDict((k[len('encoder.'):], v) for k, v in enc_ckpt['state_dict'].items() if k.startswith('encoder.'))
         self.encoder.load_state_dict(enc_dict, strict=True)
@@ -376,15 +369,11 @@ class ood_faceGAN_FeatureStyle(ood_faceGAN_e4e):
             raise NotImplementedError("ood_faceGAN_FeatureStyle: encoder must be 'FeatureStyle'")
         if FeatureStyle_pth is None:
             raise AssertionError('FeatureStyle_pth is required (reference :73)')
-        impl = kwargs.pop('encoder_impl', 'hip')
         kwargs.pop('build_encoder', None)
         kwargs.pop('E4E_pth', None)
         super().__init__(out_size=out_size, style_dim=style_dim, StyleGAN_pth_key=StyleGAN_pth_key, encoder='E4E', build_encoder=False, **kwargs)
         self.encoder_type = encoder
-        if impl == 'hip':
-            from .encoder_hip import fs_encoder_v2HIP as Enc
-        else:
-            from .encoder import fs_encoder_v2 as Enc
+        from .encoder_hip import fs_encoder_v2HIP as Enc
         self.encoder = Enc(n_styles=self.style_cnt, stride=(2, 2))
         enc_ckpt = torch.load(FeatureStyle_pth, map_location='cpu') if isinstance(FeatureStyle_pth, (str, bytes)) or hasattr(FeatureStyle_pth, '__fspath__') else FeatureStyle_pth
         self.encoder.load_state_dict(enc_ckpt, strict=True)

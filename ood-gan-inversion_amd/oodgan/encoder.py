@@ -1,22 +1,20 @@
-"""e4e encoder — the step immediately BEFORE the accelerated path.
+"""Parameter containers of the encoders that run BEFORE the accelerated path.
 
-Mirror of ``Encoder4Editing(num_layers, mode='ir_se', opts, bn=True)`` (reference
-src/ops/e4e/encoders/psp_encoders.py:125-216; IR-SE-50 backbone helpers.py:33-57,60-76,479-501; FPN
-``_upsample_add`` :504-521; ``GradualStyleBlock`` psp_encoders.py:35-57) with the same state-dict keys
-(621 entries for num_layers=50), forward signature and ``channels`` / ``progressive_stage`` attributes.
-
-This module is the parameter container + a plain-torch forward (MIOpen / rocBLAS through ``torch.nn.functional``);
-``oodgan.encoder_hip.Encoder4EditingHIP`` subclasses it and runs the same graph on the HIP kernels — that is what
-``ood_faceGAN_e4e`` instantiates (``encoder_impl='torch'`` selects this one).  The plain-torch forward is kept as the
-CPU-checkable restatement of the graph (tests/test_encoder.py); it is NOT a fallback for the hot path — generator,
-SAMM and the W+ loop have none."""
+Same constructor arguments, state-dict keys (621 entries for the IR-SE-50 e4e encoder), ``channels`` /
+``progressive_stage`` attributes as the reference classes —
+  ``Encoder4Editing``            src/ops/e4e/encoders/psp_encoders.py:125-216 (IR-SE-50 helpers.py:33-57,60-76,479-501)
+  ``ProgressiveBackboneEncoder`` src/ops/restyle/restyle_e4e_encoder.py:37-112
+  ``fs_encoder_v2``              src/ops/FeatureStyle/feature_style_encoder.py:12-74 (IResNet-50 arcface/iresnet.py:30-61)
+— and NOTHING ELSE: these classes hold parameters (``torch.nn`` modules are used as containers only) and have no forward.
+The forward passes live in ``oodgan.encoder_hip`` (``Encoder4EditingHIP`` ... subclass these containers and run every conv,
+normalisation, gate and resize through ``liboodgan_hip.so``).  A plain-torch restatement of the same graphs exists only as
+test infrastructure (``tests/torch_encoder_mirror.py``): the product package has no PyTorch / MIOpen compute path."""
 import math
 from collections import namedtuple
 from enum import Enum
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 
@@ -40,6 +38,14 @@ class ProgressiveStage(Enum):
     Delta16Training = 16
     Delta17Training = 17
     Inference = 18
+
+
+class _Container(nn.Module):
+    """parameter container: the forward pass is implemented by the HIP subclass in oodgan.encoder_hip"""
+
+    def forward(self, *a, **k):
+        raise RuntimeError(f'{type(self).__name__} is a parameter container; instantiate oodgan.encoder_hip.{type(self).__name__}HIP '
+                           '(the encoders run on the HIP kernels only: there is no PyTorch fallback)')
 
 
 _Unit = namedtuple('_Unit', ['in_channel', 'depth', 'stride'])
@@ -66,11 +72,6 @@ class SEModule(nn.Module):
         self.fc1 = nn.Conv2d(channels, channels // reduction, kernel_size=1, padding=0, bias=False)
         self.fc2 = nn.Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
 
-    def forward(self, x):
-        g = x.mean(dim=(2, 3), keepdim=True)
-        g = torch.sigmoid(self.fc2(F.relu(self.fc1(g))))
-        return x * g
-
 
 class bottleneck_IR_SE(nn.Module):
     """helpers.py:479-501: BN -> conv3x3 -> PReLU -> conv3x3(stride) -> BN -> SE, plus identity / 1x1+BN shortcut."""
@@ -85,9 +86,6 @@ class bottleneck_IR_SE(nn.Module):
                                        nn.PReLU(depth), nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
                                        nn.BatchNorm2d(depth), SEModule(depth, 16))
 
-    def forward(self, x):
-        return self.res_layer(x) + self.shortcut_layer(x)
-
 
 class bottleneck_IR(nn.Module):
     def __init__(self, in_channel, depth, stride, bn=True):
@@ -100,9 +98,6 @@ class bottleneck_IR(nn.Module):
                                        nn.PReLU(depth), nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
                                        nn.BatchNorm2d(depth))
 
-    def forward(self, x):
-        return self.res_layer(x) + self.shortcut_layer(x)
-
 
 class _EqualLinear(nn.Module):
     """EqualLinear of src/ops/StyleGAN/modules.py:136-170 (no activation on this path)."""
@@ -113,9 +108,6 @@ class _EqualLinear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_dim))
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
-
-    def forward(self, x):
-        return F.linear(x, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 
 class GradualStyleBlock(nn.Module):
@@ -130,16 +122,8 @@ class GradualStyleBlock(nn.Module):
         self.convs = nn.Sequential(*mods)
         self.linear = _EqualLinear(out_c, out_c, lr_mul=1)
 
-    def forward(self, x):
-        return self.linear(self.convs(x).view(-1, self.out_c))
 
-
-def _upsample_add(x, y):
-    """helpers.py:504-521: bicubic(align_corners=True) to y's size, plus y."""
-    return F.interpolate(x, size=y.shape[-2:], mode='bicubic', align_corners=True) + y
-
-
-class Encoder4Editing(nn.Module):
+class Encoder4Editing(_Container):
     def __init__(self, num_layers, mode='ir', opts=None, bn=True):
         super().__init__()
         assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
@@ -170,46 +154,12 @@ class Encoder4Editing(nn.Module):
     def set_progressive_stage(self, new_stage):
         self.progressive_stage = new_stage
 
-    def forward(self, x, **kwargs):
-        x = self.input_layer(x)
-        feats = [x]
-        c1 = c2 = c3 = None
-        for i, layer in enumerate(self.body):
-            x = layer(x)
-            if i == 2:
-                feats.append(x)
-            if i == 6:
-                c1 = x
-                feats.append(x)
-            elif i == 20:
-                c2 = x
-                feats.append(x)
-            elif i == 23:
-                c3 = x
-                feats.append(x)
-        w0 = self.styles[0](c3)
-        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2)
-        stage = self.progressive_stage.value
-        features = c3
-        p2 = None
-        for i in range(1, min(stage + 1, self.style_count)):
-            if i == self.coarse_ind:
-                p2 = _upsample_add(c3, self.latlayer1(c2))
-                features = p2
-            elif i == self.middle_ind:
-                features = _upsample_add(p2, self.latlayer2(c1))
-            w[:, i] += self.styles[i](features)
-        if kwargs.get('return_feats', False):
-            return w, feats
-        return w
 
-
-class ProgressiveBackboneEncoder(nn.Module):
+class ProgressiveBackboneEncoder(_Container):
     """ReStyle's encoder (reference src/ops/restyle/restyle_e4e_encoder.py:37-112): the same IR-SE-50 trunk on
     ``opts.input_nc`` input channels (6: image + current reconstruction); all ``n_styles`` codes come from
     ``GradualStyleBlock(512, 512, 16)`` heads on the final 16x16 map (no FPN).  Same state-dict keys, ``channels`` and
-    ``progressive_stage`` as the reference; plain-torch forward (``encoder_hip.ProgressiveBackboneEncoderHIP`` runs it on
-    the HIP kernels)."""
+    ``progressive_stage`` as the reference (forward: ``encoder_hip.ProgressiveBackboneEncoderHIP``)."""
 
     def __init__(self, num_layers, mode='ir', n_styles=18, opts=None):
         super().__init__()
@@ -235,21 +185,6 @@ class ProgressiveBackboneEncoder(nn.Module):
     def set_progressive_stage(self, new_stage):
         self.progressive_stage = new_stage
 
-    def forward(self, x, **kwargs):
-        x = self.input_layer(x)
-        feats = [x]
-        for i, layer in enumerate(self.body):
-            x = layer(x)
-            if i in (2, 6, 20, 23):
-                feats.append(x)
-        w0 = self.styles[0](x)
-        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2)
-        for i in range(1, min(self.progressive_stage.value + 1, self.style_count)):
-            w[:, i] += self.styles[i](x)
-        if kwargs.get('return_feats', False):
-            return w, feats
-        return w
-
 
 class IBasicBlock(nn.Module):
     """Pre-activation basic block of the ArcFace IResNet (reference src/ops/FeatureStyle/arcface/iresnet.py:30-61):
@@ -268,16 +203,12 @@ class IBasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout, eps=1e-5))
         self.stride = stride
 
-    def forward(self, x):
-        out = self.bn3(self.conv2(self.prelu(self.bn2(self.conv1(self.bn1(x))))))
-        return out + (x if self.downsample is None else self.downsample(x))
-
 
 def _iresnet_stage(cin, cout, n):
     return nn.Sequential(IBasicBlock(cin, cout, 2), *[IBasicBlock(cout, cout, 1) for _ in range(n - 1)])
 
 
-class fs_encoder_v2(nn.Module):
+class fs_encoder_v2(_Container):
     """Feature-Style encoder (reference src/ops/FeatureStyle/feature_style_encoder.py:12-74): IResNet-50 trunk (stem +
     stages of 3/4/14/3 blocks), 3x3 adaptive-average-pooled descriptors of the four stages (64+128+256+512 channels x 9)
     -> ``n_styles`` Linear(8640, 512) heads; ``content_layer`` on the 256-channel stage; the stem and the first three
@@ -296,22 +227,3 @@ class fs_encoder_v2(nn.Module):
                                            nn.PReLU(512), nn.Conv2d(512, 512, 3, stride, 1, bias=False), nn.BatchNorm2d(512))
         self.avg_pool = nn.AdaptiveAvgPool2d((3, 3))
         self.styles = nn.ModuleList([nn.Linear(960 * 9, 512) for _ in range(n_styles)])
-
-    def forward(self, x, return_feats=False):
-        x = self.conv(x)
-        taps, pooled = [x], []
-        x = self.block_1(x)
-        taps.append(x)
-        pooled.append(self.avg_pool(x))
-        x = self.block_2(x)
-        taps.append(x)
-        pooled.append(self.avg_pool(x))
-        x = self.block_3(x)
-        taps.append(x)
-        content = self.content_layer(x)
-        pooled.append(self.avg_pool(x))
-        x = self.block_4(x)
-        pooled.append(self.avg_pool(x))
-        d = torch.cat(pooled, dim=1).flatten(1)
-        out = torch.stack([s(d) for s in self.styles], dim=1)
-        return (out, content, taps) if return_feats else (out, content)

@@ -6,9 +6,7 @@ from .modules import basicsr_to_rosinality_key
 
 
 def load_generator_checkpoint(generator, path, key='params_ema'):
-    ckpt = torch.load(path, map_location='cpu')
-    if isinstance(ckpt, dict) and key in ckpt:
-        ckpt = ckpt[key]
+    ckpt = torch.load(path, map_location='cpu')[key]       # KeyError for a wrong key, as the reference (:138)
     if any(k.startswith('style_mlp.') or k.startswith('style_conv1.') for k in ckpt):
         ckpt = {basicsr_to_rosinality_key(k): v for k, v in ckpt.items()}
     return generator.load_state_dict(ckpt, strict=False)

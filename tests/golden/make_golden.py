@@ -381,6 +381,57 @@ def gold_ood(B=1):
     return m, x, enc_lats, enc_feats, noises, out
 
 
+def _load_real(name, relpath):
+    """import ONE real reference file as module `name` (the package __init__ files pull cv2 / torchvision / lmdb)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def gold_imgio():
+    """Image I/O + PSNR of the harness from the REAL BasicSR functions: ``tensor2img`` / ``img2tensor``
+    (BasicSR/basicsr/utils/img_util.py:9-94) and ``calculate_psnr`` (basicsr/metrics/psnr_ssim.py:9-46 with
+    metric_util.py / matlab_functions.py).  cv2 is absent from the image: an EMPTY module stands in for the import, and only
+    code paths that never call it are exercised (no channel swap: rgb2bgr / bgr2rgb = False; single-channel masks).
+    ``calculate_ssim`` needs cv2.filter2D / getGaussianKernel: it stays unpinned."""
+    _stub('cv2')
+    sys.modules['torchvision.utils'].make_grid = None
+    _load_real('basicsr.utils.matlab_functions', 'BasicSR/basicsr/utils/matlab_functions.py')
+    sys.modules['basicsr.utils'].bgr2ycbcr = sys.modules['basicsr.utils.matlab_functions'].bgr2ycbcr
+    _stub('basicsr.metrics')
+    _load_real('basicsr.metrics.metric_util', 'BasicSR/basicsr/metrics/metric_util.py')
+    ps = _load_real('basicsr.metrics.psnr_ssim', 'BasicSR/basicsr/metrics/psnr_ssim.py')
+    iu = _load_real('basicsr.utils.img_util', 'BasicSR/basicsr/utils/img_util.py')
+    rng = np.random.default_rng(7)
+    g = {}
+    # values that land exactly on .5 after x255 (numpy rounds half to even), outside the clamp range, and random ones
+    k = np.arange(0, 48, dtype=np.float64)
+    halves = ((k + 0.5) / 255.0) * 2 - 1
+    t = np.concatenate([halves, [-1.3, 1.7, -1.0, 1.0, 0.0], rng.uniform(-1.1, 1.1, 3 * 20 * 21 - 53)]).astype(np.float32).reshape(3, 20, 21)
+    t = torch.from_numpy(t)
+    g['t'] = t
+    g['t2i_rgb_u8'] = iu.tensor2img(t.clone(), rgb2bgr=False, min_max=(-1, 1))
+    g['t2i_rgb_f32'] = iu.tensor2img(t.clone(), rgb2bgr=False, out_type=np.float32, min_max=(-1, 1))
+    g['t2i_batch1_u8'] = iu.tensor2img(t.clone().unsqueeze(0), rgb2bgr=False, min_max=(-1, 1))
+    m = torch.from_numpy(rng.uniform(-0.2, 1.2, (1, 20, 21)).astype(np.float32))
+    g['mask'] = m
+    g['t2i_mask_u8'] = iu.tensor2img(m.clone(), min_max=(0, 1))              # run_ood_faceGAN_inversion.py:84
+    img = rng.integers(0, 256, (20, 21, 3)).astype(np.float64) / 255.0
+    g['img_f64'] = img
+    g['i2t'] = iu.img2tensor(img.copy(), bgr2rgb=False, float32=True)
+    a = rng.integers(0, 256, (24, 28, 3)).astype(np.uint8)
+    b = np.clip(a.astype(np.float64) + rng.normal(0, 6, a.shape), 0, 255).round().astype(np.uint8)
+    g['psnr_a'], g['psnr_b'] = a, b
+    g['psnr_vals'] = np.array([ps.calculate_psnr(a, b, crop_border=0), ps.calculate_psnr(a, b, crop_border=4),
+                               ps.calculate_psnr(a, b, crop_border=4, test_y_channel=True),
+                               ps.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
+                               ps.calculate_psnr(a.astype(np.float64), b.astype(np.float64), crop_border=0, test_y_channel=True)])
+    save('imgio.npz', **g)
+
+
 def main():
     install_stubs()
     torch.set_num_threads(8)
@@ -407,6 +458,8 @@ def main():
         gold_featurestyle()
     if 'featin' in which:
         gold_features_in()
+    if 'imgio' in which:
+        gold_imgio()
 
 
 

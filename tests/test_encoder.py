@@ -1,10 +1,12 @@
-"""e4e encoder: the mirror module against vectors produced by the reference encoder
-(tests/golden/make_golden.py gold_encoder).  CPU test = structure/key parity + numerics of the restated
-graph; GPU test = the same module on ROCm and the end-to-end ``ood_faceGAN_e4e.forward(x)`` from an image."""
+"""e4e encoder against vectors produced by the reference encoder (tests/golden/make_golden.py
+gold_encoder).  CPU test = the parameter container's structure / key parity, checked numerically through the plain-torch
+restatement that lives in tests/ (torch_encoder_mirror.py); GPU tests = ``Encoder4EditingHIP`` (the product's forward) and
+the end-to-end ``ood_faceGAN_e4e.forward(x)`` from an image."""
 import pytest
 import torch
 
 from oodgan import synth
+import torch_encoder_mirror as TM
 
 
 def _build():
@@ -34,21 +36,11 @@ def test_encoder_cpu_vs_reference_golden(golden):
     enc = _build()
     x = synth.make_images(256, 1, seed=42)
     with torch.no_grad():
-        w, feats = enc(x, return_feats=True)
+        w, feats = TM.encoder4editing_forward(enc, x, return_feats=True)
     assert enc.channels == [64, 64, 128, 256, 512] and w.shape == (1, 18, 512)
     _check(w, feats, g, 1e-4)
-
-
-@pytest.mark.gpu
-def test_encoder_gpu_vs_reference_golden(golden):
-    g = golden('encoder_256.npz')
-    dev = torch.device('cuda:0')
-    enc = _build().to(dev)
-    x = synth.make_images(256, 1, seed=42).to(dev)
-    with torch.no_grad():
-        w, feats = enc(x, return_feats=True)
-    # MIOpen's fp32 convolution algorithms (Winograd / implicit GEMM) are not bit-compatible with oneDNN
-    _check(w, feats, g, 1e-4)
+    with pytest.raises(RuntimeError):          # the container itself has no compute path
+        enc(x)
 
 
 @pytest.mark.gpu

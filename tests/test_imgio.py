@@ -82,3 +82,27 @@ def test_mask_strip_matches_oracle():
     exp = (torch.cat(cols, dim=3)[0, 0].clamp(0, 1) * 255).round().numpy().astype(np.uint8)
     assert strip.shape == (64, 64 * 4) and np.array_equal(strip, exp)
     assert imgio.extract_masks({1: torch.rand(2)}) is None            # any failure -> None, like the reference
+
+
+def test_tensor2img_img2tensor_psnr_vs_reference_vectors(golden):
+    """Vectors produced by the REAL BasicSR functions (tests/golden/make_golden.py gold_imgio): the uint8 rounding rule of
+    ``tensor2img`` (x255 then numpy round = half to even, after the clamp), its float and batch-of-one paths, the
+    single-channel mask path of the CLI, ``img2tensor`` and ``calculate_psnr`` (crop, CHW order, BT.601 Y channel of a
+    BGR image, uint8 and float inputs).  The channel swap itself (cv2.cvtColor) and SSIM (cv2.filter2D) cannot be run
+    here — cv2 is absent — and stay unpinned."""
+    import numpy as np
+    z = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'imgio.npz'))
+    t = torch.from_numpy(z['t'])
+    assert np.array_equal(imgio.tensor2img(t.clone(), rgb2bgr=False, min_max=(-1, 1)), z['t2i_rgb_u8'])
+    assert np.array_equal(imgio.tensor2img(t.clone(), rgb2bgr=False, out_type=np.float32, min_max=(-1, 1)), z['t2i_rgb_f32'])
+    assert np.array_equal(imgio.tensor2img(t.clone().unsqueeze(0), rgb2bgr=False, min_max=(-1, 1)), z['t2i_batch1_u8'])
+    assert np.array_equal(imgio.tensor2img(t.clone(), rgb2bgr=True, min_max=(-1, 1)), z['t2i_rgb_u8'][:, :, ::-1])
+    assert np.array_equal(imgio.tensor2img(torch.from_numpy(z['mask']), min_max=(0, 1)), z['t2i_mask_u8'])
+    got = imgio.img2tensor(z['img_f64'].copy(), bgr2rgb=False, float32=True)
+    assert got.dtype == torch.float32 and torch.equal(got, torch.from_numpy(z['i2t']))
+    a, b, v = z['psnr_a'], z['psnr_b'], z['psnr_vals']
+    mine = [imgio.calculate_psnr(a, b, crop_border=0), imgio.calculate_psnr(a, b, crop_border=4),
+            imgio.calculate_psnr(a, b, crop_border=4, test_y_channel=True),
+            imgio.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
+            imgio.calculate_psnr(a.astype(np.float64), b.astype(np.float64), crop_border=0, test_y_channel=True)]
+    assert np.allclose(mine, v, rtol=1e-7, atol=0), (mine, v.tolist())

@@ -99,8 +99,9 @@ def test_fs_encoder_keys_and_cpu_forward_shapes():
     from oodgan.encoder import fs_encoder_v2
     enc = fs_encoder_v2(18, stride=(2, 2)).eval()
     enc.load_state_dict(synth.featurestyle_state(seed=61), strict=True)
+    import torch_encoder_mirror as TM
     with torch.no_grad():
-        lats, content, taps = enc(synth.make_images(64, 1, seed=5), return_feats=True)
+        lats, content, taps = TM.fs_encoder_forward(enc, synth.make_images(64, 1, seed=5), return_feats=True)
     assert lats.shape == (1, 18, 512) and content.shape == (1, 512, 4, 4)
     assert [tuple(t.shape[1:]) for t in taps] == [(64, 64, 64), (64, 32, 32), (128, 16, 16), (256, 8, 8)]
     assert enc.styles[0].weight.shape == (512, 960 * 9)
