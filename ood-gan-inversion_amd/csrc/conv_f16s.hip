@@ -35,6 +35,8 @@ int launch_s1_strip(const oodgan_conv_args& a, const void* wpk16, const float* u
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 bool s2_big_eligible(const oodgan_conv_args& a);
+bool t2_big_eligible(const oodgan_conv_args& a);
+int launch_t2_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 }
 
@@ -439,6 +441,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
             if (legacy_s1) return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
             return launch_s1pp(a, a.wpk, unscale2, st);
         case OODGAN_CONV_T2:
+            if (a.x_sform && t2_big_eligible(a)) return launch_t2_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_t2v2(a, a.wpk, unscale2, st);
             return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:

@@ -90,17 +90,19 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
 
-    auto dma_stage = [&](int t, int buf) {
+    // piece i of this wave for stage t (buffer buf); pieces are issued ONE AT A TIME between the MFMA groups of the
+    // previous stage: a global_load_lds costs the issuing wave ~60-180 cycles (MI355X_MICROARCH.md), and a burst of ten of
+    // them right after the barrier stalls every wave of the CU at once — DMA time and MFMA time then add up
+    auto dma_piece = [&](int t, int buf, int i) {
+        const int pc = wave + NW * i;
+        if (pc >= BG_PIECES) return;
         unsigned char* dst = smem + buf * BG_STAGE;
-        const unsigned char* xsrc = xb + (long)t * xplane_bytes;
-        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
+        const unsigned char* src = (pc < BG_XPIECES ? xb + (long)t * xplane_bytes : wb + (long)t * wchunk_bytes) + off[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
+    };
+    auto dma_stage = [&](int t, int buf) {
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int pc = wave + NW * i;
-            if (pc >= BG_PIECES) break;
-            const unsigned char* src = (pc < BG_XPIECES ? xsrc : wsrc) + off[i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < NPW; ++i) dma_piece(t, buf, i);
     };
 
     f32x16 acc[2][NT];
@@ -162,22 +164,27 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     for (int t = 0; t < nchunk; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nchunk && !(p.ablate & 2)) dma_stage(t + 1, (t + 1) & 1);
-        if (p.ablate & 1) continue;
+        const bool pf = t + 1 < nchunk && !(p.ablate & 2);
+        const int nb = (t + 1) & 1;
+        if (p.ablate & 1) { if (pf) dma_stage(t + 1, nb); continue; }
         const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * NT) * (BG_C * 64);
         const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES + lwf;
         Frag f0, f1;
+        static_assert(NPW <= 10, "one DMA piece per tap slot below");
+#define BG_DMA(i) if (pf && (i) < NPW) dma_piece(t + 1, nb, (i));
         load_tap(f0, lx, lw, BG_IC(0));
         BG_SB();
-        load_tap(f1, lx, lw, BG_IC(1)); BG_SB(); mfma_tap(f0); BG_SB();
-        load_tap(f0, lx, lw, BG_IC(2)); BG_SB(); mfma_tap(f1); BG_SB();
-        load_tap(f1, lx, lw, BG_IC(3)); BG_SB(); mfma_tap(f0); BG_SB();
-        load_tap(f0, lx, lw, BG_IC(4)); BG_SB(); mfma_tap(f1); BG_SB();
-        load_tap(f1, lx, lw, BG_IC(5)); BG_SB(); mfma_tap(f0); BG_SB();
-        load_tap(f0, lx, lw, BG_IC(6)); BG_SB(); mfma_tap(f1); BG_SB();
-        load_tap(f1, lx, lw, BG_IC(7)); BG_SB(); mfma_tap(f0); BG_SB();
-        load_tap(f0, lx, lw, BG_IC(8)); BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(1)); BG_DMA(0) BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(2)); BG_DMA(1) BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(3)); BG_DMA(2) BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(4)); BG_DMA(3) BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(5)); BG_DMA(4) BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(6)); BG_DMA(5) BG_SB(); mfma_tap(f1); BG_SB();
+        load_tap(f1, lx, lw, BG_IC(7)); BG_DMA(6) BG_SB(); mfma_tap(f0); BG_SB();
+        load_tap(f0, lx, lw, BG_IC(8)); BG_DMA(7) BG_SB(); mfma_tap(f1); BG_SB();
+        BG_DMA(8) BG_DMA(9) BG_SB();
         mfma_tap(f0);
+#undef BG_DMA
     }
 #undef BG_IC
 #undef BG_SB

@@ -488,3 +488,27 @@ def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, monkeypatch):
     dx3, dot3 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
     assert (dx3 - dx).abs().max().item() <= 1e-5 * dx.abs().max().item()
     assert (dot3 - dot).abs().max().item() <= 1e-4 * dot.abs().max().item()
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 48, 128, 9, 40), (2, 32, 96, 23, 31), (1, 80, 64, 8, 64)])
+def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, monkeypatch):
+    """Transposed stride-2 conv (the up-sampling ModulatedConv2d before its blur) from an S-form input through
+    conv_f16s_t2big.hip — ragged position grids, partial channel blocks — against conv_transpose2d and against the
+    4-wave kernel it replaces."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    monkeypatch.setenv('OODGAN_T2_BIG_MIN_ITEMS', '0')
+    x = synth.normal('t2b.x', (B, Ci, H, W), 1)
+    w = synth.normal('t2b.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
+    s = synth.normal('t2b.s', (B, Ci), 3, 0.3, 1.0)
+    d = synth.normal('t2b.d', (B, Co), 4, 0.3, 1.0)
+    xs = ops.to_sform(x.to(dev), s.to(dev))
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    ref = F.conv_transpose2d(x * s[:, :, None, None], w.transpose(0, 1), stride=2) * d[:, :, None, None]
+    z = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
+    close(z[..., :2 * W + 1], ref, 2e-4)
+    z2 = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
+    assert torch.equal(z2[..., :2 * W + 1], z[..., :2 * W + 1])
+    monkeypatch.setenv('OODGAN_T2_BIG_MIN_ITEMS', '1000000000')
+    z3 = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
+    assert (z3[..., :2 * W + 1] - z[..., :2 * W + 1]).abs().max().item() <= 1e-5 * ref.abs().max().item()

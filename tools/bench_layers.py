@@ -15,6 +15,7 @@ from oodgan import ops  # noqa: E402
 dev = torch.device('cuda:0')
 which = sys.argv[1].split(',') if len(sys.argv) > 1 else ['S1', 'T2', 'S2']
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+only = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else None      # resolutions
 CH = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
 
 
@@ -36,6 +37,8 @@ def report(tag, ms, flops, byts):
 
 
 for res in (8, 16, 32, 64, 128, 256, 512, 1024):
+    if only and res not in only:
+        continue
     cin, cout = CH[res // 2], CH[res]
     g = torch.Generator().manual_seed(res)
     if 'S1' in which:           # plain conv at `res`: cout -> cout
