@@ -111,35 +111,41 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     }
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + (long)b * p.sp.KC * 4 * p.sp.plane * 16;
     const long plane_bytes = p.sp.plane * 16;
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16) + ((long)m0 + lane) * 16;
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16) + (long)m0 * 16;     // uniform; the lane adds lane16
+    const unsigned lane16 = lane * 16;
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const long wrow_bytes = (long)p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
     const int nstage = 2 * nchunk;
 
-    // stage st = (chunk t = st>>1, py = st&1); weights: py 0 -> taps ky in {0,2} (LDS slot (ky>>1)*3 + kx), py 1 -> ky = 1
-    auto dma_stage = [&](int st) {
+    // stage st = (chunk t = st>>1, py = st&1); weights: py 0 -> taps ky in {0,2} (LDS slot (ky>>1)*3 + kx), py 1 -> ky = 1.
+    // Piece j of this wave: j < 5 -> x piece, else weight piece j-5.  Pieces are issued one at a time between the MFMA groups
+    // of the previous stage (a burst of 8-11 global_load_lds right after the barrier stalls every wave of the CU at once).
+    auto dma_piece = [&](int st, int j) {
         const int t = st >> 1, py = st & 1;
-        unsigned char* dx_ = smem + (py ? C::OFF_XB : C::OFF_XA);
-        unsigned char* dw_ = smem + (py ? C::OFF_WB : C::OFF_WA);
-        const unsigned char* xsrc = xb + ((long)t * 4 + py * 2) * plane_bytes;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + offx[i]),
-                                             (lds_void*)(dx_ + (wave + 8 * i) * 1024), 16, 0, 0);
-        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
-        const int nw = py ? C::WB : C::WA, npieces = (py ? 3 : 6) * C::PPT;
-#pragma unroll
-        for (int i = 0; i < C::WA; ++i) {
-            if (i >= nw) break;
-            int pw = wave + 8 * i;
-            if (pw >= npieces) pw -= 8;                    // MH = 1, stage B: waves 4-7 repeat a piece (uniform load count)
-            const int sl = pw / C::PPT, q = pw % C::PPT;
-            const int tap = py ? 3 + sl : (sl / 3) * 6 + sl % 3;
-            const int row = (q * 64) / C::MBW, j0 = (q * 64) % C::MBW;      // [hi|lo][k-half] row and channel offset of the piece
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long)(tap * 4 + row) * wrow_bytes + j0 * 16),
-                                             (lds_void*)(dw_ + pw * 1024), 16, 0, 0);
+        if (j < 5) {
+            unsigned char* dx_ = smem + (py ? C::OFF_XB : C::OFF_XA);
+            const unsigned char* xsrc = xb + ((long)t * 4 + py * 2) * plane_bytes;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + offx[j]),
+                                             (lds_void*)(dx_ + (wave + 8 * j) * 1024), 16, 0, 0);
+            return;
         }
+        const int i = j - 5;
+        const int nw = py ? C::WB : C::WA, npieces = (py ? 3 : 6) * C::PPT;
+        if (i >= nw) return;
+        unsigned char* dw_ = smem + (py ? C::OFF_WB : C::OFF_WA);
+        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
+        int pw = wave + 8 * i;
+        if (pw >= npieces) pw -= 8;                        // MH = 1, stage B: waves 4-7 repeat a piece (uniform load count)
+        const int sl = pw / C::PPT, q = pw % C::PPT;
+        const int tap = py ? 3 + sl : (sl / 3) * 6 + sl % 3;
+        const int row = (q * 64) / C::MBW, j0 = (q * 64) % C::MBW;      // [hi|lo][k-half] row and channel offset of the piece
+        const unsigned char* sb = wsrc + (long)(tap * 4 + row) * wrow_bytes + j0 * 16;      // scalar base + 32-bit lane offset
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + lane16), (lds_void*)(dw_ + pw * 1024), 16, 0, 0);
+    };
+    auto dma_stage = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < C::NA; ++j) dma_piece(st, j);
     };
 
     f32x16 acc[2][RW];
@@ -204,23 +210,32 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         const int py = st & 1;
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();
-        if (st + 1 < nstage && !(p.ablate & 2)) dma_stage(st + 1);
-        if (p.ablate & 1) continue;
+        const bool pf = st + 1 < nstage && !(p.ablate & 2);
+        if (p.ablate & 1) { if (pf) dma_stage(st + 1); continue; }
         const unsigned char* lx = smem + (py ? C::OFF_XB : C::OFF_XA);
         const unsigned char* lw = smem + (py ? C::OFF_WB : C::OFF_WA) + lwf;
         Frag f0, f1;
+        // MH = 2 runs at the 256-register limit: interleaving the pieces there costs spills (measured 261 -> 355 us), so it
+        // keeps the burst right after the barrier; MH = 1 interleaves (139 -> 125 us on the 64² -> 32² layer)
+        if (MH == 2 && pf) dma_stage(st + 1);
+#define S2B_DMA(j) if (MH == 1 && pf) dma_piece(st + 1, (j));
         load_tap(f0, lx, lw, S2B_IC(0));
         S2B_SB();
-        load_tap(f1, lx, lw, S2B_IC(1)); S2B_SB(); mfma_tap(f0); S2B_SB();
-        load_tap(f0, lx, lw, S2B_IC(2)); S2B_SB(); mfma_tap(f1); S2B_SB();
-        if (py == 0) {
-            load_tap(f1, lx, lw, S2B_IC(3)); S2B_SB(); mfma_tap(f0); S2B_SB();
-            load_tap(f0, lx, lw, S2B_IC(4)); S2B_SB(); mfma_tap(f1); S2B_SB();
-            load_tap(f1, lx, lw, S2B_IC(5)); S2B_SB(); mfma_tap(f0); S2B_SB();
+        if (py == 0) {      // 6 taps; prefetch the 5 + WB pieces of the following py = 1 stage
+            load_tap(f1, lx, lw, S2B_IC(1)); S2B_DMA(0) S2B_DMA(1) S2B_SB(); mfma_tap(f0); S2B_SB();
+            load_tap(f0, lx, lw, S2B_IC(2)); S2B_DMA(2) S2B_DMA(3) S2B_SB(); mfma_tap(f1); S2B_SB();
+            load_tap(f1, lx, lw, S2B_IC(3)); S2B_DMA(4) S2B_SB(); mfma_tap(f0); S2B_SB();
+            load_tap(f0, lx, lw, S2B_IC(4)); S2B_DMA(5) S2B_SB(); mfma_tap(f1); S2B_SB();
+            load_tap(f1, lx, lw, S2B_IC(5)); S2B_DMA(6) S2B_SB(); mfma_tap(f0); S2B_SB();
+            S2B_DMA(7) S2B_SB();
             mfma_tap(f1);
-        } else {
+        } else {            // 3 taps; prefetch the 5 + WA pieces of the following py = 0 stage
+            load_tap(f1, lx, lw, S2B_IC(1)); S2B_DMA(0) S2B_DMA(1) S2B_DMA(2) S2B_DMA(3) S2B_SB(); mfma_tap(f0); S2B_SB();
+            load_tap(f0, lx, lw, S2B_IC(2)); S2B_DMA(4) S2B_DMA(5) S2B_DMA(6) S2B_DMA(7) S2B_SB(); mfma_tap(f1); S2B_SB();
+            S2B_DMA(8) S2B_DMA(9) S2B_DMA(10) S2B_SB();
             mfma_tap(f0);
         }
+#undef S2B_DMA
     }
     __builtin_amdgcn_s_barrier();            // LDS is reused by the dot reduction below
 #undef S2B_IC

@@ -84,17 +84,16 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
 
+    // piece i of this wave for stage t; issued one at a time between the MFMA groups of the previous stage
+    auto dma_piece = [&](int t, int buf, int i) {
+        int pc = wave + 8 * i;
+        if (pc >= TB_PIECES) pc = TB_PIECES - 1;            // wave 7 repeats the last piece (uniform load count)
+        const unsigned char* src = (pc < TB_XPIECES ? xb + (long)t * xplane_bytes : wb + (long)t * wchunk_bytes) + off[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(smem + buf * TB_STAGE + pc * 1024), 16, 0, 0);
+    };
     auto dma_stage = [&](int t, int buf) {
-        unsigned char* dst = smem + buf * TB_STAGE;
-        const unsigned char* xsrc = xb + (long)t * xplane_bytes;
-        const unsigned char* wsrc = wb + (long)t * wchunk_bytes;
 #pragma unroll
-        for (int i = 0; i < TB_NPW; ++i) {
-            int pc = wave + 8 * i;
-            if (pc >= TB_PIECES) pc = TB_PIECES - 1;        // wave 7 repeats the last piece (uniform load count)
-            const unsigned char* src = (pc < TB_XPIECES ? xsrc : wsrc) + off[i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < TB_NPW; ++i) dma_piece(t, buf, i);
     };
 
     f32x16 acc[2][4];
@@ -145,7 +144,9 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
     for (int t = 0; t < nchunk; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nchunk) dma_stage(t + 1, (t + 1) & 1);
+        const bool pf = t + 1 < nchunk;
+        const int nb = (t + 1) & 1;
+#define TB_DMA(i) if (pf) dma_piece(t + 1, nb, (i));
         const unsigned char* lx = smem + (t & 1) * TB_STAGE;
         const unsigned char* lw = lx + TB_XBYTES + lwf;
 #pragma unroll
@@ -158,15 +159,16 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
         AFrag f0, f1;
         load_a(f0, lw, TB_IC(0));
         TB_SB();
-        load_a(f1, lw, TB_IC(1)); TB_SB(); mfma_tap(f0, TB_IC(0)); TB_SB();     // phase 0
-        load_a(f0, lw, TB_IC(3)); TB_SB(); mfma_tap(f1, TB_IC(1)); TB_SB();     // phase 1
-        load_a(f1, lw, TB_IC(4)); TB_SB(); mfma_tap(f0, TB_IC(3)); TB_SB();     // phase 2
-        load_a(f0, lw, TB_IC(2)); TB_SB(); mfma_tap(f1, TB_IC(4)); TB_SB();     // phase 3
-        load_a(f1, lw, TB_IC(7)); TB_SB(); mfma_tap(f0, TB_IC(2)); TB_SB();     // phase 0
-        load_a(f0, lw, TB_IC(5)); TB_SB(); mfma_tap(f1, TB_IC(7)); TB_SB();     // phase 1
-        load_a(f1, lw, TB_IC(6)); TB_SB(); mfma_tap(f0, TB_IC(5)); TB_SB();     // phase 2
+        load_a(f1, lw, TB_IC(1)); TB_DMA(0) TB_SB(); mfma_tap(f0, TB_IC(0)); TB_SB();     // phase 0
+        load_a(f0, lw, TB_IC(3)); TB_DMA(1) TB_SB(); mfma_tap(f1, TB_IC(1)); TB_SB();     // phase 1
+        load_a(f1, lw, TB_IC(4)); TB_DMA(2) TB_SB(); mfma_tap(f0, TB_IC(3)); TB_SB();     // phase 2
+        load_a(f0, lw, TB_IC(2)); TB_DMA(3) TB_SB(); mfma_tap(f1, TB_IC(4)); TB_SB();     // phase 3
+        load_a(f1, lw, TB_IC(7)); TB_DMA(4) TB_SB(); mfma_tap(f0, TB_IC(2)); TB_SB();     // phase 0
+        load_a(f0, lw, TB_IC(5)); TB_DMA(5) TB_SB(); mfma_tap(f1, TB_IC(7)); TB_SB();     // phase 1
+        load_a(f1, lw, TB_IC(6)); TB_DMA(6) TB_SB(); mfma_tap(f0, TB_IC(5)); TB_SB();     // phase 2
         load_a(f0, lw, TB_IC(8)); TB_SB(); mfma_tap(f1, TB_IC(6)); TB_SB();     // phase 0
         mfma_tap(f0, TB_IC(8));                                                 // phase 0 (its predecessor in phase 0 is 6 MFMAs back)
+#undef TB_DMA
     }
 #undef TB_IC
 #undef TB_SB
