@@ -566,13 +566,12 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
     p.tiles_x = (W + 31) / 32;
     p.xd = hform_dims(K, H, W);
     p.yd = hform_dims(M, H, W);
-    static const int no_vm4 = getenv("OODGAN_F16_NO_VM4") ? atoi(getenv("OODGAN_F16_NO_VM4")) : 0;
 #ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: 2 no stores, 4 no loads (wrong results)
     static const int ablate = getenv("OODGAN_F16_ABLATE") ? atoi(getenv("OODGAN_F16_ABLATE")) : 0;
 #else
     const int ablate = 0;
 #endif
-    p.flags = (no_vm4 ? 0 : 1) | ablate;
+    p.flags = 1 | ablate;          // bit 0: counted vmcnt waits
     const long T = (long)p.tiles_x * p.tiles_y * B;
     OODGAN_REQUIRE(T < (1L << 31), "modconv_f16: too many tiles");
     static int num_cu = 0;
@@ -585,7 +584,6 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
         }
         num_cu = prop.multiProcessorCount;
     }
-    static const int force_bpc = getenv("OODGAN_F16_BLOCKS_PER_CU") ? atoi(getenv("OODGAN_F16_BLOCKS_PER_CU")) : 0;
     const int KC = (K + 15) / 16;
 #define OODGAN_LAUNCH(KC_, LR_)                                                                                            \
     {                                                                                                                   \
@@ -597,16 +595,13 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, modconv_f16_kernel<KC_, LR_>, 256, sm) != hipSuccess || occ < 1) \
                 occ = 1;                                                                                                \
         }                                                                                                               \
-        static const bool dbg = getenv("OODGAN_DEBUG") != nullptr;                                                     \
-        if (dbg) fprintf(stderr, "modconv_f16: occupancy %d blocks/CU, %d CUs, smem %d\n", occ, num_cu, sm);            \
-        long g = (long)num_cu * (force_bpc ? force_bpc : occ);                                                          \
+        long g = (long)num_cu * occ;                                                                                    \
         g = (g + 7) / 8 * 8;                                                                                            \
         if (g > T) g = T;                                                                                               \
         hipLaunchKernelGGL((modconv_f16_kernel<KC_, LR_>), dim3((unsigned)g), dim3(256), sm, as_stream(stream), p);          \
     }
     const bool lr = act == OODGAN_ACT_LRELU;
-    static const int no_strip = getenv("OODGAN_F16_NO_STRIP") ? atoi(getenv("OODGAN_F16_NO_STRIP")) : 0;
-    if (KC == 2 && !no_strip) {
+    if (KC == 2) {
         // strips of 32 columns; cut into segments only when there are fewer strips than ~2 workgroups per CU
         StripArgs sa;
         sa.m = p;
@@ -615,8 +610,6 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
         if (nseg < 1) nseg = 1;
         int seg_tiles = (p.tiles_y + nseg - 1) / nseg;
         if (seg_tiles < 4) seg_tiles = p.tiles_y < 4 ? p.tiles_y : 4;
-        static const int force_seg = getenv("OODGAN_F16_SEG_TILES") ? atoi(getenv("OODGAN_F16_SEG_TILES")) : 0;
-        if (force_seg > 0) seg_tiles = force_seg < p.tiles_y ? force_seg : p.tiles_y;
         sa.seg_tiles = seg_tiles;
         sa.nseg = (p.tiles_y + seg_tiles - 1) / seg_tiles;
         const long nblk = strips * sa.nseg;
@@ -630,8 +623,7 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
         else hipLaunchKernelGGL((modconv_f16_strip_kernel<false>), dim3((unsigned)nblk), dim3(256), RG_SMEM, as_stream(stream), sa);
         return check_launch("modconv_f16_strip");
     }
-    if (KC == 2) { if (lr) OODGAN_LAUNCH(2, true) else OODGAN_LAUNCH(2, false) }
-    else { if (lr) OODGAN_LAUNCH(1, true) else OODGAN_LAUNCH(1, false) }
+    if (lr) OODGAN_LAUNCH(1, true) else OODGAN_LAUNCH(1, false)            // <= 16 input channels: the tile-order persistent kernel
 #undef OODGAN_LAUNCH
     return check_launch("modconv_f16");
 }

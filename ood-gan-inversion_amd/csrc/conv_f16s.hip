@@ -390,7 +390,7 @@ extern "C" int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sfo
 }
 
 extern "C" int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win) {
-    if (mode == OODGAN_CONV_S1) return ((Hin + 7) / 8) * ((Win + 31) / 32) * (getenv("OODGAN_S1_LEGACY") ? 4 : 1);
+    if (mode == OODGAN_CONV_S1) return ((Hin + 7) / 8) * ((Win + 31) / 32) ;
     if (mode == OODGAN_CONV_S2) return (((Hin - 1) / 2 + 7) / 8) * (((Win - 1) / 2 + 31) / 32) * 4;
     return 0;
 }
@@ -430,7 +430,6 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
     hipStream_t st = as_stream(stream);
-    static const bool legacy_s1 = getenv("OODGAN_S1_LEGACY") != nullptr;   // A/B switch: single-pipeline S1 kernel
     switch (a.mode) {
         case OODGAN_CONV_S1:
             if (a.x_sform && s1_strip_eligible(a)) return launch_s1_strip(a, a.wpk, unscale2, st);
@@ -438,7 +437,6 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
             if (a.x_sform && s1_big_eligible(a)) return launch_s1_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_s1v2(a, a.wpk, unscale2, st);
             OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");
-            if (legacy_s1) return launch_mode<OODGAN_CONV_S1>(a, a.wpk, unscale2, st);
             return launch_s1pp(a, a.wpk, unscale2, st);
         case OODGAN_CONV_T2:
             if (a.x_sform && t2_big_eligible(a)) return launch_t2_big(a, a.wpk, unscale2, st);

@@ -296,11 +296,10 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
     // per SIMD) it is slower than v2 (474 / 475 / 552): ablating its DMA does not change the time — the MFMA +
     // fragment-read stream of a single wave per SIMD runs at 31 ns per MFMA (a bare MFMA loop: 17-20 ns), two waves per
     // SIMD overlap each other's LDS waits.
-    const char* ek = getenv("OODGAN_S1_BIG_MIN_K");
     // In the inversion loop (rocprof, per launch): forward 397 us, input gradient with the dot epilogue 443 us, against
     // ~458 us for either v2 instance.  (The dot epilogue first cost 561 us: one conditional load per value serialised
     // 64 memory latencies; the loads of a row are now issued together.)
-    const int min_k = ek ? atoi(ek) : 64;      // 64 -> 64 channels @512²: 589 -> 491 us forward
+    const int min_k = 64;                // 64 -> 64 channels @512²: 589 -> 491 us forward
     if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr && a.in_shift == nullptr &&
           !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))

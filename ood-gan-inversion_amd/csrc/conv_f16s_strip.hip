@@ -354,8 +354,6 @@ namespace oodgan {
 
 // true when the strip kernel can take this call (launch_s1v2 remains the general path)
 bool s1_strip_eligible(const oodgan_conv_args& a) {
-    static const int off = getenv("OODGAN_S1_STRIP") ? atoi(getenv("OODGAN_S1_STRIP")) == 0 : 0;
-    if (off) return false;
     return a.mode == OODGAN_CONV_S1 && a.x_sform && a.K > 16 && a.K <= 32 && a.M > 16 && a.M <= 32 && a.ys == nullptr &&
            a.y != nullptr && (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr &&
            a.in_shift == nullptr && !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE));
@@ -396,8 +394,7 @@ int launch_s1_strip(const oodgan_conv_args& a_in, const void* wpk16, const float
     if (seg_tiles < 4) seg_tiles = p.tiles_y < 4 ? p.tiles_y : 4;
     p.seg_tiles = seg_tiles;
     p.nseg = (p.tiles_y + seg_tiles - 1) / seg_tiles;
-    static const int no_count = getenv("OODGAN_STRIP_NO_COUNT") ? atoi(getenv("OODGAN_STRIP_NO_COUNT")) : 0;
-    p.counted_wait = no_count ? 0 : 1;
+    p.counted_wait = 1;
     const long nblk = strips * p.nseg;
     OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 strip: grid too large");
     OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 strip: plane too large");

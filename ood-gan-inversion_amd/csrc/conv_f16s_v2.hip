@@ -829,14 +829,11 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     // few work items and a long K loop (the 4x4 ... 32x32 layers): at most one workgroup per CU, every stage is a bare
     // DMA latency and the tile's MFMAs all sit on one CU -> 32-channel M tiles (twice the workgroups) and two K chunks
     // per stage
-    static const int force_cps = getenv("OODGAN_V2_CPS") ? atoi(getenv("OODGAN_V2_CPS")) : 0;
     const long items64 = (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64);
-    const bool deep = force_cps ? force_cps == 2 : (items64 <= 256 && a.K >= 64);
+    const bool deep = items64 <= 256 && a.K >= 64;
     // < 128 input channels (the 512² layer): the single-group 64-channel instance needs 256 registers (two workgroups per
     // CU); 32-channel M tiles fit three and are 7 % faster although the x tile is fetched once per M block
-    static const int s1_mt2 = getenv("OODGAN_S1_MT2") ? atoi(getenv("OODGAN_S1_MT2")) : 0;
-    static const int s1_mt1 = getenv("OODGAN_S1_MT1") ? atoi(getenv("OODGAN_S1_MT1")) : 0;
-    const bool mt2 = a.M > 32 && !deep && (a.K >= 128 || s1_mt2) && !s1_mt1;
+    const bool mt2 = a.M > 32 && !deep && a.K >= 128;
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {
@@ -859,8 +856,7 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     const int items = (int)total;
     // NG = 2: two anti-phase pipelines per 512-thread workgroup (1 workgroup per CU); NG = 1: independent 256-thread
     // workgroups, 2-3 per CU — better when K is small and the epilogue dominates (it then overlaps other blocks)
-    static const int force_ng = getenv("OODGAN_V2_GROUPS") ? atoi(getenv("OODGAN_V2_GROUPS")) : 0;
-    const int ng = force_ng ? force_ng : (a.K >= 128 ? 2 : 1);
+    const int ng = a.K >= 128 ? 2 : 1;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
 #define OODGAN_LAUNCH(MT_, NG_, CPS_)                                                                                    \
     {                                                                                                                    \
@@ -872,9 +868,7 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                                \
         hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_, CPS_>), grid, block, sm, st, p, w16, items, sc);             \
     }
-    static const int deep_cps = getenv("OODGAN_V2_DEEP_CPS") ? atoi(getenv("OODGAN_V2_DEEP_CPS")) : 2;   // 3 chunks per stage measured equal: these layers are MFMA-bound on their padded tiles
-    if (deep && deep_cps == 3) OODGAN_LAUNCH(1, 1, 3)
-    else if (deep) OODGAN_LAUNCH(1, 1, 2)
+    if (deep) OODGAN_LAUNCH(1, 1, 2)          // 3 chunks per stage measured equal: these layers are MFMA-bound on their padded tiles
     else if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2, 1) else OODGAN_LAUNCH(2, 1, 1) }
     else { if (ng == 2) OODGAN_LAUNCH(1, 2, 1) else OODGAN_LAUNCH(1, 1, 1) }
 #undef OODGAN_LAUNCH
@@ -900,9 +894,7 @@ int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     // few tiles (low-resolution layers): 32-channel M tiles put twice as many CUs to work on the same K loop
     // 32-channel M tiles: the 64-channel instance needs 276 registers (accumulators of 4 output phases x 2 M tiles), i.e.
     // one workgroup per CU; the 32-channel one fits three (140 registers, 32 KB of LDS) and is 30-35 % faster
-    static const int t2_mt2 = getenv("OODGAN_T2_MT2") ? atoi(getenv("OODGAN_T2_MT2")) : 0;
-    const bool mt2 = t2_mt2 && a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;
-    const int MB = mt2 ? 64 : 32;
+    const int MB = 32;
     p.mblocks = (a.M + MB - 1) / MB;
     SConv sc;
     sc.xs = reinterpret_cast<const uint4*>(a.x);
@@ -912,13 +904,8 @@ int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     dim3 grid((unsigned)total), block(256);
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (mt2) {
-        constexpr int sm = T2_XBYTES + 36 * 64 * 16;
-        hipLaunchKernelGGL((conv_f16s_t2v2_kernel<2>), grid, block, sm, st, p, w16, sc);
-    } else {
-        constexpr int sm = T2_XBYTES + 36 * 32 * 16;
-        hipLaunchKernelGGL((conv_f16s_t2v2_kernel<1>), grid, block, sm, st, p, w16, sc);
-    }
+    constexpr int sm = T2_XBYTES + 36 * 32 * 16;
+    hipLaunchKernelGGL((conv_f16s_t2v2_kernel<1>), grid, block, sm, st, p, w16, sc);
     return check_launch("conv3x3_f16s_t2v2");
 }
 
@@ -936,8 +923,7 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.tiles_y = (p.Hn + 7) / 8;
     p.tiles_x = (p.Wn + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
-    static const int s2_mt1 = getenv("OODGAN_S2_MT1") ? atoi(getenv("OODGAN_S2_MT1")) : 0;
-    const bool mt2 = !s2_mt1 && a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;    // as in launch_t2v2
+    const bool mt2 = a.M > 32 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) > 256;    // as in launch_t2v2
     const int MB = mt2 ? 64 : 32;
     p.mblocks = (a.M + MB - 1) / MB;
     if (a.dotx) {
@@ -954,7 +940,6 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     const int items = (int)total;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    static const int s2_ng = getenv("OODGAN_S2_GROUPS") ? atoi(getenv("OODGAN_S2_GROUPS")) : 2;
 #define OODGAN_LAUNCH(MT_, NG_)                                                                                    \
     {                                                                                                              \
         constexpr int sm = NG_ * s2_group_bytes<MT_>();                                                            \
@@ -965,8 +950,7 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         hipLaunchKernelGGL((conv_f16s_s2v2_kernel<MT_, NG_>), grid, block, sm, st, p, w16, items, sc, sp);         \
     }
     // few tiles (low-resolution layers, already on 32-channel M tiles): one stage per channel chunk instead of two
-    static const int s2_pym = getenv("OODGAN_S2_PYM") ? atoi(getenv("OODGAN_S2_PYM")) : 1;
-    if (!mt2 && s2_pym && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) <= 256 && a.K >= 64) {
+    if (!mt2 && (long)p.tiles_x * p.tiles_y * a.B * ((a.M + 63) / 64) <= 256 && a.K >= 64) {
         constexpr int sm = 2 * S2_XBYTES + 9 * 4 * 32 * 16;
         static bool once1 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2v2_kernel<1, 1, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
@@ -974,8 +958,7 @@ int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         hipLaunchKernelGGL((conv_f16s_s2v2_kernel<1, 1, true>), dim3((unsigned)total), dim3(256), sm, st, p, w16, items, sc, sp);
         return check_launch("conv3x3_f16s_s2v2");
     }
-    if (s2_ng == 1) { if (mt2) OODGAN_LAUNCH(2, 1) else OODGAN_LAUNCH(1, 1) }
-    else { if (mt2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(1, 2) }
+    if (mt2) OODGAN_LAUNCH(2, 2) else OODGAN_LAUNCH(1, 2)
 #undef OODGAN_LAUNCH
     return check_launch("conv3x3_f16s_s2v2");
 }

@@ -253,10 +253,13 @@ class ood_faceGAN_e4e(nn.Module):
         return out
 
     # ---------------------------------------------------------------- build-defined: W+ refinement
-    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, use_graph=False, **kwargs):
+    def invert(self, x, steps=100, lr=0.01, noise=None, streams=2, use_graph=False, **kwargs):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
-        latents (masks + blend).  Returns (out, lats, losses[steps,B])."""
+        latents (masks + blend).  Returns (out, lats, losses[steps,B]).
+        ``streams``: the batch is advanced as that many independent sub-batches on concurrent HIP streams (images are
+        independent; the HBM-bound layout kernels of one sub-batch run beside the matrix kernels of the other: +6-8 %
+        at batch 8, bit-reproducible — DESIGN.md §10); 1 = every kernel owns the GPU."""
         lats0, enc_feats = self.encode(x, **kwargs)
         B = x.shape[0]
         if noise is None:

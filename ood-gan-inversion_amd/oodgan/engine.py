@@ -77,20 +77,20 @@ class GeneratorEngine:
             rgb(f'to_rgbs.{j}', cout, res, i + 2)
             cin, i = cout, i + 2
         self.layers = layers
-        import os
-        # fused backward producers (csrc/bwd_producers.hip): per-layer range scale carried from one W+ step to the next
-        self.fused_bwd = os.environ.get('OODGAN_FUSED_BWD', '1') != '0'
+        # fused backward producers (csrc/bwd_producers.hip): per-layer range scale carried from one W+ step to the next;
+        # the flags below exist for the exact-scale fallback and for A/B tests (tests flip them on the instance)
+        self.fused_bwd = True
         self.bwd_state, self.bwd_flag = {}, None
         styled = [L for L in layers if L.kind != 'rgb']
-        self.fused_fwd = os.environ.get('OODGAN_FUSED_FWD', '1') != '0'
+        self.fused_fwd = True
         self.next_conv = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b.kind == 'conv'}
         # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
         self.rgb_next_up = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'rgb' and b.kind == 'up'}
         self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
         self.by_name = {L.name: L for L in layers}
         self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
-        self.fused_rgb = os.environ.get('OODGAN_FUSED_RGB', '1') != '0'
-        self.batched_tail = os.environ.get('OODGAN_BATCHED_TAIL', '1') != '0'
+        self.fused_rgb = True
+        self.batched_tail = True
         src = 'input'
         for L in layers:            # producer of every layer's input feature
             L.src = src
@@ -443,10 +443,6 @@ class GeneratorEngine:
         return ops.style_affine_backward(gs_all, self.wcat, self.lat_start, self.n_latent, grad_div=grad_scale)
 
 
-import os as _os
-_DBG_SERIAL = _os.environ.get('OODGAN_GRAPH_SERIAL', '0') == '1'
-
-
 _SIDE = {}
 
 
@@ -526,8 +522,6 @@ class WPlusInverter:
                 with torch.cuda.stream(st):
                     if graphs[i] is not None:
                         graphs[i].replay()
-                        if _DBG_SERIAL:
-                            st.synchronize()
                         parts[i]['lbuf'][t - 1].copy_(parts[i]['lstat'])
                     else:
                         parts[i]['lbuf'][t - 1].copy_(one_step(parts[i], engines[i]))

@@ -360,7 +360,6 @@ def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
     import torch.nn.functional as F
     from oodgan import ops
     monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1')
-    monkeypatch.setenv('OODGAN_S1_BIG_MIN_K', '128')
     x = synth.normal('bg.x', (B, Ci, H, W), 1)
     w = synth.normal('bg.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
     s = synth.normal('bg.s', (B, Ci), 3, 0.3, 1.0)
