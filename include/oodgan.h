@@ -337,6 +337,11 @@ int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s
 int oodgan_rgb_finish(const float* partial, const float* bias, const float* skip, const float* kernel, float* y, int B, int H,
                       int W, void* stream);
 
+/* feature_modulation(gen_feats, conditions, None, mod_type) (src/ops/StyleGAN/model.py:588-610; called from
+ * Generator.forward :558-566 and StyleGAN2Generator.forward, stylegan2_arch.py:583-588, for cond_type != 'NOISE'), clss = 1:
+ * mode 0 'SFT'  y = x*(1 + c0) + c1;  1 'ADD'  y = x + c1 (c0 may be NULL);  2 'FUSE'  y = x + c1*sigmoid(c0).  n elements. */
+int oodgan_feature_modulation(const float* x, const float* c0, const float* c1, float* y, long n, int mode, void* stream);
+
 /* Backward through (bias + noise + lrelu*sqrt2) of one StyledConv, merged with the ToRGB branch that
  * reads the same feature (build-defined W+ loop):
  *   t[b,c,p]   = rgb_scale * sum_k w_rgb[k,c]*g_rgb[b,k,p]                (0 if g_rgb NULL)

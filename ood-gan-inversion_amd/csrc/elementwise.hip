@@ -315,6 +315,28 @@ extern "C" int oodgan_bias_act_bwd(const float* gy, const float* y, float* gx, f
     return check_launch("bias_act_bwd/gbias");
 }
 
+namespace {
+// feature_modulation (reference src/ops/StyleGAN/model.py:588-610), clss = 1: mode 0 SFT y = x*(1+c0) + c1,
+// 1 ADD y = x + c1, 2 FUSE y = x + c1*sigmoid(c0)
+__global__ __launch_bounds__(256) void feature_modulation_kernel(const float* __restrict__ x, const float* __restrict__ c0,
+                                                                 const float* __restrict__ c1, float* __restrict__ y, long n, int mode) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i], b = c1[i];
+        float o;
+        if (mode == 0) o = v * (1.f + c0[i]) + b;
+        else if (mode == 1) o = v + b;
+        else o = v + b * (1.f / (1.f + expf(-c0[i])));
+        y[i] = o;
+    }
+}
+}  // namespace
+
+extern "C" int oodgan_feature_modulation(const float* x, const float* c0, const float* c1, float* y, long n, int mode, void* stream) {
+    OODGAN_REQUIRE(x && c1 && y && n > 0 && mode >= 0 && mode <= 2 && (mode == 1 || c0), "feature_modulation: bad args");
+    hipLaunchKernelGGL(feature_modulation_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), x, c0, c1, y, n, mode);
+    return check_launch("feature_modulation");
+}
+
 extern "C" int oodgan_act_bwd_nparts(long HW) { return (int)((HW + kActChunk - 1) / kActChunk); }
 
 extern "C" int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float* noise, int noise_batch,

@@ -110,6 +110,7 @@ _SIGS = {
     'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),
+    'oodgan_feature_modulation': (c_int, [P, P, P, P, c_long, c_int, P]),
     'oodgan_act_bwd_fused_max': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_absmax_scale': (c_int, [P, c_long, P, P]),
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),

@@ -173,16 +173,18 @@ class GeneratorEngine:
         return ops.style_affine(latent, self.wcat, self.bcat, self.row_lat)
 
     def forward(self, latent, noises, save=False, cond_hook=None, cond_layers=None, return_features=False, features_in=None,
-                feature_scale=1.0, range_mode='exact'):
+                feature_scale=1.0, range_mode='exact', post_hook=None):
         """latent (B,n_latent,S); noises list[num_layers] of (B|1,1,r,r).
         cond_hook(k, raw, latent_i, noise, noise_w) -> cond tensor replacing the raw up-conv output
         (the algebra of OOD_faceGAN_e4e_arch.py:239-242 + model.py:292: layer = cond + w*noise).
         features_in[i] (or None), feature_scale: `insert_feature` of the Feature-Style variant (model.py:541-546,557,572):
         the input of the styled conv that reads latent i becomes (1-fs)*x + fs*features_in[i].
+        post_hook(k, out) -> tensor replacing the ACTIVATED output of the up-conv reading latent cond_layers[k]
+        (feature_modulation for cond_type 'SFT' / 'ADD' / 'FUSE', model.py:558-566).
         range_mode (split-f16 only, ops.FwdRange): 'exact' measures max|x*s| of every conv input before converting it;
         'carry' (the W+ loop) uses the scales of the previous forward with the fused producers and verifies them."""
-        if save and features_in is not None:
-            raise NotImplementedError('backward through an injected feature is not part of the path')
+        if save and (features_in is not None or post_hook is not None):
+            raise NotImplementedError('backward through an injected feature / feature modulation is not part of the path')
         B = latent.shape[0]
         s_all = self.styles(latent)
         d_all = torch.empty(B, self.DR, device=self.device, dtype=torch.float32)
@@ -202,7 +204,7 @@ class GeneratorEngine:
         s_use, d_use = s_all, d_all
         if self.sform:
             rng = self._range(B)
-            carry = range_mode == 'carry' and rng.valid and self.carry_range and cond_hook is None and features_in is None
+            carry = range_mode == 'carry' and rng.valid and self.carry_range and cond_hook is None and features_in is None and post_hook is None
             if carry:
                 rng.plan(s_all, d_all)
             s_use, d_use = rng.s_sc, rng.d_sc
@@ -296,6 +298,9 @@ class GeneratorEngine:
                     out = ops.blur_bias_act(z, self.k4x4, (1, 1), L.bias, nz, L.noise_w, act=True, in_hw=(H2, H2),
                                             in_pitch=z.shape[3])
                 del z
+                if post_hook is not None and cond_layers is not None and lat_idx in cond_layers:
+                    out = post_hook(cond_layers.index(lat_idx), out)
+                    pending = None
             acts[L.name] = out
         if rng is not None:
             if carry:

@@ -296,10 +296,21 @@ class Generator(nn.Module):
         latent = latent.contiguous().float()
         B = latent.shape[0]
         hook = None
+        post = None
         cl = None
-        if cond_layers is not None and conditions is not None:
-            if cond_type != 'NOISE':
-                raise NotImplementedError("only cond_type='NOISE' (the OOD inversion path) is implemented")
+        if cond_layers is not None and conditions is not None and cond_type != 'NOISE':
+            # model.py:561-564: the styled conv runs as usual, then feature_modulation(out, condition, None, cond_type)
+            cl = list(cond_layers)
+            cb = kwargs.get('callback', None)
+
+            def post(k, out):
+                cond = conditions[k]
+                if cond_type == 'ADD' and cb is not None:        # feature_modulation's 'ADD' branch asks the callback
+                    kw = dict(kwargs)
+                    kw.update({'style': latent[:, cl[k]], 'index': k})
+                    return ops.feature_modulation(out, [None, cb(out, **kw)], None, 'ADD')
+                return ops.feature_modulation(out, cond, None, cond_type)
+        elif cond_layers is not None and conditions is not None:
             cl = list(cond_layers)
             direct = kwargs.get('cond_hook', None)
             cb = kwargs.get('callback', None)
@@ -316,7 +327,7 @@ class Generator(nn.Module):
                 if conditions[k] is not None and len(conditions[k]) > 1 and conditions[k][1] is not None:
                     noise[i] = conditions[k][1]
         noises = self._draw_noises(B, noise, randomize_noise)
-        image, feat = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=True,
+        image, feat = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=True, post_hook=post,
                                             features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
         if return_latents:
             return image, latent
@@ -416,11 +427,12 @@ class StyleGAN2Generator(nn.Module):
     def forward(self, styles, input_is_latent=False, input_is_tensor=False, noise=None, randomize_noise=True, truncation=1,
                 truncation_latent=None, inject_index=None, return_latents=False, conditions=None, cond_layers=None,
                 cond_weights=None, cond_type='SFT'):
-        if cond_layers is not None and conditions is not None:
-            raise NotImplementedError('SFT/ADD feature modulation of the BasicSR flavour is not on the OOD path')
+        if cond_layers is not None and conditions is not None and cond_type == 'NOISE':
+            raise NotImplementedError('unknown mod_type NOISE')      # feature_modulation raises the same (stylegan2_arch.py:594)
         # reference quirk (stylegan2_arch.py:555,570): input_is_latent alone skips the MLP *and* the broadcast
         if input_is_latent and not input_is_tensor:
             input_is_tensor = True
         return self._inner[0](styles, return_latents=return_latents, inject_index=inject_index, truncation=truncation,
                               truncation_latent=truncation_latent, input_is_latent=input_is_latent,
-                              input_is_tensor=input_is_tensor, noise=noise, randomize_noise=randomize_noise)
+                              input_is_tensor=input_is_tensor, noise=noise, randomize_noise=randomize_noise,
+                              conditions=conditions, cond_layers=cond_layers, cond_type=cond_type)

@@ -131,6 +131,27 @@ def blur_bias_act(x, kernel, pad, bias=None, noise=None, noise_weight=None, act=
     return y
 
 
+_MOD_TYPES = {'SFT': 0, 'ADD': 1, 'FUSE': 2}
+
+
+def feature_modulation(gen_feats, conditions, clss=None, mod_type='SFT'):
+    """reference: feature_modulation(gen_feats, conditions, clss=None, mod_type='SFT') (src/ops/StyleGAN/model.py:588-610);
+    ``clss`` other than None is not used by any caller.  conditions = [c0, c1] tensors of gen_feats' shape."""
+    if clss is not None:
+        raise NotImplementedError('feature_modulation: clss is None at every call site of the reference')
+    if mod_type not in _MOD_TYPES:
+        raise NotImplementedError(f'unknown mod_type {mod_type}')
+    x = _dev(gen_feats)
+    c1 = _dev(conditions[1], 'conditions[1]')
+    c0 = None if (mod_type == 'ADD' or conditions[0] is None) else _dev(conditions[0], 'conditions[0]')
+    if c1.shape != x.shape or (c0 is not None and c0.shape != x.shape):
+        c1 = c1.expand_as(x).contiguous()
+        c0 = None if c0 is None else c0.expand_as(x).contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().oodgan_feature_modulation(_p(x), _p(c0), _p(c1), _p(y), x.numel(), _MOD_TYPES[mod_type], _stream()), 'feature_modulation')
+    return y
+
+
 # ----------------------------------------------------------------------------- style path
 def style_affine(latent, wcat, bcat=None, row_lat=None, lr_mul=1.0):
     """s[b,r] = (1/sqrt(S)) * lr_mul * W[r]·latent[b,row_lat[r]] + bias[r]*lr_mul  (EqualLinear, model.py:129-158)."""

@@ -133,8 +133,19 @@ def to_rgb(P, prefix, x, w_lat, skip=None, blur_taps=(1, 3, 3, 1)):
 
 
 # --------------------------------------------------------------------------- Generator (A11 + loop)
+def feature_modulation(gen_feats, conditions, mod_type='SFT'):
+    """reference model.py:588-610 with clss=None (-> 1); FUSE does not mutate ``conditions`` here."""
+    if mod_type == 'SFT':
+        return gen_feats * (1 + conditions[0]) + conditions[1]
+    if mod_type == 'ADD':
+        return gen_feats + conditions[1]
+    if mod_type == 'FUSE':
+        return gen_feats + conditions[1] * torch.sigmoid(conditions[0])
+    raise NotImplementedError(f'unknown mod_type {mod_type}')
+
+
 def generator_forward(P, latent, noises, size, prefix='', cond_layers=None, hook=None,
-                      return_features=False):
+                      return_features=False, post_hook=None):
     """``Generator.forward(latent, input_is_tensor=True, input_is_latent=True, noise=noises, ...)``.
     reference model.py:548-585.  ``latent`` (B, n_latent, style_dim); ``noises`` list of
     (B|1,1,r,r).  For layer index i in ``cond_layers`` the up-conv runs with
@@ -153,6 +164,8 @@ def generator_forward(P, latent, noises, size, prefix='', cond_layers=None, hook
             k = cond_layers.index(i)
             h = (lambda raw, wl, nz, nw, _k=k: hook(_k, raw, wl, nz, nw))
         out = styled_conv(P, f'{prefix}convs.{2 * j}', out, latent[:, i], noises[2 * j + 1], True, h)
+        if cond_layers is not None and post_hook is not None and i in cond_layers:      # cond_type != 'NOISE' (model.py:561-564)
+            out = post_hook(cond_layers.index(i), out)
         feats.append(out)
         out = styled_conv(P, f'{prefix}convs.{2 * j + 1}', out, latent[:, i + 1], noises[2 * j + 2])
         feats.append(out)

@@ -381,6 +381,30 @@ def gold_ood(B=1):
     return m, x, enc_lats, enc_feats, noises, out
 
 
+def gold_cond_types(size=32):
+    """Generator.forward with conditions on the up-convs reading latents 1 and 3 for cond_type 'SFT' / 'ADD' / 'FUSE'
+    (feature_modulation, model.py:558-566,588-610) and StyleGAN2Generator.forward with the same conditions
+    (stylegan2_arch.py:583-595).  A fresh copy of the conditions goes into every call ('FUSE' overwrites conditions[0])."""
+    from src.ops.StyleGAN.model import Generator
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(synth.generator_state(size, seed=5), strict=True)
+    B = 2
+    lat = synth.make_latents(size, B, seed=6)
+    noises = synth.make_noises(size, B, seed=7)
+    conds = lambda: [[synth.normal(f'cond.{k}.0', (B, 512, r, r), 9, 0.5), synth.normal(f'cond.{k}.1', (B, 512, r, r), 10, 0.5)] for k, r in ((0, 8), (1, 16))]
+    g = {}
+    with torch.no_grad():
+        for ct in ('SFT', 'ADD', 'FUSE'):
+            img, feat = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True, conditions=conds(),
+                          cond_layers=[1, 3], cond_type=ct)
+            g[f'image_{ct}'] = img
+            g[f'feat_{ct}_sub'] = feat[:, ::16]
+        cb = lambda feats, **kw: conds()[kw['index']][0] * 0.25 + kw['style'][:, :1, None, None]
+        img, _ = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, conditions=conds(), cond_layers=[1, 3], cond_type='ADD', callback=cb)
+        g['image_ADD_callback'] = img
+    save(f'cond_types_s{size}.npz', **g)
+
+
 def _load_real(name, relpath):
     """import ONE real reference file as module `name` (the package __init__ files pull cv2 / torchvision / lmdb)."""
     import importlib.util
@@ -460,6 +484,8 @@ def main():
         gold_features_in()
     if 'imgio' in which:
         gold_imgio()
+    if 'cond' in which:
+        gold_cond_types()
 
 
 

@@ -307,3 +307,36 @@ def test_engine_cache_follows_weight_changes(dev):
         m.generator.conv1.activate.bias.add_(0.25)
     img_c = run()
     assert (img_c - img_b).abs().max().item() > 1e-3
+
+
+def test_cond_types_sft_add_fuse_vs_golden(dev, golden):
+    """Generator.forward / StyleGAN2Generator.forward with ``conditions`` for cond_type 'SFT', 'ADD' (with and without the
+    callback) and 'FUSE' (feature_modulation, model.py:558-566,588-610; stylegan2_arch.py:583-595) against vectors
+    produced by the reference Generator."""
+    from oodgan.modules import Generator, StyleGAN2Generator
+    size, B = 32, 2
+    g = golden('cond_types_s32.npz')
+    ros = synth.generator_state(size, seed=5)
+    G = Generator(size, 512, 8)
+    G.load_state_dict(ros, strict=True)
+    G = G.to(dev).eval()
+    G2 = StyleGAN2Generator(size)
+    G2.load_state_dict({G2._ros_to_basicsr(k): v for k, v in ros.items() if not k.endswith('.kernel')}, strict=True)
+    G2 = G2.to(dev)
+    lat = synth.make_latents(size, B, seed=6).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    conds = lambda: [[synth.normal(f'cond.{k}.0', (B, 512, r, r), 9, 0.5).to(dev), synth.normal(f'cond.{k}.1', (B, 512, r, r), 10, 0.5).to(dev)]
+                     for k, r in ((0, 8), (1, 16))]
+    for ct in ('SFT', 'ADD', 'FUSE'):
+        img, feat = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True, conditions=conds(),
+                      cond_layers=[1, 3], cond_type=ct)
+        ref = g[f'image_{ct}']
+        assert maxdiff(img, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), ct
+        assert maxdiff(feat[:, ::16], g[f'feat_{ct}_sub']) <= 1e-4 * max(1.0, g[f'feat_{ct}_sub'].abs().max().item())
+        img2, _ = G2(lat, input_is_latent=True, noise=noises, conditions=conds(), cond_layers=[1, 3], cond_type=ct)
+        assert maxdiff(img2, ref) <= 1e-4 * max(1.0, ref.abs().max().item()), ct
+    cb = lambda feats, **kw: conds()[kw['index']][0] * 0.25 + kw['style'][:, :1, None, None]
+    img, _ = G(lat, input_is_tensor=True, input_is_latent=True, noise=noises, conditions=conds(), cond_layers=[1, 3], cond_type='ADD', callback=cb)
+    assert maxdiff(img, g['image_ADD_callback']) <= 1e-4 * max(1.0, g['image_ADD_callback'].abs().max().item())
+    with pytest.raises(NotImplementedError):
+        G2(lat, input_is_latent=True, noise=noises, conditions=conds(), cond_layers=[1, 3], cond_type='NOISE')

@@ -154,3 +154,18 @@ def test_ood_forward_1024(golden):
     strip = R.extract_masks(aligns)
     close(strip[:, :, ::16, ::16], g['mask_strip_sub'], tol)
     close(strip[:, :, 500:502, :], g['mask_strip_rows'], tol)
+
+
+def test_cond_types_vs_reference(golden):
+    """feature_modulation conditioning (cond_type 'SFT' / 'ADD' / 'FUSE', model.py:558-566,588-610) of the oracle."""
+    g = golden('cond_types_s32.npz')
+    P = synth.generator_state(32, seed=5)
+    B = 2
+    lat, noises = synth.make_latents(32, B, seed=6), synth.make_noises(32, B, seed=7)
+    conds = [[synth.normal(f'cond.{k}.0', (B, 512, r, r), 9, 0.5), synth.normal(f'cond.{k}.1', (B, 512, r, r), 10, 0.5)] for k, r in ((0, 8), (1, 16))]
+    with torch.no_grad():
+        for ct in ('SFT', 'ADD', 'FUSE'):
+            img, feats = R.generator_forward(P, lat, noises, 32, cond_layers=[1, 3], return_features=True,
+                                             post_hook=lambda k, out, ct=ct: R.feature_modulation(out, conds[k], ct))
+            close(img, g[f'image_{ct}'], 1e-4)
+            close(feats[-1][:, ::16], g[f'feat_{ct}_sub'], 1e-4)
