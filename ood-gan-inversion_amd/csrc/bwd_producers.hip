@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "sform.hpp"
 #include <cstdint>
+#include <cstdlib>
 
 using namespace oodgan;
 
@@ -400,6 +401,282 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// STRIP WALK of the same producer (no ToRGB branch: every up-sampling layer of the generator).
+// The tile kernel above fetches an 11 x 72 input tile for every 8 x 64 interior (1.55x, and PMC shows 1.41x of the
+// algorithmic bytes reaching HBM) and only loads during the first of its three phases.  Here a workgroup owns
+// (b, 16-channel block, 64 g columns = 32 positions) and walks DOWN a segment of position rows:
+//   * one iteration = position row i = g2 rows 2i, 2i+1; it consumes the two NEW g rows 2i+1, 2i+2 (72 columns incl. the
+//     horizontal halo: 1.125x), whose loads were issued one iteration earlier (register prefetch);
+//   * activation gradient on arrival -> LDS row buffer -> the four horizontal 4-tap passes of the row (any 4x4 kernel, no
+//     rank-1 assumption) are added to three PENDING output rows kept in registers (no vertical halo re-read, no
+//     sliding-window moves: the state is three float4);
+//   * scaled results -> LDS [row parity][channel][64] -> one thread gathers 8 channels of a position and writes the hi
+//     and the lo 16-byte slot of its 64-byte record.
+// Two barriers per iteration; segments of the image height give >= 4 workgroups per CU.  The two warm-up iterations of
+// a segment re-read three rows of its upper neighbour.  Partial sums go to the slots of the tile kernel's layout
+// (tiles of 4 x 32 positions), one slot per (strip, segment), the segment's other slots are zeroed.
+
+struct StripGeo {
+    int nstrips, nseg, seg_rows;      // seg_rows: position rows per segment (>= 16)
+    int tiles_x, tiles_y;             // partial-sum slot table of the tile kernel (nstrips <= tiles_x, nseg <= tiles_y)
+    int extra;                        // 1: W is a multiple of the strip's positions — the last strip also emits position j = W
+};
+
+// QN = float4 column groups per channel: the strip is SW = 4*QN g columns = 2*QN positions wide, the workgroup 16*QN threads.
+// Every strip boundary costs two extra 64-byte sectors per row, channel and tensor (the halo loads miss L2: +37 % fetched
+// bytes and +25 % time at QN = 16); wider strips did not pay for it (below).
+// Measured alternatives (1024² layer, us): 64-column strips x 16 channels (this kernel) 935; 128 columns x 16 channels with
+// 512 threads 981-1012; 128 columns x 8 channels (256 threads, half records per workgroup) 1092; no halo loads at all 742.
+template <int QN, bool XTRA>
+__global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
+                                                                   int H, int W, SPDims sp, StripGeo geo) {
+    constexpr int SW = 4 * QN, NT = 16 * QN, NWV = NT / 64;
+    constexpr int BS_RP = SW + 4;       // LDS pitch of a g_pre row: 2 + SW + 1 columns, 16-byte aligned rows
+    constexpr int BS_GP = SW + 4;       // gather pitch
+    __shared__ __attribute__((aligned(16))) float raw[2][16][BS_RP];
+    __shared__ __attribute__((aligned(16))) float gat[2][16][BS_GP];
+    __shared__ __attribute__((aligned(16))) float nzl[2][2][SW];      // [iteration parity][row a/b][own column]: the noise rows, loaded once per workgroup
+    __shared__ float cst[7][16];
+    __shared__ float redm[NWV];
+    const int tid = threadIdx.x;
+    int w;
+    {
+        const int total = gridDim.x, bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int strip = w % geo.nstrips; w /= geo.nstrips;
+    const int seg = w % geo.nseg; w /= geo.nseg;
+    const int kc = w % sp.KC, b = w / sp.KC;
+    const int Hg = 2 * H, Wg = 2 * W;
+    const long HW = (long)Hg * Wg;
+    const int i0 = seg * geo.seg_rows;
+    const int i1 = min(i0 + geo.seg_rows, H + 1);
+    const int X0 = SW * strip, j0 = (SW / 2) * strip;
+    // position j = W (g2 column 2W, the one beyond the last pair of g columns) would need a strip of its own: the last
+    // strip emits it as a 65th / 129th output column from the two g columns it already holds
+    const bool xtra = XTRA && strip == geo.nstrips - 1;
+    load_consts(a, b, kc, cst);
+    __syncthreads();
+    // the 16 taps (uniform: scalar registers); g2[Y][X] = sum_{a,b} kp[a][b] * g[Y+a-2][X+b-2], kp = the flipped kernel
+    float kp[4][4];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) kp[aa][bb] = kern[(3 - aa) * 4 + (3 - bb)];
+    const int ch = tid / QN, q = tid % QN, c = kc * 16 + ch;
+    const float bv = cst[4][ch], sc_ = cst[5][ch];
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
+    const long cbase = ((long)b * a.C + c) * HW;
+    const bool cok = c < a.C;
+    // Columns of a row in LDS: index l = X - X0 + 2, l = 0,1 the left halo, 2..65 the strip's own 64 columns, 66 the right
+    // halo.  Thread q owns the aligned float4 X0+4q .. +3 (all of it "owned": counted in the sums); the three halo columns are
+    // extras of two threads: q = 0 loads the float2 (X0-2, X0-1), q = QN-1 the single column X0+SW.
+    const int gxm = X0 + 4 * q;
+    const bool vm = cok && gxm + 3 < Wg;
+    const bool vl = cok && q == 0 && X0 >= 2;                    // left pair exists (not the image border)
+    const bool vr = cok && q == QN - 1 && X0 + SW < Wg;          // right column exists
+
+    struct Rows { float4 o[2], g[2]; float2 oe[2], ge[2]; };    // [row a/b]; oe/ge: the halo extras (q = 0: two columns, q = 15: .x)
+    auto load_rows = [&](int i, Rows& R) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * i + 1 + rr;
+            const bool rok = r >= 0 && r < Hg;
+            const long p = (long)r * Wg + gxm;
+            R.o[rr] = R.g[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            R.oe[rr] = R.ge[rr] = make_float2(0.f, 0.f);
+            if (rok && vm) {
+                R.o[rr] = *reinterpret_cast<const float4*>(a.out + cbase + p);
+                if (a.g_feat) R.g[rr] = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
+            }
+            if (rok && vl) {
+                R.oe[rr] = *reinterpret_cast<const float2*>(a.out + cbase + p - 2);
+                if (a.g_feat) R.ge[rr] = *reinterpret_cast<const float2*>(a.g_feat + cbase + p - 2);
+            }
+            if (rok && vr) {
+                R.oe[rr].x = a.out[cbase + p + 4];
+                if (a.g_feat) R.ge[rr].x = a.g_feat[cbase + p + 4];
+            }
+        }
+    };
+    // the noise map is shared by all channels: threads 0..15 fetch the 64 own columns of a row TWO iterations ahead and put
+    // them into LDS one iteration ahead; every thread reads them from there (the halo columns do not enter the sums)
+    float4 nn[2];
+    auto load_noise = [&](int i) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * i + 1 + rr, gx = X0 + 4 * tid;
+            nn[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (np && tid < QN && r >= 0 && r < Hg && gx + 3 < Wg) nn[rr] = *reinterpret_cast<const float4*>(np + (long)r * Wg + gx);
+        }
+    };
+    auto put_noise = [&](int i) {
+        if (tid < QN) {
+            *reinterpret_cast<float4*>(&nzl[i & 1][0][4 * tid]) = nn[0];
+            *reinterpret_cast<float4*>(&nzl[i & 1][1][4 * tid]) = nn[1];
+        }
+    };
+
+    float acc_r = 0.f, amax = 0.f;
+    // pending sums of this thread's 4 columns: before iteration i, pend[0] = g2 row 2i (rows 2i-2..2i in), pend[1] = row 2i+1
+    // (rows 2i-1, 2i in), pend[2] = row 2i+2 (row 2i in).  A new g row r adds its four horizontal passes to rows r-1 .. r+2.
+    float pend[3][4], pendx[3] = {0.f, 0.f, 0.f};          // pendx: the extra column of the last strip (thread q = QN-1)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pend[k][e] = 0.f;
+
+    auto step = [&](int i, const Rows& R) {
+        // the noise rows of this iteration were put into LDS one iteration ago (published by that iteration's barriers)
+        const int par = i & 1;
+        put_noise(i + 1);
+        load_noise(i + 2);
+        // ---- A/B: activation gradient of the two new rows -> LDS
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * i + 1 + rr;
+            const bool own = r >= 2 * i0 + 1 || (seg == 0 && r == 0);      // warm-up rows belong to the segment above
+            const float4 n4 = *reinterpret_cast<const float4*>(&nzl[par][rr][4 * q]);
+            const float ov[4] = {R.o[rr].x, R.o[rr].y, R.o[rr].z, R.o[rr].w}, gv[4] = {R.g[rr].x, R.g[rr].y, R.g[rr].z, R.g[rr].w};
+            const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+            float gp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o = ov[e];
+                gp[e] = gv[e] * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                if (own) {
+                    const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nv[e] - bv;
+                    acc_r += gp[e] * ycv;
+                    amax = fmaxf(amax, fabsf(gp[e]));
+                }
+            }
+            float2* dst = reinterpret_cast<float2*>(&raw[rr][ch][4 * q + 2]);
+            dst[0] = make_float2(gp[0], gp[1]);
+            dst[1] = make_float2(gp[2], gp[3]);
+            // halo extras (no sums): q = 0 -> l = 0,1; q = 15 -> l = 66
+            const float e0 = R.ge[rr].x * (R.oe[rr].x > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+            const float e1 = R.ge[rr].y * (R.oe[rr].y > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+            if (q == 0) *reinterpret_cast<float2*>(&raw[rr][ch][0]) = make_float2(e0, e1);
+            if (q == QN - 1) raw[rr][ch][SW + 2] = e0;
+        }
+        __syncthreads();
+        // ---- C: the four horizontal 4-tap passes of each new row for columns X0 + 4q .. +3 feed the pending rows; g row 2i+1
+        // completes g2 row 2i, g row 2i+2 completes g2 row 2i+1.  Output column e needs l = 4q+e .. 4q+e+3.
+        float done[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const float* row = &raw[rr][ch][4 * q];
+            const float4 p0 = *reinterpret_cast<const float4*>(row);
+            const float2 p1 = *reinterpret_cast<const float2*>(row + 4);
+            const float p2 = row[6];
+            const float x[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p2};
+            float fresh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // row r contributes kp[a] to g2 row r + 2 - a: a = 3 completes pend[0], a = 0 opens a new row
+                done[rr][e] = pend[0][e] + (kp[3][0] * x[e] + kp[3][1] * x[e + 1] + kp[3][2] * x[e + 2] + kp[3][3] * x[e + 3]);
+                pend[0][e] = pend[1][e] + (kp[2][0] * x[e] + kp[2][1] * x[e + 1] + kp[2][2] * x[e + 2] + kp[2][3] * x[e + 3]);
+                pend[1][e] = pend[2][e] + (kp[1][0] * x[e] + kp[1][1] * x[e + 1] + kp[1][2] * x[e + 2] + kp[1][3] * x[e + 3]);
+                fresh[e] = kp[0][0] * x[e] + kp[0][1] * x[e + 1] + kp[0][2] * x[e + 2] + kp[0][3] * x[e + 3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pend[2][e] = fresh[e];
+            if (XTRA && xtra && q == QN - 1) {       // output column X0+SW = 2W: its taps b = 0,1 see the last two g columns, b = 2,3 the border
+                const float dx_ = pendx[0] + (kp[3][0] * x[4] + kp[3][1] * x[5]);
+                pendx[0] = pendx[1] + (kp[2][0] * x[4] + kp[2][1] * x[5]);
+                pendx[1] = pendx[2] + (kp[1][0] * x[4] + kp[1][1] * x[5]);
+                pendx[2] = kp[0][0] * x[4] + kp[0][1] * x[5];
+                if (i >= i0) gat[rr][ch][SW] = dx_ * sc_;
+            }
+        }
+        if (i >= i0) {
+            *reinterpret_cast<float4*>(&gat[0][ch][4 * q]) = make_float4(done[0][0] * sc_, done[0][1] * sc_, done[0][2] * sc_, done[0][3] * sc_);
+            *reinterpret_cast<float4*>(&gat[1][ch][4 * q]) = make_float4(done[1][0] * sc_, done[1][1] * sc_, done[1][2] * sc_, done[1][3] * sc_);
+        }
+        __syncthreads();
+        // ---- E: 4 phase rows x SW/2 positions x 4 sixteen-byte slots = 8*SW slot tasks, two per thread, ordered so that the 64
+        // lanes of a store instruction write 64 CONSECUTIVE slots (1 KB contiguous: 16 whole records) — one thread per record
+        // would issue 16-byte pieces at a 64-byte stride, four times the memory transactions
+        if (i >= i0) {
+            constexpr int TASKS = 2 * SW * 4;                 // 4 phase rows x SW/2 positions x 4 slots
+#pragma unroll
+            for (int k = 0; k < TASKS / NT; ++k) {
+                const int u = tid + NT * k;
+                const int ph = u / (2 * SW), v = u % (2 * SW);
+                const int py = ph >> 1, px = ph & 1, jl = v >> 2, sl = v & 3;       // sl: 0,1 the hi halves, 2,3 the lo halves
+                const int j = j0 + jl, Xl = 2 * jl + px;
+                if (j > W) continue;
+                const bool zero = (2 * i + py > 2 * H) || (X0 + Xl > 2 * W);
+                half8 o8;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    float val = gat[py][8 * (sl & 1) + cc][Xl];
+                    if (zero) val = 0.f;
+                    const _Float16 hh = (_Float16)val;
+                    o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
+                }
+                half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
+                recp[sl] = o8;
+            }
+            if (XTRA && xtra && tid < 16) {          // the four records of position j = W (px = 1 lies beyond the image: zeros)
+                const int ph = tid >> 2, sl = tid & 3, py = ph >> 1, px = ph & 1;
+                const bool zero = px == 1 || (2 * i + py > 2 * H);
+                half8 o8;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    float val = zero ? 0.f : gat[py][8 * (sl & 1) + cc][SW];
+                    const _Float16 hh = (_Float16)val;
+                    o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
+                }
+                half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + W) * 4));
+                recp[sl] = o8;
+            }
+        }
+    };
+
+    // two warm-up iterations fill the history (rows 2*i0-3 .. 2*i0), then one iteration per position row; the loads of
+    // iteration i+1 are in flight while iteration i computes
+    Rows ra, rb;
+    load_noise(i0 - 2);
+    put_noise(i0 - 2);
+    load_noise(i0 - 1);
+    load_rows(i0 - 2, ra);
+    __syncthreads();
+    int i = i0 - 2;
+    for (; i + 1 < i1; i += 2) {
+        load_rows(i + 1, rb);
+        step(i, ra);
+        load_rows(i + 2, ra);
+        step(i + 1, rb);
+    }
+    if (i < i1) step(i, ra);
+
+    // ---- per-channel sums and the block maximum -> the tile kernel's slot layout
+#pragma unroll
+    for (int o = QN / 2; o > 0; o >>= 1) acc_r += __shfl_xor(acc_r, o, 64);
+    // One slot of the tile kernel's (tiles_y x tiles_x) slot table per workgroup: row = segment, column = strip.  The workgroup of the last used row /
+    // column also zeroes the unused rows / columns, so that a plain sum / max over the table stays correct.
+    auto put = [&](float* tab, int row, int rows_used, float v) {
+        const int r1 = row == rows_used - 1 ? geo.tiles_y : row + 1;
+        const int c1 = strip == geo.nstrips - 1 ? geo.tiles_x : strip + 1;
+        for (int r = row; r < r1; ++r)
+            for (int cx = strip; cx < c1; ++cx) tab[(long)r * geo.tiles_x + cx] = (r == row && cx == strip) ? v : 0.f;
+    };
+    if (q == 0 && cok) put(a.part_r + ((long)b * a.C + c) * a.nparts, seg, geo.nseg, acc_r);
+    amax *= cst[6][ch];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((tid & 63) == 0) redm[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = redm[0];
+        for (int wv = 1; wv < NWV; ++wv) m = fmaxf(m, redm[wv]);
+        put(a.part_max + ((long)b * sp.KC + kc) * a.nparts, seg, geo.nseg, m);
+    }
+}
+
 // max over the per-block partial maxima -> next range scale; verifies the scale that was USED.
 // state[0..1] = {unscale, scale} (in: used by the pass that produced `part`, out: for the next step);
 // flag[0] |= 1 when max*scale_used left [2^-8, 2^15] (the window in which hi+lo is exact to fp32 and cannot overflow
@@ -480,6 +757,11 @@ extern "C" int oodgan_act_bwd_sform(const float* g_feat, const float* out, const
     return check_launch("act_bwd_sform");
 }
 
+static bool blurT_strip_enabled() {
+    const char* e = getenv("OODGAN_BLURT_STRIP");      // tests set 0 to compare with the tile kernel
+    return !(e && e[0] == '0');
+}
+
 extern "C" int oodgan_act_bwd_blurT_nparts(int H, int W) { return ((W + 1 + 31) / 32) * ((H + 1 + 3) / 4); }
 
 extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, const float* noise, int noise_batch,
@@ -500,6 +782,36 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
     a.nparts = tiles_x * tiles_y;
     const long nb = (long)tiles_x * tiles_y * d.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "act_bwd_blurT: grid too large");
+    // strip walk (no ToRGB branch; every up-sampling layer of the generator): enough rows to amortise the two warm-up
+    // iterations of a segment
+    if (!g_rgb && !part_t && H >= 32 && W >= 32 && blurT_strip_enabled()) {
+        constexpr int QN = 16;
+        StripGeo geo;
+        // the extra-column form saves the (W+1)-th strip and costs registers in every workgroup (20 spilled): it pays on the
+        // narrowest layer only (64²: 87 -> 75 us; 128² and 256²: 139 -> 146, 252 -> 275)
+        geo.extra = ((W % (2 * QN)) == 0 && W <= 32) ? 1 : 0;
+        geo.nstrips = geo.extra ? W / (2 * QN) : (W + 1 + 2 * QN - 1) / (2 * QN);
+        geo.tiles_x = tiles_x;
+        geo.tiles_y = tiles_y;
+        // about four rounds of the 1024 workgroups the chip holds (4 x 256 threads per CU; 1088 workgroups would run as two
+        // rounds, the second 6 % full); segments of at least 16 position rows (two warm-up iterations each)
+        const long base = (long)B * d.KC * geo.nstrips;
+        long nseg = (4L * 1024) / base;
+        if (nseg < 1) nseg = 1;
+        int seg_rows = (int)((H + 1 + nseg - 1) / nseg);
+        if (seg_rows < 16) seg_rows = 16;
+        geo.seg_rows = seg_rows;
+        geo.nseg = (H + 1 + seg_rows - 1) / seg_rows;
+        OODGAN_REQUIRE(geo.nseg <= tiles_y && geo.nstrips <= tiles_x, "act_bwd_blurT strip: slot table too small");
+        const long nbs = base * geo.nseg;
+        if (geo.extra)
+            hipLaunchKernelGGL((act_bwd_blurT_strip_kernel<QN, true>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, kernel,
+                               reinterpret_cast<uint4*>(out_phases), H, W, d, geo);
+        else
+            hipLaunchKernelGGL((act_bwd_blurT_strip_kernel<QN, false>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, kernel,
+                               reinterpret_cast<uint4*>(out_phases), H, W, d, geo);
+        return check_launch("act_bwd_blurT_sform_phases/strip");
+    }
     if (g_rgb)
         hipLaunchKernelGGL(act_bwd_blurT_sp_kernel<true>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, kernel,
                            reinterpret_cast<uint4*>(out_phases), H, W, d, tiles_x, tiles_y);

@@ -177,3 +177,42 @@ def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, monkeypatc
     # the border of the S-form must stay zero (only the interior is written)
     full = dst.data.float().abs().sum().item()
     assert full > 0
+
+
+@pytest.mark.parametrize('B,C,H,W,sep', [(1, 32, 32, 32, True), (2, 16, 40, 64, True), (1, 48, 37, 66, True), (1, 24, 64, 34, False), (1, 16, 33, 128, True)])
+def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, sep, monkeypatch):
+    """The strip-walking form of the blur^T producer (up-sampling layers with H, W >= 32 and no ToRGB branch) against the
+    two-pass path (act_bwd_fused -> blurT_to_sform_phases) and against the tile kernel; ragged strips / segments, partial
+    channel blocks, and a kernel that is not rank-1."""
+    from oodgan import ops
+    from oracle import ref_cpu as R
+    dev = torch.device('cuda:0')
+    out, g_feat, noise, nw, bias, d, kw = _inputs(B, C, 2 * H, 2 * W, 9 + C, False, dev)
+    k = torch.flip(R.make_kernel([1, 3, 3, 1]) * 4.0, [0, 1]).contiguous()
+    if not sep:
+        k[1, 2] += 0.37
+        k[3, 0] -= 0.11
+    k = k.to(dev)
+    g_pre, r0, t0, mul2 = ops.act_bwd_fused(out, g_feat, noise, nw, bias, want_scale=True, dscale=d)
+    ref = ops.blurT_to_sform_phases(g_pre, k, d, mul2)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('OODGAN_BLURT_STRIP', mode)
+        dst = ops.SFormPhases(B, C, H, W, dev)
+        dst.data.fill_(float('nan'))                 # every record of the (H+1) x (W+1) grid must be written
+        r1, t1, part_m = ops.act_bwd_producer(out, g_feat, noise, nw, bias, d, mul2.clone(), dst, blur_kernel=k)
+        res[mode] = (dst, r1, part_m)
+    for mode, (dst, r1, part_m) in res.items():
+        va = dst.data.view(-1, 4, 8).float()
+        vb = ref.data.view(-1, 4, 8).float()
+        va, vb = va[:, :2] + va[:, 2:], vb[:, :2] + vb[:, 2:]
+        nz = vb != 0
+        assert torch.isfinite(va[nz]).all(), mode
+        assert (va[nz] - vb[nz]).abs().max().item() <= 1e-6 * vb.abs().max().item(), mode
+        assert (r1 - r0).abs().max().item() <= 1e-5 * max(1e-30, r0.abs().max().item()), mode
+        state, flag = mul2.clone(), torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.absmax_scale_check(part_m, state, flag)
+        assert flag.item() == 0 and torch.equal(state, mul2), mode
+    # both kernels write the same set of records (the NaN fill survives only in padding neither touches)
+    a, b_ = res['1'][0].data, res['0'][0].data
+    assert torch.equal(torch.isnan(a.float()), torch.isnan(b_.float()))

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Timing of the layout producers at the production shapes of the inversion loop (B=8): the backward producer of the
+up-sampling layers (activation gradient + blur^T + phase split, `act_bwd_blurT`), HIP events around 10 launches.
+`OODGAN_BLURT_STRIP=0` selects the tile kernel.  Algorithmic bytes: read 2 tensors (2H x 2W), write 1 (4 B per element)."""
+import os
+import sys
+
+import torch
+
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R_, 'ood-gan-inversion_amd'))
+from oodgan import ops  # noqa: E402
+
+dev = torch.device('cuda:0')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+CH = {64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+k1 = torch.tensor([1., 3., 3., 1.])
+k = (k1[:, None] * k1[None, :] / 64 * 4).flip(0, 1).contiguous().to(dev)
+for res in (64, 128, 256, 512, 1024):
+    C, H = CH[res], res // 2
+    g = torch.Generator().manual_seed(res)
+    out = torch.randn(B, C, res, res, generator=g).to(dev)
+    gf = (1e-3 * torch.randn(B, C, res, res, generator=g)).to(dev)
+    nz = torch.randn(B, 1, res, res, generator=g).to(dev)
+    nw, bias = torch.tensor([0.1], device=dev), torch.zeros(C, device=dev)
+    d = (1 + 0.3 * torch.randn(B, C, generator=g)).abs().to(dev)
+    mul2 = torch.tensor([2.0 ** -9, 2.0 ** 9], device=dev)
+    dst = ops.SFormPhases(B, C, H, H, dev)
+    ms = timeit(lambda: ops.act_bwd_producer(out, gf, nz, nw, bias, d, mul2, dst, blur_kernel=k))
+    byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
+    print(f'act_bwd_blurT {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
+    del out, gf, nz, dst
