@@ -150,6 +150,10 @@ typedef struct oodgan_conv_args {
     int rgb_s_stride;
     float rgb_scale;
     const struct oodgan_actbwd_fuse* fuse;   /* optional fused activation backward (mode S2, split-f16, S-form input), or NULL */
+    int dot_actgrad;         /* 1 (mode S1 with dotx, where oodgan_conv3x3_s1_actgrad_supported): dotx is the OUTPUT of the
+                                up-sampling StyledConv below, y is the gradient w.r.t. it, and the epilogue applies that
+                                layer's FusedLeakyReLU backward (fused_act.py:25-58): y <- y * (dotx>0 ? sqrt2 : 0.2*sqrt2).
+                                oodgan_act_bwd_blurT_sform_phases then takes this y with out == NULL. */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -199,6 +203,9 @@ int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expe
 int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* same, for an S-form input */
 /* 1 when mode S2 with an S-form input of this shape accepts oodgan_conv_args.fuse (the 8-wave kernel of csrc/conv_f16s_s2big.hip) */
 int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, int Win);
+/* 1 when mode S1 with an S-form input and dotx of this shape accepts oodgan_conv_args.dot_actgrad (strip / 8-wave kernels)
+ * and oodgan_act_bwd_blurT_sform_phases(out = NULL) exists for the (H/2, W/2) layer below */
+int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
@@ -261,6 +268,13 @@ int oodgan_act_bwd_sform(const float* g_feat, const float* out, const float* noi
 /* same, followed by blur^T (adjoint of Blur(pad=(1,1)), src/ops/op/upfirdn2d.py:115-120) and the phase split of
  * oodgan_blurT_to_sform_phases; H,W = size of the up-conv's INPUT, the tensors are (B,C,2H,2W). */
 int oodgan_act_bwd_blurT_nparts(int H, int W);
+/* out == NULL: g_feat already is g_pre = dx * act'(out), made by the conv above (oodgan_conv_args.dot_actgrad, dotx = out).
+ * The demodulation-gradient sum of the layer, r = sum_p g_pre*y_cv with y_cv = act^-1(out) - noise_w*noise - bias, then
+ * splits as  sum_p dx*out - sum_p g_pre*(noise_w*noise + bias)  (g_pre * act^-1(out) = dx * out on either branch):
+ * part_r receives the partials of the SECOND term (negative sign included) and the first is out_scale[b,c] * dot of the
+ * conv above — combine with an oodgan_reduce_job that has part2 / scale2.  Exists where
+ * oodgan_act_bwd_blurT_pre_supported(H, W) says so. */
+int oodgan_act_bwd_blurT_pre_supported(int H, int W);
 int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, const float* noise, int noise_batch,
                                       const float* noise_w, const float* bias, const float* g_rgb, const float* w_rgb,
                                       const float* s_rgb, int s_rgb_stride, float rgb_scale, const float* dscale,
@@ -273,8 +287,11 @@ int oodgan_absmax_scale_check(const float* part, long n, float* state, int* flag
  * summation order as oodgan_reduce_parts[_cols] / oodgan_demod_bwd / oodgan_absmax_scale_check. */
 typedef struct oodgan_reduce_job {
     const float* part;       /* (B,C,nparts) */
-    float* out;              /* out[b*out_stride + c] (+)= sum_j part[b,c,j] */
+    float* out;              /* out[b*out_stride + c] (+)= sum_j part[b,c,j]  [+ scale2[b*scale2_stride + c] * sum_j part2[b,c,j]] */
     int B, C, nparts, out_stride, accumulate;
+    const float* part2;      /* (B,C,nparts2) or NULL */
+    const float* scale2;     /* (B,*) stride scale2_stride */
+    int nparts2, scale2_stride;
 } oodgan_reduce_job;
 typedef struct oodgan_demod_bwd_job {
     const float* s; const float* wsq; const float* d; const float* r; float* gs;

@@ -52,7 +52,6 @@ struct ActArgs {
     int B, C, H, W, nparts;
 };
 
-constexpr float kInvPos = 1.f / kSqrt2, kInvNeg = 1.f / (0.2f * kSqrt2);
 
 // per-block channel constants in LDS: [0] w0 [1] w1 [2] w2 (already x rgb_scale) [3] s_rgb [4] bias [5] d*scale [6] |d|
 __device__ __forceinline__ void load_consts(const ActArgs& a, int b, int kc, float (*cst)[16]) {
@@ -428,7 +427,7 @@ struct StripGeo {
 // bytes and +25 % time at QN = 16); wider strips did not pay for it (below).
 // Measured alternatives (1024² layer, us): 64-column strips x 16 channels (this kernel) 935; 128 columns x 16 channels with
 // 512 threads 981-1012; 128 columns x 8 channels (256 threads, half records per workgroup) 1092; no halo loads at all 742.
-template <int QN, bool XTRA>
+template <int QN, bool XTRA, bool PRE>
 __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
                                                                    int H, int W, SPDims sp, StripGeo geo) {
     constexpr int SW = 4 * QN, NT = 16 * QN, NWV = NT / 64;
@@ -478,25 +477,31 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const bool vl = cok && q == 0 && X0 >= 2;                    // left pair exists (not the image border)
     const bool vr = cok && q == QN - 1 && X0 + SW < Wg;          // right column exists
 
-    struct Rows { float4 o[2], g[2]; float2 oe[2], ge[2]; };    // [row a/b]; oe/ge: the halo extras (q = 0: two columns, q = 15: .x)
+    // PRE: g_feat already is g_pre (the conv above applied act' in its epilogue, oodgan_conv_args.dot_actgrad): `out` is not
+    // read, and the r sum keeps only its noise / bias term (the caller adds sum dx*out = out_scale * dot of that conv)
+    struct Rows { float4 o[PRE ? 1 : 2], g[2]; float2 oe[PRE ? 1 : 2], ge[2]; };    // [row a/b]; oe/ge: the halo extras (q = 0: two columns, q = 15: .x)
     auto load_rows = [&](int i, Rows& R) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * i + 1 + rr;
             const bool rok = r >= 0 && r < Hg;
             const long p = (long)r * Wg + gxm;
-            R.o[rr] = R.g[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-            R.oe[rr] = R.ge[rr] = make_float2(0.f, 0.f);
+            R.g[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            R.ge[rr] = make_float2(0.f, 0.f);
+            if (!PRE) {
+                R.o[PRE ? 0 : rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+                R.oe[PRE ? 0 : rr] = make_float2(0.f, 0.f);
+            }
             if (rok && vm) {
-                R.o[rr] = *reinterpret_cast<const float4*>(a.out + cbase + p);
+                if (!PRE) R.o[PRE ? 0 : rr] = *reinterpret_cast<const float4*>(a.out + cbase + p);
                 if (a.g_feat) R.g[rr] = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
             }
             if (rok && vl) {
-                R.oe[rr] = *reinterpret_cast<const float2*>(a.out + cbase + p - 2);
+                if (!PRE) R.oe[PRE ? 0 : rr] = *reinterpret_cast<const float2*>(a.out + cbase + p - 2);
                 if (a.g_feat) R.ge[rr] = *reinterpret_cast<const float2*>(a.g_feat + cbase + p - 2);
             }
             if (rok && vr) {
-                R.oe[rr].x = a.out[cbase + p + 4];
+                if (!PRE) R.oe[PRE ? 0 : rr].x = a.out[cbase + p + 4];
                 if (a.g_feat) R.ge[rr].x = a.g_feat[cbase + p + 4];
             }
         }
@@ -538,26 +543,42 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
         for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * i + 1 + rr;
             const bool own = r >= 2 * i0 + 1 || (seg == 0 && r == 0);      // warm-up rows belong to the segment above
+            const float gv[4] = {R.g[rr].x, R.g[rr].y, R.g[rr].z, R.g[rr].w};
+            float gp[4], e0, e1;
             const float4 n4 = *reinterpret_cast<const float4*>(&nzl[par][rr][4 * q]);
-            const float ov[4] = {R.o[rr].x, R.o[rr].y, R.o[rr].z, R.o[rr].w}, gv[4] = {R.g[rr].x, R.g[rr].y, R.g[rr].z, R.g[rr].w};
             const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
-            float gp[4];
+            if (PRE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float o = ov[e];
-                gp[e] = gv[e] * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
-                if (own) {
-                    const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nv[e] - bv;
-                    acc_r += gp[e] * ycv;
-                    amax = fmaxf(amax, fabsf(gp[e]));
+                for (int e = 0; e < 4; ++e) {
+                    gp[e] = gv[e];
+                    if (own) {
+                        acc_r -= gp[e] * (nw * nv[e] + bv);
+                        amax = fmaxf(amax, fabsf(gp[e]));
+                    }
                 }
+                e0 = R.ge[rr].x;
+                e1 = R.ge[rr].y;
+            } else {
+                const float4 o4 = R.o[PRE ? 0 : rr];
+                const float2 oe = R.oe[PRE ? 0 : rr];
+                const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = ov[e];
+                    gp[e] = gv[e] * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                    if (own) {
+                        const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nw * nv[e] - bv;
+                        acc_r += gp[e] * ycv;
+                        amax = fmaxf(amax, fabsf(gp[e]));
+                    }
+                }
+                // halo extras (no sums): q = 0 -> l = 0,1; q = 15 -> l = 66
+                e0 = R.ge[rr].x * (oe.x > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                e1 = R.ge[rr].y * (oe.y > 0.f ? kSqrt2 : 0.2f * kSqrt2);
             }
             float2* dst = reinterpret_cast<float2*>(&raw[rr][ch][4 * q + 2]);
             dst[0] = make_float2(gp[0], gp[1]);
             dst[1] = make_float2(gp[2], gp[3]);
-            // halo extras (no sums): q = 0 -> l = 0,1; q = 15 -> l = 66
-            const float e0 = R.ge[rr].x * (R.oe[rr].x > 0.f ? kSqrt2 : 0.2f * kSqrt2);
-            const float e1 = R.ge[rr].y * (R.oe[rr].y > 0.f ? kSqrt2 : 0.2f * kSqrt2);
             if (q == 0) *reinterpret_cast<float2*>(&raw[rr][ch][0]) = make_float2(e0, e1);
             if (q == QN - 1) raw[rr][ch][SW + 2] = e0;
         }
@@ -723,7 +744,8 @@ int fill_args(ActArgs& a, const float* g_feat, const float* out, const float* no
               const float* bias, const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale,
               const float* dscale, int dscale_stride, const float* mul2, float* part_r, float* part_t, float* part_max, int B,
               int C, int H, int W) {
-    OODGAN_REQUIRE(out && part_r && part_max && mul2 && B > 0 && C > 0 && H > 0 && W > 0, "act_bwd producer: bad args");
+    OODGAN_REQUIRE(part_r && part_max && mul2 && B > 0 && C > 0 && H > 0 && W > 0, "act_bwd producer: bad args");
+    OODGAN_REQUIRE(out || (g_feat && !g_rgb), "act_bwd producer: without out, g_feat must be the pre-activation gradient (no ToRGB branch)");
     OODGAN_REQUIRE(!g_rgb || (w_rgb && s_rgb && part_t), "act_bwd producer: rgb branch needs w_rgb, s_rgb and part_t");
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "act_bwd producer: noise_batch");
     OODGAN_REQUIRE((W % 4) == 0, "act_bwd producer: W must be a multiple of 4");
@@ -762,6 +784,10 @@ static bool blurT_strip_enabled() {
     return !(e && e[0] == '0');
 }
 
+// 1 when oodgan_act_bwd_blurT_sform_phases takes out == NULL (g_feat already multiplied by act'(out) by the conv above,
+// oodgan_conv_args.dot_actgrad) for an up-conv input of H x W: the strip walk only
+extern "C" int oodgan_act_bwd_blurT_pre_supported(int H, int W) { return H >= 32 && W >= 32 && blurT_strip_enabled() ? 1 : 0; }
+
 extern "C" int oodgan_act_bwd_blurT_nparts(int H, int W) { return ((W + 1 + 31) / 32) * ((H + 1 + 3) / 4); }
 
 extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, const float* noise, int noise_batch,
@@ -777,6 +803,8 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
     OODGAN_REQUIRE(kernel && out_phases, "act_bwd_blurT: null tensor");
     OODGAN_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!g_feat || (reinterpret_cast<uintptr_t>(g_feat) & 15) == 0),
                    "act_bwd_blurT: unaligned input");
+    OODGAN_REQUIRE(out || oodgan_act_bwd_blurT_pre_supported(H, W), "act_bwd_blurT: the pre-activated form (out == NULL) exists only in the "
+                   "strip walk (H, W >= 32)");
     const SPDims d = sp_dims(C, H, W);
     const int tiles_x = (W + 1 + 31) / 32, tiles_y = (H + 1 + 3) / 4;
     a.nparts = tiles_x * tiles_y;
@@ -804,12 +832,15 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
         geo.nseg = (H + 1 + seg_rows - 1) / seg_rows;
         OODGAN_REQUIRE(geo.nseg <= tiles_y && geo.nstrips <= tiles_x, "act_bwd_blurT strip: slot table too small");
         const long nbs = base * geo.nseg;
-        if (geo.extra)
-            hipLaunchKernelGGL((act_bwd_blurT_strip_kernel<QN, true>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, kernel,
-                               reinterpret_cast<uint4*>(out_phases), H, W, d, geo);
-        else
-            hipLaunchKernelGGL((act_bwd_blurT_strip_kernel<QN, false>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, kernel,
-                               reinterpret_cast<uint4*>(out_phases), H, W, d, geo);
+#define OODGAN_STRIP_LAUNCH(X, P)                                                                                              \
+    hipLaunchKernelGGL((act_bwd_blurT_strip_kernel<QN, X, P>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, kernel, \
+                       reinterpret_cast<uint4*>(out_phases), H, W, d, geo)
+        if (geo.extra) {
+            if (out) OODGAN_STRIP_LAUNCH(true, false); else OODGAN_STRIP_LAUNCH(true, true);
+        } else {
+            if (out) OODGAN_STRIP_LAUNCH(false, false); else OODGAN_STRIP_LAUNCH(false, true);
+        }
+#undef OODGAN_STRIP_LAUNCH
         return check_launch("act_bwd_blurT_sform_phases/strip");
     }
     if (g_rgb)

@@ -10,7 +10,7 @@ using namespace oodgan;
 
 namespace {
 
-constexpr int kMaxReduce = 72, kMaxDemod = 36, kMaxCheck = 36;
+constexpr int kMaxReduce = 48, kMaxDemod = 36, kMaxCheck = 36;
 
 struct ReduceTable {
     oodgan_reduce_job j[kMaxReduce];
@@ -30,6 +30,12 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable t) 
     float s = 0.f;
     for (int i = lane; i < q.nparts; i += 64) s += p[i];
     s = wave_sum(s);
+    if (q.part2) {
+        const float* p2 = q.part2 + row * q.nparts2;
+        float s2 = 0.f;
+        for (int i = lane; i < q.nparts2; i += 64) s2 += p2[i];
+        s += q.scale2[(row / q.C) * q.scale2_stride + (row % q.C)] * wave_sum(s2);
+    }
     if (lane == 0) {
         float* o = q.out + (row / q.C) * q.out_stride + (row % q.C);
         *o = q.accumulate ? *o + s : s;

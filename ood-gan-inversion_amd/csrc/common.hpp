@@ -27,6 +27,7 @@ inline int check_launch(const char* what) {
     } while (0)
 
 constexpr float kSqrt2 = 1.4142135623730951f;
+constexpr float kInvPos = 1.f / kSqrt2, kInvNeg = 1.f / (0.2f * kSqrt2);      // inverse of lrelu(0.2) * sqrt2 on either branch
 constexpr int kWave = 64;
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

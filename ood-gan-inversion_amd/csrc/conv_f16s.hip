@@ -419,6 +419,16 @@ extern "C" int oodgan_pack_conv3x3_f16s(const float* w, void* wpk16, float* unsc
     return check_launch("pack_conv3x3_f16s");
 }
 
+// 1 when oodgan_conv3x3_f16s (mode S1, S-form input, dotx) of this shape runs a kernel that has dot_actgrad AND the blur^T
+// producer of the layer below takes the pre-activated gradient (its strip walk)
+extern "C" int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W) {
+    oodgan_conv_args a = {};
+    a.mode = OODGAN_CONV_S1; a.x_sform = 1; a.B = B; a.K = K; a.M = M; a.Hin = H; a.Win = W;
+    a.y = reinterpret_cast<float*>(1);
+    a.dotx = reinterpret_cast<const float*>(1);
+    return (s1_strip_eligible(a) || s1_big_eligible(a)) && oodgan_act_bwd_blurT_pre_supported(H / 2, W / 2) && !(H & 1) && !(W & 1) ? 1 : 0;
+}
+
 extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream) {
     OODGAN_REQUIRE(args != nullptr, "conv3x3_f16s: null args");
     const oodgan_conv_args& a = *args;
@@ -429,6 +439,8 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
+    OODGAN_REQUIRE(!a.dot_actgrad || (a.mode == OODGAN_CONV_S1 && a.x_sform && a.dotx && (s1_strip_eligible(a) || s1_big_eligible(a))),
+                   "conv3x3_f16s: dot_actgrad exists only in the strip / 8-wave kernels of mode S1 (oodgan_conv3x3_s1_actgrad_supported)");
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:

@@ -44,7 +44,12 @@ struct BigConv {
     int ablate;      // debug: 1 skip MFMAs, 2 skip the per-stage DMA
 };
 
-template <bool DOT, int NW>
+// PRE (input-gradient instance, oodgan_conv_args.dot_actgrad): the result is the gradient w.r.t. dotx, the OUTPUT of the
+// up-sampling StyledConv below; the epilogue applies that layer's FusedLeakyReLU backward (fused_act.py:25-58) to the values
+// it already holds — y <- dx * (dotx > 0 ? sqrt2 : 0.2 sqrt2) — so the blur^T producer that follows reads one tensor
+// instead of two.  Three VALU operations per value: the kernel's waves have no spare issue slots for more (the sums of
+// that layer's demodulation gradient are finished by the producer and the dot partials, include/oodgan.h).
+template <bool DOT, int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const BigConv p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -194,14 +199,13 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const int px = c0 + l31;
     const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W : nullptr;
-    float dsum[2][16];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dsum[mt][r] = 0.f;
+    float* red = reinterpret_cast<float*>(smem + BG_RED);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         float osc[16], bia[16];
+        float dsum[16];      // per 32-channel half: reduced right after its rows (registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[r] = 0.f;
         unsigned moff[16], doff[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
                 const float v = acc[mt][nt][r];
                 o[r] = v * osc[r];
                 if (DOT) {
-                    dsum[mt][r] += (v * us) * dv[r];
+                    dsum[r] += (v * us) * dv[r];
+                    if (PRE) o[r] *= dv[r] > 0.f ? kSqrt2 : 0.2f * kSqrt2;
                 } else {
                     o[r] += nz + bia[r];
                     if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
@@ -260,21 +265,20 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
                 }
             }
         }
-    }
-    if (DOT) {
-        float* red = reinterpret_cast<float*>(smem + BG_RED);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        if (DOT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = dsum[mt][r];
+                float v = dsum[r];
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 if (l31 == 0) red[wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
             }
+        }
+    }
+    if (DOT) {
+        // the host sizes the partial-sum tables for 8-row tiles: this 16-row tile owns two of their slots
         __syncthreads();
         if (tid < 64 && m0 + tid < M) {
-            // the host sizes dot_part for 8-row tiles: this 16-row tile owns two of its slots
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) v += red[wv * 64 + tid];
@@ -337,14 +341,18 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
 #endif
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (the 4-wave variant was slower than the
     // v2 tile kernel: 474 / 475 / 552 us against 393 / 407 / 464 on the 64² / 128² / 256² layers)
-    if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    if (a.dot_actgrad) {
+        OODGAN_REQUIRE(a.dotx, "conv3x3 big: dot_actgrad without dotx");
+        hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8, true>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    } else if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8, false>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8, false>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_s1big");
 }
 

@@ -76,7 +76,6 @@ struct S2Cfg {
 constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15); }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-constexpr float kInvPos = 1.f / kSqrt2, kInvNeg = 1.f / (0.2f * kSqrt2);
 
 template <bool DOT, int MH, bool FUSE = false>
 __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, const uint4* __restrict__ wpk16) {

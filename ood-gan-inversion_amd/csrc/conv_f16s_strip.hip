@@ -42,7 +42,8 @@ struct StripConv {
     int counted_wait;
 };
 
-template <bool DOT, bool RGB>
+// PRE (input-gradient instance, oodgan_conv_args.dot_actgrad): as in conv_f16s_s1big_kernel — y <- dx * act'(dotx).
+template <bool DOT, bool RGB, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_strip_kernel(
     const StripConv p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a.dot_part[((long)b * M + lane) * a.dot_nparts + (long)(ty - 1) * p.tiles_x + tx] =
                     rp[lane] + rp[32 + lane] + rp[64 + lane] + rp[96 + lane];
             }
+
         }
 
         f32x16 acc[2][3];
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 o[r] = v * osc[r];
                 if (DOT) {
                     dsum[r] += (v * us) * dxv[nt][r];
+                    if (PRE) o[r] *= dxv[nt][r] > 0.f ? kSqrt2 : 0.2f * kSqrt2;
                 } else {
                     o[r] += nz + bia[r];
                     if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
@@ -398,19 +401,24 @@ int launch_s1_strip(const oodgan_conv_args& a_in, const void* wpk16, const float
     const long nblk = strips * p.nseg;
     OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 strip: grid too large");
     OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 strip: plane too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<true, false>),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<true, false, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, false>),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<true, false, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, true>),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_strip_kernel<false, true, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SC_SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (a.rgb_y) {
+    if (a.dot_actgrad) {
+        OODGAN_REQUIRE(a.dotx && !a.rgb_y, "conv3x3 strip: dot_actgrad needs dotx (and no fused ToRGB)");
+        hipLaunchKernelGGL((conv_f16s_strip_kernel<true, false, true>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    } else if (a.rgb_y) {
         OODGAN_REQUIRE(!a.dotx && a.rgb_w && a.rgb_s, "conv3x3 strip: the fused ToRGB needs rgb_w, rgb_s and no dotx");
-        hipLaunchKernelGGL((conv_f16s_strip_kernel<false, true>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
-    } else if (a.dotx) hipLaunchKernelGGL((conv_f16s_strip_kernel<true, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_strip_kernel<false, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+        hipLaunchKernelGGL((conv_f16s_strip_kernel<false, true, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    } else if (a.dotx) hipLaunchKernelGGL((conv_f16s_strip_kernel<true, false, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_strip_kernel<false, false, false>), dim3((unsigned)nblk), dim3(256), SC_SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_strip");
 }
 

@@ -24,7 +24,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int),
     ]
 
 
@@ -36,7 +36,8 @@ class ActBwdFuse(Structure):
 
 
 class ReduceJob(Structure):
-    _fields_ = [('part', P), ('out', P), ('B', c_int), ('C', c_int), ('nparts', c_int), ('out_stride', c_int), ('accumulate', c_int)]
+    _fields_ = [('part', P), ('out', P), ('B', c_int), ('C', c_int), ('nparts', c_int), ('out_stride', c_int), ('accumulate', c_int),
+                ('part2', P), ('scale2', P), ('nparts2', c_int), ('scale2_stride', c_int)]
 
 
 class DemodBwdJob(Structure):
@@ -77,6 +78,7 @@ _SIGS = {
     'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
     'oodgan_conv3x3_f16s_nparts2': (c_int, [c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_s2_fuse_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'oodgan_conv3x3_s1_actgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_sform_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_sform_phases_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
@@ -91,6 +93,7 @@ _SIGS = {
     'oodgan_act_bwd_sform_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_blurT_nparts': (c_int, [c_int, c_int]),
+    'oodgan_act_bwd_blurT_pre_supported': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_absmax_scale_check': (c_int, [P, c_long, P, P, P]),
     'oodgan_reduce_batch': (c_int, [P, c_int, P]),

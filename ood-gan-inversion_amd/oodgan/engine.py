@@ -345,6 +345,7 @@ class GeneratorEngine:
         g_feat = None
         prev_rgb = None
         fused_in = None         # ops.ActBwdFusion produced by the stride-2 conv of the layer above
+        fused_pre = None        # ops.DotActGrad: the stride-1 conv above already applied this up-conv layer's act'
         jobs = ops.BwdJobs() if (carry_scale and self.fused_bwd and self.sform and self.batched_tail) else None
         for L in reversed(self.layers):
             if L.kind == 'rgb':          # fused into the backward of the styled conv that feeds it
@@ -371,6 +372,12 @@ class GeneratorEngine:
                 if L.kind == 'conv':
                     gin = ops.sform_scratch(B, L.cout, out.shape[2], out.shape[3], self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin, t_into=t_into, jobs=jobs, **rgb_kw)
+                elif fused_pre is not None:
+                    # g_feat already is g_pre: blur^T + phase split of one tensor; r = noise / bias term + s * dot of that conv
+                    gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
+                    rsum, tsum, part_m = ops.act_bwd_producer(None, g_feat, nz, L.noise_w, L.bias, d, st, gin, blur_kernel=self.k4x4_flip,
+                                                              jobs=jobs, dot_of=fused_pre)
+                    fused_pre = None
                 else:
                     gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin,
@@ -409,9 +416,16 @@ class GeneratorEngine:
                     fz = ops.ActBwdFusion(ops.sform_scratch(B, Lp.cout, Hd, Hd, self.device), noises[Lp.noise_idx], Lp.noise_w, Lp.bias,
                                           _Cols(d_all, Lp.drow, Lp.cout), stp, g_rgb=gskip[Lp.res], w_rgb=Rp.w_rgb,
                                           s_rgb=_Cols(s_all, Rp.row, Rp.cin), t_into=_Cols(gs_all, Rp.row, Rp.cin))
+                pre = None
+                if (L.kind == 'conv' and Lp is not None and Lp.kind == 'up' and self.fuse_act_bwd and self.bwd_state.get(L.src) is not None
+                        and ops.s1_actgrad_supported(B, L.cout, L.cin, out.shape[2], out.shape[3])):
+                    # x_in is the output of the up-sampling layer below: this conv's epilogue applies that layer's act',
+                    # the blur^T producer then reads one tensor
+                    pre = ops.DotActGrad()
                 dx, dot = ops.conv3x3(gin, L.wpk_bwd, L.cin, CONV_S1 if L.kind == 'conv' else CONV_S2, out_scale=s, dotx=x_in,
-                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs, fuse=fz, want_y=fz is None)
-                fused_in = fz
+                                      in_mul2=mul2, dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs, fuse=fz, want_y=fz is None,
+                                      dot_actgrad=pre)
+                fused_in, fused_pre = fz, pre
                 del gin
                 if deferred:
                     jobs.add_check(part_m, st)

@@ -389,13 +389,12 @@ class BwdJobs:
     def __init__(self):
         self.reduce, self.reduce_acc, self.demod, self.check, self.keep = [], [], [], [], []
 
-    def add_reduce(self, part, out_ptr_obj, B, C, nparts, out_stride, accumulate):
+    def add_reduce(self, part, out_ptr_obj, B, C, nparts, out_stride, accumulate, second=None):
         # accumulating jobs (the dot products) run AFTER the demodulation gradient, as in the per-layer order: the
         # demodulation kernel's `gs += a*b` is one fused multiply-add, so the order of the two contributions is visible
         # in the last bit
-        (self.reduce_acc if accumulate else self.reduce).append(
-            _lib.ReduceJob(_p(part), _p(out_ptr_obj), B, C, nparts, out_stride, 1 if accumulate else 0))
-        self.keep += [part, out_ptr_obj]
+        (self.reduce_acc if accumulate else self.reduce).append(_reduce_job(part, out_ptr_obj, B, C, nparts, out_stride, accumulate, second))
+        self.keep += [part, out_ptr_obj, second]
 
     def add_demod(self, s, wsq, d, r, gs, B, Ci, Co, scale):
         self.demod.append(_lib.DemodBwdJob(_p(s), _p(wsq), _p(d), _p(r), _p(gs), s.shape[1], d.shape[1], gs.shape[1], B, Ci, Co,
@@ -423,6 +422,15 @@ class BwdJobs:
         self.reduce, self.reduce_acc, self.demod, self.check, self.keep = [], [], [], [], []
 
 
+def _reduce_job(part, out, B, C, nparts, out_stride, accumulate, second=None):
+    """oodgan_reduce_job; ``second`` = (part2 (B,C,nparts2), scale2 (B,*)): out += scale2 * sum part2."""
+    j = _lib.ReduceJob(_p(part), _p(out), B, C, nparts, out_stride, 1 if accumulate else 0)
+    if second is not None:
+        part2, scale2 = second
+        j.part2, j.scale2, j.nparts2, j.scale2_stride = _p(part2), _p(scale2), part2.shape[2], scale2.shape[1]
+    return j
+
+
 def _reduce_into(part, B, C, npart, into, accumulate):
     """sum the partials straight into the column block ``into`` (a Cols of the style-gradient accumulator)."""
     check(_lib.lib().oodgan_reduce_parts_cols(_p(part), _p(into), B, C, npart, into.shape[1], 1 if accumulate else 0, _stream()),
@@ -436,12 +444,17 @@ def _reduce_parts(part, rows, npart):
 
 
 def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, g_rgb=None, w_rgb=None, s_rgb=None,
-                     blur_kernel=None, t_into=None, jobs=None):
+                     blur_kernel=None, t_into=None, jobs=None, dot_of=None):
     """Fused backward producer (include/oodgan.h): the gradient of bias+noise+lrelu*sqrt2 (+ToRGB branch) of ``out``
     written straight into ``dst`` — an ``SForm`` (plain conv layer) or, with ``blur_kernel``, an ``SFormPhases``
     (up-conv layer: blur^T and phase split fused) — scaled by ``dscale[b,c] * mul2[1]``.
-    Returns (r[B,C], t[B,C] or None, part_max) — ``part_max`` goes to ``absmax_scale_check``."""
-    o = _dev(out, 'out')
+    Returns (r[B,C], t[B,C] or None, part_max) — ``part_max`` goes to ``absmax_scale_check``.
+    ``out=None`` (up-conv layers, where ``s1_actgrad_supported``): ``g_feat`` already is g_pre, made by the conv above with
+    ``dot_actgrad=dot_of`` (a ``DotActGrad``); the kernel sums the noise / bias term of r and the reduction adds
+    out_scale * dot of that conv (include/oodgan.h)."""
+    pre = out is None
+    assert not pre or (dot_of is not None and dot_of.dot_part is not None)
+    o = _dev(g_feat, 'g_feat') if pre else _dev(out, 'out')
     B, C, H, W = o.shape
     L = _lib.lib()
     up = blur_kernel is not None
@@ -451,7 +464,7 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
     part_t = torch.empty(B, C, npart, device=o.device, dtype=torch.float32) if g_rgb is not None else None
     part_m = torch.empty(B * KC * npart, device=o.device, dtype=torch.float32)
     nz = _opt(noise, 'noise')
-    common = [_p(_opt(g_feat, 'g_feat')), _p(o), _p(nz), 1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
+    common = [_p(_opt(g_feat, 'g_feat')), _p(None if pre else o), _p(nz), 1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
               _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')), _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)),
               _p(_opt(s_rgb, 's_rgb')), 0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(_dev(dscale, 'dscale')),
               dscale.shape[1], _p(mul2)]
@@ -461,13 +474,19 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
     else:
         check(L.oodgan_act_bwd_sform(*common, _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()),
               'act_bwd_sform')
+    second = (dot_of.dot_part, dot_of.scale) if pre else None
     if jobs is not None:            # deferred: the sums are only needed by the batched tail of the backward
         r = torch.empty(B, C, device=o.device, dtype=torch.float32)
-        jobs.add_reduce(part_r, r, B, C, npart, C, False)
+        jobs.add_reduce(part_r, r, B, C, npart, C, False, second)
         if part_t is not None:
             jobs.add_reduce(part_t, t_into, B, C, npart, t_into.shape[1], False)
         return r, None, part_m
-    r = _reduce_parts(part_r, B * C, npart)
+    if pre:
+        r = torch.empty(B, C, device=o.device, dtype=torch.float32)
+        job = _reduce_job(part_r, r, B, C, npart, C, False, second)
+        check(L.oodgan_reduce_batch(ctypes.byref(job), 1, _stream()), 'reduce_batch')
+    else:
+        r = _reduce_parts(part_r, B * C, npart)
     t = None
     if part_t is not None:
         if t_into is not None:          # ToRGB style gradient straight into its columns of the accumulator
@@ -578,7 +597,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv."""
@@ -631,6 +650,9 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
             npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
         part = torch.empty(B, M, npart, device=dx_.device, dtype=torch.float32)
         a.dotx, a.dot_part, a.dot_nparts = _p(dx_), _p(part), npart
+        if dot_actgrad is not None:     # DotActGrad: y <- y * act'(dotx); the producer below needs these partials for its r
+            a.dot_actgrad = 1
+            dot_actgrad.dot_part, dot_actgrad.scale = part, out_scale
     if wpk.precision == 'f16s':
         check(_lib.lib().oodgan_conv3x3_f16s(ctypes.byref(a), _p(wpk.unscale), _stream()), 'conv3x3_f16s')
     else:
@@ -654,6 +676,22 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
 
 def s2_fuse_supported(B, K, M, Hin, Win):
     return bool(_lib.lib().oodgan_conv3x3_s2_fuse_supported(B, K, M, Hin, Win))
+
+
+def s1_actgrad_supported(B, K, M, H, W):
+    """mode S1 with an S-form input and ``dotx`` takes ``dot_actgrad`` and the blur^T producer below takes ``out=None``."""
+    return bool(_lib.lib().oodgan_conv3x3_s1_actgrad_supported(B, K, M, H, W))
+
+
+class DotActGrad:
+    """Link between ``conv3x3(..., mode=CONV_S1, dotx=out_below, dot_actgrad=this)`` — the stride-1 input-gradient conv
+    above an up-sampling layer, which then returns g_pre = dx * act'(out_below) instead of dx — and
+    ``act_bwd_producer(None, g_pre, ..., blur_kernel=k, dot_of=this)``, which finishes that layer's activation backward
+    from g_pre alone: carries the conv's dot partials and out_scale, the ``sum dx*out`` term of the layer's r."""
+    __slots__ = ('dot_part', 'scale')
+
+    def __init__(self):
+        self.dot_part = self.scale = None
 
 
 class ActBwdFusion:

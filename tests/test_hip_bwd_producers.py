@@ -216,3 +216,54 @@ def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, s
     # both kernels write the same set of records (the NaN fill survives only in padding neither touches)
     a, b_ = res['1'][0].data, res['0'][0].data
     assert torch.equal(torch.isnan(a.float()), torch.isnan(b_.float()))
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(1, 64, 64, 64, 64), (2, 128, 64, 72, 96), (1, 32, 32, 64, 128), (2, 24, 20, 80, 64)])
+@pytest.mark.parametrize('deferred', [False, True])
+def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, deferred, monkeypatch):
+    """oodgan_conv_args.dot_actgrad: the stride-1 input-gradient conv above an up-sampling layer returns
+    g_pre = dx * act'(out_below) (8-wave kernel for >= 64 channels, strip conv kernel for 17..32); the blur^T producer then
+    runs on g_pre alone (out=None) and the layer's r sum is finished from its noise / bias term plus out_scale * dot.
+    Against conv -> act_bwd_producer(out, dx): same g_pre bits, same phase-split S-form bits, same maxima, r to 1e-5."""
+    import math
+    from oodgan import ops
+    from oracle import ref_cpu as R
+    dev = torch.device('cuda:0')
+    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '0')
+    assert ops.s1_actgrad_supported(B, Co, Ci, H, W)
+    t = lambda n, shp, std=1.0, mean=0.0: synth.normal('pre.' + n, shp, 60 + Ci + Co, std, mean).to(dev)
+    out_below = t('out', (B, Ci, H, W))                      # output of the up-sampling layer below (= dotx)
+    w = t('w', (Co, Ci, 3, 3), 1.0 / math.sqrt(Ci * 9))
+    s2, d2 = t('s', (B, Ci), 0.3, 1.0), t('d2', (B, Co), 0.3, 1.0)
+    g2 = t('g2', (B, Co, H, W), 3e-4)                        # g_pre of the conv layer above
+    noise, nw, bias = t('nz', (B, 1, H, W)), torch.tensor([0.1], device=dev), t('bias', (Ci,), 0.1)
+    d_below = t('d', (B, Ci), 0.2, 1.0).abs()
+    k = torch.flip(R.make_kernel([1, 3, 3, 1]) * 4.0, [0, 1]).contiguous().to(dev)
+    wpk_t = ops.pack_conv3x3(w, 1.0, transpose=True, flip=True, precision='f16s')
+    mul_up = torch.tensor([2.0 ** -10, 2.0 ** 10], device=dev)
+    gin = ops.to_sform(g2, d2, mul_up)
+    # two passes
+    dx, dot0 = ops.conv3x3(gin, wpk_t, Ci, ops.CONV_S1, out_scale=s2, dotx=out_below, in_mul2=mul_up)
+    g_pre0, r0, _, state = ops.act_bwd_fused(out_below, dx, noise, nw, bias, want_scale=True, dscale=d_below)
+    ref = ops.SFormPhases(B, Ci, H // 2, W // 2, dev)
+    r0p, _, pm0 = ops.act_bwd_producer(out_below, dx, noise, nw, bias, d_below, state.clone(), ref, blur_kernel=k)
+    # fused
+    link = ops.DotActGrad()
+    g_pre1, dot1 = ops.conv3x3(gin, wpk_t, Ci, ops.CONV_S1, out_scale=s2, dotx=out_below, in_mul2=mul_up, dot_actgrad=link)
+    assert torch.equal(g_pre1, g_pre0)                       # the same fp32 product, only made in the conv's epilogue
+    assert torch.equal(dot1, dot0)
+    dst = ops.SFormPhases(B, Ci, H // 2, W // 2, dev)
+    jobs = ops.BwdJobs() if deferred else None
+    r1, tn, pm1 = ops.act_bwd_producer(None, g_pre1, noise, nw, bias, d_below, state.clone(), dst, blur_kernel=k, jobs=jobs, dot_of=link)
+    if deferred:
+        jobs.run(torch.zeros(1, dtype=torch.int32, device=dev))
+    assert tn is None
+    assert torch.equal(dst.data, ref.data)
+    assert pm1.max().item() == pm0.max().item()
+    tol = 1e-5 * max(1e-30, r0.abs().max().item())
+    assert (r1 - r0).abs().max().item() <= tol and (r1 - r0p).abs().max().item() <= tol
+    # the tile kernel has no such form: loud error, no silent fallback
+    monkeypatch.setenv('OODGAN_BLURT_STRIP', '0')
+    assert not ops.s1_actgrad_supported(B, Co, Ci, H, W)
+    with pytest.raises(RuntimeError):
+        ops.act_bwd_producer(None, g_pre1, noise, nw, bias, d_below, state.clone(), dst, blur_kernel=k, dot_of=link)

@@ -285,10 +285,11 @@ def test_conv3x3_sform_input_and_output(dev, B, Ci, Co, H, W):
         close(z, F.conv2d(ref * s2[:, :, None, None], w2, padding=1), 2e-4)
 
 
-@pytest.mark.parametrize('B,C,H,W,act', [(2, 32, 8, 8, True), (1, 40, 9, 20, True), (1, 16, 4, 36, False)])
+@pytest.mark.parametrize('B,C,H,W,act', [(2, 32, 8, 8, True), (1, 40, 9, 20, True), (1, 16, 4, 36, False),
+                                         (2, 32, 32, 32, True), (1, 40, 37, 50, True), (1, 16, 33, 47, False), (1, 16, 80, 32, True)])
 def test_blur_act_sform_vs_two_pass_and_oracle(dev, B, C, H, W, act):
     """Fused up-conv tail: y equals the oracle's blur + noise + bias + lrelu, and the S-form output equals
-    to_sform(y, next style)."""
+    to_sform(y, next style).  The kernel also records the range maximum of the S-form values."""
     from oodgan import ops
     seed = 23 + C
     Hz, Wz = 2 * H + 1, 2 * W + 1
@@ -309,6 +310,11 @@ def test_blur_act_sform_vs_two_pass_and_oracle(dev, B, C, H, W, act):
     close(y, ref)
     ref_s = ops.to_sform(y, s_next.to(dev))
     assert torch.equal(ys.data, ref_s.data)
+    vm = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+    ops.blur_act_sform(zp.to(dev), k.to(dev), H, W, bias.to(dev), noise.to(dev), nw.to(dev), act=act, ys=ys,
+                       ys_scale=s_next.to(dev), vmax=vm)
+    want = (y * s_next.to(dev)[:, :, None, None]).abs().amax(dim=(1, 2, 3))
+    assert torch.equal(vm.view(torch.float32).amax(dim=1), want)
     # non-separable kernel -> generic 16-tap path
     k2 = k.clone()
     k2[1, 2] += 0.37

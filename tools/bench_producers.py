@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timing of the layout producers at the production shapes of the inversion loop (B=8): the backward producer of the
 up-sampling layers (activation gradient + blur^T + phase split, `act_bwd_blurT`), HIP events around 10 launches.
-`OODGAN_BLURT_STRIP=0` selects the tile kernel.  Algorithmic bytes: read 2 tensors (2H x 2W), write 1 (4 B per element)."""
+`OODGAN_BLURT_STRIP=0` selects the tile kernel.  Algorithmic bytes: read 2 tensors (2H x 2W), write 1 (4 B per element).
+Second block: the forward tail of the same layers (blur + noise + bias + lrelu + S-form of the next conv, `blur_act_sform`): read z (4 B), write y (4 B) and the S-form (4 B) per element."""
 import os
 import sys
 
@@ -45,3 +46,19 @@ for res in (64, 128, 256, 512, 1024):
     byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
     print(f'act_bwd_blurT {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
     del out, gf, nz, dst
+
+kf = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+for res in (64, 128, 256, 512, 1024):
+    C, H = CH[res], res // 2
+    g = torch.Generator().manual_seed(res)
+    pitch = (res + 1 + 3) // 4 * 4
+    z = torch.randn(B, C, res + 1, pitch, generator=g).to(dev)
+    nz = torch.randn(B, 1, res, res, generator=g).to(dev)
+    nw, bias = torch.tensor([0.1], device=dev), torch.zeros(C, device=dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    ys = ops.SForm(B, C, res, res, dev)
+    vm = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: ops.blur_act_sform(z, kf, H, H, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm))
+    byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
+    print(f'blur_act_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
+    del z, nz, ys
