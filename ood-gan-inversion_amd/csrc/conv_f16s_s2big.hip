@@ -71,6 +71,9 @@ struct S2Cfg {
     static constexpr int NA = 5 + WA, NB = 5 + WB;         // loads per wave in flight for a stage
     static constexpr int OFF_XA = 0, OFF_WA = SB_XBYTES, OFF_XB = OFF_WA + 6 * TAPB, OFF_WB = OFF_XB + SB_XBYTES;
     static constexpr int SMEM = OFF_WB + 3 * TAPB;         // 155648 (MH = 2) / 118784 (MH = 1)
+    // FUSE: [7][MBW] floats of channel constants.  MH = 1 stages them BEFORE the K loop: outside the stage buffers
+    static constexpr int OFF_CST = MH == 1 ? SMEM : 8192;
+    static constexpr int SMEM_FUSE = MH == 1 ? SMEM + 7 * MBW * 4 : SMEM;
 };
 
 constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15); }
@@ -202,6 +205,52 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
 #define S2B_IC(n) std::integral_constant<int, n>{}
 #define S2B_SB() __builtin_amdgcn_sched_barrier(0)
 
+    // ---- FUSE, MH = 1: everything the fused epilogue reads from global memory is requested BEFORE the K loop — the channel
+    // constants (-> LDS), the ToRGB gradient / noise of this wave's pixels and the saved activations of both M-tiles
+    // (32 registers) — so that their latency runs under the K loop.  Measured on the 32 -> 64 channel layer @1024² -> 512²
+    // (two 16-channel chunks: a K loop of 4 short stages), loads issued after the loop: K loop alone 427 us, epilogue alone
+    // 891 us, together 1128 us; with the early loads 1010 us (in the W+ loop 1059 -> 923 us).  MH = 2 has no registers left
+    // for this (it already spills; routing both forms through shared code cost it 16 more spilled registers and 8 % of
+    // its time) and keeps its loads in the epilogue: the two forms are written out separately below.
+    constexpr bool EARLY = FUSE && MH == 1;
+    float eq0 = 0.f, eq1 = 0.f, eq2 = 0.f, enz = 0.f, edv[EARLY ? 2 : 1][16];
+    bool eok = false;
+    if constexpr (EARLY) {
+        static_assert(!EARLY || RW == 1, "one row per wave");
+        const oodgan_actbwd_fuse& f = p.f;
+        float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);
+        if (tid < C::MBW) {
+            const int m = m0 + tid;
+            const bool mok = m < M;
+            cst[0 * C::MBW + tid] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f;
+            cst[1 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[0 * M + m] * f.rgb_scale : 0.f;
+            cst[2 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[1 * M + m] * f.rgb_scale : 0.f;
+            cst[3 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[2 * M + m] * f.rgb_scale : 0.f;
+            cst[4 * C::MBW + tid] = (mok && f.g_rgb) ? f.s_rgb[(long)b * f.s_rgb_stride + m] : 0.f;
+            cst[5 * C::MBW + tid] = (mok && f.bias) ? f.bias[m] : 0.f;
+            cst[6 * C::MBW + tid] = mok ? f.dscale[(long)b * f.dscale_stride + m] * f.mul2[1] : 0.f;
+        }
+        const int px = c0 + l31, py_ = r0 + rg;
+        const long HW = (long)H * W, pix = (long)py_ * W + px;
+        eok = py_ < H && px < W;
+        if (eok) {
+            if (f.g_rgb) {
+                const float* gr = f.g_rgb + (long)b * 3 * HW + pix;
+                eq0 = gr[0]; eq1 = gr[HW]; eq2 = gr[2 * HW];
+            }
+            if (f.noise) enz = (f.noise_w ? f.noise_w[0] : 1.f) * f.noise[(long)(f.noise_batch > 1 ? b : 0) * HW + pix];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float* dr = a.dotx + ((long)b * M + m0 + mh * 64 + mt * 32) * HW + pix;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                edv[EARLY ? mt : 0][r] = (eok && m0 + mh * 64 + mt * 32 + ch < M) ? dr[(long)ch * HW] : 0.f;
+            }
+        }
+    }
+
     // single barrier per stage: after it every wave has finished stage st-1 (its slot is free) and stage st has landed
     // (each wave waited for its own loads); the fetch of stage st+1 is issued first and runs under this stage's MFMAs
     dma_stage(0);
@@ -246,10 +295,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         static_assert(DOT, "the fused epilogue includes the dot");
         const oodgan_actbwd_fuse& f = p.f;
         float* red = reinterpret_cast<float*>(smem);                     // [row group][3][MBW]
-        float* cst = reinterpret_cast<float*>(smem + 8192);              // [7][MBW]: a*us->g_feat scale, w0, w1, w2, s_rgb, bias, d*scale
+        float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);        // [7][MBW]: a*us->g_feat scale, w0, w1, w2, s_rgb, bias, d*scale
         const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
         const float rscale = f.mul2[1];
-        if (tid < C::MBW) {
+        if (!EARLY && tid < C::MBW) {
             const int m = m0 + tid;
             const bool mok = m < M;
             cst[0 * C::MBW + tid] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f;
@@ -260,7 +309,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             cst[5 * C::MBW + tid] = (mok && f.bias) ? f.bias[m] : 0.f;
             cst[6 * C::MBW + tid] = mok ? f.dscale[(long)b * f.dscale_stride + m] * rscale : 0.f;
         }
-        __syncthreads();
+        if (!EARLY) __syncthreads();
         const int px = c0 + l31;
         const long HW = (long)H * W;
         const float nw = f.noise ? (f.noise_w ? f.noise_w[0] : 1.f) : 0.f;
@@ -272,7 +321,9 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             const int py_ = r0 + rg * RW + nt;
             okr[nt] = py_ < H && px < W;
             q0[nt] = q1[nt] = q2[nt] = nzv[nt] = 0.f;
-            if (okr[nt]) {
+            if constexpr (EARLY) {
+                okr[nt] = eok; q0[nt] = eq0; q1[nt] = eq1; q2[nt] = eq2; nzv[nt] = enz;
+            } else if (okr[nt]) {
                 const long pix = (long)py_ * W + px;
                 if (f.g_rgb) {
                     const float* gr = f.g_rgb + (long)b * 3 * HW + pix;
@@ -294,7 +345,8 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    dv[nt][r] = (okr[nt] && m0 + chb + ch < M) ? dr[(long)ch * HW] : 0.f;
+                    if constexpr (EARLY) dv[nt][r] = edv[EARLY ? mt : 0][r];
+                    else dv[nt][r] = (okr[nt] && m0 + chb + ch < M) ? dr[(long)ch * HW] : 0.f;
                 }
             }
             unsigned hi[RW][8], lo[RW][8];
@@ -537,13 +589,13 @@ int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM_FUSE),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM_FUSE), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     if (fuse) {
-        if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
-        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM, st, p, w16);
+        if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM_FUSE, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM_FUSE, st, p, w16);
     } else if (mh2) {
         if (a.dotx) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
         else hipLaunchKernelGGL((conv_f16s_s2big_kernel<false, 2>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);

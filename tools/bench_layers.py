@@ -81,4 +81,17 @@ for res in (8, 16, 32, 64, 128, 256, 512, 1024):
         wb = ops.pack_conv3x3(w, transpose=True, flip=False, precision='f16s')
         fl = 2.0 * B * cin * cout * 9 * H * H
         report(f'S2 bwd+dot {cout}->{cin} @{res}->{H}', timeit(lambda: ops.conv3x3(gp, wb, cin, ops.CONV_S2, out_scale=s, dotx=x)), fl, 4.0 * B * (cout * Hin * Hin + 2 * cin * H * H))
+        if ops.s2_fuse_supported(B, cout, cin, Hin, Hin):
+            # the same conv with the activation backward of the conv layer below in its epilogue (the form the W+ loop runs)
+            nz = torch.randn(B, 1, H, H, generator=g).to(dev)
+            grgb = (1e-3 * torch.randn(B, 3, H, H, generator=g)).to(dev)
+            wrgb, srgb = torch.randn(3, cin, generator=g).to(dev), (1 + 0.3 * torch.randn(B, cin, generator=g)).to(dev)
+            dl = (1 + 0.3 * torch.randn(B, cin, generator=g)).abs().to(dev)
+            mul2 = torch.tensor([2.0 ** -9, 2.0 ** 9], device=dev)
+            dst = ops.SForm(B, cin, H, H, dev)
+
+            def fused():
+                fz = ops.ActBwdFusion(dst, nz, torch.tensor([0.1], device=dev), torch.zeros(cin, device=dev), dl, mul2, g_rgb=grgb, w_rgb=wrgb, s_rgb=srgb)
+                ops.conv3x3(gp, wb, cin, ops.CONV_S2, out_scale=s, dotx=x, fuse=fz, want_y=False)
+            report(f'S2 bwd+dot+actbwd {cout}->{cin} @{res}->{H}', timeit(fused), fl, 4.0 * B * (cout * Hin * Hin + 2 * cin * H * H))
         del gp, x
