@@ -46,6 +46,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the 32 lanes of each half of the wave with DPP operands (VALU only): quad swaps, row_half_mirror, row_mirror and
+// row_bcast:15 — the total of lanes 0-31 lands in lanes 16-31 (read it in lane 31), that of lanes 32-63 in lanes 48-63 (lane
+// 63).  A __shfl_xor butterfly is five ds_bpermute_b32 per value: the fused epilogue of the stride-2 conv issued 486 of them
+// per wave and tile, all eight waves of the CU at once on its one LDS pipe.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float half_sum_dpp(float v) {
+    v += dpp_take<0xB1, 0xF>(v);         // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);         // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);        // row_half_mirror: the other quad of each 8
+    v += dpp_take<0x140, 0xF>(v);        // row_mirror: the other half of each 16
+    v += dpp_take<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3 (rows 0 and 2 add the `old` operand, 0)
+    return v;
+}
+constexpr int kHalfSumLane = 31;         // l31 of the lanes that hold half_sum_dpp's result
+
 // sum over a 256-thread block; result valid in thread 0 (all threads must call)
 __device__ __forceinline__ float block_sum_256(float v, float* red /*>=4 floats LDS*/) {
     v = wave_sum(v);

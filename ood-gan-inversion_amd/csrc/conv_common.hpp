@@ -108,11 +108,9 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& p, f32x16 (&acc)[MT][
         if (db) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float s = dsum[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                const float s = half_sum_dpp(dsum[r]);
                 const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (l31 == 0 && m < a.M)
+                if (l31 == kHalfSumLane && m < a.M)
                     a.dot_part[((long)b * a.M + m) * a.dot_nparts + c.tile * 4 + wave] = s;
             }
         }

@@ -268,10 +268,8 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
         if (DOT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = dsum[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (l31 == 0) red[wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+                const float v = half_sum_dpp(dsum[r]);
+                if (l31 == kHalfSumLane) red[wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
             }
         }
     }

@@ -403,14 +403,8 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             // the three per-channel sums of this M-tile: lanes -> row group -> LDS
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v0 = sd[r], v1 = sr_[r], v2 = st_[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) {
-                    v0 += __shfl_xor(v0, o, 64);
-                    v1 += __shfl_xor(v1, o, 64);
-                    v2 += __shfl_xor(v2, o, 64);
-                }
-                if (l31 == 0) {
+                const float v0 = half_sum_dpp(sd[r]), v1 = half_sum_dpp(sr_[r]), v2 = half_sum_dpp(st_[r]);
+                if (l31 == kHalfSumLane) {
                     const int ch = chb + (r & 3) + 8 * (r >> 2) + 4 * half;
                     red[(rg * 3 + 0) * C::MBW + ch] = v0;
                     red[(rg * 3 + 1) * C::MBW + ch] = v1;
@@ -500,10 +494,8 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = dsum[mt][r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (l31 == 0) red[rg * C::MBW + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+                const float v = half_sum_dpp(dsum[mt][r]);
+                if (l31 == kHalfSumLane) red[rg * C::MBW + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
             }
         __syncthreads();
         if (tid < C::MBW && m0 + tid < M) {

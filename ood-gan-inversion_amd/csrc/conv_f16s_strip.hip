@@ -329,12 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // sum over the 32 pixels of the row pair held by this half wave, then hand the 32 channel sums to LDS
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = dsum[r];
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                dsum[r] = v;
+                dsum[r] = half_sum_dpp(dsum[r]);
             }
-            if (l31 == 0) {
+            if (l31 == kHalfSumLane) {
                 float* rp = red + (t & 1) * 128 + wave * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rp[(r & 3) + 8 * (r >> 2) + 4 * half] = dsum[r];

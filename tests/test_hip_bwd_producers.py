@@ -133,7 +133,8 @@ def test_violated_scale_falls_back_to_exact_loop():
     assert torch.isfinite(w).all() and (l - l_ref).abs().max().item() <= 1e-5 * l_ref.abs().max().item()
 
 
-@pytest.mark.parametrize('B,Co,Ci,H,W,rgb', [(2, 32, 128, 16, 32, True), (1, 48, 64, 9, 40, True), (1, 64, 256, 8, 36, False)])
+@pytest.mark.parametrize('B,Co,Ci,H,W,rgb', [(2, 32, 128, 16, 32, True), (1, 48, 64, 9, 40, True), (1, 64, 256, 8, 36, False),
+                                             (2, 32, 64, 40, 72, True), (3, 20, 64, 19, 36, True), (1, 16, 64, 8, 32, False)])
 def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, monkeypatch):
     """The stride-2 input-gradient conv whose epilogue continues with the activation backward of the layer below
     (oodgan_actbwd_fuse) == the same conv followed by act_bwd_producer on its fp32 result: S-form gradient, the three
