@@ -146,23 +146,24 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
     if ((tid & 63) == 0) redm[tid >> 6] = amax;
     __syncthreads();
     if (tid == 0) a.part_max[(long)bk * a.nparts + blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    // Phase C: 4 sixteen-byte slots per pixel (slots 0,1 = hi halves of channels 0-7 / 8-15, slots 2,3 = lo halves), one slot
+    // task per thread and pass, ordered so that the 64 lanes of a store write 64 CONSECUTIVE slots (1 KB contiguous).  One
+    // thread per record would issue its four 16-byte pieces at a 64-byte stride: four times the memory transactions.
 #pragma unroll
-    for (int rep = 0; rep < kP1Chunk / 256; ++rep) {
-        const int lp = tid + rep * 256;
+    for (int rep = 0; rep < kP1Chunk * 4 / 256; ++rep) {
+        const int u = tid + rep * 256;
+        const int lp = u >> 2, sl = u & 3;
         const long p = p0 + lp;
         if (p >= HW) continue;
-        unsigned hp[8], lq[8];
+        half8 o8;
 #pragma unroll
-        for (int cp = 0; cp < 8; ++cp) {
-            const float v0 = lst[(2 * cp) * kP1Pitch + lp], v1 = lst[(2 * cp + 1) * kP1Pitch + lp];
-            split_pair(v0, v1, hp[cp], lq[cp]);
+        for (int cc = 0; cc < 8; ++cc) {
+            const float val = lst[(8 * (sl & 1) + cc) * kP1Pitch + lp];
+            const _Float16 hh = (_Float16)val;
+            o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
         }
         const int y = (int)(p / a.W), x = (int)(p % a.W);
-        uint4* rec = ys + sform_unit(yd, b, kc, y, x, 0);
-        rec[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-        rec[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
-        rec[2] = make_uint4(lq[0], lq[1], lq[2], lq[3]);
-        rec[3] = make_uint4(lq[4], lq[5], lq[6], lq[7]);
+        reinterpret_cast<half8*>(ys + sform_unit(yd, b, kc, y, x, 0))[sl] = o8;
     }
 }
 

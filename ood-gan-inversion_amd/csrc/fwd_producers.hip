@@ -14,6 +14,7 @@
 using namespace oodgan;
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int j = 0; j < 32; ++j) lst[ch * LS_CH + yrow * LS_ROW + 32 * xh + j] = o[j];
     __syncthreads();
-    // ---- C: thread = pixel: noise + bias + activation for its 16 channels, fp32 store per channel plane, one record
+    // ---- C: thread = pixel: noise + bias + activation for its 16 channels, fp32 store per channel plane; the value for the
+    // S-form (x the next conv's style) goes back to the same LDS cell
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const long HWo = (long)Ho * Wo;
     float vm = 0.f;
@@ -172,27 +174,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (Y >= Ho || X >= Wo) continue;
         const float nz = a.noise ? nw * a.noise[(long)(a.noise_batch > 1 ? b : 0) * HWo + (long)Y * Wo + X] : 0.f;
         float* yp = a.y + ((long)b * a.C + kc * 16) * HWo + (long)Y * Wo + X;
-        unsigned hp[8], lp[8];
 #pragma unroll
-        for (int cp = 0; cp < 8; ++cp) {
-            float v[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int cc = 2 * cp + e;
-                float t = lst[cc * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)] + nz + cb[0][cc];
-                if (a.act == OODGAN_ACT_LRELU) t = (t > 0.f ? t : 0.2f * t) * kSqrt2;
-                if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
-                v[e] = t * cb[1][cc];
-            }
-            vm = fmaxf(vm, fmaxf(fabsf(v[0]), fabsf(v[1])));
-            split_pair(v[0], v[1], hp[cp], lp[cp]);
+        for (int cc = 0; cc < 16; ++cc) {
+            float* cell = &lst[cc * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)];
+            float t = *cell + nz + cb[0][cc];
+            if (a.act == OODGAN_ACT_LRELU) t = (t > 0.f ? t : 0.2f * t) * kSqrt2;
+            if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
+            const float v = t * cb[1][cc];
+            vm = fmaxf(vm, fabsf(v));
+            *cell = v;
         }
-        if (a.ys) {
-            uint4* rec = a.ys + sform_unit(a.yd, b, kc, Y, X, 0);
-            rec[0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            rec[1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
-            rec[2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
-            rec[3] = make_uint4(lp[4], lp[5], lp[6], lp[7]);
+    }
+    if (a.ys) {
+        // ---- D: the 64-byte records, one 16-byte slot per thread and pass (slots 0,1 = hi halves of channels 0-7 / 8-15, slots
+        // 2,3 = lo halves), ordered so that the 64 lanes of a store write 64 CONSECUTIVE slots (1 KB contiguous): one thread per
+        // record issues four 16-byte pieces at a 64-byte stride, four times the memory transactions
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) {
+            const int u = tid + rep * 256;
+            const int pos = u >> 2, sl = u & 3;
+            const int Y = Y0 + (pos >> 6), X = X0 + (pos & 63);
+            if (Y >= Ho || X >= Wo) continue;
+            half8 o8;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                const float val = lst[(8 * (sl & 1) + cc) * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)];
+                const _Float16 hh = (_Float16)val;
+                o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
+            }
+            reinterpret_cast<half8*>(a.ys + sform_unit(a.yd, b, kc, Y, X, 0))[sl] = o8;
         }
     }
     if (a.vmax) record_vmax(a.vmax, b, vm);

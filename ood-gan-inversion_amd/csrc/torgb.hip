@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void torgb_fwd_small_kernel(const float* __res
 
 // ToRGB that ALSO emits the S-form input of the following up-sampling conv (x * its style, hi/lo split): the feature map
 // is read once for both consumers instead of once by ToRGB and once by to_sform_kernel.  Same arithmetic as
-// torgb_fwd_kernel for y.  Needs Ci % 16 == 0 and W % 4 == 0 (a thread's 4 pixels share a row).
+// torgb_fwd_kernel for y.  Needs Ci % 16 == 0 and W % 4 == 0 (a thread's pixels share a row).
+// A thread owns TS_PX = 2 consecutive pixels: their two records of a channel block are 128 contiguous bytes, but stored from
+// the owning lane every store instruction would write 16-byte pieces at a 128-byte stride (with 4 pixels per thread: 256).
+// Full waves pass the records through a per-wave LDS buffer (slot index rotated by lane/2: conflict free both ways) and
+// store them as slot tasks — 64 lanes write 64 CONSECUTIVE slots, 1 KB per instruction.
+constexpr int TS_PX = 2;
 __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ s, int s_stride, const float* __restrict__ bias,
                                                               const float* __restrict__ skip, const float* __restrict__ kern,
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     __shared__ float ws[3 * kMaxCi];
     __shared__ float sc[kMaxCi];
     __shared__ float kf[16];
+    __shared__ __attribute__((aligned(16))) uint4 xbuf[4][64 * TS_PX * 4];      // per wave: 64 lanes x 2 records x 4 slots
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     for (int e = threadIdx.x; e < 3 * Ci; e += 256) {
@@ -167,45 +173,78 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     for (int e = threadIdx.x; e < Ci; e += 256) sc[e] = ys_scale ? ys_scale[(long)b * ys_scale_stride + e] : 1.f;
     if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
     __syncthreads();
-    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * TS_PX;
     const bool full_wave = __all(p < HW);        // evaluated before any lane leaves
     if (p >= HW) return;
     const float* xp = x + (long)b * Ci * HW + p;
     const int Y0 = (int)(p / W), X0 = (int)(p % W);
-    float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    float a0[TS_PX] = {0, 0}, a1[TS_PX] = {0, 0}, a2[TS_PX] = {0, 0};
     float vm = 0.f;
+    // slot tasks of the record stores (full waves): task t = i*64 + lane -> owner lane t/8, its pixel (t%8)/4, slot t%4: the
+    // wave's 128 records are consecutive in memory (W % 128 == 0 or not: the unit is computed per task)
+    const int lane = threadIdx.x & 63;
+    uint4* xb = xbuf[threadIdx.x >> 6];
+    uint4* ysb = ys + sform_unit(yd, b, 0, -1, -1, 0);          // first unit of the sample's channel block 0
+    int rel[2 * TS_PX * 4 / 2];
+    if (full_wave) {
+        const long pw = p - (long)TS_PX * lane;
+#pragma unroll
+        for (int i = 0; i < TS_PX * 4; ++i) {
+            const int t = i * 64 + lane;
+            const long po = pw + TS_PX * (t >> 3) + ((t >> 2) & 1);
+            rel[i] = (int)sform_unit(yd, 0, 0, (int)(po / W), (int)(po % W), t & 3);
+        }
+    }
     for (int kc = 0; kc < Ci / 16; ++kc) {
-        unsigned hp[4][8], lp[4][8];
+        unsigned hp[TS_PX][8], lp[TS_PX][8];
 #pragma unroll
         for (int cp = 0; cp < 8; ++cp) {
             const int ci = kc * 16 + 2 * cp;
-            const float4 v0 = *reinterpret_cast<const float4*>(xp + (long)ci * HW);
-            const float4 v1 = *reinterpret_cast<const float4*>(xp + (long)(ci + 1) * HW);
-            const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w};
+            const float2 v0 = *reinterpret_cast<const float2*>(xp + (long)ci * HW);
+            const float2 v1 = *reinterpret_cast<const float2*>(xp + (long)(ci + 1) * HW);
+            const float e0[TS_PX] = {v0.x, v0.y}, e1[TS_PX] = {v1.x, v1.y};
             const float w00 = ws[ci], w01 = ws[Ci + ci], w02 = ws[2 * Ci + ci];
             const float w10 = ws[ci + 1], w11 = ws[Ci + ci + 1], w12 = ws[2 * Ci + ci + 1];
             const float s0 = sc[ci], s1 = sc[ci + 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TS_PX; ++j) {
                 a0[j] += w00 * e0[j]; a1[j] += w01 * e0[j]; a2[j] += w02 * e0[j];
                 a0[j] += w10 * e1[j]; a1[j] += w11 * e1[j]; a2[j] += w12 * e1[j];
                 split_pair(e0[j] * s0, e1[j] * s1, hp[j][cp], lp[j][cp]);
                 vm = fmaxf(vm, fmaxf(fabsf(e0[j] * s0), fabsf(e1[j] * s1)));
             }
         }
+        if (full_wave) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4* rec = ys + sform_unit(yd, b, kc, Y0, X0 + j, 0);
-            rec[0] = make_uint4(hp[j][0], hp[j][1], hp[j][2], hp[j][3]);
-            rec[1] = make_uint4(hp[j][4], hp[j][5], hp[j][6], hp[j][7]);
-            rec[2] = make_uint4(lp[j][0], lp[j][1], lp[j][2], lp[j][3]);
-            rec[3] = make_uint4(lp[j][4], lp[j][5], lp[j][6], lp[j][7]);
+            for (int k = 0; k < 8; ++k) {
+                const int j = k >> 2, sl = k & 3, o = 4 * (sl & 1);
+                const unsigned* src = (sl & 2) ? lp[j] : hp[j];
+                xb[lane * 8 + ((k + (lane >> 1)) & 7)] = make_uint4(src[o], src[o + 1], src[o + 2], src[o + 3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = i * 64 + lane, lo_ = t >> 3, k = t & 7;
+                ysb[rel[i] + (long)kc * yd.plane] = xb[lo_ * 8 + ((k + (lo_ >> 1)) & 7)];
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int j = 0; j < TS_PX; ++j) {
+                uint4* rec = ys + sform_unit(yd, b, kc, Y0, X0 + j, 0);
+                rec[0] = make_uint4(hp[j][0], hp[j][1], hp[j][2], hp[j][3]);
+                rec[1] = make_uint4(hp[j][4], hp[j][5], hp[j][6], hp[j][7]);
+                rec[2] = make_uint4(lp[j][0], lp[j][1], lp[j][2], lp[j][3]);
+                rec[3] = make_uint4(lp[j][4], lp[j][5], lp[j][6], lp[j][7]);
+            }
         }
     }
     const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
     const int h2 = H >> 1, w2_ = W >> 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TS_PX; ++j) {
         float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
         if (skip) {
             const int Y = Y0, X = X0 + j;
@@ -307,7 +346,7 @@ extern "C" int oodgan_torgb_fwd_sform(const float* x, const float* w, const floa
     OODGAN_REQUIRE(Ci <= kMaxCi && (Ci % 16) == 0 && (W % 4) == 0, "torgb_fwd_sform: needs Ci %% 16 == 0, Ci <= %d, W %% 4 == 0", kMaxCi);
     OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "torgb_fwd_sform: skip needs kernel and even H,W");
     const long HW = (long)H * W;
-    dim3 grid((unsigned)((HW + 1023) / 1024), B);
+    dim3 grid((unsigned)((HW + 256 * TS_PX - 1) / (256 * TS_PX)), B);
     hipLaunchKernelGGL(torgb_fwd_sform_kernel, grid, dim3(256), 0, as_stream(stream), x, w, s, s_stride, bias, skip, kernel, y,
                        reinterpret_cast<uint4*>(ys), ys_scale, ys_scale_stride, sform_dims(Ci, H, W), Ci, H, W, scale, vmax);
     return check_launch("torgb_fwd_sform");

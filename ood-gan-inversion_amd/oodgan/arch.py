@@ -253,7 +253,7 @@ class ood_faceGAN_e4e(nn.Module):
         return out
 
     # ---------------------------------------------------------------- build-defined: W+ refinement
-    def invert(self, x, steps=100, lr=0.01, noise=None, streams=2, use_graph=False, **kwargs):
+    def invert(self, x, steps=100, lr=0.01, noise=None, streams=3, use_graph=False, **kwargs):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
         latents (masks + blend).  Returns (out, lats, losses[steps,B]).

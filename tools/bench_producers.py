@@ -62,3 +62,37 @@ for res in (64, 128, 256, 512, 1024):
     byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
     print(f'blur_act_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
     del z, nz, ys
+
+# third block: the plain-conv layers' activation backward -> S-form (`act_bwd_sform`, with the ToRGB branch): in the W+ loop
+# only the 1024² layer and the low resolutions run it (the others are fused into the stride-2 conv's epilogue)
+for res in (64, 256, 1024):
+    C = CH[res]
+    g = torch.Generator().manual_seed(res)
+    out = torch.randn(B, C, res, res, generator=g).to(dev)
+    nz = torch.randn(B, 1, res, res, generator=g).to(dev)
+    nw, bias = torch.tensor([0.1], device=dev), torch.zeros(C, device=dev)
+    d = (1 + 0.3 * torch.randn(B, C, generator=g)).abs().to(dev)
+    mul2 = torch.tensor([2.0 ** -9, 2.0 ** 9], device=dev)
+    grgb = (1e-3 * torch.randn(B, 3, res, res, generator=g)).to(dev)
+    wrgb, srgb = torch.randn(3, C, generator=g).to(dev), (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    dst = ops.SForm(B, C, res, res, dev)
+    ms = timeit(lambda: ops.act_bwd_producer(out, None, nz, nw, bias, d, mul2, dst, g_rgb=grgb, w_rgb=wrgb, s_rgb=srgb))
+    byts = 4.0 * B * C * 2 * res * res
+    print(f'act_bwd_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
+    del out, nz, dst
+
+# fourth block: ToRGB that also writes the S-form input of the following up-sampling conv (`torgb_fwd_sform`, 128² .. 512²)
+k4 = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+for res in (128, 256, 512):
+    C = CH[res]
+    g = torch.Generator().manual_seed(res)
+    x = torch.randn(B, C, res, res, generator=g).to(dev)
+    w = torch.randn(3, C, generator=g).to(dev)
+    s, s2 = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev), (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    skip = torch.randn(B, 3, res // 2, res // 2, generator=g).to(dev)
+    bias = torch.zeros(3, device=dev)
+    ys = ops.SForm(B, C, res, res, dev)
+    ms = timeit(lambda: ops.torgb(x, w, s, bias, skip, k4, ys=ys, ys_scale=s2))
+    byts = 4.0 * B * C * 2 * res * res
+    print(f'torgb_fwd_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
+    del x, ys
