@@ -127,7 +127,7 @@ def test_wplus_streams_and_graph_match_single_stream(dev):
     torch.cuda.synchronize()
     assert maxdiff(l2, l1.cpu()) <= 1e-5 * l1.abs().max().item()
     assert ((w2 - w1).abs() < 1e-4).float().mean().item() > 0.999
-    for streams, graph in ((2, False), (4, True)):
+    for streams, graph in ((2, False), (3, False), (4, True)):
         runs = []
         for _ in range(3):
             w2, l2 = WPlusInverter(eng).invert(target, w0, noises, steps=6, streams=streams, use_graph=graph)
