@@ -55,7 +55,7 @@ def parse():
 class ConvProbe:
     """HIP-event timing of every launch of the dominant kernel inside the timed region.  Dominant kernel (largest
     share of GPU time in profiles/): the plain 3x3 stride-1 implicit-GEMM conv with S-form input and >= 64 input
-    channels — template instances ``conv_f16s_s1big_kernel<false, 8>`` (forward) and ``<true, 8>`` (input gradient + style-gradient dot) (split-f16) / ``conv_mfma_kernel<0, 2>`` (fp32):
+    channels — template instances ``conv_f16s_s1big_kernel<false, false>`` (forward) and ``<true, *>`` (input gradient + style-gradient dot) (split-f16) / ``conv_mfma_kernel<0, 2>`` (fp32):
     forward of the plain ModulatedConv2d layers, their input gradients, and the dense AlignNet convs.
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
@@ -315,7 +315,7 @@ def main():
         peak = MFMA_F16_PEAK_TFLOPS if f16s else MFMA_F32_PEAK_TFLOPS
         return dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
                     frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a),
-                    kernel=('conv_f16s_s1big_kernel<false|true, 8>' if f16s else 'conv_mfma_kernel<0, 2>') +
+                    kernel=('conv_f16s_s1big_kernel<false|true, *>' if f16s else 'conv_mfma_kernel<0, 2>') +
                            ' (plain 3x3 stride-1 implicit GEMM, >=64 input channels: forward + input gradient)',
                     measured_on=where,
                     alg_bytes_per_launch=ps['bytes_per_launch'],

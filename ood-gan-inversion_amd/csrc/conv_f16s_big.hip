@@ -1,15 +1,13 @@
-// Split-f16 3x3 stride-1 conv for the >= 128-channel layers (64² ... 256² images): the matrix-bound middle of the
+// Split-f16 3x3 stride-1 conv for the >= 64-channel layers (64² ... 512² images): the matrix-bound middle of the
 // generator (reference src/ops/StyleGAN/model.py:233-274, forward and input gradient).  Same arithmetic as
 // conv_f16s_s1v2_kernel; different pipeline.  The v2 kernel keeps two 64 KB stages in LDS as two anti-phase groups and
-// is bound by the LDS-DMA latency of one stage per step (each step moves 64 KB for 108 MFMAs per wave).  Here ONE
-// workgroup of 8 waves owns a 16 x 32 pixel tile (twice the pixels per weight byte): a K stage is 39 KB of x + 36 KB
-// of weights feeding 108 MFMAs in each of the 8 waves, two stages live in LDS, and the fetch of stage t+2 runs under
-// the MFMAs of stage t+1; both waves of a SIMD issue MFMAs, so one covers the other's fragment-read latency.
+// is bound by the LDS-DMA latency of one stage per step.  Here ONE workgroup of 8 waves owns a 16 x 32 pixel tile (twice
+// the pixels per weight byte): a K stage is 39 KB of x + 36 KB of weights feeding 224 MFMAs (16x16x32) in each of the 8
+// waves, two stages live in LDS, and the fetch of stage t+1 runs under the MFMAs of stage t; both waves of a SIMD issue
+// MFMAs, so one covers the other's fragment-read latency.
 //   * x tile 18 x 34 records of 64 B, slots rotated by (c>>2)&3 through the DMA source address (conflict-free reads,
 //     no padding);  weights in the packed order [tap][hi|lo][k-half][64][8] (36 KB per 16 input channels);
-//   * accumulators 2 M-tiles x 4 rows = 8 tiles per wave, MFMAs issued product-type-major so a tile is revisited
-//     after 8 instructions;
-//   * register epilogue: fp32 rows of 128 contiguous bytes per half wave, fused out-scale / noise / bias / lrelu, or
+//   * register epilogue: fp32 runs of 64 contiguous bytes per lane row, fused out-scale / noise / bias / lrelu, or
 //     the style-gradient dot (backward) reduced through DPP + LDS.
 #include "conv_common.hpp"
 #include "sform.hpp"
@@ -41,22 +39,37 @@ struct BigConv {
     const float* w_unscale;
     int tiles_x, tiles_y, mblocks, Mp;
     long out_plane;
-    int ablate;      // debug: 1 skip MFMAs, 2 skip the per-stage DMA
 };
 
+// The matrix instruction is v_mfma_f32_16x16x32_f16: under a dense MFMA stream the chip holds a higher clock with this shape
+// than with 32x32x16 (MI355X_MICROARCH.md, DVFS item 7; tools/mfma_shape_probe.hip: this kernel's bare tap loop 10 % faster;
+// the whole kernel, against its 32x32x16 predecessor on the same box: -2.6 % over the four layers, -5 % on the input-gradient
+// instances).  K = 32 of one instruction = the 16 channels of TWO TAPS: A = [w(tap a) | w(tap b)] (16 channels x 32), B = [x shifted by tap a ; by tap b]
+// (32 x 16 pixels), so the hi*hi, hi*lo and lo*hi products of a tap pair are three instructions per 16 x 16 tile and the
+// fragment reads per tap stay at 8.  The ninth tap of a chunk takes the hi/lo form instead: [w_hi|w_hi] x [x_hi;x_lo] gives
+// hi*hi + hi*lo, [w_lo|w_lo] x [x_hi;0] gives lo*hi (zeros from an LDS region).  A wave owns 64 channels x 2 rows x 32 pixels =
+// 4 x 4 tiles of 16 x 16 (64 accumulator registers).  Two stages in LDS, ONE barrier per stage: after it every wave has
+// finished stage t-1 (its buffer is free: the LDS-DMA pieces of stage t+1 are issued one at a time BETWEEN the MFMA groups of
+// stage t — a global_load_lds costs the issuing wave ~60-180 cycles (MI355X_MICROARCH.md), and a burst of ten right after the
+// barrier stalls every wave of the CU at once) and stage t has landed (each wave waited for its own loads).
 // PRE (input-gradient instance, oodgan_conv_args.dot_actgrad): the result is the gradient w.r.t. dotx, the OUTPUT of the
 // up-sampling StyledConv below; the epilogue applies that layer's FusedLeakyReLU backward (fused_act.py:25-58) to the values
 // it already holds — y <- dx * (dotx > 0 ? sqrt2 : 0.2 sqrt2) — so the blur^T producer that follows reads one tensor
 // instead of two.  Three VALU operations per value: the kernel's waves have no spare issue slots for more (the sums of
 // that layer's demodulation gradient are finished by the producer and the dot partials, include/oodgan.h).
-template <bool DOT, int NW, bool PRE>
-__global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
-    const BigConv p, const uint4* __restrict__ wpk16) {
+constexpr int BG_ZERO = BG_SMEM;                           // 3.5 KB of zeros (the B operand's second half of the lo*hi product of tap 8)
+constexpr int BG_ZBYTES = 3584;
+constexpr int BG_SMEM16 = BG_SMEM + BG_ZBYTES;            // 159232
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool DOT, bool PRE>
+__global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, const uint4* __restrict__ wpk16) {
+    constexpr int NW = 8, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const oodgan_conv_args& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
+    const int n16 = lane & 15, g = lane >> 4;
 
     int w = xcd_remap(blockIdx.x, gridDim.x);
     const int mblk = w % p.mblocks;
@@ -67,10 +80,7 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const int r0 = ty * 16, c0 = tx * 32, m0 = mblk * 64;
     const int H = a.Hin, W = a.Win, M = a.M;
 
-    // ---- per-lane DMA source offsets (bytes): x pieces relative to (plane of chunk 0, row r0, col c0), rotation applied;
-    // weight pieces relative to the chunk's block.  Piece pc = wave + 4*i, i < 19 (pc < 75).
-    constexpr int NT = 16 / NW;                              // rows per wave
-    constexpr int NPW = (BG_PIECES + NW - 1) / NW;          // 19 (4 waves) / 10 (8 waves)
+    constexpr int NPW = (BG_PIECES + NW - 1) / NW;          // 10
     unsigned off[NPW];
     const int KC = p.xd.KC;
 #pragma unroll
@@ -80,11 +90,11 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
             int P = pc * 64 + lane;
             if (P >= BG_XSLOTS) P = BG_XSLOTS - 1;
             const int row = P / (BG_C * 4), q = P % (BG_C * 4);
-            const int c = q >> 2, s = ((q & 3) - ((c >> 2) & 3)) & 3;
-            const int rr = min(r0 + row, p.xd.Hp - 1);      // tiles of 16 rows may reach below the 8-row padding
-            off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + s) * 16);
+            const int c = q >> 2, sl = ((q & 3) - ((c >> 2) & 3)) & 3;
+            const int rr = min(r0 + row, p.xd.Hp - 1);
+            off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + sl) * 16);
         } else {
-            const int u = (pc - BG_XPIECES) * 64 + lane;    // 16-byte unit inside the 36 x 64 weight block
+            const int u = (pc - BG_XPIECES) * 64 + lane;
             const int row = u >> 6, j = u & 63;
             off[i] = (unsigned)((((long)row * p.Mp) + m0 + j) * 16);
         }
@@ -94,10 +104,6 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16);
     const long wchunk_bytes = (long)36 * p.Mp * 16;
     const int nchunk = (a.K + 15) / 16;
-
-    // piece i of this wave for stage t (buffer buf); pieces are issued ONE AT A TIME between the MFMA groups of the
-    // previous stage: a global_load_lds costs the issuing wave ~60-180 cycles (MI355X_MICROARCH.md), and a burst of ten of
-    // them right after the barrier stalls every wave of the CU at once — DMA time and MFMA time then add up
     auto dma_piece = [&](int t, int buf, int i) {
         const int pc = wave + NW * i;
         if (pc >= BG_PIECES) return;
@@ -105,186 +111,194 @@ __global__ __launch_bounds__(64 * NW) void conv_f16s_s1big_kernel(
         const unsigned char* src = (pc < BG_XPIECES ? xb + (long)t * xplane_bytes : wb + (long)t * wchunk_bytes) + off[i];
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
     };
-    auto dma_stage = [&](int t, int buf) {
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) dma_piece(t, buf, i);
-    };
+    for (int i = tid; i < BG_ZBYTES / 16; i += 512) reinterpret_cast<uint4*>(smem + BG_ZERO)[i] = make_uint4(0, 0, 0, 0);
 
-    f32x16 acc[2][NT];
+    f32x4v acc[4][4];        // [M-tile of 16 channels][row nt * 2 + column half]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int n = 0; n < 4; ++n) acc[mt][n] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    // lane-constant fragment offsets
-    unsigned lrd[3][2];
+    // ---- lane-constant fragment offsets.  Lane = (row / column 16 index n16, K group g): K groups 0,1 = channels 0-7 / 8-15 of
+    // the pair's first tap, 2,3 = of its second tap.  Pairs are consecutive taps (2p, 2p+1), tap = ky*3 + kx.
+    const unsigned laneA = (unsigned)((((g & 1) * 64 + n16) * 16) + (g >> 1) * 4096);       // + 2p*4096 + hl*2048 + mt*256
+    const unsigned laneA1 = (unsigned)(((g & 1) * 64 + n16) * 16);                             // ninth tap: both halves the same tap
+    unsigned offBh[4], offBl[4];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int lo = 0; lo < 2; ++lo) {
-            const int c = kx + l31;
-            lrd[kx][lo] = c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
-        }
-    const unsigned lwf = (half * 64 + l31) * 16;
+    for (int pp = 0; pp < 4; ++pp) {
+        const int tp = 2 * pp + (g >> 1), ky = tp / 3, kx = tp % 3, col = n16 + kx;
+        offBh[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + ((col >> 2) & 3)) & 3) << 4));
+        offBl[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + 2 + ((col >> 2) & 3)) & 3) << 4));
+    }
+    const int col8 = n16 + 2;
+    const unsigned offB1 = (unsigned)(2 * (BG_C * 64) + col8 * 64 + (((g + ((col8 >> 2) & 3)) & 3) << 4));      // [x_hi ; x_lo] of tap 8: slot g
 
-    // One stage = 9 taps on the same accumulators, taken column-major (kx outer): the three taps of a kernel column read the
-    // SAME x rows (rows nt + ky of the column shift kx), so a column's NT + 2 rows are fetched from LDS once (hi and lo: 8
-    // fragments for NT = 2) instead of NT per tap — 24 B-fragment reads per stage instead of 36, 60 ds_read_b128 instead of 72
-    // with the 36 weight fragments.  The weight fragments of tap i+1 and, in halves, the x rows of the next column are
-    // fetched while the MFMAs of tap i issue (two register sets each, order pinned with sched_barrier).  ONE barrier per
-    // stage: after it every wave has finished stage t-1 (its buffer is free: the fetch of stage t+1 is issued right there and
-    // runs under this stage's MFMAs) and stage t has landed (each wave waited for its own loads).
-    struct AF { half8 ah[2], al[2]; };
-    struct BF { half8 bh[NT + 2], bl[NT + 2]; };
-    auto load_a = [&](AF& f, const unsigned char* lw, auto tp_c) {
-        constexpr int tp = decltype(tp_c)::value;
+    struct AF { half8 x[2], y[2]; };         // pair: w_hi, w_lo of two M-tiles; ninth tap: [w_hi|w_hi], [w_lo|w_lo]
+    struct BF { half8 u[4], v[4]; };         // pair: x_hi, x_lo of the four N-tiles; ninth tap: [x_hi;x_lo], [x_hi;0]
+    auto load_a = [&](AF& f, const unsigned char* lw, auto pp_c, auto mh_c) {
+        constexpr int pp = decltype(pp_c)::value, mh = decltype(mh_c)::value;
+        const unsigned char* q = lw + (pp < 4 ? laneA + 2 * pp * 4096 : laneA1 + 8 * 4096);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f.ah[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 0) * 2) * 64 + mt * 32) * 16);
-            f.al[mt] = *reinterpret_cast<const half8*>(lw + (((tp * 2 + 1) * 2) * 64 + mt * 32) * 16);
+        for (int i = 0; i < 2; ++i) {
+            f.x[i] = *reinterpret_cast<const half8*>(q + (2 * mh + i) * 256);
+            f.y[i] = *reinterpret_cast<const half8*>(q + 2048 + (2 * mh + i) * 256);
         }
     };
-    auto load_b = [&](BF& f, const unsigned char* lx, auto kx_c, auto r0_c, auto r1_c) {      // rows [r0, r1) of column kx
-        constexpr int kx = decltype(kx_c)::value, ra = decltype(r0_c)::value, rb = decltype(r1_c)::value;
+    auto load_b = [&](BF& f, const unsigned char* lx, const unsigned char* lz, auto pp_c, auto part_c) {       // part 0: u, 1: v
+        constexpr int pp = decltype(pp_c)::value, part = decltype(part_c)::value;
 #pragma unroll
-        for (int r = ra; r < rb; ++r) {
-            f.bh[r] = *reinterpret_cast<const half8*>(lx + r * (BG_C * 64) + lrd[kx][0]);
-            f.bl[r] = *reinterpret_cast<const half8*>(lx + r * (BG_C * 64) + lrd[kx][1]);
+        for (int n = 0; n < 4; ++n) {
+            const int o = (n >> 1) * (BG_C * 64) + (n & 1) * 1024;
+            if (pp < 4) {
+                if (part == 0) f.u[n] = *reinterpret_cast<const half8*>(lx + offBh[pp < 4 ? pp : 0] + o);
+                else f.v[n] = *reinterpret_cast<const half8*>(lx + offBl[pp < 4 ? pp : 0] + o);
+            } else {
+                if (part == 0) f.u[n] = *reinterpret_cast<const half8*>(lx + offB1 + o);
+                else f.v[n] = *reinterpret_cast<const half8*>(lz + o);         // K groups 0,1: x_hi of tap 8; groups 2,3: zeros
+            }
         }
     };
-    auto mfma_tap = [&](const AF& fa, const BF& fb, auto ky_c) {
-        constexpr int ky = decltype(ky_c)::value;
+    auto mfma_half = [&](const AF& fa, const BF& fb, auto pp_c, auto mh_c) {
+        constexpr int pp = decltype(pp_c)::value, mh = decltype(mh_c)::value;
+        if (pp < 4) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.ah[mt], fb.bh[nt + ky], acc[mt][nt], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.x[i], fb.u[n], acc[2 * mh + i][n], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.ah[mt], fb.bl[nt + ky], acc[mt][nt], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.x[i], fb.v[n], acc[2 * mh + i][n], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.al[mt], fb.bh[nt + ky], acc[mt][nt], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.y[i], fb.u[n], acc[2 * mh + i][n], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.x[i], fb.u[n], acc[2 * mh + i][n], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.y[i], fb.v[n], acc[2 * mh + i][n], 0, 0, 0);
+        }
     };
-#define BG_IC(n) std::integral_constant<int, n>{}
-#define BG_SB() __builtin_amdgcn_sched_barrier(0)
-    static_assert(NT == 2, "the half-column prefetch below assumes four x rows per column");
-    dma_stage(0, 0);
+#define BH_IC(n) std::integral_constant<int, n>{}
+#define BH_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
     for (int t = 0; t < nchunk; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
-        const bool pf = t + 1 < nchunk && !(p.ablate & 2);
+        const bool pf = t + 1 < nchunk;
         const int nb = (t + 1) & 1;
-        if (p.ablate & 1) { if (pf) dma_stage(t + 1, nb); continue; }
         const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * NT) * (BG_C * 64);
-        const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES + lwf;
+        const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES;
+        // [x_hi ; 0] of tap 8: K groups 0,1 read the hi slots of the record, groups 2,3 the zero region (same immediate offsets)
+        const unsigned col8r = (unsigned)(2 * (BG_C * 64) + col8 * 64 + ((((g & 1) + ((col8 >> 2) & 3)) & 3) << 4));
+        const unsigned char* lz = g < 2 ? lx + col8r : smem + BG_ZERO;
         AF a0, a1;
         BF b0, b1;
-        static_assert(NPW <= 10, "one DMA piece per tap slot below");
-#define BG_DMA(i) if (pf && (i) < NPW) dma_piece(t + 1, nb, (i));
-        // tap (ky, kx) has weight index ky*3 + kx
-        load_b(b0, lx, BG_IC(0), BG_IC(0), BG_IC(4));
-        load_a(a0, lw, BG_IC(0));
-        BG_SB();
-        load_a(a1, lw, BG_IC(3)); load_b(b1, lx, BG_IC(1), BG_IC(0), BG_IC(2)); BG_DMA(0) BG_SB(); mfma_tap(a0, b0, BG_IC(0)); BG_SB();
-        load_a(a0, lw, BG_IC(6)); load_b(b1, lx, BG_IC(1), BG_IC(2), BG_IC(4)); BG_DMA(1) BG_SB(); mfma_tap(a1, b0, BG_IC(1)); BG_SB();
-        load_a(a1, lw, BG_IC(1)); BG_DMA(2) BG_SB(); mfma_tap(a0, b0, BG_IC(2)); BG_SB();
-        load_a(a0, lw, BG_IC(4)); load_b(b0, lx, BG_IC(2), BG_IC(0), BG_IC(2)); BG_DMA(3) BG_SB(); mfma_tap(a1, b1, BG_IC(0)); BG_SB();
-        load_a(a1, lw, BG_IC(7)); load_b(b0, lx, BG_IC(2), BG_IC(2), BG_IC(4)); BG_DMA(4) BG_SB(); mfma_tap(a0, b1, BG_IC(1)); BG_SB();
-        load_a(a0, lw, BG_IC(2)); BG_DMA(5) BG_SB(); mfma_tap(a1, b1, BG_IC(2)); BG_SB();
-        load_a(a1, lw, BG_IC(5)); BG_DMA(6) BG_SB(); mfma_tap(a0, b0, BG_IC(0)); BG_SB();
-        load_a(a0, lw, BG_IC(8)); BG_DMA(7) BG_SB(); mfma_tap(a1, b0, BG_IC(1)); BG_SB();
-        BG_DMA(8) BG_DMA(9) BG_SB();
-        mfma_tap(a0, b0, BG_IC(2));
-#undef BG_DMA
+#define BH_DMA(i) if (pf && (i) < NPW) dma_piece(t + 1, nb, (i));
+        // ten half steps: pairs 0..3 and the ninth tap (index 4), each for the M-tile halves 0 and 1; the A fragments of the next
+        // half step and half of the next pair's B fragments are read under the MFMAs of the current one
+        load_b(b0, lx, lz, BH_IC(0), BH_IC(0)); load_b(b0, lx, lz, BH_IC(0), BH_IC(1));
+        load_a(a0, lw, BH_IC(0), BH_IC(0));
+        BH_SB();
+        load_a(a1, lw, BH_IC(0), BH_IC(1)); load_b(b1, lx, lz, BH_IC(1), BH_IC(0)); BH_DMA(0) BH_SB(); mfma_half(a0, b0, BH_IC(0), BH_IC(0)); BH_SB();
+        load_a(a0, lw, BH_IC(1), BH_IC(0)); load_b(b1, lx, lz, BH_IC(1), BH_IC(1)); BH_DMA(1) BH_SB(); mfma_half(a1, b0, BH_IC(0), BH_IC(1)); BH_SB();
+        load_a(a1, lw, BH_IC(1), BH_IC(1)); load_b(b0, lx, lz, BH_IC(2), BH_IC(0)); BH_DMA(2) BH_SB(); mfma_half(a0, b1, BH_IC(1), BH_IC(0)); BH_SB();
+        load_a(a0, lw, BH_IC(2), BH_IC(0)); load_b(b0, lx, lz, BH_IC(2), BH_IC(1)); BH_DMA(3) BH_SB(); mfma_half(a1, b1, BH_IC(1), BH_IC(1)); BH_SB();
+        load_a(a1, lw, BH_IC(2), BH_IC(1)); load_b(b1, lx, lz, BH_IC(3), BH_IC(0)); BH_DMA(4) BH_SB(); mfma_half(a0, b0, BH_IC(2), BH_IC(0)); BH_SB();
+        load_a(a0, lw, BH_IC(3), BH_IC(0)); load_b(b1, lx, lz, BH_IC(3), BH_IC(1)); BH_DMA(5) BH_SB(); mfma_half(a1, b0, BH_IC(2), BH_IC(1)); BH_SB();
+        load_a(a1, lw, BH_IC(3), BH_IC(1)); load_b(b0, lx, lz, BH_IC(4), BH_IC(0)); BH_DMA(6) BH_SB(); mfma_half(a0, b1, BH_IC(3), BH_IC(0)); BH_SB();
+        load_a(a0, lw, BH_IC(4), BH_IC(0)); load_b(b0, lx, lz, BH_IC(4), BH_IC(1)); BH_DMA(7) BH_SB(); mfma_half(a1, b1, BH_IC(3), BH_IC(1)); BH_SB();
+        load_a(a1, lw, BH_IC(4), BH_IC(1)); BH_DMA(8) BH_SB(); mfma_half(a0, b0, BH_IC(4), BH_IC(0)); BH_SB();
+        BH_DMA(9) BH_SB();
+        mfma_half(a1, b0, BH_IC(4), BH_IC(1));
+#undef BH_DMA
     }
-#undef BG_IC
-#undef BG_SB
+#undef BH_IC
+#undef BH_SB
 
-    // ---- epilogue from the accumulators
+    // ---- epilogue from the accumulators: lane (n16, g) holds, per M-tile mt and N-tile n, channels 16*mt + 4*g + r (r = 0..3) of
+    // pixel (row nt = n >> 1, column 16*(n & 1) + n16): 64-byte runs per channel and store
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
-    const int px = c0 + l31;
     const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W : nullptr;
     float* red = reinterpret_cast<float*>(smem + BG_RED);
+    float osc[16], bia[16];
+    unsigned moff[16], doff[16];
+    float dsum[16];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        float osc[16], bia[16];
-        float dsum[16];      // per 32-channel half: reduced right after its rows (registers)
+    for (int q = 0; q < 16; ++q) {
+        const int m = m0 + 16 * (q >> 2) + 4 * g + (q & 3);
+        const bool mok = m < M;
+        osc[q] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
+        bia[q] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
+        moff[q] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
+        doff[q] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
+        dsum[q] = 0.f;
+    }
+    const bool mfull = m0 + 64 <= M;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dsum[r] = 0.f;
-        unsigned moff[16], doff[16];
+    for (int n = 0; n < 4; ++n) {
+        const int py = r0 + wave * NT + (n >> 1), px = c0 + 16 * (n & 1) + n16;
+        const bool ok = py < H && px < W;
+        float nz = 0.f;
+        if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
+        unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + px) * 4;
+        const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py * W + px) * 4 : nullptr;
+        float o[16], dv[16];
+        if (DOT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool mok = m < M;
-            osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
-            bia[r] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
-            moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
-            doff[r] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
-        }
-        const bool mfull = m0 + mt * 32 + 32 <= M;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int py = r0 + wave * NT + nt;
-            const bool ok = py < H && px < W;
-            float nz = 0.f;
-            if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
-            unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + px) * 4;
-            const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py * W + px) * 4 : nullptr;
-            float o[16], dv[16];
-            if (DOT) {
-                // all 16 loads of the row are issued before the first use (one conditional load per value would serialise
-                // them into 16 memory latencies)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
-                if (ok) {
-                    if (mfull) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (moff[r] != 0xFFFFFFFFu) dv[r] = *reinterpret_cast<const float*>(dr + doff[r]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[mt][nt][r];
-                o[r] = v * osc[r];
-                if (DOT) {
-                    dsum[r] += (v * us) * dv[r];
-                    if (PRE) o[r] *= dv[r] > 0.f ? kSqrt2 : 0.2f * kSqrt2;
-                } else {
-                    o[r] += nz + bia[r];
-                    if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
-                }
-            }
+            for (int q = 0; q < 16; ++q) dv[q] = 0.f;
             if (ok) {
                 if (mfull) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
+                    for (int q = 0; q < 16; ++q) dv[q] = *reinterpret_cast<const float*>(dr + doff[q]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
+                    for (int q = 0; q < 16; ++q)
+                        if (moff[q] != 0xFFFFFFFFu) dv[q] = *reinterpret_cast<const float*>(dr + doff[q]);
                 }
             }
         }
-        if (DOT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = half_sum_dpp(dsum[r]);
-                if (l31 == kHalfSumLane) red[wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+        for (int q = 0; q < 16; ++q) {
+            const float v = acc[q >> 2][n][q & 3];
+            o[q] = v * osc[q];
+            if (DOT) {
+                dsum[q] += (v * us) * dv[q];
+                if (PRE) o[q] *= dv[q] > 0.f ? kSqrt2 : 0.2f * kSqrt2;
+            } else {
+                o[q] += nz + bia[q];
+                if (a.act == OODGAN_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : 0.2f * o[q]) * kSqrt2;
+            }
+        }
+        if (ok) {
+            if (mfull) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) *reinterpret_cast<float*>(yr + moff[q]) = o[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (moff[q] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[q]) = o[q];
             }
         }
     }
     if (DOT) {
-        // the host sizes the partial-sum tables for 8-row tiles: this 16-row tile owns two of their slots
+        // sum over the 16 pixels of a lane row (DPP, the total in every lane of the row), then across the waves through LDS
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v = dsum[q];
+            v += dpp_take<0xB1, 0xF>(v);
+            v += dpp_take<0x4E, 0xF>(v);
+            v += dpp_take<0x141, 0xF>(v);
+            v += dpp_take<0x140, 0xF>(v);
+            if (n16 == 0) red[wave * 64 + 16 * (q >> 2) + 4 * g + (q & 3)] = v;
+        }
         __syncthreads();
         if (tid < 64 && m0 + tid < M) {
             float v = 0.f;
@@ -341,26 +355,19 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
                        ((a.Hin + 7) / 8) * p.tiles_x);
     }
     OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32) && (long)a.M * a.Hin * a.Win * 4 < (1L << 32), "conv3x3 big: plane too large");
-#ifdef OODGAN_DEBUG_ABLATE      // profiling builds only: the ablation bits make the kernel skip work (wrong results)
-    static const int abl = getenv("OODGAN_BIG_ABLATE") ? atoi(getenv("OODGAN_BIG_ABLATE")) : 0;
-    p.ablate = abl;
-#else
-    p.ablate = 0;
-#endif
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (the 4-wave variant was slower than the
+    // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (a 4-wave variant was slower than the
     // v2 tile kernel: 474 / 475 / 552 us against 393 / 407 / 464 on the 64² / 128² / 256² layers)
-    if (a.dot_actgrad) {
-        OODGAN_REQUIRE(a.dotx, "conv3x3 big: dot_actgrad without dotx");
-        hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8, true>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
-    } else if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, 8, false>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, 8, false>), dim3((unsigned)total), dim3(512), BG_SMEM, st, p, w16);
+    OODGAN_REQUIRE(!a.dot_actgrad || a.dotx, "conv3x3 big: dot_actgrad without dotx");
+    if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    else if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     return check_launch("conv3x3_f16s_s1big");
 }
 
