@@ -210,14 +210,17 @@ int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
  * fetch their halo'd tiles as contiguous runs by LDS-DMA.  Buffers must be zero-initialised once (border).
- * oodgan_to_sform converts an fp32 NCHW tensor: value = x*scale[b,c]*mul2[1].
+ * oodgan_to_sform converts an fp32 NCHW tensor: value = (x*scale[b,c] + shift[b,c])*mul2[1].
  * Every forward producer of an S-form (oodgan_to_sform, oodgan_blur_act_sform, oodgan_torgb_fwd_sform) takes an optional
  * `vmax` (B x OODGAN_VMAX_SLOTS unsigned, float bit patterns, atomically maxed into one of the sample's slots): the
  * largest |value| it wrote for each sample — the input of the forward range control below. */
 #define OODGAN_VMAX_SLOTS 64
 long oodgan_sform_bytes(int B, int C, int H, int W);
-int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
-                    int H, int W, int in_pitch, unsigned* vmax, void* stream);
+/* value = (x*scale[b,c] + shift[b,c]) * mul2[1]; scale / shift / mul2 may be NULL.  The shift only reaches image pixels — the
+ * border of the S-form stays zero, as the zero padding of a conv applied AFTER an affine normalisation requires (the SAMM
+ * bottlenecks: InstanceNorm folded into scale and shift, src/ops/SAMM/helpers.py bottleneck_IR). */
+int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* shift, int shift_stride,
+                    const float* mul2, void* out, int B, int C, int H, int W, int in_pitch, unsigned* vmax, void* stream);
 /* Phase-split S-form for the stride-2 conv (mode S2 with x_sform): the (2H+1)x(2W+1) input is stored as its four
  * parity images G[py][px][i][j] = x[2i+py][2j+px], each in S-form without border, so that the stride-2 conv
  * becomes stride-1 taps on contiguous runs.  H,W = OUTPUT size of the S2 conv. */

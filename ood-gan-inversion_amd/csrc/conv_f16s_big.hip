@@ -228,15 +228,17 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W : nullptr;
     float* red = reinterpret_cast<float*>(smem + BG_RED);
-    float osc[16], bia[16];
+    float osc[16], bia[16], slp[16];
     unsigned moff[16], doff[16];
     float dsum[16];
+    const bool prelu = !DOT && a.act == OODGAN_ACT_PRELU;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int m = m0 + 16 * (q >> 2) + 4 * g + (q & 3);
         const bool mok = m < M;
         osc[q] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
         bia[q] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
+        slp[q] = (prelu && mok) ? a.slope[m] : 1.f;
         moff[q] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
         doff[q] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
         dsum[q] = 0.f;
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
             } else {
                 o[q] += nz + bia[q];
                 if (a.act == OODGAN_ACT_LRELU) o[q] = (o[q] > 0.f ? o[q] : 0.2f * o[q]) * kSqrt2;
+                else if (prelu) o[q] = o[q] > 0.f ? o[q] : slp[q] * o[q];
             }
         }
         if (ok) {
@@ -327,7 +330,8 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
     // 64 memory latencies; the loads of a row are now issued together.)
     const int min_k = 64;                // 64 -> 64 channels @512²: 589 -> 491 us forward
     if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
-          (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && a.in_scale == nullptr && a.in_shift == nullptr &&
+          (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU || (a.act == OODGAN_ACT_PRELU && a.slope)) && a.in_scale == nullptr &&
+          a.in_shift == nullptr &&
           !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))
         return false;
     // enough 16x32 tiles to fill the chip; smaller layers keep the latency-oriented instances

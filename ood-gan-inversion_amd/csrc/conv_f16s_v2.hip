@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void blurT_sp_kernel(const float* __restrict__
 
 // F-form (B,C,H,W) fp32 -> S-form, value = x*scale[b,c]*mul2[1]; one thread per (b,kc,y,x) record
 __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                       int scale_stride, const float* __restrict__ mul2, uint4* __restrict__ out,
+                                                       int scale_stride, const float* __restrict__ shift, int shift_stride,
+                                                       const float* __restrict__ mul2, uint4* __restrict__ out,
                                                        int B, SDims d, int in_pitch, unsigned* __restrict__ vmax) {
     const long total = (long)B * d.KC * d.H * d.W;
     const float gm = mul2 ? mul2[1] : 1.f;
@@ -748,7 +749,9 @@ __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__
         for (int j = 0; j < 16; ++j) {
             const int c = kc * 16 + j;
             float v = 0.f;
-            if (c < d.C) v = x[((long)b * d.C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) * gm;
+            if (c < d.C)
+                v = (x[((long)b * d.C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) +
+                     (shift ? shift[(long)b * shift_stride + c] : 0.f)) * gm;
             vm = fmaxf(vm, fabsf(v));
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
@@ -768,14 +771,14 @@ extern "C" long oodgan_sform_bytes(int B, int C, int H, int W) {
     return (long)B * d.KC * d.plane * 16;
 }
 
-extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B, int C,
-                               int H, int W, int in_pitch, unsigned* vmax, void* stream) {
+extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const float* shift, int shift_stride,
+                               const float* mul2, void* out, int B, int C, int H, int W, int in_pitch, unsigned* vmax, void* stream) {
     OODGAN_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "to_sform: bad args");
     const SDims d = sform_dims(C, H, W);
     if (in_pitch == 0) in_pitch = W;
     const long total = (long)B * d.KC * H * W;
     hipLaunchKernelGGL(to_sform_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale, scale_stride,
-                       mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch, vmax);
+                       shift, shift_stride, mul2, reinterpret_cast<uint4*>(out), B, d, in_pitch, vmax);
     return check_launch("to_sform");
 }
 

@@ -306,15 +306,16 @@ def sform_scratch(B, C, H, W, device, tag=0):
     return buf
 
 
-def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0, vmax=None):
-    """fp32 NCHW -> S-form of x*scale[b,c]*mul2[1].  ``vmax`` (B int32, zero-initialised float bit patterns): per-sample
-    max |value written| for the forward range control (``FwdRange``)."""
+def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0, vmax=None, shift=None):
+    """fp32 NCHW -> S-form of (x*scale[b,c] + shift[b,c])*mul2[1].  ``vmax`` (B int32, zero-initialised float bit patterns):
+    per-sample max |value written| for the forward range control (``FwdRange``)."""
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
     H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
     if out is None:
         out = SForm(B, C, H, W, x.device)
-    check(_lib.lib().oodgan_to_sform(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2), _p(out),
+    check(_lib.lib().oodgan_to_sform(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1],
+                                     _p(_opt(shift, 'shift')), 0 if shift is None else shift.shape[1], _p(mul2), _p(out),
                                      B, C, H, W, in_pitch, _p(vmax), _stream()), 'to_sform')
     return out
 

@@ -222,11 +222,21 @@ class bottleneck_IR(nn.Module):
         prep = self._prepared()
         rl = self.res_layer
         sc, sh = instnorm_coeffs(instnorm_stats(x), rl[0].weight, rl[0].bias)
-        r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)
-        if self.depth > 8:
-            r = ops.conv3x3(r, prep['w2'], self.depth, CONV_S1)
+        if self.in_channel >= 64 and self.depth >= 64:
+            # the AlignNet convs (2C -> 2C channels, 7x the generator's FLOPs per image): through the S-form and
+            # the 8-wave kernel of the generator's own >= 64-channel layers; InstanceNorm's affine folded into the conversion
+            B, _, H, W = x.shape
+            xs = ops.to_sform(x, sc, shift=sh, out=ops.sform_scratch(B, self.in_channel, H, W, x.device))
+            r = ops.conv3x3(xs, prep['w1'], self.depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight)
+            rs = ops.to_sform(r, out=ops.sform_scratch(B, self.depth, H, W, x.device))
+            r = ops.conv3x3(rs, prep['w2'], self.depth, CONV_S1)
+            del xs, rs
         else:
-            r = conv3x3_small(r, rl[3].weight)
+            r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)
+            if self.depth > 8:
+                r = ops.conv3x3(r, prep['w2'], self.depth, CONV_S1)
+            else:
+                r = conv3x3_small(r, rl[3].weight)
         if self.in_channel == self.depth:
             shortcut = x
         else:

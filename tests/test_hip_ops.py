@@ -385,9 +385,18 @@ def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
     y2, dot = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
     close(y2, raw * d[:, :, None, None])
     close(dot, (raw * dotx).sum(dim=(2, 3)), 2e-4)
-    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1000000000')         # same call through the tile kernel
+    # affine input (the SAMM bottlenecks: InstanceNorm folded into the S-form conversion, zero padding AFTER it) + PReLU epilogue
+    sh = synth.normal('bg.sh', (B, Ci), 9, 0.5)
+    slope = synth.normal('bg.sl', (Co,), 10, 0.1, 0.25)
+    xa = ops.to_sform(x.to(dev), s.to(dev), shift=sh.to(dev))
+    y4 = ops.conv3x3(xa, wpk, Co, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev))
+    ref4 = F.conv2d(x * s[:, :, None, None] + sh[:, :, None, None], w, padding=1)
+    close(y4, torch.where(ref4 > 0, ref4, ref4 * slope.view(1, -1, 1, 1)))
+    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1000000000')         # same calls through the tile kernel
     y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
     assert (y3 - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
+    y5 = ops.conv3x3(xa, wpk, Co, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev))
+    assert (y5 - y4).abs().max().item() <= 1e-5 * y4.abs().max().item()
 
 
 @pytest.mark.parametrize('B,C,H,W', [(2, 32, 16, 32), (1, 64, 72, 128), (2, 16, 6, 4)])
