@@ -520,7 +520,9 @@ bool s2_big_eligible(const oodgan_conv_args& a) {
     const int Hn = (a.Hin - 1) / 2, Wn = (a.Win - 1) / 2;
     const long items = (long)((Hn + 7) / 8) * ((Wn + 31) / 32) * a.B * ((a.M + 63) / 64);
     const char* e = getenv("OODGAN_S2_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
-    return items >= (e ? atol(e) : 256);     // 512 -> 512 @64² -> 32² (256 items): 229 -> 139 us against the merged-parity tile kernel
+    // 128 work items = half the CUs: what a sub-batch of 2-3 images (three concurrent streams) brings to the 64² / 32² layers.  Whole loop,
+    // 3 streams, same box: threshold 256 -> 5.67 img/s, 128 -> 5.79 (one stream, batch 8: the 32² input gradient 169 -> 150 us)
+    return items >= (e ? atol(e) : 128);     // 512 -> 512 @64² -> 32² (256 items): 229 -> 139 us against the merged-parity tile kernel
 }
 
 }  // namespace oodgan
