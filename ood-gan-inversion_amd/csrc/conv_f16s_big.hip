@@ -5,8 +5,10 @@
 // the pixels per weight byte): a K stage is 39 KB of x + 36 KB of weights feeding 224 MFMAs (16x16x32) in each of the 8
 // waves, two stages live in LDS, and the fetch of stage t+1 runs under the MFMAs of stage t; both waves of a SIMD issue
 // MFMAs, so one covers the other's fragment-read latency.
-//   * x tile 18 x 34 records of 64 B, slots rotated by (c>>2)&3 through the DMA source address (conflict-free reads,
-//     no padding);  weights in the packed order [tap][hi|lo][k-half][64][8] (36 KB per 16 input channels);
+//   * x tile 18 x 34 records of 64 B, the four 16-byte slots of record c rotated by 2*((c>>2)&1) through the DMA source
+//     address: with this kernel's lane layout (lane = pixel + 16 * K group) every one of ds_read_b128's four 16-lane groups
+//     ({0-3,12-15,20-27}, ...) then covers the 16 slots of a bank row once, for every tap shift (the (c>>2)&3 rotation of the
+//     32x32x16 kernels gave 2-way conflicts on a quarter of the slots here: 32 % of the LDS-active cycles), no padding;  weights in the packed order [tap][hi|lo][k-half][64][8] (36 KB per 16 input channels);
 //   * register epilogue: fp32 runs of 64 contiguous bytes per lane row, fused out-scale / noise / bias / lrelu, or
 //     the style-gradient dot (backward) reduced through DPP + LDS.
 #include "conv_common.hpp"
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
             int P = pc * 64 + lane;
             if (P >= BG_XSLOTS) P = BG_XSLOTS - 1;
             const int row = P / (BG_C * 4), q = P % (BG_C * 4);
-            const int c = q >> 2, sl = ((q & 3) - ((c >> 2) & 3)) & 3;
+            const int c = q >> 2, sl = ((q & 3) - 2 * ((c >> 2) & 1)) & 3;
             const int rr = min(r0 + row, p.xd.Hp - 1);
             off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + sl) * 16);
         } else {
@@ -127,11 +129,11 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
         const int tp = 2 * pp + (g >> 1), ky = tp / 3, kx = tp % 3, col = n16 + kx;
-        offBh[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + ((col >> 2) & 3)) & 3) << 4));
-        offBl[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + 2 + ((col >> 2) & 3)) & 3) << 4));
+        offBh[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + 2 * ((col >> 2) & 1)) & 3) << 4));
+        offBl[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + 2 + 2 * ((col >> 2) & 1)) & 3) << 4));
     }
     const int col8 = n16 + 2;
-    const unsigned offB1 = (unsigned)(2 * (BG_C * 64) + col8 * 64 + (((g + ((col8 >> 2) & 3)) & 3) << 4));      // [x_hi ; x_lo] of tap 8: slot g
+    const unsigned offB1 = (unsigned)(2 * (BG_C * 64) + col8 * 64 + (((g + 2 * ((col8 >> 2) & 1)) & 3) << 4));      // [x_hi ; x_lo] of tap 8: slot g
 
     struct AF { half8 x[2], y[2]; };         // pair: w_hi, w_lo of two M-tiles; ninth tap: [w_hi|w_hi], [w_lo|w_lo]
     struct BF { half8 u[4], v[4]; };         // pair: x_hi, x_lo of the four N-tiles; ninth tap: [x_hi;x_lo], [x_hi;0]
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         const unsigned char* lx = smem + (t & 1) * BG_STAGE + (wave * NT) * (BG_C * 64);
         const unsigned char* lw = smem + (t & 1) * BG_STAGE + BG_XBYTES;
         // [x_hi ; 0] of tap 8: K groups 0,1 read the hi slots of the record, groups 2,3 the zero region (same immediate offsets)
-        const unsigned col8r = (unsigned)(2 * (BG_C * 64) + col8 * 64 + ((((g & 1) + ((col8 >> 2) & 3)) & 3) << 4));
+        const unsigned col8r = (unsigned)(2 * (BG_C * 64) + col8 * 64 + ((((g & 1) + 2 * ((col8 >> 2) & 1)) & 3) << 4));
         const unsigned char* lz = g < 2 ? lx + col8r : smem + BG_ZERO;
         AF a0, a1;
         BF b0, b1;
