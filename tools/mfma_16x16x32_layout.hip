@@ -1,3 +1,5 @@
+// Lane layout of v_mfma_f32_16x16x32_f16 as conv_f16s_big.hip assumes it (A: lane l = row l%16, K group l/16 of 8 values; B: column l%16,
+// K group l/16; D: column l%16, rows 4*(l/16)+r), checked against a host product.  hipcc --offload-arch=gfx950 -O2 tools/mfma_16x16x32_layout.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
