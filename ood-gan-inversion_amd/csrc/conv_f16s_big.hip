@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
     };
     for (int i = tid; i < BG_ZBYTES / 16; i += 512) reinterpret_cast<uint4*>(smem + BG_ZERO)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();         // the loop's barriers wait for vmcnt only: make the zero region visible to every wave here
 
     f32x4v acc[4][4];        // [M-tile of 16 channels][row nt * 2 + column half]
 #pragma unroll
