@@ -55,7 +55,8 @@ def test_cli_end_to_end(tmp_path):
     os.makedirs(tmp_path / 'data')
     rng = np.random.default_rng(1)
     for n in ('00002.png', '00001.png'):
-        imgio.imwrite(str(tmp_path / 'data' / n), rng.integers(0, 256, (64, 64, 3), dtype=np.uint8))
+        # BASELINE configs[0]: a single 256x256 face through the E4E_Face_test.yml option surface
+        imgio.imwrite(str(tmp_path / 'data' / n), rng.integers(0, 256, (256, 256, 3), dtype=np.uint8))
     with open(tmp_path / 'opt.yml', 'w') as f:
         yaml.safe_dump(opts, f)
     summary = cli.main(['--opt', str(tmp_path / 'opt.yml'), '--wplus-steps', '2'])

@@ -77,3 +77,36 @@ def test_modconv_f16_is_deterministic_and_persistent_grid_covers_all_tiles():
     x2 = ops.to_hform((2 * x).to(dev))
     y3 = ops.modconv_f16(x2, packed).to_nchw()
     assert (y3 - 2 * y1).abs().max().item() <= 2.0 ** -23      # equal up to f16 subnormal rounding of tiny outputs
+
+
+def test_modconv_f16_at_the_benchmarked_size_crops_vs_oracle():
+    """BASELINE configs[4] itself — 32 -> 32 channels, 1024x1024, batch 16 (what bench.py's M2 leg times): crops of three samples
+    (a corner with the image border, the centre, the far corner) against the oracle evaluated on the crop plus its halo."""
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    B, K, M, H, W = 16, 32, 32, 1024, 1024
+    g = torch.Generator().manual_seed(11)
+    wgt = torch.randn(1, M, K, 3, 3, generator=g)
+    s = 1 + 0.3 * torch.randn(B, K, generator=g)
+    bias = 0.1 * torch.randn(M, generator=g)
+    nw = torch.tensor([0.2])
+    xd = torch.empty(B, K, H, W, device=dev)
+    for b in range(B):                          # generated per sample: no 2 GB host tensor
+        xd[b] = torch.randn(K, H, W, generator=g).half().float().to(dev)
+    noise = torch.randn(B, 1, H, W, generator=g).to(dev)
+    xh = ops.to_hform(xd)
+    packed = ops.modconv_f16_pack(wgt.to(dev), s.to(dev), act='lrelu')
+    y = ops.modconv_f16(xh, packed, noise, nw.to(dev), bias.to(dev)).to_nchw()
+    assert torch.isfinite(y).all()
+    for b, (y0, x0) in ((0, (0, 0)), (7, (480, 500)), (15, (H - 64, W - 96))):
+        ya, xa = max(y0 - 1, 0), max(x0 - 1, 0)
+        yb, xb = min(y0 + 65, H), min(x0 + 97, W)
+        xc = xd[b:b + 1, :, ya:yb, xa:xb].cpu()
+        ref = R.modulated_conv2d(xc, s[b:b + 1], wgt, torch.eye(K) * math.sqrt(K), torch.zeros(K))
+        ref = R.fused_leaky_relu(ref + nw * noise[b:b + 1, :, ya:yb, xa:xb].cpu(), bias)
+        # rows / columns of the crop whose 3x3 neighbourhood lies inside the crop (or is the true image border)
+        r0, c0 = (0 if ya == 0 else 1), (0 if xa == 0 else 1)
+        r1, c1 = ref.shape[2] - (0 if yb == H else 1), ref.shape[3] - (0 if xb == W else 1)
+        got = y[b:b + 1, :, ya + r0:ya + r1, xa + c0:xa + c1].cpu()
+        err = (got - ref[:, :, r0:r1, c0:c1]).abs().max().item()
+        assert err <= 4e-3 * max(1.0, ref.abs().max().item()), (b, err)
