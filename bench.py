@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--streams', type=int, default=3, help='independent sub-batches of the per-GPU batch advanced on separate HIP streams (DESIGN.md §10)')
     ap.add_argument('--roofline-steps', type=int, default=10, help='W+ steps of the exclusive single-stream pass that times the dominant kernel')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the extra leg that times the inversion including the e4e encoder')
+    ap.add_argument('--no-forward-only', action='store_true', help="skip the leg that times the reference's own path: encoder + OOD forward, no W+ steps")
     ap.add_argument('--no-single-stream', action='store_true', help='skip the extra leg that times the same job on ONE HIP stream')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
@@ -203,27 +204,31 @@ def cpu_baseline(size):
     with torch.no_grad():
         R.ood_forward(P, target, lat, synth.make_encoder_feats(1, seed=4000), noises, size)
     ood = time.time() - t0
-    return dict(value=1.0 / (100.0 * step + ood), unit='images/s', cores=n, kind='port', batch=1,
+    return dict(value=1.0 / (100.0 * step + ood), unit='images/s', cores=n, kind='port', batch=1, wplus_step_s=round(step, 3), ood_forward_s=round(ood, 3),
                 sample=f'B=1 at {size}x{size} on {n} threads: 1 W+ step (fwd+bwd+Adam) = {step:.2f}s (median of 3 after 1 warm-up: '
                        f'{", ".join(f"{t:.2f}" for t in ts)}), final OOD forward = {ood:.2f}s (1 run); inversion = 100 steps + 1 OOD forward')
 
 
-def end_to_end(a, model, x, noises, dev):
-    """The same inversion INCLUDING the step before the path (SURVEY.md §8f N1): the e4e encoder (IR-SE-50 + FPN + 18
-    GradualStyleBlocks, `Encoder4EditingHIP` on the HIP conv kernels, recipe weights) predicts the start latents and the
-    4-level feature pyramid from the 256x256-pooled input; then the timed workload of `value` runs unchanged.
-    1 warm-up + 1 timed inversion of the same batch; reported beside `value`."""
+def build_full_model(a, dev):
+    """``ood_faceGAN_e4e`` WITH its e4e encoder (recipe weights), as the CLI builds it."""
     from oodgan import synth
     from oodgan.arch import ood_faceGAN_e4e
-    B = x.shape[0]
     m = ood_faceGAN_e4e(out_size=a.size, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08, cycle_align=2,
                         blend_with_gen=True, ModSize=256)
     sd = synth.ood_state(a.size, seed=0)
     enc = synth.encoder_state({k: tuple(v.shape) for k, v in m.encoder.state_dict().items()}, seed=41)
     sd.update({'encoder.' + k: (v * 0.1 if k.endswith('linear.weight') else v) for k, v in enc.items()})
     m.load_state_dict(sd, strict=True)
-    m = m.to(dev).eval()
-    run = lambda: m.invert(x, steps=a.wsteps, noise=noises)
+    return m.to(dev).eval()
+
+
+def end_to_end(a, m, x, noises):
+    """The same inversion INCLUDING the step before the path (SURVEY.md §8f N1): the e4e encoder (IR-SE-50 + FPN + 18
+    GradualStyleBlocks, `Encoder4EditingHIP` on the HIP conv kernels, recipe weights) predicts the start latents and the
+    4-level feature pyramid from the 256x256-pooled input; then the timed workload of `value` runs unchanged.
+    1 warm-up + 1 timed inversion of the same batch; reported beside `value`."""
+    B = x.shape[0]
+    run = lambda: m.invert(x, steps=a.wsteps, noise=noises, streams=a.streams)
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -239,6 +244,41 @@ def end_to_end(a, model, x, noises, dev):
                 note=f'encoder (Encoder4EditingHIP, batch {B} at 256x256) + {a.wsteps} W+ steps + OOD forward; recipe encoder weights')
 
 
+def forward_only(a, m, x, noises, reps=7):
+    """The reference's OWN hot path: ``model(input_im)`` — e4e encoder at 256² + OOD forward (generator
+    with the four SAMM hooks, mask compose, blend), no W+ steps — the call run_ood_faceGAN_inversion.py:167-172 brackets with
+    ``time.time()`` + ``torch.cuda.synchronize()`` ("Average process time", :187).  B=1 latency as that script runs it
+    (median of ``reps`` after 2 warm-ups) and B=8 throughput; the legs (encoder / OOD forward) from HIP events."""
+    import statistics
+    B = x.shape[0]
+    out = {}
+    for tag, b in (('b1', 1), (f'b{B}', B)):
+        xb = x[:b].contiguous()
+        nb = [n[:b].contiguous() for n in noises]
+        for _ in range(2):
+            m(xb, noise=nb)
+        torch.cuda.synchronize()
+        ts, enc_ms, ood_ms = [], [], []
+        for _ in range(reps):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            t0 = time.perf_counter()
+            e0.record()
+            lats, feats = m.encode(xb)
+            e1.record()
+            m._ood_forward(xb, lats, feats, noise=nb)
+            e2.record()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            enc_ms.append(e0.elapsed_time(e1))
+            ood_ms.append(e1.elapsed_time(e2))
+        t = statistics.median(ts)
+        out[tag] = dict(batch=b, latency_ms=round(t * 1e3, 3), images_per_s=round(b / t, 3),
+                        encoder_ms=round(statistics.median(enc_ms), 3), ood_forward_ms=round(statistics.median(ood_ms), 3))
+    out['note'] = ('model(x): e4e encoder (256x256) + OOD forward (generator + SAMM 2 cycles x 4 levels + mask blend) at '
+                   f'{a.size}x{a.size}, host wall time incl. synchronize, median of {reps}; the reference times exactly this call')
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -248,6 +288,11 @@ def main():
     # launched by torch.distributed.run (also with ONE rank): the process group is RCCL ('nccl') and the barrier / MAX
     # all_reduce / all_gather below run through it; a plain `python bench.py` has no process group
     dist_on = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    cpus = None
+    if world > 1:
+        # one rank per GPU: pin the launch thread near its GPU before anything touches the device (plain sched_setaffinity)
+        from oodgan.parallel import bind_rank_to_cpus
+        cpus = bind_rank_to_cpus(local_rank)
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (the hot path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -304,9 +349,15 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     probe.on = False
+    per_rank = None
     if dist_on:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt, float(len(cpus) if cpus else 0)], device=dev, dtype=torch.float64)
+        tmax = mine[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if world > 1:                                   # launch skew / a slow rank must be visible in the line
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = dict(seconds=[round(float(t[0].item()), 4) for t in allr], cpus_bound=[int(t[1].item()) for t in allr])
         dt = tmax.item()
     def roofline_of(ps, where):
         if not ps:
@@ -356,9 +407,18 @@ def main():
             t2 = time.perf_counter()
             single = dict(streams=1, value=round(B / (t2 - t1), 4), unit='images/s', ms_per_step=round((t2 - t1) * 1e3, 2),
                           final_loss_mean=float(ml[-1].mean().item()), note='same workload on one HIP stream')
-        e2e = None
-        if not a.no_end_to_end and world == 1 and size == 1024:
-            e2e = end_to_end(a, model, x, noises, dev)
+        e2e = fwd_only = None
+        if not (a.no_end_to_end and a.no_forward_only) and world == 1 and size == 1024:
+            full = build_full_model(a, dev)
+            if not a.no_end_to_end:
+                e2e = end_to_end(a, full, x, noises)
+            if not a.no_forward_only:
+                fwd_only = forward_only(a, full, x, noises)
+            del full
+        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size)     # rank 0 at N=1 only
+        if fwd_only is not None and cpu is not None:
+            fwd_only['cpu_baseline'] = dict(ood_forward_s=cpu['ood_forward_s'], cores=cpu['cores'], kind='port', batch=1,
+                                            note='CPU oracle, OOD forward after the encoder (the encoder is not part of the oracle)')
         line = {
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
@@ -375,7 +435,9 @@ def main():
             'modconv2d': modconv,
             'single_stream': single,
             'end_to_end': e2e,
-            'cpu_baseline': None if (a.no_cpu_baseline or world > 1) else cpu_baseline(size),     # rank 0 at N=1 only
+            'forward_only': fwd_only,
+            'per_rank': per_rank,
+            'cpu_baseline': cpu,
         }
         print(json.dumps(line, ensure_ascii=False))
     if dist_on:

@@ -253,13 +253,19 @@ class ood_faceGAN_e4e(nn.Module):
         return out
 
     # ---------------------------------------------------------------- build-defined: W+ refinement
-    def invert(self, x, steps=100, lr=0.01, noise=None, streams=3, use_graph=False, **kwargs):
+    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, use_graph=False, **kwargs):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
         latents (masks + blend).  Returns (out, lats, losses[steps,B]).
-        ``streams``: the batch is advanced as that many independent sub-batches on concurrent HIP streams (images are
-        independent; the HBM-bound layout kernels of one sub-batch run beside the matrix kernels of the other: +6-8 %
-        at batch 8, bit-reproducible — DESIGN.md §10); 1 = every kernel owns the GPU."""
+        ``streams`` (opt-in; ``bench.py`` and the CLI's ``inversion.streams`` use 3): the W+ loop advances the batch as
+        that many independent sub-batches on concurrent HIP streams (images are independent; the HBM-bound layout
+        kernels of one sub-batch run beside the matrix kernels of the other: +4 % at batch 8).  The
+        default 1 keeps every kernel alone on the GPU: concurrent queues are only exact for kernels built without
+        packed-fp32 instructions (this library's are; a caller's own torch-ROCm work on another stream is not covered).
+        Results are bit-reproducible run to run for a given (batch, streams); they are NOT bit-invariant under the
+        stream count or an image's position in the batch — kernel selection follows the sub-batch geometry (8-wave
+        kernels from 128 work items) and every sub-batch carries its own range scales — the difference is fp32
+        rounding (losses within 1e-5 relative: ``tests/test_hip_generator.py``)."""
         lats0, enc_feats = self.encode(x, **kwargs)
         B = x.shape[0]
         if noise is None:

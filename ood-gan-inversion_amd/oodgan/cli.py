@@ -9,9 +9,11 @@ YAML option surface of the reference's run_ood_faceGAN_inversion.py (SURVEY.md ย
 
 Per image it does what the reference does (read -> [-1,1] RGB 1024ยฒ -> model -> save inversion + mask strip -> metrics)
 and, when the build-defined block ``inversion: {wplus_steps: N, lr: 0.01, batch: B}`` (or ``--wplus-steps``) is
-present, refines the encoder latents with N W+ Adam steps before the OOD forward (SURVEY.md ยง8 A9).
-Only ``ood_faceGAN_e4e`` is registered (ReStyle / FeatureStyle are ยง8f N4).  LPIPS / identity need third-party
-weights that do not ship: they are reported as skipped."""
+present, refines the encoder latents with N W+ Adam steps before the OOD forward (SURVEY.md ยง8 A9; ``streams: S``
+in the same block advances the loop on S concurrent HIP streams, default 1).
+``model_dict`` holds the reference's three variants (run_ood_faceGAN_inversion.py:23-27): the ``network_g`` blocks of
+options/test/{E4E,ReStyle,FeatureStyle}_Face_test.yml resolve unchanged.  LPIPS / identity need third-party weights that
+do not ship: they are reported as skipped."""
 import argparse
 import logging
 import os
@@ -22,10 +24,14 @@ import torch
 import yaml
 
 from . import imgio
-from .arch import ood_faceGAN_e4e
+from .arch import ood_faceGAN_e4e, ood_faceGAN_FeatureStyle, ood_faceGAN_restyle
 from .io import load_direction, load_network_g
 
-model_dict = {'ood_faceGAN_e4e': ood_faceGAN_e4e}
+model_dict = {                                   # run_ood_faceGAN_inversion.py:23-27
+    'ood_faceGAN_e4e': ood_faceGAN_e4e,
+    'ood_faceGAN_restyle': ood_faceGAN_restyle,
+    'ood_faceGAN_FeatureStyle': ood_faceGAN_FeatureStyle,
+}
 IMG_EXT = ('.png', '.jpg', '.jpeg', '.bmp', '.webp')
 
 
@@ -74,6 +80,7 @@ def run(opts, wplus_steps=None, log=None):
     inv = opts.get('inversion') or {}
     steps = int(wplus_steps if wplus_steps is not None else inv.get('wplus_steps', 0))
     lr = float(inv.get('lr', 0.01))
+    streams = int(inv.get('streams', 1))
     size = model.generator.size
     summary = {}
     for name, dopt in opts['datasets'].items():
@@ -83,15 +90,15 @@ def run(opts, wplus_steps=None, log=None):
         times, metrics = [], None
         for f in files:
             bgr = imgio.imread(f).astype(np.float64)
-            x = imgio.image_to_input(bgr, size).cuda()
+            x = imgio.image_to_input(bgr, size, device='cuda')
             with torch.no_grad():
                 t0 = time.time()
-                out = model.invert(x, steps=steps, lr=lr)[0] if steps > 0 else model(x)[0]
+                out = model.invert(x, steps=steps, lr=lr, streams=streams)[0] if steps > 0 else model(x)[0]
                 torch.cuda.synchronize()
                 times.append(time.time() - t0)
             res = imgio.tensor2img(out, rgb2bgr=True, min_max=(-1, 1))
             imgio.imwrite(os.path.join(save_dir, 'inversion', os.path.basename(f)), res)
-            gt = bgr if bgr.shape[0] == size else imgio.tensor2img(x, rgb2bgr=True, min_max=(-1, 1)).astype(np.float64)
+            gt = bgr if bgr.shape[:2] == (size, size) else imgio.tensor2img(x, rgb2bgr=True, min_max=(-1, 1)).astype(np.float64)
             metrics = evaluate(gt, res, metrics, opts.get('metrics'))
             masks = imgio.extract_masks(model.aligns, size)
             if masks is not None:

@@ -147,6 +147,7 @@ class GeneratorEngine:
         if self.fwd_range is not None:
             self.fwd_range.valid = False
             self.fwd_range.flag.zero_()
+            self.fwd_range.vm.zero_()       # maxima an aborted carry pass left behind must not enter the next measurement
 
     def fwd_range_violated(self):
         """True if a carried forward scale left the exact window in any forward since reset_fwd_state() (host sync)."""
@@ -489,10 +490,19 @@ class WPlusInverter:
         then share the GPU with the matrix kernels of the other instead of running back to back."""
         B = w0.shape[0]
         streams = max(1, min(int(streams), B))
+        if steps <= 0:
+            return w0.detach().clone().contiguous(), torch.empty(0, B, device=w0.device, dtype=torch.float32)
         if (streams == 1 and not use_graph) or return_trajectory:
             return self._invert_one(target, w0, noises, steps, return_trajectory)
         cur = torch.cuda.current_stream()
         side = _side_streams(w0.device, streams)
+        # the state resets enqueue zero-fills on the CALLER's stream: they must precede the wait_stream below, or nothing
+        # orders them against the atomicOr / atomic max the side streams do on the same flags (engines[0] keeps its
+        # FwdRange and bwd_flag across calls)
+        engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
+        for eng in engines:
+            eng.reset_bwd_state()
+            eng.reset_fwd_state()
         cuts = [(i * B) // streams for i in range(streams + 1)]
         parts = []
         for i, st in enumerate(side):
@@ -504,10 +514,6 @@ class WPlusInverter:
         for st in side:
             st.wait_stream(cur)                 # AFTER the slices / clones above were enqueued on the caller's stream
         gmul = ops.loss_scale_for(target.numel() // B)
-        engines = [self.engine] + [self.engine.clone_shared() for _ in range(streams - 1)]
-        for eng in engines:
-            eng.reset_bwd_state()
-            eng.reset_fwd_state()
         dev = w0.device
 
         def one_step(pr, eng):
@@ -564,6 +570,9 @@ class WPlusInverter:
 
     def _invert_one(self, target, w0, noises, steps, return_trajectory):
         w = w0.detach().clone().contiguous()
+        if steps <= 0:
+            empty = torch.empty(0, w.shape[0], device=w.device, dtype=torch.float32)
+            return (w, empty, []) if return_trajectory else (w, empty)
         m = torch.zeros_like(w)
         v = torch.zeros_like(w)
         losses, traj = [], []

@@ -70,19 +70,31 @@ def tensor2img(tensor, rgb2bgr=True, out_type=np.uint8, min_max=(0, 1)):
     return out[0] if len(out) == 1 else out
 
 
-def image_to_input(bgr, size=1024):
+def image_to_input(bgr, size=1024, device=None):
     """What the reference CLI feeds the network (run_ood_faceGAN_inversion.py:159-163): [0,255] BGR -> RGB NCHW in
-    [-1,1], bilinearly resized (align_corners=False) to ``size`` if needed."""
+    [-1,1], bilinearly resized (align_corners=False) to ``size`` if needed.  With a GPU ``device`` the image is uploaded
+    at its own size and resized there by ``oodgan_resize_bilinear`` (the harness then runs no torch-ROCm kernel);
+    without one the resize is the host-side ATen call the reference makes before its ``.cuda()``."""
     x = (img2tensor(bgr.astype(np.float64) / 255.0, bgr2rgb=True).unsqueeze(0) - 0.5) * 2
+    if device is not None:
+        x = x.to(device)
     if x.shape[-1] != size:
-        x = torch.nn.functional.interpolate(x, size=(size, size), mode='bilinear')
+        if x.is_cuda:
+            from . import samm
+            x = samm.resize_bilinear(x.contiguous(), size)
+        else:
+            x = torch.nn.functional.interpolate(x, size=(size, size), mode='bilinear')
     return x
 
 
 def extract_masks(aligns, size=1024):
     """aligns: dict level -> (B,3,H,W); channel 2 of every level, nearest-resized to ``size`` and concatenated along
-    the width; returns the HxW*n uint8 strip of the first batch item (None on any failure, like the reference)."""
+    the width; returns the HxW*n uint8 strip of the first batch item (None on any failure, like the reference).
+    Device tensors go through ``oodgan_resize_nearest`` (one strip buffer, written in place); host tensors through ATen."""
     try:
+        if all(v.is_cuda for v in aligns.values()):
+            from . import samm
+            return tensor2img(samm.extract_masks(aligns, size)[0], min_max=(0, 1))
         masks = []
         for k in sorted(aligns.keys()):
             m = aligns[k][:, 2:, ...]

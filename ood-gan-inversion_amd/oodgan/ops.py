@@ -337,6 +337,20 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
 VMAX_SLOTS = 64      # OODGAN_VMAX_SLOTS (include/oodgan.h)
 
 
+def absmax_mul2(x):
+    """{2^-e, 2^e} (device, 2 floats) with max|x| * 2^e in [512,1024): the power-of-two range scale of a tensor that is
+    about to be converted to the S-form (``to_sform(x, mul2=...)``, undone by the consuming conv through ``in_mul2=``).
+    e = 0 for an all-zero or non-finite tensor."""
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    vm = torch.zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)     # float bit patterns, atomic max
+    mul2 = torch.empty(2, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    check(L.oodgan_absmax_scaled(_p(x), None, 0, _p(vm), B, C, x.numel() // (B * C), _stream()), 'absmax_scaled')
+    check(L.oodgan_absmax_scale(_p(vm), vm.numel(), _p(mul2), _stream()), 'absmax_scale')
+    return mul2
+
+
 class FwdRange:
     """Forward range control of the split-f16 path (csrc/fwd_range.hip): one power-of-two scale per styled
     conv and sample, q[l][b], such that the S-form input of conv l holds max|x*s|*q in [512,1024) — an f16 pair cannot

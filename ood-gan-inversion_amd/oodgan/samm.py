@@ -171,15 +171,15 @@ def resize_bilinear(x, size):
     return y
 
 
-def extract_masks(aligns):
+def extract_masks(aligns, size=1024):
     """run_ood_faceGAN_inversion.py:74-87: alpha channel of every level, nearest to 1024, side by side."""
     keys = sorted(aligns)
     B = aligns[keys[0]].shape[0]
     dev = aligns[keys[0]].device
-    strip = torch.empty(B, 1, 1024, 1024 * len(keys), device=dev, dtype=torch.float32)
+    strip = torch.empty(B, 1, size, size * len(keys), device=dev, dtype=torch.float32)
     for i, k in enumerate(keys):
         a = aligns[k][:, 2:3].contiguous()
-        resize_nearest(a, 1024, out=strip, xoff=1024 * i)
+        resize_nearest(a, size, out=strip, xoff=size * i)
     return strip
 
 
@@ -225,11 +225,16 @@ class bottleneck_IR(nn.Module):
         if self.in_channel >= 64 and self.depth >= 64:
             # the AlignNet convs (2C -> 2C channels, 7x the generator's FLOPs per image): through the S-form and
             # the 8-wave kernel of the generator's own >= 64-channel layers; InstanceNorm's affine folded into the conversion
+            # Range of the two S-form conversions (an f16 pair holds |v| < 65504 and loses its lo half far below 1; the fp32
+            # reference has no such limit): the first operand is InstanceNorm's output, |v| <= |gamma|*sqrt(HW) + |beta| by
+            # construction; the second is the UN-normalised PReLU(conv) — measured, scaled by a power of two into
+            # [512,1024) for the conversion and unscaled in the conv's epilogue (exact).
             B, _, H, W = x.shape
             xs = ops.to_sform(x, sc, shift=sh, out=ops.sform_scratch(B, self.in_channel, H, W, x.device))
             r = ops.conv3x3(xs, prep['w1'], self.depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight)
-            rs = ops.to_sform(r, out=ops.sform_scratch(B, self.depth, H, W, x.device))
-            r = ops.conv3x3(rs, prep['w2'], self.depth, CONV_S1)
+            mul2 = ops.absmax_mul2(r)
+            rs = ops.to_sform(r, mul2=mul2, out=ops.sform_scratch(B, self.depth, H, W, x.device))
+            r = ops.conv3x3(rs, prep['w2'], self.depth, CONV_S1, in_mul2=mul2)
             del xs, rs
         else:
             r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)

@@ -486,8 +486,84 @@ def main():
         gold_imgio()
     if 'cond' in which:
         gold_cond_types()
+    if 'c1' in which:
+        gold_cli_c1()
 
 
+def gold_cli_c1():
+    """BASELINE configs[0] / SURVEY §8f N2: what the reference CLI WRITES for one 256x256 image, as uint8.
+    The per-image body of run_ood_faceGAN_inversion.py:159-180 on the real classes: ``cv2.imread(f) / 255.0`` ->
+    ``img2tensor`` (real, img_util.py:9-37) -> ``(t - 0.5) * 2`` -> ``F.interpolate(bilinear)`` to 1024² (:162-163) ->
+    the reference ``ood_faceGAN_e4e`` INCLUDING its e4e encoder (recipe weights, preset noise maps) -> real ``tensor2img``
+    (img_util.py:40-94: clamp, [0,1], x255, ``.round()``, uint8) -> ``extract_masks`` (:74-87: nearest to 1024, side by
+    side, real ``tensor2img``).  cv2 is absent: the run script itself cannot be imported, so its ten lines are spelled out
+    here around the real functions; the BGR<->RGB swap (``cv2.cvtColor``, a channel reversal) is done with numpy and the
+    real functions are called with ``bgr2rgb`` / ``rgb2bgr`` = False.  The input image is stored; of the 1024² uint8
+    outputs a 4x sub-sampling and a full-resolution crop are stored, the masks at their native resolutions (the strip is
+    their nearest up-sampling: every strip pixel can be rebuilt from them)."""
+    import torch.nn.functional as F
+    from src.archs.OOD_faceGAN_e4e_arch import ood_faceGAN_e4e
+    _stub('cv2')
+    sys.modules['torchvision.utils'].make_grid = None
+    _load_real('basicsr.utils.matlab_functions', 'BasicSR/basicsr/utils/matlab_functions.py')
+    sys.modules['basicsr.utils'].bgr2ycbcr = sys.modules['basicsr.utils.matlab_functions'].bgr2ycbcr
+    _stub('basicsr.metrics')
+    _load_real('basicsr.metrics.metric_util', 'BasicSR/basicsr/metrics/metric_util.py')
+    ps = _load_real('basicsr.metrics.psnr_ssim', 'BasicSR/basicsr/metrics/psnr_ssim.py')
+    iu = _load_real('basicsr.utils.img_util', 'BasicSR/basicsr/utils/img_util.py')
+
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True,
+                        warp_scale=0.08, cycle_align=2, blend_with_gen=True, ModSize=256).eval()
+    sd = synth.ood_state(1024, seed=31)
+    shapes = {k: tuple(v.shape) for k, v in m.encoder.state_dict().items()}
+    enc = synth.encoder_state(shapes, seed=41)
+    sd.update({'encoder.' + k: (v * 0.1 if k.endswith('linear.weight') else v) for k, v in enc.items()})
+    print('c1 load:', m.load_state_dict(sd, strict=True))
+
+    # a smooth random field plus pixel noise, 256x256 BGR uint8 ("single 256x256 random face")
+    rng = np.random.default_rng(71)
+    low = rng.uniform(0, 255, (3, 8, 8))
+    low = F.interpolate(torch.from_numpy(low)[None], size=(256, 256), mode='bicubic', align_corners=False)[0].numpy()
+    bgr = np.clip(low.transpose(1, 2, 0) + rng.normal(0, 20, (256, 256, 3)), 0, 255).round().astype(np.uint8)
+
+    cv2im = bgr / 255.0                                                      # :160
+    rgb = np.ascontiguousarray(cv2im[:, :, ::-1])                            # cv2.cvtColor(BGR2RGB) inside img2tensor
+    input_im = (torch.stack(iu.img2tensor([rgb], bgr2rgb=False), dim=0) - 0.5) * 2
+    assert input_im.dtype == torch.float32
+    if input_im.shape[-1] != 1024:
+        input_im = F.interpolate(input_im, size=(1024, 1024), mode='bilinear')
+    noises = synth.make_noises(1024, 1, seed=35)
+    feed = _NoiseFeed(noises)
+    feed.install()
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        inversion_im, lats = m(input_im)
+    feed.remove()
+    assert feed.calls == 17, feed.calls
+    res_rgb = iu.tensor2img(inversion_im, rgb2bgr=False, min_max=(-1, 1))     # save_img_to :64-72
+    result = np.ascontiguousarray(res_rgb[:, :, ::-1])                        # cv2.cvtColor(RGB2BGR) inside tensor2img
+    assert result.dtype == np.uint8 and result.shape == (1024, 1024, 3)
+    masks = []
+    for key_ in sorted(m.aligns.keys()):                                      # extract_masks :74-87
+        mask = m.aligns[key_][:, 2:, ...]
+        masks.append(F.interpolate(mask, size=(1024, 1024)))
+    strip = iu.tensor2img(torch.cat(masks, dim=3)[0, ...], min_max=(0, 1))
+    assert strip.dtype == np.uint8 and strip.shape == (1024, 5 * 1024)
+    g = dict(bgr=bgr, out_u8_sub=result[::4, ::4], out_u8_crop=result[448:576, 448:576], lats=lats,
+             out_f32_sub=inversion_im[0, :, ::16, ::16], n_saturated=np.int64(((result == 0) | (result == 255)).sum()))
+    for i, s_ in enumerate((32, 64, 128, 256)):
+        st = 1024 // s_
+        native = strip[::st, 1024 * i:1024 * (i + 1):st]
+        assert np.array_equal(np.repeat(np.repeat(native, st, 0), st, 1), strip[:, 1024 * i:1024 * (i + 1)])
+        g[f'mask{i + 1}_u8'] = native
+    g['mask1024_u8_sub'] = strip[::4, 4096::4]
+    g['mask1024_u8_crop'] = strip[448:576, 4096 + 448:4096 + 576]
+    # metrics as the harness evaluates them when the input is not 1024² (the reference asserts equal shapes: its gt is then
+    # the resized input): PSNR from the real function
+    gt = np.ascontiguousarray(iu.tensor2img(input_im, rgb2bgr=False, min_max=(-1, 1))[:, :, ::-1])
+    g['psnr_resized_gt'] = np.float64(ps.calculate_psnr(gt.astype(np.float64), result, crop_border=2, test_y_channel=False))
+    print('c1: saturated', int(g['n_saturated']), 'of', result.size, 'psnr', float(g['psnr_resized_gt']))
+    save('cli_c1.npz', **g)
 
 
 def gold_encoder():

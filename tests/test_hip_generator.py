@@ -186,6 +186,34 @@ def test_full_size_inversion_properties(dev):
     assert ((w2 - w).abs() < 1e-4).float().mean().item() > 0.999
 
 
+def test_three_streams_vs_one_at_full_size(dev):
+    """The bench configuration (1024², B=8, sub-batches of 2 / 3 / 3 images on three HIP streams) against the single-stream
+    loop: every production kernel — the 8-wave stride-1 / stride-2 (fused activation backward) / transposed kernels as
+    neighbours, every HBM-bound producer (rgb_finish, blur_act_sform, act_bwd_*, ToRGB) as bystander — runs beside the other
+    queues' work here.  (a) bit-identical run to run; (b) equal to one stream up to the fp32 rounding that the different
+    kernel selection of a 2-3 image sub-batch and its own range scales bring."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, B, steps = 1024, 8, 3
+    P = synth.generator_state(size, seed=0)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    target = torch.cat([synth.make_images(size, 1, seed=1000 + g) for g in range(B)]).to(dev)
+    noises = [torch.cat([synth.make_noises(size, 1, seed=2000 + g)[i] for g in range(B)]).to(dev) for i in range(17)]
+    w0 = torch.cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in range(B)]).to(dev)
+    inv = WPlusInverter(eng)
+    w1, l1 = inv.invert(target, w0, noises, steps=steps, streams=1)
+    runs = []
+    for _ in range(3):
+        w3, l3 = inv.invert(target, w0, noises, steps=steps, streams=3)
+        torch.cuda.synchronize()
+        runs.append((w3.clone(), l3.clone()))
+    assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:])
+    w3, l3 = runs[0]
+    rel = (l3 - l1).abs().max().item() / l1.abs().max().item()
+    frac = ((w3 - w1).abs() < 5e-4).float().mean().item()
+    print(f'3 streams vs 1 at 1024², B=8: loss rel diff {rel:.2e}, {100 * frac:.3f}% of w within 5e-4')
+    assert rel <= 1e-5 and frac > 0.999 and (l3[-1] < l3[0]).all()
+
+
 def test_torgb_reproducible_beside_matrix_kernels_of_another_stream(dev):
     """Guard for DESIGN.md §10: a ToRGB launch that shares the GPU with the stride-2 / transposed matrix kernels of
     another HIP stream must give the same bits as alone (with packed-fp32 instructions in the kernels 70–85 % of such

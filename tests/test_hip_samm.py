@@ -89,6 +89,30 @@ def test_alignnet_and_spm_warp_vs_golden(dev, golden):
     close(f, g['warp_field_prev'], 3e-4)
 
 
+@pytest.mark.parametrize('wscale', [1.0, 1e-3, 3e5])
+def test_bottleneck_8wave_path_range_and_batch(dev, wscale):
+    """The AlignNet bottleneck on the S-form + 8-wave kernels (>= 64 channels), batch 3, against the oracle — with the first
+    conv's weights scaled so that the UN-normalised PReLU(conv) handed to the second S-form conversion is ~1e-3 or ~3e5 (beyond the f16 maximum): the
+    fp32 reference has no range limit (the InstanceNorm behind it undoes the scale), an unscaled f16 pair would lose its lo
+    half / overflow."""
+    from oodgan import samm
+    from oodgan.synth import _bottleneck
+    from collections import OrderedDict
+    C, B, H = 64, 3, 32
+    sd = OrderedDict()
+    _bottleneck(sd, 'b', C, C, 77)
+    sd['b.res_layer.1.weight'] = sd['b.res_layer.1.weight'] * wscale
+    x = synth.normal('bn.x', (B, C, H, H), 78, 1.5, 0.2)
+    ref = R.bottleneck_ir(sd, 'b', x)
+    m = samm.bottleneck_IR(C, C, 1, 'InstanceNorm', False)
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(dev)
+    y = m(x.to(dev))
+    close(y, ref, 2e-5)
+    y1 = m(x[1:2].contiguous().to(dev))                   # sample 1 alone == sample 1 in the batch
+    close(y1, ref[1:2], 2e-5)
+
+
 def test_mask_blend_vs_oracle(dev):
     from oodgan import samm
     B = 2
@@ -143,3 +167,56 @@ def test_ood_forward_1024_vs_golden(dev, golden):
     strip = samm.extract_masks(m.aligns)
     absclose(strip[:, :, ::16, ::16], g['mask_strip_sub'], 1e-3, 'mask strip')
     absclose(strip[:, :, 500:502, :], g['mask_strip_rows'], 1e-3, 'mask strip rows')
+
+
+def test_ood_forward_1024_batch8_image_k_vs_golden(dev, golden):
+    """The OOD forward as ``bench.py`` / ``invert`` run it — B=8 — reproduces, for the image in slot 5, the vectors the
+    reference produced for that image ALONE (``ood_1024.npz``): SAMM / AlignNet (S-form + 8-wave convs with the PReLU
+    epilogue at batch > 1), warp, mask compose and blend are per-sample.  Also through ``invert(steps=0)`` and after two
+    W+ steps' worth of stream set-up (``steps=0`` must return the encoder latents untouched)."""
+    from oodgan.arch import ood_faceGAN_e4e
+    g = golden('ood_1024.npz')
+    B, k = 8, 5
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
+                        cycle_align=2, blend_with_gen=True, ModSize=256, build_encoder=False)
+    m.load_state_dict(synth.ood_state(1024, seed=31), strict=True)
+    m = m.to(dev).eval()
+
+    def batch(make, gold_seed):
+        parts = [make(100 * gold_seed + j) for j in range(B)]
+        parts[k] = make(gold_seed)
+        return parts
+
+    enc_lats = torch.cat(batch(lambda sd: synth.make_latents(1024, 1, seed=sd, std=0.3), 32)).to(dev)
+    feats = batch(lambda sd: synth.make_encoder_feats(1, seed=sd), 33)
+    enc_feats = [torch.cat([f[i] for f in feats]).to(dev) for i in range(4)]
+    x = torch.cat(batch(lambda sd: synth.make_images(1024, 1, seed=sd), 34)).to(dev)
+    nz = batch(lambda sd: synth.make_noises(1024, 1, seed=sd), 35)
+    noises = [torch.cat([n[i] for n in nz]).to(dev) for i in range(17)]
+
+    def check(out, lats, tag):
+        def absclose(a, b, tol, what):
+            a = a.detach().cpu()
+            assert a.shape == b.shape, (what, a.shape, b.shape)
+            err = (a - b).abs().max().item()
+            print(f'ood_1024 B=8 slot {k} [{tag}] {what}: max abs err {err:.3e}')
+            assert err < tol, (tag, what, err)
+        absclose(lats[k:k + 1], g['lats'], 1e-6, 'lats')
+        absclose(out[k:k + 1, :, ::16, ::16], g['out_sub'], 1e-4, 'out ::16')
+        absclose(out[k:k + 1, :, 480:544, 480:544], g['out_crop'], 1e-4, 'out centre crop')
+        absclose(out[k:k + 1].double().mean(dim=(2, 3)).float(), g['out_mean'], 1e-5, 'per-channel mean')
+        for lv in (1, 2, 3, 4):
+            a = m.aligns[lv]
+            assert a.shape[0] == B
+            step = max(1, a.shape[-1] // 32)
+            absclose(a[k:k + 1, :, ::step, ::step], g[f'align{lv}_sub'], 1e-4, f'aligns[{lv}]')
+        absclose(m.aligns[1024][k:k + 1, :, ::16, ::16], g['align1024_sub'], 1e-4, 'aligns[1024]')
+        assert torch.isfinite(out).all()
+
+    out, lats = m(x, enc_lats=enc_lats, enc_feats=enc_feats, noise=noises)
+    check(out, lats, 'forward')
+    for streams in (1, 3):
+        out0, lats0, losses = m.invert(x, steps=0, noise=noises, streams=streams, enc_lats=enc_lats, enc_feats=enc_feats)
+        assert losses.shape == (0, B) and torch.equal(lats0, lats)
+        check(out0, lats0, f'invert(steps=0, streams={streams})')
+        assert torch.equal(out0, out)                        # same launches on the same stream: bit-identical

@@ -46,6 +46,80 @@ def _worker(rank, world, port, gB, q):
     dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, gB, fail_rank, q):
+    """BASELINE configs[3] geometry: global batch 64 over 8 ranks; ``fail_rank`` raises inside its inversion."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'ood-gan-inversion_amd'))
+    import torch.distributed as dist
+    from oodgan import parallel, synth
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    target = synth.make_images(8, gB, seed=1)
+    w0 = synth.make_latents(1024, gB, seed=3)                       # (64, 18, 512): the real latent shape
+    noises = [synth.normal('n', (gB, 1, 4, 4), 2)]
+    full = _fake_invert(target, w0, noises)
+
+    def inv(target, w0, noises):
+        if rank == fail_rank:
+            raise RuntimeError('liboodgan_hip: injected failure')
+        return _fake_invert(target, w0, noises)
+
+    sl = parallel.shard_slice(gB, rank, world)
+    try:
+        got = parallel.invert_sharded(inv, dict(target=target, w0=w0, noises=noises), gB, rank, world)
+        res = ('ok', bool(got.shape == full.shape and torch.equal(got, full)))
+    except parallel.ShardFailed as e:
+        fs = parallel.shard_slice(gB, fail_rank, world)
+        good = torch.ones(gB, dtype=torch.bool)
+        good[fs] = False
+        res = ('peer', e.ranks == [fail_rank] and bool(torch.isnan(e.latents[fs]).all()) and torch.equal(e.latents[good], full[good]))
+    except RuntimeError as e:
+        res = ('own', 'injected failure' in str(e))
+    q.put((rank, sl.stop - sl.start) + res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail_rank', [-1, 5])
+def test_world8_global_batch_64(fail_rank):
+    """8 ranks x 8 images, one all_gather; with a failing rank EVERY rank raises (its own error / ShardFailed) after the
+    collective and nobody returns NaN rows silently."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, 64, fail_rank, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [8] * 8
+    for rank, _, kind, ok in res:
+        assert ok, res
+        assert kind == ('ok' if fail_rank < 0 else 'own' if rank == fail_rank else 'peer'), res
+
+
+def test_cpu_slices_for_ranks():
+    from oodgan.parallel import _parse_cpulist, bind_rank_to_cpus, cpu_slice_for_rank
+    cpus = list(range(128))
+    parts = [cpu_slice_for_rank(cpus, r, 8) for r in range(8)]
+    assert all(len(p) == 16 for p in parts) and sorted(sum(parts, [])) == cpus            # disjoint, covering
+    assert cpu_slice_for_rank(cpus, 3, 8, numa_cpus=range(64, 128)) == list(range(64, 128))
+    assert cpu_slice_for_rank([0, 1], 5, 8) == [0, 1]                                       # more ranks than CPUs: never empty
+    assert cpu_slice_for_rank(cpus, 0, 8, numa_cpus=[500]) == list(range(16))               # NUMA list outside the allowed set
+    assert _parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    assert bind_rank_to_cpus(0, 1) is None                                                  # single process: not bound
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        got = bind_rank_to_cpus(1, 2)
+        assert got and set(got) <= set(before) and sorted(os.sched_getaffinity(0)) == sorted(got)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 @pytest.mark.parametrize('gB', [4, 5, 1])
 def test_sharded_inversion_matches_unsharded(gB):
     ctx = mp.get_context('spawn')
