@@ -154,6 +154,11 @@ typedef struct oodgan_conv_args {
                                 up-sampling StyledConv below, y is the gradient w.r.t. it, and the epilogue applies that
                                 layer's FusedLeakyReLU backward (fused_act.py:25-58): y <- y * (dotx>0 ? sqrt2 : 0.2*sqrt2).
                                 oodgan_act_bwd_blurT_sform_phases then takes this y with out == NULL. */
+    int groups;              /* G > 1: grouped convolution (nn.Conv2d(groups=G) semantics, e.g. the 18 GradualStyleBlock heads of the
+                                e4e encoder run side by side, src/ops/e4e/encoders/psp_encoders.py:14-34): x is (B, G*K, Hin, Win), the
+                                packed weights hold G*Mg output channels (M = G*Mg, Mg %% 64 == 0) of K inputs each, and output
+                                channel m convolves input channels [g*K, (g+1)*K) with g = m / Mg; in_scale / in_shift are then
+                                (B, G*K).  0 / 1 = dense.  Supported by oodgan_conv3x3_f16s for fp32 NCHW input in mode S2. */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -426,6 +431,14 @@ int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, 
 /* small direct 3x3 conv (K,M <= 8), pad 1, with optional in scale/shift (B,K) and PReLU */
 int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, const float* in_sh,
                          const float* slope, float* y, int B, int K, int M, int H, int W, void* stream);
+/* 3x3 conv, stride 1, pad 1, from many input channels to M <= 4 outputs, exact fp32, K split over workgroups with a
+ * deterministic combine: the head conv 2C -> 3 of AlignNet's second bottleneck (src/ops/SAMM/helpers.py:58-60,
+ * bottleneck_IR(2C, 3) of src/ops/e4e/encoders/helpers.py:439-444) incl. the preceding InstanceNorm as in_sc / in_sh (B,K)
+ * (shift on in-bounds samples only) and the following PReLU (slope (M) or NULL).  w is the raw (M,K,3,3) weight.
+ * part: workspace (B, oodgan_conv3x3_fewout_ksplit(B,K,H,W), M, H, W) floats. */
+int oodgan_conv3x3_fewout_ksplit(int B, int K, int H, int W);
+int oodgan_conv3x3_fewout(const float* x, const float* w, const float* in_sc, const float* in_sh, const float* slope,
+                          float* part, float* y, int B, int K, int M, int H, int W, void* stream);
 /* AlignNet head (helpers.py:104-107): ch0,1 -> tanh*scale ; ch2 -> sigmoid */
 int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream);
 /* SPM_Warp.add / upsample_add (helpers.py:129-147) with new_PRM (:62-77):

@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     const BlockCtx ctx = decode_block<TR, MB>(p);
     const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
 
-    const float* xb = a.x + (long)b * a.K * p.in_plane;
-    const float* isc = a.in_scale ? a.in_scale + (long)b * a.in_scale_stride : nullptr;
-    const float* ish = a.in_shift ? a.in_shift + (long)b * a.in_scale_stride : nullptr;
+    // grouped convolution (oodgan_conv_args.groups): the output-channel block m0 selects the input-channel group
+    const int ngrp = a.groups > 1 ? a.groups : 1;
+    const int grp = ngrp > 1 ? m0 / (a.M / ngrp) : 0;
+    const float* xb = a.x + ((long)b * ngrp + grp) * a.K * p.in_plane;
+    const float* isc = a.in_scale ? a.in_scale + (long)b * a.in_scale_stride + grp * a.K : nullptr;
+    const float* ish = a.in_shift ? a.in_shift + (long)b * a.in_scale_stride + grp * a.K : nullptr;
     const float in_mul = a.in_mul2 ? a.in_mul2[1] : 1.f;
     const int row_org = (MODE == OODGAN_CONV_S2) ? 2 * r0 : r0 - 1;
     const int col_org = (MODE == OODGAN_CONV_S2) ? 2 * c0 : c0 - 4;
@@ -304,6 +307,9 @@ int launch_mode(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y * 4, "conv3x3: dot_nparts %d != %d", a.dot_nparts,
                        p.tiles_x * p.tiles_y * 4);
     }
+    if (a.groups > 1)
+        OODGAN_REQUIRE(MODE == OODGAN_CONV_S2 && mt2 && a.M % a.groups == 0 && (a.M / a.groups) % 64 == 0 && a.dotx == nullptr,
+                       "conv3x3 grouped: mode S2, M = groups * Mg with Mg %% 64 == 0, no dot (groups %d, M %d)", a.groups, a.M);
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     dim3 grid((unsigned)total), block(256);
@@ -439,6 +445,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
+    OODGAN_REQUIRE(a.groups <= 1 || (a.mode == OODGAN_CONV_S2 && !a.x_sform), "conv3x3_f16s: groups > 1 only for mode S2 with fp32 NCHW input");
     OODGAN_REQUIRE(!a.dot_actgrad || (a.mode == OODGAN_CONV_S1 && a.x_sform && a.dotx && (s1_strip_eligible(a) || s1_big_eligible(a))),
                    "conv3x3_f16s: dot_actgrad exists only in the strip / 8-wave kernels of mode S1 (oodgan_conv3x3_s1_actgrad_supported)");
     hipStream_t st = as_stream(stream);

@@ -158,6 +158,72 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restr
         }
 }
 
+// ---------------------------------------------------------------- 3x3 conv from MANY input channels to a FEW outputs (M <= 4)
+// The head conv of AlignNet's second bottleneck: 2C -> 3 channels, C = 512 ... 128 at 32² ... 256² (reference
+// src/ops/SAMM/helpers.py:58-60 -> bottleneck_IR(2C, 3), src/ops/e4e/encoders/helpers.py:439-444), with InstanceNorm's affine
+// as in_sc / in_sh (shift on in-bounds samples only = norm followed by zero padding).  It reads K*H*W values once and
+// writes 3*H*W: HBM-bound streaming work, exact fp32 — on the matrix kernels it was a 32-channel M tile with 3 live rows
+// and, at 32² / 64², four to sixteen workgroups walking 64 K-chunks one after the other (327 us per launch at B = 1).
+// Here the K range is split over gridDim.y so that every level fills the chip; partial sums are combined in a fixed
+// order by conv3x3_fewout_finish_kernel (deterministic, no atomics), which also applies the PReLU.
+constexpr int FO_TH = 8, FO_TW = 32, FO_KC = 8, FO_P = FO_TW + 4;      // 8 x 32 pixel tile, 8 channels per LDS stage
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ in_sc, const float* __restrict__ in_sh,
+                                                             float* __restrict__ part, int K, int M, int H, int W, int kslice,
+                                                             int tiles_x) {
+    __shared__ float tile[FO_KC][FO_TH + 2][FO_P];
+    __shared__ float wl[FO_KC][9][4];
+    const int b = blockIdx.z, ks = blockIdx.y, KS = gridDim.y;
+    const int r0 = (blockIdx.x / tiles_x) * FO_TH, c0 = (blockIdx.x % tiles_x) * FO_TW;
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const long HW = (long)H * W;
+    const int k_begin = ks * kslice, k_end = min(K, k_begin + kslice);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = k_begin; k0 < k_end; k0 += FO_KC) {
+        __syncthreads();
+        for (int e = tid; e < FO_KC * (FO_TH + 2) * (FO_TW + 2); e += 256) {
+            const int c = e / ((FO_TH + 2) * (FO_TW + 2)), r = (e / (FO_TW + 2)) % (FO_TH + 2), q = e % (FO_TW + 2);
+            const int k = k0 + c, iy = r0 + r - 1, ix = c0 + q - 1;
+            float v = 0.f;
+            if (k < k_end && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = x[((long)b * K + k) * HW + (long)iy * W + ix];
+                if (in_sc) v *= in_sc[(long)b * K + k];
+                if (in_sh) v += in_sh[(long)b * K + k];
+            }
+            tile[c][r][q] = v;
+        }
+        for (int e = tid; e < FO_KC * 9 * 4; e += 256) {
+            const int c = e / 36, t = (e / 4) % 9, m = e & 3, k = k0 + c;
+            wl[c][t][m] = (k < k_end && m < M) ? w[((long)m * K + k) * 9 + t] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < FO_KC; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = tile[c][ty + t / 3][tx + t % 3];
+                const float4 wv = *reinterpret_cast<const float4*>(&wl[c][t][0]);
+                acc[0] += wv.x * v; acc[1] += wv.y * v; acc[2] += wv.z * v; acc[3] += wv.w * v;
+            }
+    }
+    const int py = r0 + ty, px = c0 + tx;
+    if (py < H && px < W)
+        for (int m = 0; m < M; ++m) part[(((long)b * KS + ks) * M + m) * HW + (long)py * W + px] = acc[m];
+}
+
+__global__ __launch_bounds__(256) void conv3x3_fewout_finish_kernel(const float* __restrict__ part, const float* __restrict__ slope,
+                                                                    float* __restrict__ y, int KS, int M, long HW, long total) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long p = e % HW;
+        const int m = (int)((e / HW) % M);
+        const long b = e / (HW * M);
+        float v = 0.f;
+        for (int ks = 0; ks < KS; ++ks) v += part[((b * KS + ks) * M + m) * HW + p];
+        if (slope) v = v > 0.f ? v : slope[m] * v;
+        y[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void align_head_kernel(const float* __restrict__ x, float* __restrict__ y, long HW, long total,
                                                          float scale) {
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -250,10 +316,13 @@ __device__ __forceinline__ float linspace_pm1(int i, int n) {
     return i < n / 2 ? -1.f + step * i : 1.f - step * (n - 1 - i);
 }
 
-// grid (chunks of pixels, B); each thread one pixel, loops over channels (coalesced per plane)
+// grid (chunks of 256 pixels, chunks of WB_CPB channels, B); each thread one pixel and WB_CPB channels (coalesced per plane).
+// The sampling weights depend on the pixel only.  (One thread per pixel looping over ALL channels left the 32² level with four
+// workgroups walking 512 planes one dependent gather at a time: 335 us per launch at B = 1, 87 % of the wave time waiting.)
+constexpr int WB_CPB = 8;
 __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict__ target, const float* __restrict__ field,
                                                          float* __restrict__ y, int C, int H, int W) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     const long HW = (long)H * W;
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
@@ -269,17 +338,31 @@ __global__ __launch_bounds__(256) void warp_blend_kernel(const float* __restrict
     const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;   // nw, ne, sw, se
-    const float* tb = target + (long)b * C * HW;
-    float* yb = y + (long)b * C * HW;
-    for (int c = 0; c < C; ++c) {
+    const bool v00 = vy0 && vx0, v01 = vy0 && vx1, v10 = vy1 && vx0, v11 = vy1 && vx1;
+    const long o00 = (long)y0 * W + x0, o01 = (long)y0 * W + x1, o10 = (long)y1 * W + x0, o11 = (long)y1 * W + x1;
+    const int cb = blockIdx.y * WB_CPB;
+    const float* tb = target + ((long)b * C + cb) * HW;
+    float* yb = y + ((long)b * C + cb) * HW;
+    float t00[WB_CPB], t01[WB_CPB], t10[WB_CPB], t11[WB_CPB], tv[WB_CPB];
+#pragma unroll
+    for (int c = 0; c < WB_CPB; ++c) {          // all gathers of the chunk are issued before the first use
+        const bool ok = cb + c < C;
         const float* t = tb + (long)c * HW;
-        float v = 0.f;
-        if (vy0 && vx0) v += t[(long)y0 * W + x0] * w00;
-        if (vy0 && vx1) v += t[(long)y0 * W + x1] * w01;
-        if (vy1 && vx0) v += t[(long)y1 * W + x0] * w10;
-        if (vy1 && vx1) v += t[(long)y1 * W + x1] * w11;
-        const float tv = t[p];
-        yb[(long)c * HW + p] = v * alpha + tv * (1.f - alpha);
+        t00[c] = (ok && v00) ? t[o00] : 0.f;
+        t01[c] = (ok && v01) ? t[o01] : 0.f;
+        t10[c] = (ok && v10) ? t[o10] : 0.f;
+        t11[c] = (ok && v11) ? t[o11] : 0.f;
+        tv[c] = ok ? t[p] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < WB_CPB; ++c) {
+        if (cb + c >= C) break;
+        float v = 0.f;                           // the reference's accumulation order (nw, ne, sw, se)
+        if (v00) v += t00[c] * w00;
+        if (v01) v += t01[c] * w01;
+        if (v10) v += t10[c] * w10;
+        if (v11) v += t11[c] * w11;
+        yb[(long)c * HW + p] = v * alpha + tv[c] * (1.f - alpha);
     }
 }
 
@@ -461,6 +544,32 @@ extern "C" int oodgan_conv3x3_small(const float* x, const float* w, const float*
     return check_launch("conv3x3_small");
 }
 
+// K-split of oodgan_conv3x3_fewout for this shape: the caller allocates part (B, ksplit, M, H, W)
+extern "C" int oodgan_conv3x3_fewout_ksplit(int B, int K, int H, int W) {
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return 0;
+    const long tiles = (long)((H + FO_TH - 1) / FO_TH) * ((W + FO_TW - 1) / FO_TW) * B;
+    long ks = 1024 / tiles;                       // aim at ~4 workgroups per CU
+    if (ks > K / 16) ks = K / 16;
+    if (ks < 1) ks = 1;
+    const int kslice = (int)(((K + ks - 1) / ks + FO_KC - 1) / FO_KC * FO_KC);
+    return (K + kslice - 1) / kslice;
+}
+
+extern "C" int oodgan_conv3x3_fewout(const float* x, const float* w, const float* in_sc, const float* in_sh, const float* slope,
+                                     float* part, float* y, int B, int K, int M, int H, int W, void* stream) {
+    OODGAN_REQUIRE(x && w && part && y && B > 0 && K > 0 && M > 0 && M <= 4 && H > 0 && W > 0, "conv3x3_fewout: bad args");
+    const int KS = oodgan_conv3x3_fewout_ksplit(B, K, H, W);
+    const int kslice = ((K + KS - 1) / KS + FO_KC - 1) / FO_KC * FO_KC;
+    const int tiles_x = (W + FO_TW - 1) / FO_TW, tiles_y = (H + FO_TH - 1) / FO_TH;
+    OODGAN_REQUIRE(B <= 65535 && KS <= 65535 && (long)(KS - 1) * kslice < K, "conv3x3_fewout: split");
+    hipLaunchKernelGGL(conv3x3_fewout_kernel, dim3((unsigned)(tiles_x * tiles_y), KS, B), dim3(256), 0, as_stream(stream), x, w, in_sc,
+                       in_sh, part, K, M, H, W, kslice, tiles_x);
+    const long HW = (long)H * W, total = (long)B * M * HW;
+    hipLaunchKernelGGL(conv3x3_fewout_finish_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), part, slope, y, KS,
+                       M, HW, total);
+    return check_launch("conv3x3_fewout");
+}
+
 extern "C" int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream) {
     OODGAN_REQUIRE(x && y && B > 0 && HW > 0, "align_head: bad args");
     const long total = (long)B * 3 * HW;
@@ -479,7 +588,8 @@ extern "C" int oodgan_field_compose(const float* acc, const float* cur, const fl
 
 extern "C" int oodgan_warp_blend(const float* target, const float* field, float* y, int B, int C, int H, int W, void* stream) {
     OODGAN_REQUIRE(target && field && y && B > 0 && C > 0 && H > 0 && W > 0, "warp_blend: bad args");
-    dim3 grid((unsigned)(((long)H * W + 255) / 256), B);
+    OODGAN_REQUIRE(B <= 65535 && (C + WB_CPB - 1) / WB_CPB <= 65535, "warp_blend: B or C too large");
+    dim3 grid((unsigned)(((long)H * W + 255) / 256), (unsigned)((C + WB_CPB - 1) / WB_CPB), B);
     hipLaunchKernelGGL(warp_blend_kernel, grid, dim3(256), 0, as_stream(stream), target, field, y, C, H, W);
     return check_launch("warp_blend");
 }

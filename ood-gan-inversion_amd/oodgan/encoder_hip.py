@@ -9,7 +9,7 @@ convolution, normalisation, gate application and resize runs through ``liboodgan
   conv3x3 stride 2, pad 1          -> the stride-2 kernel (mode S2) on the input shifted by one zero row / column
   SE gate + residual               -> ``oodgan_instnorm_stats`` (mean), ``oodgan_conv1x1`` x2, ``oodgan_affine_apply``
   FPN ``_upsample_add``            -> ``oodgan_resize_bicubic_ac`` (helpers.py:504-521)
-  GradualStyleBlock                -> stride-2 convs + ``oodgan_equal_linear``
+  GradualStyleBlock                -> stride-2 convs, all heads side by side (stacked / grouped launches) + ``oodgan_equal_linear``
 
 torch is used for plumbing only (zero-padding copy, strided slice of the shortcut, ReLU / sigmoid on (B,C) vectors).
 The encoder runs once per image at 256² and is not part of the measured loop."""
@@ -80,47 +80,110 @@ class _HipTrunk:
             p = self._pk[name] = _Packed()
         return p.get(w)
 
+    def _memo(self, key, deps, fn):
+        """Derived device constants (folded BatchNorm rows, stacked head weights, ...) are rebuilt only when a parameter
+        they come from changes — not with ~600 small torch launches per forward."""
+        if not hasattr(self, '_cache'):
+            self._cache = {}
+        ver = tuple((t.data_ptr(), t._version) for t in deps)
+        c = self._cache.get(key)
+        if c is None or c[0] != ver:
+            c = self._cache[key] = (ver, fn())
+        return c[1]
+
+    def _bn_rows(self, key, bn, B):
+        """eval-mode BatchNorm2d as per-(b,c) rows (scale, shift) and the (C,) shift."""
+        def build():
+            sc, sh = _bn_affine(bn)
+            return _rows(sc, B), _rows(sh, B), sh.detach().float().contiguous()
+        return self._memo((key, B), (bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+
+    def _const_rows(self, B, C, value, device):
+        return self._memo(('const', B, C, value, str(device)), (), lambda: torch.full((B, C), float(value), device=device))
+
     # ---- one bottleneck_IR(_SE) unit (helpers.py:439-501)
     def _unit(self, idx, u, x):
         B = x.shape[0]
         rl = u.res_layer
         depth = rl[1].weight.shape[0]
         stride = rl[3].stride[0]
-        sc1, sh1 = _bn_affine(rl[0])
-        r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=_rows(sc1, B), in_shift=_rows(sh1, B),
+        sc1, sh1, _ = self._bn_rows(f'{idx}.bn1', rl[0], B)
+        r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=sc1, in_shift=sh1,
                      act=ACT_PRELU, slope=rl[2].weight.detach())
-        sc2, sh2 = _bn_affine(rl[4])
-        r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=_rows(sc2, B), bias=sh2.detach().contiguous())
+        sc2, _, sh2 = self._bn_rows(f'{idx}.bn2', rl[4], B)
+        r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=sc2, bias=sh2)
         if isinstance(u.shortcut_layer, torch.nn.MaxPool2d):
             sc = x if stride == 1 else x[:, :, ::stride, ::stride].contiguous()
         else:
             xs = x if stride == 1 else x[:, :, ::stride, ::stride].contiguous()
             s = samm.conv1x1(xs, u.shortcut_layer[0].weight.detach())
-            a, b = _bn_affine(u.shortcut_layer[1])
-            sc = samm.affine_apply(s, _rows(a, B), _rows(b, B))
+            a, b, _ = self._bn_rows(f'{idx}.bns', u.shortcut_layer[1], B)
+            sc = samm.affine_apply(s, a, b)
         if self._mode == 'ir_se':
             se = rl[5]
             g = samm.instnorm_stats(r)[..., 0].reshape(B, depth, 1, 1).contiguous()            # per-(b,c) mean
             g = torch.relu(samm.conv1x1(g, se.fc1.weight.detach()))
             g = torch.sigmoid(samm.conv1x1(g, se.fc2.weight.detach())).reshape(B, depth)
-            return samm.affine_apply(r, g.contiguous(), torch.zeros_like(g), res=sc)
-        return samm.affine_apply(r, torch.ones(B, depth, device=x.device), torch.zeros(B, depth, device=x.device), res=sc)
+            return samm.affine_apply(r, g.contiguous(), self._const_rows(B, depth, 0.0, x.device), res=sc)
+        return samm.affine_apply(r, self._const_rows(B, depth, 1.0, x.device), self._const_rows(B, depth, 0.0, x.device), res=sc)
 
     def _style(self, i, feat):
-        blk = self.styles[i]
-        x = feat
-        convs = [m for m in blk.convs if isinstance(m, torch.nn.Conv2d)]
-        slope = torch.full((blk.out_c,), 0.01, device=feat.device)
-        for j, c in enumerate(convs):
-            x = _conv3x3(x, self._packed(f's{i}.{j}', c.weight), blk.out_c, 2, bias=c.bias.detach(), act=ACT_PRELU, slope=slope)
-        return ops.equal_linear(x.reshape(-1, blk.out_c), blk.linear.weight.detach(), blk.linear.bias.detach(), lr_mul=blk.linear.lr_mul)
+        return self._style_heads([i], {i: feat})[i]
+
+    def _head_level(self, heads, js):
+        """Stacked parameters of conv js[n] of head heads[n]: packed (G*512, 512, 3, 3) weight, (G*512,) bias and slopes."""
+        convs = [[m for m in self.styles[i].convs if isinstance(m, torch.nn.Conv2d)][j] for i, j in zip(heads, js)]
+
+        def build():
+            w = torch.cat([c.weight.detach().float() for c in convs], 0).contiguous()
+            bias = torch.cat([c.bias.detach().float() for c in convs], 0).contiguous()
+            return ops.pack_conv3x3(w, precision='f16s'), bias, torch.full((w.shape[0],), 0.01, device=w.device)
+        return self._memo(('heads', tuple(heads), tuple(js)), [t for c in convs for t in (c.weight, c.bias)], build)
+
+    def _style_heads(self, heads, feat_of):
+        """GradualStyleBlock.forward (psp_encoders.py:14-34) of several heads at once.  A head is a chain of stride-2 3x3
+        convs (512 -> 512, LeakyReLU(0.01)) down to 1x1 and an EqualLinear; at B = 1 every conv of the chain is a ~10 MB
+        weight stream over a handful of output pixels — 98 launches of a latency-bound kernel when run head by head.  Here
+        heads that read the same feature map run their first conv as ONE launch over the stacked output channels, and
+        from there on all chains advance together as ONE grouped convolution per step (oodgan_conv_args.groups); the
+        chains that start on smaller maps join when the running ones have come down to their size (all chains end at
+        1x1, so after every step the live maps have one size): 18 heads = 8 conv launches instead of 98.
+        ``feat_of[i]`` is head i's input map.  Returns {i: (B, 512)}."""
+        out_c = self.styles[heads[0]].out_c
+        nconv = {i: sum(isinstance(m, torch.nn.Conv2d) for m in self.styles[i].convs) for i in heads}
+        sets = {}
+        for i in heads:                             # heads sharing one input map
+            sets.setdefault(id(feat_of[i]), []).append(i)
+        steps = max(nconv.values())
+        live, nxt, x_all = [], {}, None             # live heads in channel order, their next conv index, (B, G*512, h, w)
+        for step in range(steps):
+            y = None
+            if live:
+                pk, bias, slope = self._head_level(live, [nxt[i] for i in live])
+                y = _conv3x3(x_all, pk, out_c * len(live), 2, bias=bias, act=ACT_PRELU, slope=slope, groups=len(live))
+                for i in live:
+                    nxt[i] += 1
+            for hs in sets.values():
+                if nconv[hs[0]] == steps - step:    # this set's chains start now, on their shared map
+                    pk, bias, slope = self._head_level(hs, [0] * len(hs))
+                    y0 = _conv3x3(feat_of[hs[0]], pk, out_c * len(hs), 2, bias=bias, act=ACT_PRELU, slope=slope)
+                    y = y0 if y is None else torch.cat([y, y0], 1)
+                    live = live + hs
+                    nxt.update({i: 1 for i in hs})
+            x_all = y
+        B = x_all.shape[0]
+        x_all = x_all.reshape(B, len(live), out_c)
+        res = {}
+        for g, i in enumerate(live):
+            blk = self.styles[i]
+            res[i] = ops.equal_linear(x_all[:, g].contiguous(), blk.linear.weight.detach(), blk.linear.bias.detach(), lr_mul=blk.linear.lr_mul)
+        return res
 
     def _input(self, x):
         B = x.shape[0]
         il = self.input_layer
-        a, b = _bn_affine(il[1])
-        return _conv3x3(x, self._packed('in', il[0].weight), 64, 1, out_scale=_rows(a, B), bias=b.detach().contiguous(), act=ACT_PRELU,
-                        slope=il[2].weight.detach())
+        a, _, b = self._bn_rows('in.bn', il[1], B)
+        return _conv3x3(x, self._packed('in', il[0].weight), 64, 1, out_scale=a, bias=b, act=ACT_PRELU, slope=il[2].weight.detach())
 
 
 class Encoder4EditingHIP(_HipTrunk, Encoder4Editing):
@@ -149,9 +212,8 @@ class Encoder4EditingHIP(_HipTrunk, Encoder4Editing):
             elif i == 23:
                 c3 = x
                 feats.append(x)
-        w0 = self._style(0, c3)
-        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
         stage = self.progressive_stage.value
+        feat_of = {0: c3}
         features, p2 = c3, None
         for i in range(1, min(stage + 1, self.style_count)):
             if i == self.coarse_ind:
@@ -159,7 +221,12 @@ class Encoder4EditingHIP(_HipTrunk, Encoder4Editing):
                 features = p2
             elif i == self.middle_ind:
                 features = _resize_bicubic_ac(p2, c1.shape[-2:], add=samm.conv1x1(c1, self.latlayer2.weight.detach(), self.latlayer2.bias.detach()))
-            w[:, i] += self._style(i, features)
+            feat_of[i] = features
+        deltas = self._style_heads(sorted(feat_of), feat_of)
+        w = deltas[0].repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
+        for i in sorted(feat_of):
+            if i > 0:
+                w[:, i] += deltas[i]
         if kwargs.get('return_feats', False):
             return w, feats
         return w
@@ -183,10 +250,11 @@ class ProgressiveBackboneEncoderHIP(_HipTrunk, ProgressiveBackboneEncoder):
             x = self._unit(i, layer, x)
             if i in (2, 6, 20, 23):
                 feats.append(x)
-        w0 = self._style(0, x)
-        w = w0.repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
-        for i in range(1, min(self.progressive_stage.value + 1, self.style_count)):
-            w[:, i] += self._style(i, x)
+        heads = list(range(0, min(self.progressive_stage.value + 1, self.style_count)))
+        deltas = self._style_heads(heads, {i: x for i in heads})
+        w = deltas[0].repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
+        for i in heads[1:]:
+            w[:, i] += deltas[i]
         if kwargs.get('return_feats', False):
             return w, feats
         return w

@@ -612,14 +612,16 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
-            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None):
+            in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,
+            groups=1):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
-    act(y)*ys_scale in S-form for the next conv."""
+    act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
+    packed weight G*Mg output channels of K inputs (mode S2, fp32 input)."""
     sform_in = isinstance(x, (SForm, SFormPhases))
     if not sform_in:
         x = _dev(x)
-    B, K = x.shape[0], x.shape[1]
+    B, K = x.shape[0], x.shape[1] // max(1, groups)
     H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
     if mode == CONV_S1:
         oh, ow = H, W
@@ -644,6 +646,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.mode, a.act = mode, act
     a.in_mul2 = _p(in_mul2)
     a.x_sform = 1 if sform_in else 0
+    a.groups = int(groups)
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
     rgb_y = None
     if rgb is not None:         # (w_rgb (3,M), s_rgb Cols/(B,M)): also emit the ToRGB colour sums of the activated output

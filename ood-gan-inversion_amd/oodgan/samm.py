@@ -23,6 +23,8 @@ _lib.bind_extra({
     'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_conv3x3_fewout_ksplit': (c_int, [c_int, c_int, c_int, c_int]),
+    'oodgan_conv3x3_fewout': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_align_head': (c_int, [P, P, c_int, c_long, c_float, P]),
     'oodgan_field_compose': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'oodgan_warp_blend': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -90,6 +92,21 @@ def conv3x3_small(x, weight, in_sc=None, in_sh=None, slope=None):
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
     check(_lib.lib().oodgan_conv3x3_small(_p(x), _p(w), _p(in_sc), _p(in_sh), _p(_opt(slope, 'slope')), _p(y), B, K, M, H, W,
                                           _stream()), 'conv3x3_small')
+    return y
+
+
+def conv3x3_fewout(x, weight, in_sc=None, in_sh=None, slope=None):
+    """3x3 conv (pad 1) from many channels to M <= 4, exact fp32, K split over workgroups (include/oodgan.h)."""
+    x = _dev(x)
+    B, K, H, W = x.shape
+    w = _dev(weight)
+    M = w.shape[0]
+    L = _lib.lib()
+    ks = L.oodgan_conv3x3_fewout_ksplit(B, K, H, W)
+    part = torch.empty(B, ks, M, H, W, device=x.device, dtype=torch.float32)
+    y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
+    check(L.oodgan_conv3x3_fewout(_p(x), _p(w), _p(in_sc), _p(in_sh), _p(_opt(slope, 'slope')), _p(part), _p(y), B, K, M, H, W,
+                                  _stream()), 'conv3x3_fewout')
     return y
 
 
@@ -212,6 +229,9 @@ class bottleneck_IR(nn.Module):
         w1, w2 = self.res_layer[1].weight, self.res_layer[3].weight
         key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version)
         if key != self._key:
+            if self.depth <= 4 and self.in_channel > 8:
+                self._key, self._prep = key, {}          # conv3x3_fewout / conv3x3_small take the raw weights
+                return self._prep
             prep = {'w1': ops.pack_conv3x3(w1.detach())}
             if self.depth > 8:
                 prep['w2'] = ops.pack_conv3x3(w2.detach())
@@ -236,6 +256,10 @@ class bottleneck_IR(nn.Module):
             rs = ops.to_sform(r, mul2=mul2, out=ops.sform_scratch(B, self.depth, H, W, x.device))
             r = ops.conv3x3(rs, prep['w2'], self.depth, CONV_S1, in_mul2=mul2)
             del xs, rs
+        elif self.depth <= 4 and self.in_channel > 8:
+            # AlignNet's head: 2C -> 3 -> 3 channels.  Streaming work, exact fp32, K split over the chip
+            r = conv3x3_fewout(x, rl[1].weight, sc, sh, slope=rl[2].weight)
+            r = conv3x3_small(r, rl[3].weight)
         else:
             r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)
             if self.depth > 8:

@@ -519,6 +519,7 @@ def gold_cli_c1():
     enc = synth.encoder_state(shapes, seed=41)
     sd.update({'encoder.' + k: (v * 0.1 if k.endswith('linear.weight') else v) for k, v in enc.items()})
     print('c1 load:', m.load_state_dict(sd, strict=True))
+    m.delta_latent.data = torch.zeros_like(m.delta_latent)                    # load_model, run_ood_faceGAN_inversion.py:45
 
     # a smooth random field plus pixel noise, 256x256 BGR uint8 ("single 256x256 random face")
     rng = np.random.default_rng(71)
@@ -540,6 +541,7 @@ def gold_cli_c1():
         inversion_im, lats = m(input_im)
     feed.remove()
     assert feed.calls == 17, feed.calls
+    out_f32_sub = inversion_im[0, :, ::16, ::16].clone()                      # tensor2img clamps its argument IN PLACE
     res_rgb = iu.tensor2img(inversion_im, rgb2bgr=False, min_max=(-1, 1))     # save_img_to :64-72
     result = np.ascontiguousarray(res_rgb[:, :, ::-1])                        # cv2.cvtColor(RGB2BGR) inside tensor2img
     assert result.dtype == np.uint8 and result.shape == (1024, 1024, 3)
@@ -550,7 +552,7 @@ def gold_cli_c1():
     strip = iu.tensor2img(torch.cat(masks, dim=3)[0, ...], min_max=(0, 1))
     assert strip.dtype == np.uint8 and strip.shape == (1024, 5 * 1024)
     g = dict(bgr=bgr, out_u8_sub=result[::4, ::4], out_u8_crop=result[448:576, 448:576], lats=lats,
-             out_f32_sub=inversion_im[0, :, ::16, ::16], n_saturated=np.int64(((result == 0) | (result == 255)).sum()))
+             out_f32_sub=out_f32_sub, n_saturated=np.int64(((result == 0) | (result == 255)).sum()))
     for i, s_ in enumerate((32, 64, 128, 256)):
         st = 1024 // s_
         native = strip[::st, 1024 * i:1024 * (i + 1):st]

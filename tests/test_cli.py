@@ -205,7 +205,8 @@ def test_cli_c1_uint8_outputs_vs_reference(tmp_path, golden, monkeypatch):
     """BASELINE configs[0] at the pixel level: the PNGs the CLI writes for one 256x256 image — inversion
     and mask strip — against the uint8 arrays the reference pipeline produces for the same file (tests/golden/make_golden.py
     gold_cli_c1: real img2tensor / F.interpolate / ood_faceGAN_e4e incl. encoder / tensor2img with its ``.round()``).
-    The only way to differ is a float within rounding of a .5 boundary: at most 1 LSB, on a small fraction of the pixels."""
+    The only way to differ is a float within rounding of a .5 boundary: at most 1 LSB, on at most 5e-4 of the values
+    (measured: 37 of 196 608 = 1.9e-4 in the image, 0-4 values per mask level)."""
     from oodgan import cli, imgio, modules
     from PIL import Image
     g = {k: v.numpy() for k, v in golden('cli_c1.npz').items()}
@@ -236,8 +237,8 @@ def test_cli_c1_uint8_outputs_vs_reference(tmp_path, golden, monkeypatch):
         print(f'c1 {what}: {int((d > 0).sum())} of {d.size} values differ, max {int(d.max())} LSB')
         assert d.max() <= 1 and (d > 0).mean() <= frac, (what, int(d.max()), float((d > 0).mean()))
 
-    lsb_check(res[::4, ::4], g['out_u8_sub'], 'inversion ::4', 2e-3)
-    lsb_check(res[448:576, 448:576], g['out_u8_crop'], 'inversion crop', 2e-3)
+    lsb_check(res[::4, ::4], g['out_u8_sub'], 'inversion ::4', 5e-4)
+    lsb_check(res[448:576, 448:576], g['out_u8_crop'], 'inversion crop', 5e-4)
     with Image.open(root / 'masks' / 'face.png') as im:
         strip = np.asarray(im)
     assert strip.shape == (1024, 5 * 1024) and strip.dtype == np.uint8
@@ -246,7 +247,7 @@ def test_cli_c1_uint8_outputs_vs_reference(tmp_path, golden, monkeypatch):
         part = strip[:, 1024 * i:1024 * (i + 1)]
         native = part[::st, ::st]
         assert np.array_equal(np.repeat(np.repeat(native, st, 0), st, 1), part)       # nearest indexing: bit-exact structure
-        lsb_check(native, g[f'mask{i + 1}_u8'], f'mask level {i + 1}', 2e-3)
-    lsb_check(strip[::4, 4096::4], g['mask1024_u8_sub'], 'mask 1024 ::4', 2e-3)
-    lsb_check(strip[448:576, 4096 + 448:4096 + 576], g['mask1024_u8_crop'], 'mask 1024 crop', 2e-3)
+        lsb_check(native, g[f'mask{i + 1}_u8'], f'mask level {i + 1}', 5e-4)
+    lsb_check(strip[::4, 4096::4], g['mask1024_u8_sub'], 'mask 1024 ::4', 5e-4)
+    lsb_check(strip[448:576, 4096 + 448:4096 + 576], g['mask1024_u8_crop'], 'mask 1024 crop', 5e-4)
     assert abs(summary['val_1']['psnr'] - float(g['psnr_resized_gt'])) < 1e-3

@@ -208,10 +208,13 @@ def test_three_streams_vs_one_at_full_size(dev):
         runs.append((w3.clone(), l3.clone()))
     assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:])
     w3, l3 = runs[0]
+    # step 1 sees the same w: its loss differs by rounding only.  Adam's first steps move every coordinate by ~lr*sign(g), so a
+    # handful of ~0 gradient coordinates take the other sign and the later losses follow them (measured 2e-4 relative)
+    rel0 = (l3[0] - l1[0]).abs().max().item() / l1[0].abs().max().item()
     rel = (l3 - l1).abs().max().item() / l1.abs().max().item()
     frac = ((w3 - w1).abs() < 5e-4).float().mean().item()
-    print(f'3 streams vs 1 at 1024², B=8: loss rel diff {rel:.2e}, {100 * frac:.3f}% of w within 5e-4')
-    assert rel <= 1e-5 and frac > 0.999 and (l3[-1] < l3[0]).all()
+    print(f'3 streams vs 1 at 1024², B=8: loss rel diff step 1 {rel0:.2e}, all steps {rel:.2e}, {100 * frac:.3f}% of w within 5e-4')
+    assert rel0 <= 1e-5 and rel <= 1e-3 and frac > 0.999 and (l3[-1] < l3[0]).all()
 
 
 def test_torgb_reproducible_beside_matrix_kernels_of_another_stream(dev):

@@ -40,6 +40,31 @@ def test_instance_norm_and_small_convs(dev):
     close(samm.conv3x3_small(x.to(dev), w3.to(dev), slope=sl.to(dev)), F.prelu(F.conv2d(x, w3, padding=1), sl))
 
 
+def test_conv3x3_fewout_vs_aten(dev):
+    """The many-to-few 3x3 conv (AlignNet head, 2C -> 3) incl. in-bounds-only shift, PReLU, ragged K / sizes and the K split."""
+    from oodgan import samm
+    for (B, K, H, W, M) in ((2, 200, 20, 45, 3), (1, 1024, 32, 32, 3), (3, 16, 9, 7, 4), (1, 256, 64, 64, 1)):
+        x = synth.normal('fo.x', (B, K, H, W), 1, 1.3, 0.1)
+        w = synth.normal('fo.w', (M, K, 3, 3), 2, 0.05)
+        sc = synth.normal('fo.sc', (B, K), 3, 0.2, 1.0)
+        sh = synth.normal('fo.sh', (B, K), 4, 0.3)
+        sl = synth.normal('fo.sl', (M,), 5, 0.05, 0.25)
+        ref = F.prelu(torch.cat([F.conv2d(x[b:b + 1] * sc[b].view(1, K, 1, 1) + sh[b].view(1, K, 1, 1), w, padding=1) for b in range(B)]), sl)
+        y = samm.conv3x3_fewout(x.to(dev), w.to(dev), sc.to(dev), sh.to(dev), slope=sl.to(dev))
+        close(y, ref, 2e-5)
+        close(samm.conv3x3_fewout(x.to(dev), w.to(dev)), F.conv2d(x, w, padding=1), 2e-5)
+        assert torch.equal(y, samm.conv3x3_fewout(x.to(dev), w.to(dev), sc.to(dev), sh.to(dev), slope=sl.to(dev)))    # deterministic
+
+
+def test_warp_blend_channel_chunks(dev):
+    """grid_sample + lerp with channel counts that are not a multiple of the kernel's channel chunk, B > 1."""
+    from oodgan import samm
+    for (B, C, H, W) in ((2, 13, 24, 40), (3, 512, 32, 32), (1, 5, 7, 9)):
+        t = synth.normal('wc.t', (B, C, H, W), 1)
+        f = torch.cat([synth.normal('wc.f', (B, 2, H, W), 2, 0.4), synth.uniform('wc.a', (B, 1, H, W), 3)], 1)
+        close(samm.warp_blend(t.to(dev), f.to(dev)), R.warp_blend(t, f), 1e-5)
+
+
 def test_resize_index_math_exact(dev):
     """nearest / bilinear source-index math must match ATen bit for bit (mask indexing)."""
     from oodgan import samm
