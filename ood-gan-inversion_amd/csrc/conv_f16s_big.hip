@@ -64,6 +64,14 @@ constexpr int BG_ZBYTES = 3584;
 constexpr int BG_SMEM16 = BG_SMEM + BG_ZBYTES;            // 159232
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifdef OODGAN_CLOCK_STAMP
+// Diagnostic build only (make STAMP=1 -> liboodgan_hip_stamp.so; MI355X_MICROARCH.md, DVFS item 6): the in-kernel clock is
+// d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped once around the K loop.  The stamps go to a buffer of their own that no
+// kernel reads; the production library contains none of this.
+__device__ unsigned long long* g_s1big_stamp = nullptr;
+__device__ long g_s1big_stamp_n = 0;
+#endif
+
 template <bool DOT, bool PRE>
 __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, const uint4* __restrict__ wpk16) {
     constexpr int NW = 8, NT = 2;
@@ -189,6 +197,9 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     };
 #define BH_IC(n) std::integral_constant<int, n>{}
 #define BH_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef OODGAN_CLOCK_STAMP
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
     for (int t = 0; t < nchunk; ++t) {
@@ -224,6 +235,12 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     }
 #undef BH_IC
 #undef BH_SB
+#ifdef OODGAN_CLOCK_STAMP
+    if (tid == 0 && g_s1big_stamp && (long)blockIdx.x < g_s1big_stamp_n) {
+        g_s1big_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_t0;
+        g_s1big_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
 
     // ---- epilogue from the accumulators: lane (n16, g) holds, per M-tile mt and N-tile n, channels 16*mt + 4*g + r (r = 0..3) of
     // pixel (row nt = n >> 1, column 16*(n & 1) + n16): 64-byte runs per channel and store
@@ -381,3 +398,16 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
 }
 
 }  // namespace oodgan
+
+#ifdef OODGAN_CLOCK_STAMP
+// stamp build only: buf = n pairs {shader cycles, 100 MHz ticks} of the K loop of workgroup blockIdx.x (last launch wins)
+extern "C" int oodgan_debug_set_stamp_buffer(void* buf, long n) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_s1big_stamp), &p, sizeof(p)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_s1big_stamp_n), &n, sizeof(n)) != hipSuccess) {
+        oodgan::set_error("debug_set_stamp_buffer: hipMemcpyToSymbol failed");
+        return OODGAN_E_LAUNCH;
+    }
+    return 0;
+}
+#endif

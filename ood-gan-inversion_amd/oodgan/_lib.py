@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liboodgan_hip.so')
+# OODGAN_LIB: load another build of the same ABI (the diagnostic stamp build of tools/clock_probe.py); default = the product
+LIB_PATH = os.environ.get('OODGAN_LIB') or os.path.join(_HERE, 'liboodgan_hip.so')
 
 CONV_S1, CONV_T2, CONV_S2 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
