@@ -335,18 +335,26 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         float vmaxv = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            if (MH == 2) __builtin_amdgcn_sched_barrier(0);                // the second M-tile's 32 loads stay below the first one's work
             const int chb = mh * 64 + mt * 32;                             // first channel of the M-tile inside the workgroup
             // saved activations of the tile: all loads of the M-tile are issued before the first use
+            // Unconditional loads from a clamped pixel (M % 32 == 0: every channel of the tile exists; a conditional load is a
+            // branch per value), out-of-image pixels masked by a select.  Address = uniform base + a uniform channel offset per
+            // value + ONE 32-bit lane offset per row (sixteen 64-bit lane addresses per row would cost 32 registers).
             float dv[RW][16];
+            const unsigned char* ub = reinterpret_cast<const unsigned char*>(a.dotx + ((long)b * M + m0 + chb) * HW);
 #pragma unroll
             for (int nt = 0; nt < RW; ++nt) {
                 const int py_ = r0 + rg * RW + nt;
-                const float* dr = a.dotx + ((long)b * M + m0 + chb) * HW + (long)py_ * W + px;
+                const unsigned voff = (unsigned)((((long)min(py_, H - 1) * W + min(px, W - 1)) + (long)(4 * half) * HW) * 4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
                     if constexpr (EARLY) dv[nt][r] = edv[EARLY ? mt : 0][r];
-                    else dv[nt][r] = (okr[nt] && m0 + chb + ch < M) ? dr[(long)ch * HW] : 0.f;
+                    else dv[nt][r] = *reinterpret_cast<const float*>(ub + (long)((r & 3) + 8 * (r >> 2)) * HW * 4 + voff);
+                }
+                if constexpr (!EARLY) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dv[nt][r] = okr[nt] ? dv[nt][r] : 0.f;
                 }
             }
             unsigned hi[RW][8], lo[RW][8];
@@ -441,13 +449,15 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         for (int r = 0; r < 16; ++r) dsum[mt][r] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        float osc[16];
+        float osc[16], bia[16], slp[16];
         unsigned moff[16], doff[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool mok = m < M;
             osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
+            bia[r] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
+            slp[r] = (!DOT && a.act == OODGAN_ACT_PRELU && mok) ? a.slope[m] : 1.f;
             moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
             doff[r] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
         }
@@ -476,13 +486,23 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                 for (int r = 0; r < 16; ++r) dsum[mt][r] += (acc[mt][nt][r] * us) * dv[r];
             }
             if (ok && a.y) {
+                float o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[r] = acc[mt][nt][r] * osc[r];
+                    if (!DOT) {          // forward use (the stride-2 convs of the e4e encoder): bias + PReLU / leaky ReLU
+                        o[r] += bia[r];
+                        if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
+                        else if (a.act == OODGAN_ACT_PRELU) o[r] = o[r] > 0.f ? o[r] : slp[r] * o[r];
+                    }
+                }
                 if (mfull) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + moff[r]) = acc[mt][nt][r] * osc[r];
+                    for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = acc[mt][nt][r] * osc[r];
+                        if (moff[r] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[r]) = o[r];
                 }
             }
         }
@@ -513,8 +533,10 @@ namespace oodgan {
 
 bool s2_big_eligible(const oodgan_conv_args& a) {
     if (!(a.mode == OODGAN_CONV_S2 && a.x_sform && a.ys == nullptr && a.in_scale == nullptr && a.in_shift == nullptr &&
-          a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && (a.y != nullptr || a.dotx != nullptr) && a.M >= 64))
+          a.noise == nullptr && (a.y != nullptr || a.dotx != nullptr) && a.M >= 64))
         return false;
+    // bias / activation: only in the plain (no dot, no fused backward) epilogue — the forward use by the encoder
+    if ((a.bias != nullptr || a.act != OODGAN_ACT_NONE) && (a.dotx != nullptr || a.fuse != nullptr || a.y == nullptr)) return false;
     if (a.fuse) return true;                // the fused epilogue exists only here (the caller checked s2_fuse_supported)
     // enough 8x32 tiles x 64-channel blocks to fill the chip; the low-resolution layers keep their latency-oriented instance
     const int Hn = (a.Hin - 1) / 2, Wn = (a.Win - 1) / 2;

@@ -12,6 +12,14 @@
 // a stage are read once; the A fragments of tap i+1 are read under the MFMAs of tap i.
 // The previous kernel (conv_f16s_t2v2_kernel<1>: 4 waves, 4 rows x 32 channels, one stage in LDS, DMA -> wait -> 27 MFMAs)
 // moved 31 KB per 108 wave-MFMAs; this one moves 55 KB per 432.
+//
+// Position grid (round 3).  The (H+1) x (W+1) grid on 8 x 32 tiles leaves a tile row / column with ONE valid row or column
+// (33 columns = two 32-wide tiles: 57 / 39 / 24 / 13 % of the tiles of the 32² ... 256² layers were such slivers).  The MAIN
+// launch now covers the positions (i' < H, j' < W) — exact tiles for the generator's sizes — which produce z rows
+// 0..2H-1 and columns 0..2W-1 completely; the last z row (i' = H: taps ky = 2 on x row H-1) and the last z column
+// (j' = W: taps kx = 2 on x column W-1) form ONE sequence of H+W+1 edge positions that the EDGE instance of the same
+// kernel walks 256 at a time: its x "tile" is the 1-D run S(e) = x[H-1][e] (e <= W), x[e-W-1][W-1] (e > W) and a zero
+// record; a tap reads S(e), S(e-1) or zeros.  10 -> 5, 27 -> 17, 85 -> 66, 297 -> 259 workgroup tiles per (image, 64 channels).
 #include "conv_common.hpp"
 #include "sform.hpp"
 #include <cstdint>
@@ -40,10 +48,14 @@ struct T2Big {
     const uint4* xs;
     SDims xd;
     const float* w_unscale;
-    int Hn, Wn, Hout, Wout, tiles_x, tiles_y, mblocks, Mp;
+    int Hn, Wn, Hout, Wout, tiles_x, tiles_y, mblocks, Mp;      // Hn x Wn = H x W: the positions of the main launch
     long out_plane;
+    int etiles;                                                  // EDGE: ceil((H + W + 1) / 256)
 };
 
+constexpr int TE_RECS = 257;                               // EDGE: records S(e0-1) .. S(e0+255); record 257 = zeros
+
+template <bool EDGE>
 __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const oodgan_conv_args& a = p.a;
@@ -54,10 +66,11 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
     int w = xcd_remap(blockIdx.x, gridDim.x);
     const int mblk = w % p.mblocks;
     w /= p.mblocks;
-    const int ntile = p.tiles_x * p.tiles_y;
+    const int ntile = EDGE ? p.etiles : p.tiles_x * p.tiles_y;
     const int tile = w % ntile, b = w / ntile;
     const int r0 = (tile / p.tiles_x) * 8, c0 = (tile % p.tiles_x) * 32, m0 = mblk * 64;
-    const int M = a.M;
+    const int e0 = tile * 256;                              // EDGE: first edge position of the tile
+    const int M = a.M, H = p.Hn, W = p.Wn;
 
     // ---- per-lane DMA source offsets (bytes): piece pc = wave + 8*i; x pieces relative to (plane of the chunk), rotation
     // applied; weight pieces relative to the chunk's block
@@ -66,7 +79,13 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
     for (int i = 0; i < TB_NPW; ++i) {
         int pc = wave + 8 * i;
         if (pc >= TB_PIECES) pc = TB_PIECES - 1;
-        if (pc < TB_XPIECES) {
+        if (pc < TB_XPIECES && EDGE) {
+            const int P = pc * 64 + lane, rec = P >> 2, e = e0 - 1 + rec;
+            int prow = 0, pcol = 0;                          // padded (0,0): a zero record of the border
+            if (rec < TE_RECS && e <= W) { prow = H; pcol = e + 1; }                    // x[H-1][e]   (e = -1, W: zero border)
+            else if (rec < TE_RECS && e <= W + H) { prow = e - W; pcol = W; }           // x[e-W-1][W-1]
+            off[i] = (unsigned)((((long)prow * p.xd.Wp + pcol) * 4 + (P & 3)) * 16);
+        } else if (pc < TB_XPIECES) {
             int P = pc * 64 + lane;
             if (P >= TB_XSLOTS) P = TB_XSLOTS - 1;
             const int row = P / (TB_C * 4), q = P % (TB_C * 4);
@@ -112,6 +131,17 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int lo = 0; lo < 2; ++lo) {
+                if (EDGE) {
+                    // edge position e: the last z row (e <= W: i' = H, j' = e; x row H is outside the image, so only the
+                    // taps with da = 1 read data: x[H-1][j'-db] = S(e-db)) or the last z column (j' = W, i' = e-W-1: only db = 1:
+                    // x[i'-da][W-1] = S(e-da)); S(e) sits in record e-e0+1, record TE_RECS holds zeros
+                    const int el = 32 * wave + l31, e = e0 + el;
+                    int rec = TE_RECS;
+                    if (e <= W) { if (da == 1) rec = el + 1 - db; }
+                    else if (e <= W + H) { if (db == 1) rec = el + 1 - da; }
+                    lrd[da][db][lo] = rec * 64 + (((half + 2 * lo) & 3) << 4);
+                    continue;
+                }
                 const int c = l31 + 1 - db;
                 lrd[da][db][lo] = ((wave + 1 - da) * TB_C + c) * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
             }
@@ -175,10 +205,34 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
 
     // ---- epilogue: z rows 2i', 2i'+1; the two x-phases of a position are one aligned float2
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    float* yb = a.y + (long)b * M * p.out_plane;
+    if constexpr (EDGE) {
+        const int e = e0 + 32 * wave + l31;
+        if (e > W + H) return;
+        const bool rowt = e <= W;                           // last z row (2H), columns 2e, 2e+1 | last z column (2W), rows 2i', 2i'+1
+        const int ie = e - W - 1;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const float sc = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
+                float* zp = yb + (long)m * p.out_plane;
+                if (rowt) {
+                    float* q = zp + (long)(2 * H) * a.out_pitch + 2 * e;
+                    q[0] = acc[mt][0][r] * sc;
+                    if (e < W) q[1] = acc[mt][1][r] * sc;
+                } else {
+                    zp[(long)(2 * ie) * a.out_pitch + 2 * W] = acc[mt][0][r] * sc;
+                    zp[(long)(2 * ie + 1) * a.out_pitch + 2 * W] = acc[mt][2][r] * sc;
+                }
+            }
+        return;
+    }
     const int ip = r0 + wave, jp = c0 + l31;
     const int zx = 2 * jp;
-    if (ip >= p.Hn || zx >= p.Wout) return;
-    float* yb = a.y + (long)b * M * p.out_plane;
+    if (ip >= H || jp >= W) return;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -206,7 +260,7 @@ bool t2_big_eligible(const oodgan_conv_args& a) {
           a.dotx == nullptr && a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && a.ys == nullptr))
         return false;
     // enough (8x32 positions x 64 channels) items to fill the chip; smaller layers keep the latency-oriented instance
-    const long items = (long)((a.Hin + 1 + 7) / 8) * ((a.Win + 1 + 31) / 32) * a.B * ((a.M + 63) / 64);
+    const long items = (long)((a.Hin + 7) / 8) * ((a.Win + 31) / 32) * a.B * ((a.M + 63) / 64);
     const char* e = getenv("OODGAN_T2_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
     // 128 work items = half the CUs: what a sub-batch of 2-3 images (three concurrent streams) brings to the 64² / 32² layers.  Whole loop,
     // 3 streams, same box: threshold 256 -> 5.67 img/s, 128 -> 5.79 (one stream, batch 8: the 32² input gradient 169 -> 150 us)
@@ -217,7 +271,7 @@ int launch_t2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     T2Big p;
     p.a = a_in;
     oodgan_conv_args& a = p.a;
-    p.Hn = a.Hin + 1; p.Wn = a.Win + 1; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1;
+    p.Hn = a.Hin; p.Wn = a.Win; p.Hout = 2 * a.Hin + 1; p.Wout = 2 * a.Win + 1;
     if (a.out_pitch == 0) a.out_pitch = p.Wout + 1;
     OODGAN_REQUIRE((a.out_pitch & 1) == 0 && a.out_pitch >= p.Wout + 1, "conv3x3 T2: out_pitch must be even and > 2W+1 (got %d)", a.out_pitch);
     p.out_plane = (long)p.Hout * a.out_pitch;
@@ -229,11 +283,15 @@ int launch_t2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     p.Mp = (a.M + 63) / 64 * 64;
     p.mblocks = (a.M + 63) / 64;
     OODGAN_REQUIRE(p.xd.plane * 16 < (1L << 32), "conv3x3 T2 big: input plane too large");
-    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks;
+    p.etiles = (a.Hin + a.Win + 1 + 255) / 256;
+    const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks, etotal = (long)p.etiles * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM), true);
     (void)once;
-    hipLaunchKernelGGL(conv_f16s_t2big_kernel, dim3((unsigned)total), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
+    static_assert(TE_RECS * 4 + 4 <= TB_XPIECES * 64, "edge records + the zero record fit the x region");
+    hipLaunchKernelGGL(conv_f16s_t2big_kernel<false>, dim3((unsigned)total), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
+    hipLaunchKernelGGL(conv_f16s_t2big_kernel<true>, dim3((unsigned)etotal), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
     return check_launch("conv3x3_f16s_t2big");
 }
 
