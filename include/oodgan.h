@@ -33,6 +33,15 @@ int oodgan_version(void);
 const char* oodgan_last_error(void);
 /* number of HIP devices visible (0 on a CPU-only box); never throws */
 int oodgan_device_count(void);
+/* Dispatch tunables.  Each has a default, overridden ONCE (at first use) by an environment variable, and can be changed at
+ * run time here — the hot path never calls getenv().  Names / environment / default:
+ *   "s1_big_min_items" OODGAN_S1_BIG_MIN_ITEMS 128   work items (16x32-pixel tiles x images x 64-channel blocks) from which the
+ *   "s2_big_min_items" OODGAN_S2_BIG_MIN_ITEMS 128   8-wave stride-1 / stride-2 / transposed kernels take a conv (unit tests lower
+ *   "t2_big_min_items" OODGAN_T2_BIG_MIN_ITEMS 128   them to reach those kernels with small tensors, or raise them for the A/B)
+ *   "blurt_strip"      OODGAN_BLURT_STRIP      1     0: the tile kernel instead of the strip walk in oodgan_act_bwd_blurT_sform_phases
+ * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
+int oodgan_set_tunable(const char* name, long value);
+long oodgan_get_tunable(const char* name);
 
 /* ------------------------------------------------------------------ L1 custom ops ---------- */
 

@@ -780,10 +780,7 @@ extern "C" int oodgan_act_bwd_sform(const float* g_feat, const float* out, const
     return check_launch("act_bwd_sform");
 }
 
-static bool blurT_strip_enabled() {
-    const char* e = getenv("OODGAN_BLURT_STRIP");      // tests set 0 to compare with the tile kernel
-    return !(e && e[0] == '0');
-}
+static bool blurT_strip_enabled() { return oodgan::tunable(oodgan::OODGAN_TUN_BLURT_STRIP) != 0; }      // tests set 0 to compare with the tile kernel
 
 // 1 when oodgan_act_bwd_blurT_sform_phases takes out == NULL (g_feat already multiplied by act'(out) by the conv above,
 // oodgan_conv_args.dot_actgrad) for an up-conv input of H x W: the strip walk only

@@ -356,10 +356,9 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
         return false;
     // enough 16x32 tiles to fill the chip; smaller layers keep the latency-oriented instances
     const long items = (long)((a.Hin + 15) / 16) * ((a.Win + 31) / 32) * a.B * ((a.M + 63) / 64);
-    const char* e = getenv("OODGAN_S1_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
     // 128 work items = half the CUs: what a sub-batch of 2-3 images (three concurrent streams) brings to the 64² / 32² layers.  Whole loop,
     // 3 streams, same box: threshold 256 -> 5.67 img/s, 128 -> 5.79 (one stream, batch 8: the 32² input gradient 169 -> 150 us)
-    return items >= (e ? atol(e) : 128);
+    return items >= tunable(OODGAN_TUN_S1_BIG_MIN_ITEMS);      // default 128; tests lower it to reach this kernel with small tensors
 }
 
 int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {

@@ -541,10 +541,9 @@ bool s2_big_eligible(const oodgan_conv_args& a) {
     // enough 8x32 tiles x 64-channel blocks to fill the chip; the low-resolution layers keep their latency-oriented instance
     const int Hn = (a.Hin - 1) / 2, Wn = (a.Win - 1) / 2;
     const long items = (long)((Hn + 7) / 8) * ((Wn + 31) / 32) * a.B * ((a.M + 63) / 64);
-    const char* e = getenv("OODGAN_S2_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
     // 128 work items = half the CUs: what a sub-batch of 2-3 images (three concurrent streams) brings to the 64² / 32² layers.  Whole loop,
     // 3 streams, same box: threshold 256 -> 5.67 img/s, 128 -> 5.79 (one stream, batch 8: the 32² input gradient 169 -> 150 us)
-    return items >= (e ? atol(e) : 128);     // 512 -> 512 @64² -> 32² (256 items): 229 -> 139 us against the merged-parity tile kernel
+    return items >= tunable(OODGAN_TUN_S2_BIG_MIN_ITEMS);      // default 128; tests lower it to reach this kernel with small tensors     // 512 -> 512 @64² -> 32² (256 items): 229 -> 139 us against the merged-parity tile kernel
 }
 
 }  // namespace oodgan

@@ -51,19 +51,18 @@ struct T2Big {
     int Hn, Wn, Hout, Wout, tiles_x, tiles_y, mblocks, Mp;      // Hn x Wn = H x W: the positions of the main launch
     long out_plane;
     int etiles;                                                  // EDGE: ceil((H + W + 1) / 256)
+    int etotal, eblocks;                                         // edge workgroups, and their count rounded up to a multiple of 8
 };
 
 constexpr int TE_RECS = 257;                               // EDGE: records S(e0-1) .. S(e0+255); record 257 = zeros
 
 template <bool EDGE>
-__global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, const uint4* __restrict__ wpk16) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void t2big_body(const T2Big& p, const uint4* __restrict__ wpk16, unsigned char* smem, int w) {
     const oodgan_conv_args& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
-    int w = xcd_remap(blockIdx.x, gridDim.x);
     const int mblk = w % p.mblocks;
     w /= p.mblocks;
     const int ntile = EDGE ? p.etiles : p.tiles_x * p.tiles_y;
@@ -251,6 +250,20 @@ __global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, con
         }
 }
 
+
+// ONE launch: the first p.etotal (rounded up to a multiple of 8) workgroups walk the edge positions, the others the main tiles.
+// The edge workgroups are few (24-64) and latency-bound — a full K loop for a single tile, 60-70 us — so as a launch of their
+// own they cost most of what the exact main grid saves; dispatched first inside the main launch they run beside its tiles.
+__global__ __launch_bounds__(512) void conv_f16s_t2big_kernel(const T2Big p, const uint4* __restrict__ wpk16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < p.eblocks) {
+        if (bid < p.etotal) t2big_body<true>(p, wpk16, smem, bid);
+        return;
+    }
+    t2big_body<false>(p, wpk16, smem, xcd_remap(bid - p.eblocks, gridDim.x - p.eblocks));
+}
+
 }  // namespace
 
 namespace oodgan {
@@ -261,10 +274,9 @@ bool t2_big_eligible(const oodgan_conv_args& a) {
         return false;
     // enough (8x32 positions x 64 channels) items to fill the chip; smaller layers keep the latency-oriented instance
     const long items = (long)((a.Hin + 7) / 8) * ((a.Win + 31) / 32) * a.B * ((a.M + 63) / 64);
-    const char* e = getenv("OODGAN_T2_BIG_MIN_ITEMS");      // tests lower the threshold to reach this kernel with small tensors
     // 128 work items = half the CUs: what a sub-batch of 2-3 images (three concurrent streams) brings to the 64² / 32² layers.  Whole loop,
     // 3 streams, same box: threshold 256 -> 5.67 img/s, 128 -> 5.79 (one stream, batch 8: the 32² input gradient 169 -> 150 us)
-    return items >= (e ? atol(e) : 128);
+    return items >= tunable(OODGAN_TUN_T2_BIG_MIN_ITEMS);      // default 128; tests lower it to reach this kernel with small tensors
 }
 
 int launch_t2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {
@@ -286,12 +298,13 @@ int launch_t2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     p.etiles = (a.Hin + a.Win + 1 + 255) / 256;
     const long total = (long)p.tiles_x * p.tiles_y * a.B * p.mblocks, etotal = (long)p.etiles * a.B * p.mblocks;
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_t2big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TB_SMEM), true);
     (void)once;
     static_assert(TE_RECS * 4 + 4 <= TB_XPIECES * 64, "edge records + the zero record fit the x region");
-    hipLaunchKernelGGL(conv_f16s_t2big_kernel<false>, dim3((unsigned)total), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
-    hipLaunchKernelGGL(conv_f16s_t2big_kernel<true>, dim3((unsigned)etotal), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
+    p.etotal = (int)etotal;
+    p.eblocks = (int)((etotal + 7) / 8 * 8);             // keeps the main tiles' blockIdx -> XCD chunk mapping intact
+    OODGAN_REQUIRE(total + p.eblocks < (1L << 31), "conv3x3: grid too large");
+    hipLaunchKernelGGL(conv_f16s_t2big_kernel, dim3((unsigned)(total + p.eblocks)), dim3(512), TB_SMEM, st, p, reinterpret_cast<const uint4*>(wpk16));
     return check_launch("conv3x3_f16s_t2big");
 }
 

@@ -311,6 +311,144 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s1v2_kernel(const KArgs p,
     tile_epilogue<MT>(p, sc, acc, ctx, lx, active, tid, lane, wave, l31, half);
 }
 
+// Low-resolution instance (4x4 ... 32x32 images: at most 256 work items, one workgroup per CU, K = 512): the <1,1,2>
+// instance above requests a stage, waits for it (vmcnt(0)) and only then issues its MFMAs — 16 stages of a bare LDS-DMA
+// latency (3.2 us for 92 KB) plus their MFMAs (1.5 us), nothing overlapped.  Here the stages form a RING of three 46 KB
+// buffers (one K chunk each): stage t+2 is requested right after the barrier that retires stage t-1, and the wait before
+// stage t leaves stage t+1 in flight (counted vmcnt: every wave issues exactly RING_NPW pieces per stage, the tail pieces
+// duplicated).  One barrier per stage.
+constexpr int RING = 3;
+template <int MT>
+__global__ __launch_bounds__(256) void conv_f16s_s1ring_kernel(const KArgs p, const uint4* __restrict__ wpk16, int total_items,
+                                                                const SConv sc) {
+    constexpr int MB = 32 * MT;
+    constexpr int WROWS = 36;
+    constexpr int WPIECES = WROWS * MB * 16 / 1024;
+    constexpr int STAGE = XBYTES + WROWS * MB * 16;
+    constexpr int NPIECES = XPIECES + WPIECES;
+    constexpr int NPW = (NPIECES + 3) / 4;          // pieces per wave and stage (uniform: counted waits)
+    static_assert(RING * STAGE >= group_bytes<MT>(), "the epilogue image fits the ring");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int wi = xcd_remap(blockIdx.x, gridDim.x);
+    const bool active = wi < total_items;
+    BlockCtx ctx;
+    {
+        int w = active ? wi : 0;
+        const int ntile = p.tiles_x * p.tiles_y;
+        ctx.mblk = w % p.mblocks;
+        w /= p.mblocks;
+        ctx.tile = w % ntile;
+        ctx.b = w / ntile;
+        ctx.r0 = (ctx.tile / p.tiles_x) * TR;
+        ctx.c0 = (ctx.tile % p.tiles_x) * 32;
+        ctx.m0 = ctx.mblk * MB;
+    }
+    const int b = ctx.b, r0 = ctx.r0, c0 = ctx.c0, m0 = ctx.m0;
+
+    // per-lane source offsets (16-byte units) of this wave's pieces: x pieces inside one (b,kc) plane, weight pieces inside
+    // one K chunk of the packed weights
+    long src[NPW];
+    bool isx[NPW];
+    int pcs[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        int pc = wave + 4 * i;
+        if (pc >= NPIECES) pc = NPIECES - 1;    // duplicate of the last piece: same bytes to the same place
+        pcs[i] = pc;
+        isx[i] = pc < XPIECES;
+        if (pc < XPIECES) {
+            int P = pc * 64 + lane;
+            if (P >= XSLOTS) P = XSLOTS - 1;
+            const int pos = P / 5;
+            int sl = P % 5;
+            if (sl == 4) sl = 0;
+            const int r = pos / IN_C, c = pos % IN_C;
+            src[i] = ((long)(r0 + r) * sc.xd.Wp + (c0 + c)) * 4 + sl;
+        } else {
+            const int u = (pc - XPIECES) * 64 + lane;
+            src[i] = (long)(u / MB) * p.Mp + m0 + (u % MB);
+        }
+    }
+    const uint4* xplane0 = sc.xs + (long)b * sc.xd.KC * sc.xd.plane;
+    const int nchunk = (a.K + CK - 1) / CK;
+    const long wchunk = (long)WROWS * p.Mp;
+    auto dma_stage = [&](int t) {
+        unsigned char* dst = smem + (t % RING) * STAGE;
+        const uint4* xb = xplane0 + (long)t * sc.xd.plane;
+        const uint4* wb = wpk16 + (long)t * wchunk;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const uint4* sp = (isx[i] ? xb : wb) + src[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp, (lds_void*)(dst + pcs[i] * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
+
+    const unsigned lwoff = XBYTES + (half * MB + l31) * 16;
+    const unsigned lxoff = ((wave * NT) * IN_C + l31) * REC + half * 16;
+#define MFMA3(accv, ah, al, bh, bl)                                              \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
+    if (active) {
+        dma_stage(0);
+        if (nchunk > 1) dma_stage(1);
+    }
+    for (int t = 0; t < nchunk; ++t) {
+        if (t + 1 < nchunk) __builtin_amdgcn_s_waitcnt(((NPW >> 4) & 3) << 14 | 0x0F70 | (NPW & 15));       // stage t+1 stays in flight
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();                  // stage t has landed for every wave; everybody is done with stage t-1
+        if (!active) continue;
+        if (t + 2 < nchunk) dma_stage(t + 2);          // into the buffer stage t-1 occupied
+        const unsigned char* lxs = smem + (t % RING) * STAGE + lxoff;
+        const unsigned char* lws = smem + (t % RING) * STAGE + lwoff;
+#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxs + (posoff) * REC + (lo_) * 32))
+#define WFRAG(tap, lo_, mt) (*reinterpret_cast<const half8*>(lws + ((((tap) * 2 + (lo_)) * 2) * MB + (mt) * 32) * 16))
+        half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#define LOADF(buf, tp_)                                                                               \
+    {                                                                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
+            ah[buf][mt] = WFRAG(tp_, 0, mt);                                                          \
+            al[buf][mt] = WFRAG(tp_, 1, mt);                                                          \
+        }                                                                                             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+            bh[buf][nt] = XFRAG((nt + (tp_) / 3) * IN_C + (tp_) % 3, 0);                              \
+            bl[buf][nt] = XFRAG((nt + (tp_) / 3) * IN_C + (tp_) % 3, 1);                              \
+        }                                                                                             \
+    }
+        LOADF(0, 0)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int cur = tp & 1;
+            if (tp + 1 < 9) LOADF(cur ^ 1, tp + 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { MFMA3(acc[mt][nt], ah[cur][mt], al[cur][mt], bh[cur][nt], bl[cur][nt]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef LOADF
+#undef XFRAG
+#undef WFRAG
+    }
+#undef MFMA3
+    __syncthreads();
+    tile_epilogue<MT>(p, sc, acc, ctx, smem, active, tid, lane, wave, l31, half);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Transposed 3x3 stride-2 conv (the up-sampling ModulatedConv2d before its blur) with S-form input: block = 4 waves,
 // N tile = 4 rows x 32 positions (i',j') of the (H+1)x(W+1) position grid, 4 output phases per position.
@@ -871,7 +1009,12 @@ int launch_s1v2(const oodgan_conv_args& a, const void* wpk16, const float* unsca
         dim3 grid((unsigned)((total + NG_ - 1) / NG_)), block(256 * NG_);                                                \
         hipLaunchKernelGGL((conv_f16s_s1v2_kernel<MT_, NG_, CPS_>), grid, block, sm, st, p, w16, items, sc);             \
     }
-    if (deep) OODGAN_LAUNCH(1, 1, 2)          // 3 chunks per stage measured equal: these layers are MFMA-bound on their padded tiles
+    if (deep) {
+        constexpr int sm = RING * (XBYTES + 36 * 32 * 16);
+        static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1ring_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, sm), true);
+        (void)once;
+        hipLaunchKernelGGL((conv_f16s_s1ring_kernel<1>), dim3((unsigned)total), dim3(256), sm, st, p, w16, items, sc);
+    }
     else if (mt2) { if (ng == 2) OODGAN_LAUNCH(2, 2, 1) else OODGAN_LAUNCH(2, 1, 1) }
     else { if (ng == 2) OODGAN_LAUNCH(1, 2, 1) else OODGAN_LAUNCH(1, 1, 1) }
 #undef OODGAN_LAUNCH

@@ -1,5 +1,7 @@
 // Error reporting / version / device probing for the C ABI.
 #include "common.hpp"
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 namespace oodgan {
@@ -12,7 +14,48 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace oodgan
 
-extern "C" int oodgan_version(void) { return 100; }
+// ---- dispatch tunables: read from the environment ONCE (first use), changed afterwards only through oodgan_set_tunable.
+// (Round 2 called getenv() on every conv launch of the hot path.)
+namespace oodgan {
+namespace {
+struct Tunable { const char* name; const char* env; long def; std::atomic<long> val; std::atomic<int> init; };
+Tunable g_tun[OODGAN_TUN_COUNT] = {
+    {"s1_big_min_items", "OODGAN_S1_BIG_MIN_ITEMS", 128, {0}, {0}},
+    {"s2_big_min_items", "OODGAN_S2_BIG_MIN_ITEMS", 128, {0}, {0}},
+    {"t2_big_min_items", "OODGAN_T2_BIG_MIN_ITEMS", 128, {0}, {0}},
+    {"blurt_strip", "OODGAN_BLURT_STRIP", 1, {0}, {0}},
+};
+}  // namespace
+long tunable(int id) {
+    Tunable& t = g_tun[id];
+    if (!t.init.load(std::memory_order_acquire)) {
+        const char* e = getenv(t.env);
+        t.val.store(e ? atol(e) : t.def, std::memory_order_relaxed);
+        t.init.store(1, std::memory_order_release);
+    }
+    return t.val.load(std::memory_order_relaxed);
+}
+}  // namespace oodgan
+
+extern "C" int oodgan_set_tunable(const char* name, long value) {
+    OODGAN_REQUIRE(name != nullptr, "set_tunable: null name");
+    for (int i = 0; i < oodgan::OODGAN_TUN_COUNT; ++i)
+        if (strcmp(name, oodgan::g_tun[i].name) == 0) {
+            oodgan::g_tun[i].val.store(value, std::memory_order_relaxed);
+            oodgan::g_tun[i].init.store(1, std::memory_order_release);
+            return OODGAN_OK;
+        }
+    oodgan::set_error("set_tunable: unknown tunable '%s'", name);
+    return OODGAN_E_ARG;
+}
+extern "C" long oodgan_get_tunable(const char* name) {
+    if (name)
+        for (int i = 0; i < oodgan::OODGAN_TUN_COUNT; ++i)
+            if (strcmp(name, oodgan::g_tun[i].name) == 0) return oodgan::tunable(i);
+    return -1;
+}
+
+extern "C" int oodgan_version(void) { return 101; }
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;

@@ -59,6 +59,8 @@ _SIGS = {
     'oodgan_version': (c_int, []),
     'oodgan_last_error': (c_char_p, []),
     'oodgan_device_count': (c_int, []),
+    'oodgan_set_tunable': (c_int, [c_char_p, c_long]),
+    'oodgan_get_tunable': (c_long, [c_char_p]),
     'oodgan_bias_act_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_int, c_float, c_float, P]),
     'oodgan_bias_act_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, c_float, c_float, P]),
     'oodgan_upfirdn2d': (c_int, [P, P, P] + [c_int] * 15 + [P]),
@@ -158,6 +160,14 @@ def check(rc, what=''):
     if rc != 0:
         msg = lib().oodgan_last_error()
         raise RuntimeError(f'liboodgan_hip {what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def set_tunable(name, value):
+    """Dispatch tunable of the library (include/oodgan.h, oodgan_set_tunable); returns the previous value."""
+    h = lib()
+    old = h.oodgan_get_tunable(name.encode())
+    check(h.oodgan_set_tunable(name.encode(), int(value)), 'set_tunable')
+    return old
 
 
 def exported_symbols():

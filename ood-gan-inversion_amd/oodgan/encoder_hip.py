@@ -108,10 +108,25 @@ class _HipTrunk:
         depth = rl[1].weight.shape[0]
         stride = rl[3].stride[0]
         sc1, sh1, _ = self._bn_rows(f'{idx}.bn1', rl[0], B)
-        r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=sc1, in_shift=sh1,
-                     act=ACT_PRELU, slope=rl[2].weight.detach())
         sc2, _, sh2 = self._bn_rows(f'{idx}.bn2', rl[4], B)
-        r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=sc2, bias=sh2)
+        cin = x.shape[1]
+        if cin >= 64 and depth >= 64:
+            # the stride-1 convs through the S-form (BatchNorm as scale AND shift of the conversion, the border stays zero =
+            # norm followed by zero padding) and the LDS-DMA kernels of the generator: at 32² / 16² the fp32-input kernel is 16-32
+            # workgroups each walking its K chunks one exposed global-load latency at a time (140 us per conv at any batch size)
+            H, W = x.shape[2], x.shape[3]
+            xs = ops.to_sform(x, sc1, shift=sh1, out=ops.sform_scratch(B, cin, H, W, x.device, tag=1))
+            r = ops.conv3x3(xs, self._packed(f'{idx}.w1', rl[1].weight), depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight.detach())
+        else:
+            r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=sc1, in_shift=sh1,
+                         act=ACT_PRELU, slope=rl[2].weight.detach())
+        if stride == 1 and depth >= 64:
+            # un-normalised PReLU(conv) output: measured power-of-two range scale for the f16 pair, undone in the conv (exact)
+            mul2 = ops.absmax_mul2(r)
+            rs = ops.to_sform(r, mul2=mul2, out=ops.sform_scratch(B, depth, r.shape[2], r.shape[3], x.device, tag=2))
+            r = ops.conv3x3(rs, self._packed(f'{idx}.w2', rl[3].weight), depth, CONV_S1, out_scale=sc2, bias=sh2, in_mul2=mul2)
+        else:
+            r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=sc2, bias=sh2)
         if isinstance(u.shortcut_layer, torch.nn.MaxPool2d):
             sc = x if stride == 1 else x[:, :, ::stride, ::stride].contiguous()
         else:

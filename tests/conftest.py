@@ -26,3 +26,18 @@ def golden():
         return {k: torch.from_numpy(z[k]) for k in z.files}
 
     return load
+
+
+@pytest.fixture
+def tunable():
+    """Set a dispatch tunable of liboodgan_hip.so (include/oodgan.h, oodgan_set_tunable) for one test; restored afterwards."""
+    from oodgan import _lib
+    saved = {}
+
+    def set_(name, value):
+        old = _lib.set_tunable(name, value)
+        saved.setdefault(name, old)
+
+    yield set_
+    for name, old in saved.items():
+        _lib.set_tunable(name, old)

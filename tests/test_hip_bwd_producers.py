@@ -135,14 +135,14 @@ def test_violated_scale_falls_back_to_exact_loop():
 
 @pytest.mark.parametrize('B,Co,Ci,H,W,rgb', [(2, 32, 128, 16, 32, True), (1, 48, 64, 9, 40, True), (1, 64, 256, 8, 36, False),
                                              (2, 32, 64, 40, 72, True), (3, 20, 64, 19, 36, True), (1, 16, 64, 8, 32, False)])
-def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, monkeypatch):
+def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, tunable):
     """The stride-2 input-gradient conv whose epilogue continues with the activation backward of the layer below
     (oodgan_actbwd_fuse) == the same conv followed by act_bwd_producer on its fp32 result: S-form gradient, the three
     per-channel sums, and the maxima that drive the carried range scale."""
     import math
     from oodgan import ops
     dev = torch.device('cuda:0')
-    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '0')
+    tunable('s2_big_min_items', 0)
     assert ops.s2_fuse_supported(B, Co, Ci, 2 * H + 1, 2 * W + 1)
     t = lambda n, shp, std=1.0, mean=0.0: synth.normal('fz.' + n, shp, 40 + Ci, std, mean).to(dev)
     out_below = t('out', (B, Ci, H, W))                      # saved activation of the conv layer below (= dotx)
@@ -181,7 +181,7 @@ def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, monkeypatc
 
 
 @pytest.mark.parametrize('B,C,H,W,sep', [(1, 32, 32, 32, True), (2, 16, 40, 64, True), (1, 48, 37, 66, True), (1, 24, 64, 34, False), (1, 16, 33, 128, True)])
-def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, sep, monkeypatch):
+def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, sep, tunable):
     """The strip-walking form of the blur^T producer (up-sampling layers with H, W >= 32 and no ToRGB branch) against the
     two-pass path (act_bwd_fused -> blurT_to_sform_phases) and against the tile kernel; ragged strips / segments, partial
     channel blocks, and a kernel that is not rank-1."""
@@ -198,7 +198,7 @@ def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, s
     ref = ops.blurT_to_sform_phases(g_pre, k, d, mul2)
     res = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('OODGAN_BLURT_STRIP', mode)
+        tunable('blurt_strip', int(mode))
         dst = ops.SFormPhases(B, C, H, W, dev)
         dst.data.fill_(float('nan'))                 # every record of the (H+1) x (W+1) grid must be written
         r1, t1, part_m = ops.act_bwd_producer(out, g_feat, noise, nw, bias, d, mul2.clone(), dst, blur_kernel=k)
@@ -221,7 +221,7 @@ def test_act_bwd_blurT_strip_walk_matches_two_pass_and_tile_kernel(B, C, H, W, s
 
 @pytest.mark.parametrize('B,Co,Ci,H,W', [(1, 64, 64, 64, 64), (2, 128, 64, 72, 96), (1, 32, 32, 64, 128), (2, 24, 20, 80, 64)])
 @pytest.mark.parametrize('deferred', [False, True])
-def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, deferred, monkeypatch):
+def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, deferred, tunable):
     """oodgan_conv_args.dot_actgrad: the stride-1 input-gradient conv above an up-sampling layer returns
     g_pre = dx * act'(out_below) (8-wave kernel for >= 64 channels, strip conv kernel for 17..32); the blur^T producer then
     runs on g_pre alone (out=None) and the layer's r sum is finished from its noise / bias term plus out_scale * dot.
@@ -230,7 +230,7 @@ def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, 
     from oodgan import ops
     from oracle import ref_cpu as R
     dev = torch.device('cuda:0')
-    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '0')
+    tunable('s1_big_min_items', 0)
     assert ops.s1_actgrad_supported(B, Co, Ci, H, W)
     t = lambda n, shp, std=1.0, mean=0.0: synth.normal('pre.' + n, shp, 60 + Ci + Co, std, mean).to(dev)
     out_below = t('out', (B, Ci, H, W))                      # output of the up-sampling layer below (= dotx)
@@ -264,7 +264,7 @@ def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, 
     tol = 1e-5 * max(1e-30, r0.abs().max().item())
     assert (r1 - r0).abs().max().item() <= tol and (r1 - r0p).abs().max().item() <= tol
     # the tile kernel has no such form: loud error, no silent fallback
-    monkeypatch.setenv('OODGAN_BLURT_STRIP', '0')
+    tunable('blurt_strip', int('0'))
     assert not ops.s1_actgrad_supported(B, Co, Ci, H, W)
     with pytest.raises(RuntimeError):
         ops.act_bwd_producer(None, g_pre1, noise, nw, bias, d_below, state.clone(), dst, blur_kernel=k, dot_of=link)

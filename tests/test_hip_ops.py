@@ -360,12 +360,12 @@ def test_conv3x3_strip_kernel_low_channel_layers(dev, B, Ci, Co, H, W):
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 128, 128, 32, 64), (1, 144, 192, 40, 33), (2, 256, 64, 17, 32)])
-def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
+def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, tunable):
     """>= 128 -> >= 64 channel stride-1 convs with enough tiles take the 16x32-tile two-stage kernel
     (conv_f16s_big.hip); the item threshold is lowered so that small tensors reach it."""
     import torch.nn.functional as F
     from oodgan import ops
-    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1')
+    tunable('s1_big_min_items', 1)
     x = synth.normal('bg.x', (B, Ci, H, W), 1)
     w = synth.normal('bg.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
     s = synth.normal('bg.s', (B, Ci), 3, 0.3, 1.0)
@@ -392,7 +392,7 @@ def test_conv3x3_big_tile_kernel(dev, B, Ci, Co, H, W, monkeypatch):
     y4 = ops.conv3x3(xa, wpk, Co, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev))
     ref4 = F.conv2d(x * s[:, :, None, None] + sh[:, :, None, None], w, padding=1)
     close(y4, torch.where(ref4 > 0, ref4, ref4 * slope.view(1, -1, 1, 1)))
-    monkeypatch.setenv('OODGAN_S1_BIG_MIN_ITEMS', '1000000000')         # same calls through the tile kernel
+    tunable('s1_big_min_items', 1000000000)         # same calls through the tile kernel
     y3, dot3 = ops.conv3x3(xs2, wpk, Co, ops.CONV_S1, out_scale=d.to(dev), dotx=dotx.to(dev), in_mul2=mul2)
     assert (y3 - y2).abs().max().item() <= 1e-5 * y2.abs().max().item()
     y5 = ops.conv3x3(xa, wpk, Co, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev))
@@ -473,14 +473,14 @@ def test_upfirdn2d_down2_4x4_kernel_vs_oracle(dev):
 
 
 @pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 64, 128, 16, 32), (1, 48, 256, 9, 40), (2, 32, 64, 24, 33), (1, 80, 192, 8, 64)])
-def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, monkeypatch):
+def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, tunable):
     """Stride-2 conv (input gradient of the up-sampling conv: K = Co channels of the gradient, M = Ci) on the phase-split
     S-form through conv_f16s_s2big.hip — both instances (128 / 64 channels per workgroup), ragged tiles, with the
     style-gradient dot and a power-of-two input range scale — against autograd of conv_transpose2d and against the
     two-group tile kernel it replaces."""
     import torch.nn.functional as F
     from oodgan import ops
-    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '0')
+    tunable('s2_big_min_items', 0)
     x = synth.normal('s2b.x', (B, Ci, H, W), 1)
     w = synth.normal('s2b.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
     s = synth.normal('s2b.s', (B, Ci), 3, 0.3, 1.0)
@@ -498,20 +498,20 @@ def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, monkeypatch):
     assert torch.equal(dx1, dx)
     dx2, dot2 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
     assert torch.equal(dx2, dx) and torch.equal(dot2, dot)                                      # deterministic
-    monkeypatch.setenv('OODGAN_S2_BIG_MIN_ITEMS', '1000000000')                                 # the tile kernel
+    tunable('s2_big_min_items', 1000000000)                                 # the tile kernel
     dx3, dot3 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s.to(dev), dotx=x.to(dev), in_mul2=mul2)
     assert (dx3 - dx).abs().max().item() <= 1e-5 * dx.abs().max().item()
     assert (dot3 - dot).abs().max().item() <= 1e-4 * dot.abs().max().item()
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 48, 128, 9, 40), (2, 32, 96, 23, 31), (1, 80, 64, 8, 64)])
-def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, monkeypatch):
+def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, tunable):
     """Transposed stride-2 conv (the up-sampling ModulatedConv2d before its blur) from an S-form input through
     conv_f16s_t2big.hip — ragged position grids, partial channel blocks — against conv_transpose2d and against the
     4-wave kernel it replaces."""
     import torch.nn.functional as F
     from oodgan import ops
-    monkeypatch.setenv('OODGAN_T2_BIG_MIN_ITEMS', '0')
+    tunable('t2_big_min_items', 0)
     x = synth.normal('t2b.x', (B, Ci, H, W), 1)
     w = synth.normal('t2b.w', (Co, Ci, 3, 3), 2, 1.0 / math.sqrt(Ci * 9))
     s = synth.normal('t2b.s', (B, Ci), 3, 0.3, 1.0)
@@ -523,6 +523,6 @@ def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, monkeypatch):
     close(z[..., :2 * W + 1], ref, 2e-4)
     z2 = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
     assert torch.equal(z2[..., :2 * W + 1], z[..., :2 * W + 1])
-    monkeypatch.setenv('OODGAN_T2_BIG_MIN_ITEMS', '1000000000')
+    tunable('t2_big_min_items', 1000000000)
     z3 = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
     assert (z3[..., :2 * W + 1] - z[..., :2 * W + 1]).abs().max().item() <= 1e-5 * ref.abs().max().item()
