@@ -68,7 +68,16 @@ def _conv3x3(x, pk, M, stride=1, **kw):
         return ops.conv3x3(x, pk, M, CONV_S1, **kw)
     assert stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
     xp, pitch = _pad_tl(x)
-    return ops.conv3x3(xp, pk, M, CONV_S2, in_hw=(x.shape[2] + 1, x.shape[3] + 1), in_pitch=pitch, **kw)
+    B, K, H, W = x.shape
+    if kw.get('groups', 1) == 1 and 'in_scale' not in kw and ops.s2_fuse_supported(B, K, M, H + 1, W + 1):
+        # enough work for the 8-wave stride-2 kernel (the stacked first convs of the style heads: 512 -> 11 x 512 channels at
+        # 64² -> 32²): phase-split S-form of the padded input with a measured power-of-two range scale, bias + slope in the
+        # kernel's epilogue.  The fp32-input kernel ran this conv at 105 TFLOP/s (4.0 ms at batch 8).
+        mul2 = ops.absmax_mul2(x)
+        gp = ops.to_sform_phases(xp, H // 2, W // 2, mul2=mul2, in_pitch=pitch,
+                                 out=ops.sform_phases_scratch(B, K, H // 2, W // 2, x.device))
+        return ops.conv3x3(gp, pk, M, CONV_S2, in_mul2=mul2, **kw)
+    return ops.conv3x3(xp, pk, M, CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, **kw)
 
 
 class _HipTrunk:

@@ -504,6 +504,32 @@ def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, tunable):
     assert (dot3 - dot).abs().max().item() <= 1e-4 * dot.abs().max().item()
 
 
+@pytest.mark.parametrize('B,K,M,H,W,act', [(2, 64, 128, 16, 32, 'prelu'), (1, 48, 192, 10, 40, 'lrelu'), (2, 32, 64, 24, 34, 'none')])
+def test_conv3x3_s2_big_kernel_forward_use(dev, B, K, M, H, W, act, tunable):
+    """The 8-wave stride-2 kernel as a FORWARD conv (nn.Conv2d(K, M, 3, stride 2, padding 1) of the e4e encoder's
+    GradualStyleBlocks, psp_encoders.py:14-34): input padded by one zero row / column on the top / left, phase-split S-form
+    with a power-of-two range scale, bias + PReLU / leaky-ReLU*sqrt2 in the epilogue; both channel-block instances."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    tunable('s2_big_min_items', 0)
+    x = synth.normal('s2f.x', (B, K, H, W), 1, 30.0)
+    w = synth.normal('s2f.w', (M, K, 3, 3), 2, 1.0 / math.sqrt(K * 9))
+    bias = synth.normal('s2f.b', (M,), 3)
+    slope = synth.normal('s2f.sl', (M,), 4, 0.05, 0.1)
+    ref = F.conv2d(x, w, bias, stride=2, padding=1)
+    ref = {'prelu': F.prelu(ref, slope), 'lrelu': F.leaky_relu(ref, 0.2) * math.sqrt(2.0), 'none': ref}[act]
+    pitch = (W + 1 + 3) // 4 * 4
+    xp = torch.zeros(B, K, H + 1, pitch)
+    xp[:, :, 1:, 1:W + 1] = x
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    mul2 = ops.absmax_mul2(x.to(dev))
+    assert 512.0 <= x.abs().max().item() * mul2[1].item() < 1024.0
+    gp = ops.to_sform_phases(xp.to(dev), H // 2, W // 2, mul2=mul2, in_pitch=pitch)
+    kw = {'prelu': dict(act=ops.ACT_PRELU, slope=slope.to(dev)), 'lrelu': dict(act=ops.ACT_LRELU), 'none': {}}[act]
+    y = ops.conv3x3(gp, wpk, M, ops.CONV_S2, bias=bias.to(dev), in_mul2=mul2, **kw)
+    close(y, ref, 2e-5)
+
+
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 48, 128, 9, 40), (2, 32, 96, 23, 31), (1, 80, 64, 8, 64)])
 def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, tunable):
     """Transposed stride-2 conv (the up-sampling ModulatedConv2d before its blur) from an S-form input through
