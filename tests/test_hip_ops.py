@@ -504,6 +504,28 @@ def test_conv3x3_s2_big_kernel(dev, B, Co, Ci, H, W, tunable):
     assert (dot3 - dot).abs().max().item() <= 1e-4 * dot.abs().max().item()
 
 
+@pytest.mark.parametrize('B,G,K,Mg,H,W', [(2, 3, 64, 64, 8, 8), (1, 5, 48, 128, 4, 6), (3, 2, 32, 64, 2, 2)])
+def test_conv3x3_s2_grouped(dev, B, G, K, Mg, H, W):
+    """oodgan_conv_args.groups: nn.Conv2d(G*K, G*Mg, 3, stride 2, padding 1, groups=G) — the style heads of the e4e encoder
+    advancing side by side (psp_encoders.py:14-34) — with bias and per-channel slopes, down to 1x1 outputs."""
+    import torch.nn.functional as F
+    from oodgan import ops
+    x = synth.normal('gr.x', (B, G * K, H, W), 1)
+    w = synth.normal('gr.w', (G * Mg, K, 3, 3), 2, 1.0 / math.sqrt(K * 9))
+    bias = synth.normal('gr.b', (G * Mg,), 3)
+    slope = torch.full((G * Mg,), 0.01)
+    ref = F.leaky_relu(F.conv2d(x, w, bias, stride=2, padding=1, groups=G), 0.01)
+    pitch = (W + 1 + 3) // 4 * 4
+    xp = torch.zeros(B, G * K, H + 1, pitch)
+    xp[:, :, 1:, 1:W + 1] = x
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    y = ops.conv3x3(xp.to(dev), wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, bias=bias.to(dev), act=ops.ACT_PRELU,
+                    slope=slope.to(dev), groups=G)
+    close(y, ref, 2e-5)
+    with pytest.raises(RuntimeError):           # Mg must be a multiple of 64: a channel block may not straddle two groups
+        ops.conv3x3(xp.to(dev), wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, groups=G * 4)
+
+
 @pytest.mark.parametrize('B,K,M,H,W,act', [(2, 64, 128, 16, 32, 'prelu'), (1, 48, 192, 10, 40, 'lrelu'), (2, 32, 64, 24, 34, 'none')])
 def test_conv3x3_s2_big_kernel_forward_use(dev, B, K, M, H, W, act, tunable):
     """The 8-wave stride-2 kernel as a FORWARD conv (nn.Conv2d(K, M, 3, stride 2, padding 1) of the e4e encoder's
