@@ -168,6 +168,10 @@ typedef struct oodgan_conv_args {
                                 packed weights hold G*Mg output channels (M = G*Mg, Mg %% 64 == 0) of K inputs each, and output
                                 channel m convolves input channels [g*K, (g+1)*K) with g = m / Mg; in_scale / in_shift are then
                                 (B, G*K).  0 / 1 = dense.  Supported by oodgan_conv3x3_f16s for fp32 NCHW input in mode S2. */
+    int y_fform;             /* 1: y is written in F-form — [B][ceil(M/16)][Hout][Wout][16] fp32, one 64-byte record per pixel and
+                                16-channel block — instead of NCHW.  Only the split-f16 strip kernel (mode S1, 16 < K,M <= 32, no
+                                dotx): the LAST styled conv of the generator in the W+ loop, whose output is read back by nothing
+                                but its own activation backward (oodgan_act_bwd_sform_f), a pure 16-byte-per-lane stream then. */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -282,6 +286,14 @@ int oodgan_act_bwd_sform(const float* g_feat, const float* out, const float* noi
                          const float* bias, const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride,
                          float rgb_scale, const float* dscale, int dscale_stride, const float* mul2, void* ys, float* part_r,
                          float* part_t, float* part_max, int B, int C, int H, int W, void* stream);
+/* oodgan_act_bwd_sform with `out` in F-form (oodgan_conv_args.y_fform) and no g_feat: the activation backward of the LAST styled
+ * conv (its only gradient is the ToRGB branch).  Same arithmetic per element, same nparts; loads and stores are 16 bytes per lane
+ * on contiguous runs, no LDS transpose.  oodgan_from_fform converts an F-form tensor back to NCHW. */
+int oodgan_act_bwd_sform_f(const float* out_f, const float* noise, int noise_batch, const float* noise_w, const float* bias,
+                           const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale,
+                           const float* dscale, int dscale_stride, const float* mul2, void* ys, float* part_r, float* part_t,
+                           float* part_max, int B, int C, int H, int W, void* stream);
+int oodgan_from_fform(const float* f, float* y, int B, int C, int H, int W, void* stream);
 /* same, followed by blur^T (adjoint of Blur(pad=(1,1)), src/ops/op/upfirdn2d.py:115-120) and the phase split of
  * oodgan_blurT_to_sform_phases; H,W = size of the up-conv's INPUT, the tensors are (B,C,2H,2W). */
 int oodgan_act_bwd_blurT_nparts(int H, int W);

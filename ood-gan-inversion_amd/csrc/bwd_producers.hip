@@ -168,6 +168,106 @@ __global__ __launch_bounds__(256) void act_bwd_sform_kernel(const ActArgs a, uin
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same producer for an F-form `out` ([B][KC][H*W][16] fp32: oodgan_conv_args.y_fform, written by the strip kernel) and no
+// g_feat: the last styled conv.  thread = (pixel, channel quarter): one float4 of `out`, four results, and after one DPP
+// exchange with the neighbouring quarter ONE 16-byte slot of the pixel's S-form record — the four lanes of a pixel write its
+// 64 bytes in one store instruction, a wave 1 KB contiguous.  No LDS transpose: the NCHW form reads 16 planes and turns them
+// through LDS (540 us at 1024² B=8, 4.0 TB/s, 71 % of the wave time waiting).
+__global__ __launch_bounds__(256) void act_bwd_sform_f_kernel(const ActArgs a, uint4* __restrict__ ys, const SDims yd) {
+    __shared__ float cst[7][16];
+    __shared__ float redr[4][16], redt[4][16], redm[4];
+    const int KC = yd.KC;
+    const int bk = blockIdx.y, b = bk / KC, kc = bk % KC;
+    const int tid = threadIdx.x, q = tid & 3, pl = tid >> 2;
+    const long HW = (long)a.H * a.W;
+    load_consts(a, b, kc, cst);
+    __syncthreads();
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
+    const float* gr = a.g_rgb ? a.g_rgb + (long)b * 3 * HW : nullptr;
+    const float* of = a.out + ((long)b * KC + kc) * HW * 16 + 4 * q;
+    float w0[4], w1[4], w2[4], sr[4], bv[4], ds[4], da[4], acc_r[4], acc_t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w0[j] = cst[0][4 * q + j]; w1[j] = cst[1][4 * q + j]; w2[j] = cst[2][4 * q + j]; sr[j] = cst[3][4 * q + j];
+        bv[j] = cst[4][4 * q + j]; ds[j] = cst[5][4 * q + j]; da[j] = cst[6][4 * q + j];
+        acc_r[j] = acc_t[j] = 0.f;
+    }
+    const long p0 = (long)blockIdx.x * kP1Chunk;
+    float amax = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < kP1Chunk / 64; ++k) {
+        const long p = p0 + pl + 64 * k;
+        const bool ok = p < HW;
+        const long pc = ok ? p : HW - 1;
+        const float4 o4 = *reinterpret_cast<const float4*>(of + pc * 16);
+        const float r0 = gr ? gr[pc] : 0.f, r1 = gr ? gr[HW + pc] : 0.f, r2 = gr ? gr[2 * HW + pc] : 0.f;
+        const float nz = np ? nw * np[pc] : 0.f;
+        const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float o = ov[j];
+            const float t = w0[j] * r0 + w1[j] * r1 + w2[j] * r2;
+            const float g = sr[j] * t;
+            const float gp = ok ? g * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2) : 0.f;
+            const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nz - bv[j];
+            acc_r[j] += gp * ycv;
+            acc_t[j] += ok ? o * t : 0.f;
+            amax = fmaxf(amax, fabsf(gp) * da[j]);
+            v[j] = gp * ds[j];
+        }
+        unsigned h01, l01, h23, l23;
+        split_pair(v[0], v[1], h01, l01);
+        split_pair(v[2], v[3], h23, l23);
+        // quarters (0,1) and (2,3) exchange: the even one collects the hi halves of the 8 channels, the odd one the lo halves
+        const bool even = (q & 1) == 0;
+        const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+        const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        const uint4 slot = even ? make_uint4(h01, h23, g0, g1) : make_uint4(g0, g1, l01, l23);
+        if (ok) {
+            const int y = (int)(p / a.W), x = (int)(p % a.W);
+            ys[sform_unit(yd, b, kc, y, x, 0) + (even ? (q >> 1) : 2 + (q >> 1))] = slot;
+        }
+    }
+    // per-channel sums: lanes with the same quarter (lane bits 2-5), then the four waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+            acc_r[j] += __shfl_xor(acc_r[j], o, 64);
+            acc_t[j] += __shfl_xor(acc_t[j], o, 64);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { redr[wv][4 * lane + j] = acc_r[j]; redt[wv][4 * lane + j] = acc_t[j]; }
+    }
+    if (lane == 0) redm[wv] = amax;
+    __syncthreads();
+    if (tid < 16 && kc * 16 + tid < a.C) {
+        const long o = ((long)b * a.C + kc * 16 + tid) * a.nparts + blockIdx.x;
+        a.part_r[o] = (redr[0][tid] + redr[1][tid]) + (redr[2][tid] + redr[3][tid]);
+        if (a.part_t) a.part_t[o] = (redt[0][tid] + redt[1][tid]) + (redt[2][tid] + redt[3][tid]);
+    }
+    if (tid == 0) a.part_max[(long)bk * a.nparts + blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+}
+
+__global__ __launch_bounds__(256) void from_fform_kernel(const float* __restrict__ f, float* __restrict__ y, int C, long HW, long total) {
+    // element e of y (B,C,H,W); F-form [B][KC][HW][16]
+    const int KC = (C + 15) / 16;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long p = e % HW;
+        const int c = (int)((e / HW) % C);
+        const long b = e / (HW * C);
+        y[e] = f[((b * KC + (c >> 4)) * HW + p) * 16 + (c & 15)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Fused act-backward + blur^T + phase split (see blurT_sp_kernel in conv_f16s_v2.hip for the tiling): block = one
 // (b, 16-channel block) x a tile of 4x32 (i,j) positions = g2 rows 2*i0..2*i0+7, cols 2*j0..2*j0+63.  H,W = size of
 // the up-conv's INPUT; all tensors of ActArgs are at (2H)x(2W).
@@ -778,6 +878,31 @@ extern "C" int oodgan_act_bwd_sform(const float* g_feat, const float* out, const
     hipLaunchKernelGGL(act_bwd_sform_kernel, dim3(a.nparts, B * yd.KC), dim3(256), 0, as_stream(stream), a,
                        reinterpret_cast<uint4*>(ys), yd);
     return check_launch("act_bwd_sform");
+}
+
+extern "C" int oodgan_act_bwd_sform_f(const float* out_f, const float* noise, int noise_batch, const float* noise_w, const float* bias,
+                                      const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale,
+                                      const float* dscale, int dscale_stride, const float* mul2, void* ys, float* part_r, float* part_t,
+                                      float* part_max, int B, int C, int H, int W, void* stream) {
+    ActArgs a;
+    int rc = fill_args(a, nullptr, out_f, noise, noise_batch, noise_w, bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, dscale,
+                       dscale_stride, mul2, part_r, part_t, part_max, B, C, H, W);
+    if (rc != OODGAN_OK) return rc;
+    OODGAN_REQUIRE(ys != nullptr && (C % 16) == 0 && (reinterpret_cast<uintptr_t>(out_f) & 15) == 0,
+                   "act_bwd_sform_f: needs ys, C %% 16 == 0 and a 16-byte aligned F-form input");
+    const SDims yd = sform_dims(C, H, W);
+    a.nparts = oodgan_act_bwd_sform_nparts(H, W);
+    OODGAN_REQUIRE((long)B * yd.KC <= 65535, "act_bwd_sform_f: B*C too large");
+    hipLaunchKernelGGL(act_bwd_sform_f_kernel, dim3(a.nparts, B * yd.KC), dim3(256), 0, as_stream(stream), a,
+                       reinterpret_cast<uint4*>(ys), yd);
+    return check_launch("act_bwd_sform_f");
+}
+
+extern "C" int oodgan_from_fform(const float* f, float* y, int B, int C, int H, int W, void* stream) {
+    OODGAN_REQUIRE(f && y && B > 0 && C > 0 && (C % 16) == 0 && H > 0 && W > 0, "from_fform: bad args");
+    const long HW = (long)H * W, total = (long)B * C * HW;
+    hipLaunchKernelGGL(from_fform_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), f, y, C, HW, total);
+    return check_launch("from_fform");
 }
 
 static bool blurT_strip_enabled() { return oodgan::tunable(oodgan::OODGAN_TUN_BLURT_STRIP) != 0; }      // tests set 0 to compare with the tile kernel

@@ -446,6 +446,8 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
     OODGAN_REQUIRE(a.groups <= 1 || (a.mode == OODGAN_CONV_S2 && !a.x_sform), "conv3x3_f16s: groups > 1 only for mode S2 with fp32 NCHW input");
+    OODGAN_REQUIRE(!a.y_fform || (a.mode == OODGAN_CONV_S1 && a.x_sform && s1_strip_eligible(a)),
+                   "conv3x3_f16s: the F-form output exists only in the strip kernel (mode S1, S-form input, 16 < K,M <= 32)");
     OODGAN_REQUIRE(!a.dot_actgrad || (a.mode == OODGAN_CONV_S1 && a.x_sform && a.dotx && (s1_strip_eligible(a) || s1_big_eligible(a))),
                    "conv3x3_f16s: dot_actgrad exists only in the strip / 8-wave kernels of mode S1 (oodgan_conv3x3_s1_actgrad_supported)");
     hipStream_t st = as_stream(stream);

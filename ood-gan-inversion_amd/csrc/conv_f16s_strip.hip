@@ -313,7 +313,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     rp[2L * H * W] = c2s;
                 }
             }
-            if (ok) {
+            if (ok && a.y_fform) {
+                // F-form (oodgan_conv_args.y_fform): the lane's 16 channels are four float4 of the pixel's two 64-byte records
+                // (channels 8i + 4*half .. + 3): 4 stores of 16 bytes instead of 16 of 4
+                float* yf = a.y + ((((long)b * 2) * H + py) * W + px) * 16 + 4 * half;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    *reinterpret_cast<float4*>(yf + (long)(rr >> 1) * H * W * 16 + (rr & 1) * 8) =
+                        make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
+            } else if (ok) {
                 unsigned char* yr = ybt + (long)nt * a.out_pitch * 4;
                 if (mfull) {
 #pragma unroll
@@ -376,6 +384,8 @@ int launch_s1_strip(const oodgan_conv_args& a_in, const void* wpk16, const float
         OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 f16s S1: dot_nparts %d != %d", a.dot_nparts,
                        p.tiles_x * p.tiles_y);
     }
+    OODGAN_REQUIRE(!a.y_fform || (!a.dotx && a.M == 32 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0),
+                   "conv3x3 strip: F-form output needs M == 32, no dotx and a 16-byte aligned y");
     static int num_cu = 0;
     if (!num_cu) {
         int dev = 0;

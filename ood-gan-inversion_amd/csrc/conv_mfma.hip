@@ -270,6 +270,7 @@ extern "C" int oodgan_conv3x3(const oodgan_conv_args* args, void* stream) {
     OODGAN_REQUIRE(a.fuse == nullptr, "conv3x3: the fused activation backward exists only in the split-f16 stride-2 kernel");
     OODGAN_REQUIRE(!a.dot_actgrad, "conv3x3: dot_actgrad exists only in the split-f16 stride-1 kernels");
     OODGAN_REQUIRE(a.groups <= 1, "conv3x3: grouped convolution exists only in the split-f16 stride-2 kernel");
+    OODGAN_REQUIRE(!a.y_fform, "conv3x3: the F-form output exists only in the split-f16 strip kernel");
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3: bad shape B=%d K=%d M=%d H=%d W=%d",
                    a.B, a.K, a.M, a.Hin, a.Win);
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3: PReLU without slopes");

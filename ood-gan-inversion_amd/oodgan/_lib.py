@@ -25,7 +25,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int),
     ]
 
 
@@ -95,6 +95,8 @@ _SIGS = {
     'oodgan_fwd_range_plan': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_sform_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_act_bwd_sform_f': (c_int, [P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_from_fform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_blurT_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_pre_supported': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

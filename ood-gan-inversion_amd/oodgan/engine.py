@@ -82,6 +82,7 @@ class GeneratorEngine:
         self.fused_bwd = True
         self.bwd_state, self.bwd_flag = {}, None
         styled = [L for L in layers if L.kind != 'rgb']
+        self.layers_styled_last = styled[-1]
         self.fused_fwd = True
         self.next_conv = {a.name: b for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b.kind == 'conv'}
         # ToRGB layer -> the up-sampling conv that reads the same feature map next (its S-form input is written by ToRGB)
@@ -262,9 +263,15 @@ class GeneratorEngine:
                         xs = to_s(L, out)
                     Lr = self.conv_next_rgb.get(L.name) if self.fused_rgb else None
                     if Lr is not None and 16 < L.cin <= 32 and 16 < L.cout <= 32:
-                        # 32-channel 1024² layer (strip kernel): the ToRGB colour sums come out of the same epilogue
+                        # 32-channel 1024² layer (strip kernel): the ToRGB colour sums come out of the same epilogue.
+                        # Inside the W+ loop the activation of the LAST styled conv is read back by nothing but its own activation
+                        # backward: once that runs as the fused producer (a carried scale exists) it is kept in F-form — both
+                        # sides then move 16 bytes per lane on contiguous runs
+                        ff = (save and carry and self.fused_bwd and L is self.layers_styled_last and L.cout == 32
+                              and self.bwd_state.get(L.name) is not None and not return_features)
                         out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
-                                                       noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)))
+                                                       noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)),
+                                                       y_fform=ff)
                     else:
                         out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                           noise_weight=L.noise_w, act=ACT_LRELU)
@@ -353,6 +360,8 @@ class GeneratorEngine:
                 prev_rgb = L
                 continue
             out, x_in, nz = acts[L.name], acts[L.src], noises[L.noise_idx]
+            if isinstance(out, ops.FForm) and not (carry_scale and self.fused_bwd and self.bwd_state.get(L.name) is not None and g_feat is None):
+                out = out.to_nchw()         # the two-pass path reads NCHW
             s = _Cols(s_all, L.row, L.cin)
             d = _Cols(d_all, L.drow, L.cout)
             Hd = x_in.shape[2]

@@ -244,6 +244,29 @@ class SForm:
         return (self.B, self.C, self.H, self.W)
 
 
+class FForm:
+    """fp32 activations in F-form (include/oodgan.h, oodgan_conv_args.y_fform): [B][C/16][H][W][16] — one 64-byte record per pixel
+    and 16-channel block — in the storage of a (B,C,H,W) tensor.  Private hand-off between the strip conv of the last styled
+    layer and its activation backward inside the W+ loop."""
+    __slots__ = ('data', 'B', 'C', 'H', 'W')
+
+    def __init__(self, data):
+        self.data = data
+        self.B, self.C, self.H, self.W = data.shape
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    @property
+    def shape(self):
+        return (self.B, self.C, self.H, self.W)
+
+    def to_nchw(self):
+        y = torch.empty(self.B, self.C, self.H, self.W, device=self.data.device, dtype=torch.float32)
+        check(_lib.lib().oodgan_from_fform(_p(self.data), _p(y), self.B, self.C, self.H, self.W, _stream()), 'from_fform')
+        return y
+
+
 class SFormPhases:
     """Phase-split S-form of a (B, C, 2H+1, 2W+1) tensor (input of the stride-2 conv); H, W = conv output size."""
     __slots__ = ('data', 'B', 'C', 'H', 'W')
@@ -469,7 +492,12 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
     out_scale * dot of that conv (include/oodgan.h)."""
     pre = out is None
     assert not pre or (dot_of is not None and dot_of.dot_part is not None)
-    o = _dev(g_feat, 'g_feat') if pre else _dev(out, 'out')
+    fform = isinstance(out, FForm)
+    if fform:
+        assert g_feat is None and blur_kernel is None, 'F-form: the last styled conv only (no conv gradient, no blur)'
+        o = out.data
+    else:
+        o = _dev(g_feat, 'g_feat') if pre else _dev(out, 'out')
     B, C, H, W = o.shape
     L = _lib.lib()
     up = blur_kernel is not None
@@ -483,7 +511,9 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
               _p(_opt(bias, 'bias')), _p(_opt(g_rgb, 'g_rgb')), _p(None if w_rgb is None else _dev(w_rgb).reshape(3, C)),
               _p(_opt(s_rgb, 's_rgb')), 0 if s_rgb is None else s_rgb.shape[1], 1.0 / math.sqrt(C), _p(_dev(dscale, 'dscale')),
               dscale.shape[1], _p(mul2)]
-    if up:
+    if fform:
+        check(L.oodgan_act_bwd_sform_f(*common[1:], _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()), 'act_bwd_sform_f')
+    elif up:
         check(L.oodgan_act_bwd_blurT_sform_phases(*common, _p(_dev(blur_kernel)), _p(dst), _p(part_r), _p(part_t), _p(part_m),
                                                   B, C, H // 2, W // 2, _stream()), 'act_bwd_blurT_sform_phases')
     else:
@@ -613,7 +643,7 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
             in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,
-            groups=1):
+            groups=1, y_fform=False):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
@@ -647,6 +677,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.in_mul2 = _p(in_mul2)
     a.x_sform = 1 if sform_in else 0
     a.groups = int(groups)
+    a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
     rgb_y = None
     if rgb is not None:         # (w_rgb (3,M), s_rgb Cols/(B,M)): also emit the ToRGB colour sums of the activated output
@@ -687,6 +718,8 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         dot = torch.empty(B, M, device=dx_.device, dtype=torch.float32)
         check(_lib.lib().oodgan_reduce_parts(_p(part), _p(dot), B * M, a.dot_nparts, 0, _stream()), 'reduce_parts')
         return out, dot
+    if y_fform:
+        out = FForm(out)
     if rgb is not None:
         return out, rgb_y
     return out

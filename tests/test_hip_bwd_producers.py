@@ -268,3 +268,40 @@ def test_s1_conv_with_act_gradient_of_dotx_then_blurT_producer(B, Co, Ci, H, W, 
     assert not ops.s1_actgrad_supported(B, Co, Ci, H, W)
     with pytest.raises(RuntimeError):
         ops.act_bwd_producer(None, g_pre1, noise, nw, bias, d_below, state.clone(), dst, blur_kernel=k, dot_of=link)
+
+
+def test_fform_hand_off_of_the_last_styled_conv():
+    """F-form (oodgan_conv_args.y_fform): the strip conv writes the same values as its NCHW form (bit for bit, through
+    oodgan_from_fform), and oodgan_act_bwd_sform_f on it reproduces oodgan_act_bwd_sform on the NCHW tensor: S-form values and
+    maxima to an fp32 ulp (same formula per element), the per-channel sums to rounding (different summation order)."""
+    import math
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    B, C, H, W = 2, 32, 48, 64
+    x = synth.normal('ff.x', (B, C, H, W), 1)
+    w = synth.normal('ff.w', (C, C, 3, 3), 2, 1.0 / math.sqrt(C * 9))
+    s = synth.normal('ff.s', (B, C), 3, 0.3, 1.0).to(dev)
+    d = synth.normal('ff.d', (B, C), 4, 0.3, 1.0).to(dev)
+    nz = synth.normal('ff.nz', (B, 1, H, W), 5).to(dev)
+    nw = torch.tensor([0.37], device=dev)
+    bias = synth.normal('ff.b', (C,), 6).to(dev)
+    wrgb = synth.normal('ff.wr', (3, C), 7).to(dev)
+    srgb = synth.normal('ff.sr', (B, C), 8, 0.3, 1.0).to(dev)
+    xs = ops.to_sform(x.to(dev), s)
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    kw = dict(out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, rgb=(wrgb, srgb))
+    y, rgb = ops.conv3x3(xs, wpk, C, ops.CONV_S1, **kw)
+    yf, rgbf = ops.conv3x3(xs, wpk, C, ops.CONV_S1, y_fform=True, **kw)
+    assert isinstance(yf, ops.FForm) and torch.equal(yf.to_nchw(), y) and torch.equal(rgbf, rgb)
+    grgb = (1e-3 * synth.normal('ff.g', (B, 3, H, W), 9)).to(dev)
+    mul2 = torch.tensor([2.0 ** -9, 2.0 ** 9], device=dev)
+    dst_a, dst_b = ops.SForm(B, C, H, W, dev), ops.SForm(B, C, H, W, dev)
+    ra, ta, ma = ops.act_bwd_producer(y, None, nz, nw, bias, d, mul2, dst_a, g_rgb=grgb, w_rgb=wrgb, s_rgb=srgb)
+    rb, tb, mb = ops.act_bwd_producer(yf, None, nz, nw, bias, d, mul2, dst_b, g_rgb=grgb, w_rgb=wrgb, s_rgb=srgb)
+    # same formula per element; the two kernels' FMA contraction differs: values (hi + lo) agree to an fp32 ulp
+    rec = lambda t: (lambda r: torch.cat([r[:, 0] + r[:, 2], r[:, 1] + r[:, 3]], 1))(t.data.float().reshape(-1, 4, 8))
+    va, vb = rec(dst_a), rec(dst_b)
+    assert torch.equal(va != 0, vb != 0) and (va - vb).abs().max().item() <= 3e-7 * va.abs().max().item()
+    assert abs(ma.max().item() - mb.max().item()) <= 3e-7 * ma.max().item()
+    assert (ra - rb).abs().max().item() <= 1e-5 * ra.abs().max().item()
+    assert (ta - tb).abs().max().item() <= 1e-5 * ta.abs().max().item()
