@@ -113,8 +113,8 @@ def pmc_traffic(a):
 def modconv_roofline(iters=30, warmup=3):
     """BASELINE.json's second metric ("modulated-conv2d GB/s", configs[4]): ModulatedConv2d.forward (model.py:233-274) of the
     1024² layer in fp16 — x (16,32,1024,1024) f16, 32 -> 32 channels, + noise + bias + leaky ReLU.  ONE timed iteration =
-    the whole op as the reference defines it: style affine (EqualLinear 512 -> 32 on the latent, MFMA contraction),
-    weight modulation + demodulation + f16 packing, and the 3x3 conv kernel; algorithmic bytes per SURVEY.md §8(d)
+    the whole op as the reference defines it: style affine (EqualLinear 512 -> 32 on the latent) + weight modulation +
+    demodulation + f16 packing (one launch since round 3), and the 3x3 conv kernel; algorithmic bytes per SURVEY.md §8(d)
     (2.147 GB, the affine's and the weights' bytes included) over the HIP-event time of that sequence, against the 8 TB/s
     HBM peak.  The activations live in the f16 channel-blocked layout of csrc/conv_f16.hip (H-form: what an fp16 pipeline
     of this layer would keep between layers); `kernel_ms` is the conv kernel alone.  Runs after the timed region."""
@@ -143,9 +143,13 @@ def modconv_roofline(iters=30, warmup=3):
     nw = torch.tensor([0.1], device=dev)
     out = ops.HForm(B, C, H, H, dev)
 
+    wbuf = [None]
+
     def op():
-        s = ops.style_affine(lat, mod_w, mod_b)                      # EqualLinear(512, Ci, bias_init=1)  model.py:223,236
-        packed = ops.modconv_f16_pack(wgt, s, act='lrelu')           # scale*W*s, demodulate            model.py:237-241
+        # EqualLinear(512, Ci, bias_init=1) (model.py:223,236) + scale*W*s + demodulate (model.py:237-241): ONE launch
+        # (oodgan_modconv_f16_pack_affine), into a reused weight buffer
+        packed = ops.modconv_f16_pack(wgt, None, act='lrelu', latent=lat, mod_weight=mod_w, mod_bias=mod_b, out=wbuf[0])
+        wbuf[0] = packed[0]
         ops.modconv_f16(xh, packed, noise, nw, bias, out=out)        # grouped conv + noise + bias + act model.py:268-272,343-350
         return packed
 

@@ -354,6 +354,11 @@ int oodgan_from_hform(const void* in, float* y, int B, int C, int H, int W, void
 long oodgan_modconv_f16_wbytes(int B, int M, int K);
 int oodgan_modconv_f16_pack(const float* weight, const float* style, int style_stride, float scale, int demodulate,
                             int act, void* wpk, int B, int M, int K, void* stream);
+/* the same with the modulation EqualLinear inside (ModulatedConv2d's `self.modulation`, model.py:219-223,236):
+ * style[b,k] = sum_j latent[b,j] * mod_weight[k,j] / sqrt(S) + mod_bias[k] — one launch for affine + modulate + demodulate + pack */
+int oodgan_modconv_f16_pack_affine(const float* weight, const float* latent, int latent_stride, const float* mod_weight,
+                                   const float* mod_bias, int S, float scale, int demodulate, int act, void* wpk, int B, int M,
+                                   int K, void* stream);
 /* y = act(conv3x3(x, w[b]) + noise_w*noise + bias); noise (noise_batch,H,W) fp32 or NULL, act = OODGAN_ACT_NONE|LRELU */
 int oodgan_modconv_f16(const void* x, const void* wpk, const float* noise, int noise_batch, const float* noise_w,
                        const float* bias, int act, void* y, int B, int K, int M, int H, int W, void* stream);

@@ -446,25 +446,47 @@ __global__ __launch_bounds__(256) void modconv_f16_strip_kernel(const StripArgs 
     }
 }
 
-// per-sample packed weights: out[b][tap][kc][half][m 32][8 f16], value demod[b,m]*scale*W[m,k,tap]*s[b,k]
+// per-sample packed weights: out[b][tap][kc][half][m 32][8 f16], value demod[b,m]*scale*W[m,k,tap]*s[b,k].
+// latent != NULL: the style is computed here — the modulation EqualLinear of ModulatedConv2d (model.py:223,236: s = latent @
+// (mod_w / sqrt(S))^T + mod_b) — so that the op is two launches (pack, conv) instead of three.  Eight threads per style
+// entry / per output channel, sums over the fixed lane order of an 8-lane butterfly (deterministic).
 __global__ __launch_bounds__(256) void modconv_f16_pack_kernel(const float* __restrict__ w, const float* __restrict__ style,
                                                                int style_stride, float scale, int demodulate, float gain,
-                                                               half8* __restrict__ out, int B, int M, int K, int KC) {
-    __shared__ float dm[32];
+                                                               half8* __restrict__ out, int B, int M, int K, int KC,
+                                                               const float* __restrict__ latent, int latent_stride,
+                                                               const float* __restrict__ mod_w, const float* __restrict__ mod_b, int S) {
+    __shared__ float dm[32], sl[32];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* s = style + (long)b * style_stride;
-    if (tid < 32) {
-        float d = 1.f;
-        if (demodulate && tid < M) {
-            float acc = 0.f;
-            for (int k = 0; k < K; ++k) {
-                float wsq = 0.f;
-                for (int t = 0; t < 9; ++t) { const float v = w[((long)tid * K + k) * 9 + t]; wsq += v * v; }
-                acc += s[k] * s[k] * wsq;
-            }
-            d = rsqrtf(scale * scale * acc + 1e-8f);
+    const int row = tid >> 3, sub = tid & 7;           // 32 rows x 8 threads
+    if (latent) {
+        float acc = 0.f;
+        if (row < K) {
+            const float* lp = latent + (long)b * latent_stride;
+            const float* wp = mod_w + (long)row * S;
+            for (int j = sub; j < S; j += 8) acc += lp[j] * wp[j];
         }
-        dm[tid] = d;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0) sl[row] = row < K ? acc * rsqrtf((float)S) + (mod_b ? mod_b[row] : 0.f) : 0.f;
+    } else if (tid < 32) {
+        sl[tid] = tid < K ? style[(long)b * style_stride + tid] : 0.f;
+    }
+    __syncthreads();
+    {
+        float acc = 0.f;
+        if (demodulate && row < M) {
+            for (int k = sub; k < K; k += 8) {
+                float wsq = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { const float v = w[((long)row * K + k) * 9 + t]; wsq += v * v; }
+                acc += sl[k] * sl[k] * wsq;
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0) dm[row] = (demodulate && row < M) ? rsqrtf(scale * scale * acc + 1e-8f) : 1.f;
     }
     __syncthreads();
     const int n = 9 * KC * 2 * 32;
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(256) void modconv_f16_pack_kernel(const float* __re
         for (int j = 0; j < 8; ++j) {
             const int k = kc * 16 + hf * 8 + j;
             float f = 0.f;
-            if (m < M && k < K) f = gain * dm[m] * scale * w[((long)m * K + k) * 9 + tp] * s[k];
+            if (m < M && k < K) f = gain * dm[m] * scale * w[((long)m * K + k) * 9 + tp] * sl[k];
             v[j] = (_Float16)f;
         }
         out[(long)b * n + u] = v;
@@ -547,8 +569,20 @@ extern "C" int oodgan_modconv_f16_pack(const float* weight, const float* style, 
     OODGAN_REQUIRE(weight && style && wpk && B > 0, "modconv_f16_pack: bad args");
     OODGAN_REQUIRE(M >= 1 && M <= 32 && K >= 1 && K <= 32, "modconv_f16: supports up to 32 -> 32 channels (got %d -> %d)", K, M);
     hipLaunchKernelGGL(modconv_f16_pack_kernel, dim3(B), dim3(256), 0, as_stream(stream), weight, style, style_stride, scale,
-                       demodulate, act == OODGAN_ACT_LRELU ? kSqrt2 : 1.f, reinterpret_cast<half8*>(wpk), B, M, K, (K + 15) / 16);
+                       demodulate, act == OODGAN_ACT_LRELU ? kSqrt2 : 1.f, reinterpret_cast<half8*>(wpk), B, M, K, (K + 15) / 16,
+                       (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, 0);
     return check_launch("modconv_f16_pack");
+}
+
+extern "C" int oodgan_modconv_f16_pack_affine(const float* weight, const float* latent, int latent_stride, const float* mod_weight,
+                                              const float* mod_bias, int S, float scale, int demodulate, int act, void* wpk, int B,
+                                              int M, int K, void* stream) {
+    OODGAN_REQUIRE(weight && latent && mod_weight && wpk && B > 0 && S > 0, "modconv_f16_pack_affine: bad args");
+    OODGAN_REQUIRE(M >= 1 && M <= 32 && K >= 1 && K <= 32, "modconv_f16: supports up to 32 -> 32 channels (got %d -> %d)", K, M);
+    hipLaunchKernelGGL(modconv_f16_pack_kernel, dim3(B), dim3(256), 0, as_stream(stream), weight, (const float*)nullptr, 0, scale,
+                       demodulate, act == OODGAN_ACT_LRELU ? kSqrt2 : 1.f, reinterpret_cast<half8*>(wpk), B, M, K, (K + 15) / 16,
+                       latent, latent_stride, mod_weight, mod_bias, S);
+    return check_launch("modconv_f16_pack_affine");
 }
 
 extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* noise, int noise_batch, const float* noise_w,

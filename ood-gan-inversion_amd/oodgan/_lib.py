@@ -110,6 +110,7 @@ _SIGS = {
     'oodgan_from_hform': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_modconv_f16_wbytes': (c_long, [c_int, c_int, c_int]),
     'oodgan_modconv_f16_pack': (c_int, [P, P, c_int, c_float, c_int, c_int, P, c_int, c_int, c_int, P]),
+    'oodgan_modconv_f16_pack_affine': (c_int, [P, P, c_int, P, P, c_int, c_float, c_int, c_int, P, c_int, c_int, c_int, P]),
     'oodgan_modconv_f16': (c_int, [P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_reduce_parts': (c_int, [P, P, c_long, c_int, c_int, P]),
     'oodgan_reduce_parts_cols': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -573,16 +573,24 @@ def to_hform(x, out=None):
     return out
 
 
-def modconv_f16_pack(weight, style, demodulate=True, act='none'):
+def modconv_f16_pack(weight, style, demodulate=True, act='none', out=None, latent=None, mod_weight=None, mod_bias=None):
     """Per-sample modulated (+demodulated) f16 weights of ModulatedConv2d (model.py:236-241) in MFMA fragment order.
-    weight (M,K,3,3) or (1,M,K,3,3) fp32 master, style (B,K) fp32 (already through the modulation EqualLinear)."""
+    weight (M,K,3,3) or (1,M,K,3,3) fp32 master, style (B,K) fp32 (already through the modulation EqualLinear) — or
+    ``style=None`` with ``latent`` (B,S), ``mod_weight`` (K,S), ``mod_bias`` (K): the EqualLinear runs inside the pack kernel.
+    ``out``: a buffer from a previous call with the same shapes (no allocation)."""
     weight = _dev(weight).reshape(weight.shape[-4:])
-    style = _dev(style)
     M, K = weight.shape[0], weight.shape[1]
-    B = style.shape[0]
-    wpk = torch.empty(_lib.lib().oodgan_modconv_f16_wbytes(B, M, K) // 2, dtype=torch.float16, device=weight.device)
-    check(_lib.lib().oodgan_modconv_f16_pack(_p(weight), _p(style), style.stride(0), 1.0 / math.sqrt(K * 9), int(demodulate),
-                                             _F16_ACT[act], _p(wpk), B, M, K, _stream()), 'modconv_f16_pack')
+    B = (style if style is not None else latent).shape[0]
+    wpk = out if out is not None else torch.empty(_lib.lib().oodgan_modconv_f16_wbytes(B, M, K) // 2, dtype=torch.float16, device=weight.device)
+    if style is not None:
+        style = _dev(style)
+        check(_lib.lib().oodgan_modconv_f16_pack(_p(weight), _p(style), style.stride(0), 1.0 / math.sqrt(K * 9), int(demodulate),
+                                                 _F16_ACT[act], _p(wpk), B, M, K, _stream()), 'modconv_f16_pack')
+    else:
+        latent, mod_weight = _dev(latent, 'latent'), _dev(mod_weight, 'mod_weight')
+        check(_lib.lib().oodgan_modconv_f16_pack_affine(_p(weight), _p(latent), latent.stride(0), _p(mod_weight), _p(_opt(mod_bias, 'mod_bias')),
+                                                        latent.shape[1], 1.0 / math.sqrt(K * 9), int(demodulate), _F16_ACT[act], _p(wpk), B, M, K,
+                                                        _stream()), 'modconv_f16_pack_affine')
     return wpk, M, K, act
 
 

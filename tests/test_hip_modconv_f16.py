@@ -55,6 +55,27 @@ def test_modconv_f16_vs_oracle(B, K, M, H, W, noise_batch, act):
     del full
 
 
+def test_modconv_f16_pack_with_the_affine_inside():
+    """oodgan_modconv_f16_pack_affine: the modulation EqualLinear (model.py:219-223,236) inside the pack kernel gives the packed
+    weights of the two-launch form (style_affine, then pack) up to the f16 rounding of a style that differs in its last fp32 bit."""
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    B, K, M, S = 5, 32, 32, 512
+    lat = synth.normal('pa.l', (B, S), 1).to(dev)
+    mw = synth.normal('pa.w', (K, S), 2).to(dev)
+    mb = synth.normal('pa.b', (K,), 3, 0.1, 1.0).to(dev)
+    wgt = synth.normal('pa.c', (M, K, 3, 3), 4).to(dev)
+    s = ops.style_affine(lat, mw, mb)
+    ref = (lat.double() @ mw.double().t() / math.sqrt(S) + mb.double()).float()
+    assert (s - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    a = ops.modconv_f16_pack(wgt, s, act='lrelu')[0].float()
+    b = ops.modconv_f16_pack(wgt, None, act='lrelu', latent=lat, mod_weight=mw, mod_bias=mb)[0].float()
+    assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-3 * a.abs().max().item()
+    assert ((a - b).abs() > 0).float().mean().item() < 0.05          # f16 values: almost all identical
+    again = ops.modconv_f16_pack(wgt, None, act='lrelu', latent=lat, mod_weight=mw, mod_bias=mb)[0].float()
+    assert torch.equal(again, b)
+
+
 def test_modconv_f16_is_deterministic_and_persistent_grid_covers_all_tiles():
     """many more tiles than resident workgroups: every tile written exactly once, run-to-run identical."""
     from oodgan import ops
