@@ -454,6 +454,10 @@ int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, 
  * replaces feats_conv (OOD_faceGAN_e4e_arch.py:70-75) and the AlignNet shortcut (helpers.py:431-434) */
 int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,
                    void* stream);
+/* squeeze-excitation gate of bottleneck_IR_SE (SEModule.forward, src/ops/e4e/encoders/helpers.py:60-76):
+ * gate[b,c] = sigmoid(sum_j w2[c,j] * relu(sum_k w1[j,k] * mean[b,k])), mean = stats[b,k,0] of oodgan_instnorm_stats;
+ * w1 (Cr,C), w2 (C,Cr): the 1x1 conv weights of fc1 / fc2; C <= 1024, Cr <= 64 */
+int oodgan_se_gate(const float* stats, const float* w1, const float* w2, float* gate, int B, int C, int Cr, void* stream);
 /* small direct 3x3 conv (K,M <= 8), pad 1, with optional in scale/shift (B,K) and PReLU */
 int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, const float* in_sh,
                          const float* slope, float* y, int B, int K, int M, int H, int W, void* stream);

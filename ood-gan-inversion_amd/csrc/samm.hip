@@ -121,6 +121,36 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- squeeze-excitation gate of bottleneck_IR_SE
+// gate[b,c] = sigmoid(W2 relu(W1 mean_b))  (SEModule.forward, src/ops/e4e/encoders/helpers.py:60-76: AdaptiveAvgPool2d(1) -> fc1 ->
+// ReLU -> fc2 -> Sigmoid; the product with the input is the caller's oodgan_affine_apply).  One workgroup per sample.  As two
+// oodgan_conv1x1 launches on a 1x1 "image" plus a ReLU and a sigmoid launch the gate cost 70 us per block (one active thread per
+// workgroup walking K): 24 blocks = 10 % of the B = 1 forward.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ stats, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, float* __restrict__ gate, int C, int Cr) {
+    __shared__ float mean[1024], hid[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) mean[c] = stats[((long)b * C + c) * 2];
+    __syncthreads();
+    const int sub = tid & 7;
+    for (int j0 = 0; j0 < Cr; j0 += 32) {
+        const int j = j0 + (tid >> 3);
+        float acc = 0.f;
+        if (j < Cr)
+            for (int c = sub; c < C; c += 8) acc += w1[(long)j * C + c] * mean[c];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0 && j < Cr) hid[j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < Cr; ++j) acc += w2[(long)c * Cr + j] * hid[j];
+        gate[(long)b * C + c] = 1.f / (1.f + expf(-acc));
+    }
+}
+
 // ---------------------------------------------------------------- small direct 3x3 (K,M <= 8)
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ in_sc, const float* __restrict__ in_sh,
@@ -534,6 +564,12 @@ extern "C" int oodgan_conv1x1(const float* x, const float* w, const float* bias,
     dim3 grid((unsigned)((HW + 255) / 256), (M + C1_MT - 1) / C1_MT, B);
     hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, as_stream(stream), x, w, bias, y, K, M, HW);
     return check_launch("conv1x1");
+}
+
+extern "C" int oodgan_se_gate(const float* stats, const float* w1, const float* w2, float* gate, int B, int C, int Cr, void* stream) {
+    OODGAN_REQUIRE(stats && w1 && w2 && gate && B > 0 && C > 0 && C <= 1024 && Cr > 0 && Cr <= 64, "se_gate: bad args (C <= 1024, C/r <= 64)");
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, as_stream(stream), stats, w1, w2, gate, C, Cr);
+    return check_launch("se_gate");
 }
 
 extern "C" int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, const float* in_sh, const float* slope,

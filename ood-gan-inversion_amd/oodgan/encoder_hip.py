@@ -7,7 +7,7 @@ convolution, normalisation, gate application and resize runs through ``liboodgan
   BatchNorm (eval) after a conv    -> out_scale + bias of the conv epilogue
   PReLU / LeakyReLU(0.01)          -> per-channel slope in the conv epilogue
   conv3x3 stride 2, pad 1          -> the stride-2 kernel (mode S2) on the input shifted by one zero row / column
-  SE gate + residual               -> ``oodgan_instnorm_stats`` (mean), ``oodgan_conv1x1`` x2, ``oodgan_affine_apply``
+  SE gate + residual               -> ``oodgan_instnorm_stats`` (mean), ``oodgan_se_gate``, ``oodgan_affine_apply``
   FPN ``_upsample_add``            -> ``oodgan_resize_bicubic_ac`` (helpers.py:504-521)
   GradualStyleBlock                -> stride-2 convs, all heads side by side (stacked / grouped launches) + ``oodgan_equal_linear``
 
@@ -145,10 +145,8 @@ class _HipTrunk:
             sc = samm.affine_apply(s, a, b)
         if self._mode == 'ir_se':
             se = rl[5]
-            g = samm.instnorm_stats(r)[..., 0].reshape(B, depth, 1, 1).contiguous()            # per-(b,c) mean
-            g = torch.relu(samm.conv1x1(g, se.fc1.weight.detach()))
-            g = torch.sigmoid(samm.conv1x1(g, se.fc2.weight.detach())).reshape(B, depth)
-            return samm.affine_apply(r, g.contiguous(), self._const_rows(B, depth, 0.0, x.device), res=sc)
+            g = samm.se_gate(samm.instnorm_stats(r), se.fc1.weight.detach(), se.fc2.weight.detach())      # one launch for fc1-relu-fc2-sigmoid
+            return samm.affine_apply(r, g, self._const_rows(B, depth, 0.0, x.device), res=sc)
         return samm.affine_apply(r, self._const_rows(B, depth, 1.0, x.device), self._const_rows(B, depth, 0.0, x.device), res=sc)
 
     def _style(self, i, feat):

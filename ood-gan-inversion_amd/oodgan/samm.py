@@ -23,6 +23,7 @@ _lib.bind_extra({
     'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_se_gate': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'oodgan_conv3x3_fewout_ksplit': (c_int, [c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_fewout': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_align_head': (c_int, [P, P, c_int, c_long, c_float, P]),
@@ -82,6 +83,15 @@ def conv1x1(x, weight, bias=None):
     y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
     check(_lib.lib().oodgan_conv1x1(_p(x), _p(w), _p(_opt(bias, 'bias')), _p(y), B, K, M, H * W, _stream()), 'conv1x1')
     return y
+
+
+def se_gate(stats, w1, w2):
+    """sigmoid(fc2(relu(fc1(mean)))) of SEModule (e4e/encoders/helpers.py:60-76); stats from ``instnorm_stats``; -> (B, C)."""
+    B, C = stats.shape[0], stats.shape[1]
+    w1, w2 = _dev(w1).reshape(-1, C), _dev(w2).reshape(C, -1)
+    g = torch.empty(B, C, device=stats.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_se_gate(_p(stats), _p(w1), _p(w2), _p(g), B, C, w1.shape[0], _stream()), 'se_gate')
+    return g
 
 
 def conv3x3_small(x, weight, in_sc=None, in_sh=None, slope=None):

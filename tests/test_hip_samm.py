@@ -40,6 +40,18 @@ def test_instance_norm_and_small_convs(dev):
     close(samm.conv3x3_small(x.to(dev), w3.to(dev), slope=sl.to(dev)), F.prelu(F.conv2d(x, w3, padding=1), sl))
 
 
+def test_se_gate_vs_aten(dev):
+    """SEModule (e4e/encoders/helpers.py:60-76): sigmoid(fc2(relu(fc1(avgpool(x)))))."""
+    from oodgan import samm
+    for (B, C, r, H) in ((3, 64, 16, 12), (1, 512, 16, 5), (2, 256, 16, 9)):
+        x = synth.normal('se.x', (B, C, H, H + 1), 1, 1.0, 0.3)
+        w1 = synth.normal('se.w1', (C // r, C, 1, 1), 2, 0.2)
+        w2 = synth.normal('se.w2', (C, C // r, 1, 1), 3, 0.3)
+        ref = torch.sigmoid(F.conv2d(torch.relu(F.conv2d(x.mean(dim=(2, 3), keepdim=True), w1)), w2)).reshape(B, C)
+        g = samm.se_gate(samm.instnorm_stats(x.to(dev)), w1.to(dev), w2.to(dev))
+        close(g, ref, 2e-6)
+
+
 def test_conv3x3_fewout_vs_aten(dev):
     """The many-to-few 3x3 conv (AlignNet head, 2C -> 3) incl. in-bounds-only shift, PReLU, ragged K / sizes and the K split."""
     from oodgan import samm
