@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
-            if (e >= XITEMS) continue;
+            // units outside the image hold zeros for the whole K loop (written once below): on the small maps of the encoder's
+            // style heads (4x4 ... 16x16 inputs in a 17 x 68-position stride-2 tile) that is most of the tile, and converting it
+            // again for every K chunk was most of a chunk's time
+            if (e >= XITEMS || xoff[i] < 0) continue;
 #pragma unroll
             for (int px = 0; px < (VEC ? 4 : 1); ++px) {
                 half4 hi, lo;
@@ -208,9 +211,10 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accv, 0, 0, 0);        \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accv, 0, 0, 0);
 
+    for (int e = tid; e < XBYTES / 16; e += 256) reinterpret_cast<uint4*>(lx)[e] = make_uint4(0, 0, 0, 0);
     load_x(0);
     for (int t = 0; t < nchunk; ++t) {
-        __syncthreads();                       // previous chunk fully consumed
+        __syncthreads();                       // previous chunk fully consumed (first pass: the zero fill is complete)
         dma_w(t);                              // async global->LDS, lands while x is converted
         if (!(p.ablate & 8)) store_x();
         __syncthreads();                       // (hipcc drains vmcnt before the barrier: DMA complete)

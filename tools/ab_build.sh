@@ -7,9 +7,6 @@ cd "$(dirname "$0")/../ood-gan-inversion_amd"
 commit=$1; shift
 rm -rf build_ab csrc_ab && mkdir -p csrc_ab
 cp csrc/*.hip csrc/*.hpp csrc_ab/
-mkdir -p include_ab_unused
 for f in "$@"; do git show "$commit:ood-gan-inversion_amd/csrc/$f" > csrc_ab/$f; done
-sed -i 's#"../../include/oodgan.h"#"../../include/oodgan.h"#' csrc_ab/common.hpp
 make CSRC=csrc_ab BUILD=build_ab LIB=oodgan/liboodgan_hip_ab.so -j8 2>&1 | grep -v "^/opt/rocm/bin/hipcc" | tail -3
-rmdir include_ab_unused 2>/dev/null || true
 ls -la oodgan/liboodgan_hip_ab.so
