@@ -278,6 +278,20 @@ def forward_only(a, m, x, noises, reps=7):
         t = statistics.median(ts)
         out[tag] = dict(batch=b, latency_ms=round(t * 1e3, 3), images_per_s=round(b / t, 3),
                         encoder_ms=round(statistics.median(enc_ms), 3), ood_forward_ms=round(statistics.median(ood_ms), 3))
+        if b == 1:
+            # the same call replayed from a captured hipGraph (oodgan.arch.GraphedForward): no host launch overhead, no gaps
+            from oodgan.arch import GraphedForward
+            gf = GraphedForward(m)
+            gf(xb, noise=nb)
+            torch.cuda.synchronize()
+            tg = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                gf(xb, noise=nb)
+                torch.cuda.synchronize()
+                tg.append(time.perf_counter() - t0)
+            out[tag]['graph_replay_latency_ms'] = round(statistics.median(tg) * 1e3, 3)
+            del gf
     out['note'] = ('model(x): e4e encoder (256x256) + OOD forward (generator + SAMM 2 cycles x 4 levels + mask blend) at '
                    f'{a.size}x{a.size}, host wall time incl. synchronize, median of {reps}; the reference times exactly this call')
     return out

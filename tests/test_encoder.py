@@ -93,3 +93,27 @@ def test_hip_encoder_vs_reference_golden_and_torch_mirror(golden):
     x2 = torch.cat([x, synth.make_images(256, 1, seed=43).to(dev)])
     w2 = enc(x2)
     assert w2.shape == (2, 18, 512) and (w2[:1] - w).abs().max().item() <= 1e-4 * w.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_graphed_forward_equals_eager():
+    """oodgan.arch.GraphedForward: model(x) replayed from a captured hipGraph gives the eager result bit for bit (fixed noise maps),
+    follows new inputs, and refreshes model.aligns."""
+    from oodgan.arch import GraphedForward, ood_faceGAN_e4e
+    dev = torch.device('cuda:0')
+    m = ood_faceGAN_e4e(out_size=1024, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08,
+                        cycle_align=2, blend_with_gen=True, ModSize=256)
+    sd = synth.ood_state(1024, seed=31)
+    enc_sd = synth.encoder_state({k: tuple(v.shape) for k, v in m.encoder.state_dict().items()}, seed=41)
+    sd.update({'encoder.' + k: (v * 0.1 if k.endswith('linear.weight') else v) for k, v in enc_sd.items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    noises = [n.to(dev) for n in synth.make_noises(1024, 1, seed=35)]
+    gf = GraphedForward(m)
+    for seed in (34, 36):
+        x = synth.make_images(1024, 1, seed=seed).to(dev)
+        ref, ref_lats = m(x, noise=noises)
+        ref, ref_lats, ref_mask = ref.clone(), ref_lats.clone(), m.aligns[1024].clone()
+        out, lats = gf(x, noise=noises)
+        assert torch.equal(out, ref) and torch.equal(lats, ref_lats) and torch.equal(m.aligns[1024], ref_mask)
+    assert len(gf._cache) == 1
