@@ -172,6 +172,18 @@ typedef struct oodgan_conv_args {
                                 16-channel block — instead of NCHW.  Only the split-f16 strip kernel (mode S1, 16 < K,M <= 32, no
                                 dotx): the LAST styled conv of the generator in the W+ loop, whose output is read back by nothing
                                 but its own activation backward (oodgan_act_bwd_sform_f), a pure 16-byte-per-lane stream then. */
+    int x_fform;             /* != 0: x is fp32 in F-form ([B][2][Hin][Win][16]) and the kernel converts it to its split-f16 operand
+                                itself (csrc/conv_f16s_stripx.hip; mode S1, K == M == 32, Hin %% 4 == 0, Win %% 32 == 0, see
+                                oodgan_conv3x3_xf_supported) — the 1024² level of the W+ loop, where a separate S-form copy of the
+                                tensor costs a write and a read of 1 GB each per step:
+                                1 (forward): staged value = x * in_scale[b,k] * in_mul2[1]; y is written in F-form (y_fform = 1);
+                                  bias / noise / lrelu / fused ToRGB as in the strip kernel.
+                                2 (input gradient): x is the saved OUTPUT `out` of the StyledConv whose activation backward produces
+                                  this conv's input; `fuse` describes that backward exactly as for oodgan_act_bwd_sform
+                                  (g = s_rgb*t, g_pre = g*act'(out), staged value = g_pre*dscale*mul2[1]; fuse->ys unused) and
+                                  receives part_r / part_t (B,32,nparts) and part_max (B*2*nparts floats) with
+                                  nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win); dotx (F-form, dotx_fform = 1) is mandatory, y NCHW. */
+    int dotx_fform;          /* 1: dotx is in F-form (x_fform == 2 only) */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -224,6 +236,11 @@ int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, int Win);
 /* 1 when mode S1 with an S-form input and dotx of this shape accepts oodgan_conv_args.dot_actgrad (strip / 8-wave kernels)
  * and oodgan_act_bwd_blurT_sform_phases(out = NULL) exists for the (H/2, W/2) layer below */
 int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
+/* oodgan_conv_args.x_fform: 1 when the shape is supported, and the number of partial sums per (sample, channel) that the
+ * x_fform == 2 instance writes to fuse->part_r / part_t (per (sample, 16-channel block) to fuse->part_max) */
+int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W);
+int oodgan_conv3x3_xf_nparts(int B, int H, int W);
+int oodgan_conv3x3_xf_dot_nparts(int H, int W);    /* dot_nparts the x_fform == 2 instance expects (one partial per 4-row tile) */
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs
@@ -273,6 +290,11 @@ int oodgan_fwd_range_plan(const float* s_all, const float* d_all, const int* row
 int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale, int ys_scale_stride,
                           const float* bias, const float* noise, int noise_batch, const float* noise_w, int act, int B, int C,
                           int H, int W, int in_pitch, unsigned* vmax, void* stream);
+/* The same tail writing y in F-form ([B][C/16][2H][2W][16] fp32, C %% 16 == 0) and NO S-form: for the layer whose following conv
+ * converts its input itself (oodgan_conv_args.x_fform = 1).  ys_scale (the next conv's style x range scale) only enters vmax. */
+int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const float* ys_scale, int ys_scale_stride,
+                          const float* bias, const float* noise, int noise_batch, const float* noise_w, int act,
+                          int B, int C, int H, int W, int in_pitch, unsigned* vmax, void* stream);
 
 /* ---- fused backward producers (csrc/bwd_producers.hip): oodgan_act_bwd_fused's arithmetic (autograd of NoiseInjection +
  * FusedLeakyReLU merged with the ToRGB branch, src/ops/StyleGAN/model.py:283-292,343-372) written directly as the

@@ -32,6 +32,7 @@ bool s1_strip_eligible(const oodgan_conv_args& a);
 bool s1_big_eligible(const oodgan_conv_args& a);
 int launch_s1_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1_strip(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+int launch_s1_stripx(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 bool s2_big_eligible(const oodgan_conv_args& a);
@@ -446,6 +447,11 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
+    if (a.x_fform) {
+        OODGAN_REQUIRE(a.x_fform == 1 || a.x_fform == 2, "conv3x3_f16s: x_fform must be 0, 1 or 2");
+        return launch_s1_stripx(a, a.wpk, unscale2, as_stream(stream));
+    }
+    OODGAN_REQUIRE(!a.dotx_fform, "conv3x3_f16s: an F-form dotx exists only with x_fform == 2");
     OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");

@@ -1,0 +1,737 @@
+// The 32 -> 32 channel 3x3 convs of the 1024² level inside the W+ loop, reading fp32 activations in F-form
+// ([B][2][H][W][16]: one 64-byte record per pixel and 16-channel block) and doing the conversion to the split-f16 operand
+// INSIDE the kernel — the passes that used to write and re-read an S-form copy of the same tensor disappear:
+//   x_fform = 1 (forward, reference ModulatedConv2d.forward, src/ops/StyleGAN/model.py:233-274): the conv input is the
+//       activated output of the up-sampling layer; staged value = x * style[b,k] * range scale, split hi/lo on the fly
+//       (was: blur_act_sform writes y AND its S-form, 1.07 GB more per step at B = 8);
+//   x_fform = 2 (input gradient): x is the saved OUTPUT `out` of this StyledConv; the kernel runs the layer's activation
+//       backward merged with the ToRGB branch (autograd of NoiseInjection / FusedLeakyReLU / ToRGB, model.py:283-292,343-372,
+//       src/ops/op/fused_act.py:25-58 — the arithmetic of act_bwd_sform_f_kernel, bwd_producers.hip) on the rows it has just
+//       fetched, sums the partial r / t / max of that producer, and feeds g_pre * d * scale to the matrix cores
+//       (was: act_bwd_sform_f, 2.45 GB per step, then the S-form read back here).
+// Organisation: weights in registers, a workgroup (4 waves) walks down a 32-pixel strip, FOUR rows x 32 pixels per tile (one
+// row per wave), bank-conflict-free rotated records as in conv_f16s_strip.hip.  Data path:
+//   * EVERY load of the loop is an LDS-DMA (global_load_lds): the raw F-form rows go straight into their place in a ring of
+//     five 4-row groups and are converted IN PLACE two tiles later (a pixel's four channel quarters are four adjacent lanes:
+//     they read their 16 bytes of the fp32 record, exchange halves by DPP and write the four 16-byte hi / lo slots of the same
+//     64 bytes); the halo columns come through a 1 KiB staging area; the per-pixel inputs of the activation backward
+//     (g_rgb, noise) and the saved forward input of the style-gradient dot land in LDS the same way.
+//     Reason: a VMEM load into registers makes the compiler track vmcnt, and while an LDS-DMA is pending its waitcnt pass
+//     turns every such dependency into vmcnt(0) — the round-2 strip kernel drained all memory traffic at the top of every
+//     matrix phase that way.  With no register loads the only vmcnt waits are the explicit counted ones below, which leave two
+//     tiles of prefetch and the newest stores in flight (memory operations of a wave retire in issue order);
+//   * the operation counts per tile and wave are uniform (clamped duplicates instead of branches; H % 4 == 0, W % 32 == 0):
+//     backward 12 DMA + 16 stores (+1 in wave 0), forward 6 DMA + 4 (+3) stores — far below the 64 the 6-bit counter allows.
+#include "conv_common.hpp"
+#include "sform.hpp"
+#include <cstdint>
+#include <cstdlib>
+
+using namespace oodgan;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+#ifndef SX_ABL
+#define SX_ABL 0
+#endif
+
+namespace {
+
+constexpr int SX_C = 34;                               // records per ring row and channel block
+constexpr int SX_ROW = 2 * SX_C * 64;                  // 4352 bytes: [kc 2][34 records][64 B]
+constexpr int SX_GROUP = 4 * SX_ROW;                   // 17408: four rows
+constexpr int SX_NG = 5;                               // groups t-1 (its last two rows), t, t+1 (being converted), t+2, t+3 (in flight)
+constexpr int SX_RING = SX_NG * SX_GROUP;              // 87040
+constexpr int SX_HALO = SX_RING;                       // 3 x [4 waves][256 B]: raw halo records (columns 0 / 33) of a group
+constexpr int SX_SMALL = SX_HALO + 3 * 1024;           // backward: 3 x 3072 ([pixel slot][g_rgb 0..2, noise]); forward: 3 x 1 KiB noise rows
+constexpr int SX_SMALL_ONE = 3072;
+constexpr int SX_DOT = SX_SMALL + 3 * SX_SMALL_ONE;    // 3 x 16 KiB: saved forward input of a tile, thread-private slots
+constexpr int SX_DOT_ONE = 16384;
+constexpr int SX_RED = SX_DOT + 3 * SX_DOT_ONE;        // 2 x 4 waves x 32 floats: dot partials of two tiles
+constexpr int SX_FIN = SX_RED + 1024;                  // final sums: [4 waves][32 ch][r,t] + [4][2] maxima
+constexpr int SX_CST = SX_FIN + 4 * 32 * 2 * 4 + 64;   // [2 halves][16] epilogue scales, then [kc 2][quarter 4][7] float4 constants
+constexpr int SX_SMEM = SX_CST + 128 + 8 * 7 * 16;     // 152 KiB
+
+#define SX_VM(n) ((((n) >> 4) & 3) << 14 | 0x0F70 | ((n) & 15))
+#define SX_VML(n) ((((n) >> 4) & 3) << 14 | 0x0070 | ((n) & 15))      // ... and lgkmcnt(0)
+
+// LDS reads of the loop as inline assembly.  A compiler-visible LDS load issued while an LDS-DMA is pending makes the waitcnt
+// pass insert s_waitcnt vmcnt(0) in front of it (it cannot tell which DMA the load may alias), which would drain the two
+// tiles of prefetch at every conversion and every epilogue.  The data read here has been waited for explicitly (counted vmcnt
+// + barrier at the top of the tile).  Each block ends with its own lgkmcnt(0): the outputs are valid when it returns.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p);
+}
+__device__ __forceinline__ void lds_read4(unsigned a, f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_read4_16(unsigned a, f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_read7_16(unsigned a, f32x4 (&r)[7]) {
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\tds_read_b128 %3, %7 offset:48\n\t"
+                 "ds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80\n\tds_read_b128 %6, %7 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]) : "v"(a) : "memory");
+}
+// the four rows of a thread's in-place conversion (row pitch 4352) and its halo record
+__device__ __forceinline__ void lds_read_rows(unsigned a, unsigned ah, f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, f32x4& r4) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:4352\n\tds_read_b128 %2, %5 offset:8704\n\tds_read_b128 %3, %5 offset:13056\n\t"
+                 "ds_read_b128 %4, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(a), "v"(ah) : "memory");
+}
+// the per-pixel inputs of the same five units (pixel-slot pitch 16 B, 32 slots per row)
+__device__ __forceinline__ void lds_read_small(unsigned a, unsigned ah, f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, f32x4& r4) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:512\n\tds_read_b128 %2, %5 offset:1024\n\tds_read_b128 %3, %5 offset:1536\n\t"
+                 "ds_read_b128 %4, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(a), "v"(ah) : "memory");
+}
+// LDS stores of the loop: the same reason (an LDS store while a DMA is pending gets vmcnt(0) in front).  They are ordered with
+// the other LDS operations of the wave; the wait at the top of the next tile includes lgkmcnt(0) before its barrier.
+__device__ __forceinline__ void lds_write16(unsigned a, unsigned x, unsigned y, unsigned z, unsigned w) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {x, y, z, w};
+    asm volatile("ds_write_b128 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write4(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, f32x4& r0, f32x4& r1) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_read1x4(unsigned a) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ float lds_read1(unsigned a) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ float lds_read_sum4(unsigned a) {       // four floats 128 B apart
+    float r0, r1, r2, r3;
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:128\n\tds_read_b32 %2, %4 offset:256\n\tds_read_b32 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a) : "memory");
+    return r0 + r1 + r2 + r3;
+}
+
+struct StripX {
+    oodgan_conv_args a;
+    oodgan_actbwd_fuse f;    // x_fform == 2
+    const float* w_unscale;
+    const void* zeros;       // >= 64 bytes of zeros in device memory
+    int tiles_x, tiles_y, seg_tiles, nseg, Mp;     // tiles of FOUR rows
+    long out_plane;
+    int nparts;
+};
+
+// BWD: x_fform == 2 (activation backward in the conversion, style-gradient dot in the epilogue).  RGB: fused ToRGB colour
+// sums (forward).  PRE: y <- dx * act'(dotx) (oodgan_conv_args.dot_actgrad).  YF: y in F-form.
+template <bool BWD, bool RGB, bool PRE, bool YF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_stripx_kernel(
+    const StripX p, const uint4* __restrict__ wpk16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    int w = blockIdx.x;
+    {
+        const int total = gridDim.x, xcd = w & 7, idx = w >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = w % p.tiles_x;
+    const int seg = (w / p.tiles_x) % p.nseg;
+    const int b = w / (p.tiles_x * p.nseg);
+    const int t0 = seg * p.seg_tiles;
+    const int n = min(p.seg_tiles, p.tiles_y - t0);
+    const int c0 = tx * 32, R0 = 4 * t0;
+    const int H = a.Hin, W = a.Win;
+    constexpr int M = 32;
+    const long HW = (long)H * W;
+
+    // ---- weights: the whole tensor in registers.  Packed order (oodgan_pack_conv3x3_f16s): [kc][tap][hi|lo][k-half][Mp][8 f16]
+    half8 ah[9][2], al[9][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const half8* wb = reinterpret_cast<const half8*>(wpk16) + ((long)(kc * 9 + tp) * 4) * p.Mp;
+            ah[tp][kc] = wb[(0 * 2 + half) * p.Mp + l31];
+            al[tp][kc] = wb[(1 * 2 + half) * p.Mp + l31];
+        }
+
+    // ---- per-workgroup constants in LDS (read back where they are used: they would otherwise occupy registers through the
+    // matrix phase): epilogue scale out_scale * unscale of channel m(r) = (r & 3) + 8 (r >> 2) + 4 half; the seven per-channel
+    // constants of the activation backward for every (channel block, quarter)
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    if (tid < 32) {
+        const int hh = tid >> 4, r = tid & 15, m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        reinterpret_cast<float*>(smem + SX_CST)[tid] = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
+    }
+    float4* cst = reinterpret_cast<float4*>(smem + SX_CST + 128);      // [kc*4 + q][w0, w1, w2 (x rgb_scale), s_rgb, bias, d*scale, |d|]
+    float nwb = 0.f;
+    if (BWD) {
+        const oodgan_actbwd_fuse& f = p.f;
+        nwb = f.noise ? (f.noise_w ? f.noise_w[0] : 1.f) : 0.f;
+        if (tid < 8) {
+            const float m2 = f.mul2 ? f.mul2[1] : 1.f;
+            float c7[7][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = tid * 4 + j;
+                c7[0][j] = f.w_rgb[0 * M + c] * f.rgb_scale;
+                c7[1][j] = f.w_rgb[1 * M + c] * f.rgb_scale;
+                c7[2][j] = f.w_rgb[2 * M + c] * f.rgb_scale;
+                c7[3][j] = f.s_rgb[(long)b * f.s_rgb_stride + c];
+                c7[4][j] = f.bias ? f.bias[c] : 0.f;
+                const float dv = f.dscale[(long)b * f.dscale_stride + c];
+                c7[5][j] = dv * m2;
+                c7[6][j] = fabsf(dv);
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cst[tid * 7 + k] = make_float4(c7[k][0], c7[k][1], c7[k][2], c7[k][3]);
+        }
+    }
+    float bia[BWD ? 1 : 16];
+    if (!BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bia[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+    }
+    float wr[RGB ? 3 : 1][16];
+    if (RGB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sv = a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wr[RGB ? k : 0][r] = sv * a.rgb_w[k * M + m];
+        }
+    }
+    const float nwf = (!BWD && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    unsigned moff[YF ? 1 : 4];               // NCHW y: byte offset of channel 8 rr + 4 half at this lane's column
+    if (!YF) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) moff[rr] = (unsigned)((long)(8 * rr + 4 * half) * p.out_plane * 4) + l31 * 4;
+    }
+
+    // ---- conversion role of this thread: channel block ckc = wave >> 1, pixel cpx = 16 (wave & 1) + (lane >> 2) of the strip,
+    // channel quarter cq = lane & 3 (channels ckc*16 + cq*4 + 0..3), in each of the group's four rows: a wave's DMA piece for
+    // one row is 16 records = 1 KiB contiguous in the ring.  Halo columns 0 / 33 of row `wave`: lanes 0..15 = (side, kc, quarter).
+    // Rows / columns outside the image read a page of zeros (zero padding of the conv; zero `out` and zero g_rgb give a zero
+    // gradient and zero sums): no per-unit masks.
+    const int ckc = wave >> 1, cpx = 16 * (wave & 1) + (lane >> 2), cq = lane & 3;
+    const bool even = (cq & 1) == 0;
+    const int slot = even ? (cq >> 1) : 2 + (cq >> 1);
+    const unsigned crec = (unsigned)(ckc * (SX_C * 64) + (1 + cpx) * 64);                      // record of the pixel inside a ring row
+    const unsigned cwr = crec + ((((unsigned)slot + (((1 + cpx) >> 2) & 3)) & 3) << 4);          // the slot this lane writes (rotated)
+    const unsigned goff0 = (unsigned)((((long)ckc * HW + c0 + cpx) * 16 + cq * 4) * 4);
+    const int hside = (lane >> 3) & 1, hkc = (lane >> 2) & 1, hcol = hside ? 33 : 0, hgx = c0 - 1 + hcol;
+    const bool hinv = hgx < 0 || hgx >= W;
+    const unsigned hgoff = (unsigned)((((long)hkc * HW + min(max(hgx, 0), W - 1)) * 16 + cq * 4) * 4);
+    const unsigned hwr = (unsigned)(hkc * (SX_C * 64) + hcol * 64 + ((((unsigned)slot + ((hcol >> 2) & 3)) & 3) << 4));
+    const unsigned char* xfb = reinterpret_cast<const unsigned char*>(a.x) + (long)b * 2 * HW * 64;
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(p.zeros);
+    const long row_bytes = (long)W * 64;
+
+    float xs[4], xsh[4];                     // forward: staged value = x * in_scale[b,k] * in_mul2[1] (interior / halo role)
+    float acc_r[BWD ? 4 : 1], acc_t[BWD ? 4 : 1], amax = 0.f;
+    if (!BWD) {
+        const float m2 = a.in_mul2 ? a.in_mul2[1] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xs[j] = (a.in_scale ? a.in_scale[(long)b * a.in_scale_stride + ckc * 16 + cq * 4 + j] : 1.f) * m2;
+            xsh[j] = (a.in_scale ? a.in_scale[(long)b * a.in_scale_stride + hkc * 16 + cq * 4 + j] : 1.f) * m2;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc_r[j] = acc_t[j] = 0.f;
+    }
+
+    // backward: component lane & 3 of the per-pixel inputs (g_rgb 0..2, noise) of pixel slot (lane >> 2) of a piece
+    const float* sbase = nullptr;
+    bool nz_zero = false;
+    if (BWD) {
+        const oodgan_actbwd_fuse& f = p.f;
+        const int comp = lane & 3;
+        sbase = f.g_rgb + ((long)b * 3 + (comp < 3 ? comp : 0)) * HW;
+        if (comp == 3) {
+            nz_zero = f.noise == nullptr;
+            if (f.noise) sbase = f.noise + (long)(f.noise_batch > 1 ? b : 0) * HW;
+        }
+    }
+    const float* nzb = (!BWD && a.noise) ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
+    const unsigned char* dfb = BWD ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * 2 * HW) * 64 + half * 16 : nullptr;
+
+    // ---- one batch of LDS-DMA: raw rows + halo + small inputs of group g (into ring group gs, buffers g3) and, with it, the
+    // epilogue inputs of tile td (dot rows / noise; buffer d3).  Indices past the segment are clamped by the CALLER to valid
+    // groups / tiles (the duplicates land in dead buffers).  12 operations per wave (backward), 6 (forward).
+    auto issue_batch = [&](int g, int gs, int g3, int td, int d3) {
+        const int r0g = R0 + 4 * g + 1;
+        unsigned char* ring = smem + gs * SX_GROUP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0g + i;
+            const bool rok = r >= 0 && r < H;                        // wave-uniform
+            const unsigned char* src = rok ? xfb + (long)r * row_bytes + goff0 : zp;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(ring + i * SX_ROW + ckc * (SX_C * 64) + (1 + 16 * (wave & 1)) * 64), 16, 0, 0);
+        }
+        {
+            const int r = r0g + wave;
+            const unsigned char* src = (hinv || r < 0 || r >= H) ? zp : xfb + (long)r * row_bytes + hgoff;
+            if (lane < 16)
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_HALO + g3 * 1024 + wave * 256), 16, 0, 0);
+        }
+        if (BWD) {
+            unsigned char* dst = smem + SX_SMALL + g3 * SX_SMALL_ONE;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {        // pieces 0..7: row q >> 1, pixels 16 (q & 1) .. + 15
+                const int q = wave + 4 * k;
+                const int r = r0g + (q >> 1);
+                const bool rok = r >= 0 && r < H;
+                const float* src = (rok && !nz_zero) ? sbase + (long)r * W + c0 + 16 * (q & 1) + (lane >> 2) : reinterpret_cast<const float*>(zp);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + q * 256), 4, 0, 0);
+            }
+            {                                    // piece 8 (+ duplicates 9..11): halo pixels, slot 128 + row*2 + side
+                const int hs = (lane >> 2) & 7;
+                const int r = r0g + (hs >> 1), gx = c0 - 1 + ((hs & 1) ? 33 : 0);
+                const bool ok = r >= 0 && r < H && gx >= 0 && gx < W && !nz_zero;
+                const float* src = ok ? sbase + (long)r * W + gx : reinterpret_cast<const float*>(zp);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + (8 + wave) * 256), 4, 0, 0);
+            }
+            unsigned char* dd = smem + SX_DOT + d3 * SX_DOT_ONE + wave * 4096;
+            const long pix = (long)(R0 + 4 * td + wave) * W + c0 + l31;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(dfb + ((long)(rr >> 1) * HW + pix) * 64 + (rr & 1) * 32), (lds_void*)(dd + rr * 1024), 16, 0, 0);
+        } else {
+            const float* src = nzb ? nzb + (long)(R0 + 4 * td + wave) * W + c0 + l31 : reinterpret_cast<const float*>(zp);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_SMALL + d3 * 1024 + wave * 256), 4, 0, 0);
+        }
+    };
+
+    // ---- in-place conversion of group g (ring group gs, buffers g3): fp32 records -> rotated hi / lo slots.  `count`: the
+    // group's rows enter this workgroup's sums (wave-uniform; the caller excludes duplicates).
+    auto convert_unit = [&](const f32x4 rv, const f32x4 s4, const f32x4 (&cq7)[7], const float* xsc, float fi, unsigned dst, bool wr_ok) {
+        const float ov[4] = {rv[0], rv[1], rv[2], rv[3]};
+        float v[4];
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ov[j] * xsc[j];
+        } else {
+            const f32x4 w0 = cq7[0], w1 = cq7[1], w2 = cq7[2], sr = cq7[3], bv = cq7[4], ds = cq7[5], da = cq7[6];
+            const float nz = nwb * s4[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float o = ov[j];
+                const float t = w0[j] * s4[0] + w1[j] * s4[1] + w2[j] * s4[2];
+                const float gp = (sr[j] * t) * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nz - bv[j];
+                const float gi = gp * fi;
+                acc_r[BWD ? j : 0] += gi * ycv;
+                acc_t[BWD ? j : 0] += (o * fi) * t;
+                amax = fmaxf(amax, fabsf(gi) * da[j]);
+                v[j] = gp * ds[j];
+            }
+        }
+        unsigned h01, l01, h23, l23;
+        split_pair(v[0], v[1], h01, l01);
+        split_pair(v[2], v[3], h23, l23);
+        // quarters (0,1) and (2,3) exchange: the even one collects the hi halves of the 8 channels, the odd one the lo halves
+        const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+        const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        if (wr_ok) lds_write16(dst, even ? h01 : g0, even ? h23 : g1, even ? g0 : l01, even ? g1 : l23);
+    };
+    // interior role: the seven constant vectors stay in registers; the halo role (lanes 0..15, another channel block) reads its own
+    f32x4 cin[7];
+    if (BWD) {
+        __syncthreads();                             // the constant table is complete
+        lds_read7_16(lds_addr(cst + (ckc * 4 + cq) * 7), cin);
+    }
+    const unsigned smem0 = lds_addr(smem);
+    auto convert = [&](int g, int gs, int g3, bool count) {
+        const unsigned ring = smem0 + gs * SX_GROUP;
+        f32x4 rv[5], s4[5];
+        // all four quarters of a record have read it before any of them writes (one instruction stream per wave; the block
+        // ends with lgkmcnt(0))
+        lds_read_rows(smem0 + gs * SX_GROUP + crec + cq * 16, smem0 + SX_HALO + g3 * 1024 + wave * 256 + (lane & 15) * 16, rv[0], rv[1], rv[2], rv[3], rv[4]);
+        f32x4 chl[7];
+        if (BWD) {
+            const unsigned sm = smem0 + SX_SMALL + g3 * SX_SMALL_ONE;
+            lds_read_small(sm + cpx * 16, sm + (128 + wave * 2 + hside) * 16, s4[0], s4[1], s4[2], s4[3], s4[4]);
+            lds_read7_16(smem0 + SX_CST + 128 + (hkc * 4 + cq) * 7 * 16, chl);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 7; ++i) chl[i] = cin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // rows counted in this workgroup's sums: its own 4n rows (group -1 contributes its last row, the last group all
+            // but its last); the halo columns belong to the neighbouring strips
+            const float fi = (count && (g < 0 ? i == 3 : (g < n - 1 || i < 3))) ? 1.f : 0.f;
+            convert_unit(rv[i], s4[i], cin, xs, fi, ring + i * SX_ROW + cwr, true);
+        }
+        convert_unit(rv[4], s4[4], chl, xsh, 0.f, ring + wave * SX_ROW + hwr, lane < 16);
+    };
+
+    __builtin_amdgcn_s_waitcnt(SX_VM(0));            // weights, scales: retired here, never inside the loop
+    // ---- prologue: groups -1 (its last two rows are the halo above the first tile) and 0 converted, groups 1 and 2 and the
+    // epilogue inputs of tiles 0 and 1 in flight
+    issue_batch(-1, 4, 2, 0, 0);
+    issue_batch(0, 0, 0, min(1, n - 1), 1);
+    __builtin_amdgcn_s_waitcnt(SX_VM(0));
+    __syncthreads();
+    convert(-1, 4, 2, true);
+    convert(0, 0, 0, true);
+    __syncthreads();                                 // every wave is done with small-input buffer 2 before group 2's lands in it
+    __builtin_amdgcn_sched_barrier(0);
+    issue_batch(min(1, n - 1), 1, 1, 0, 0);                          // batch "-2": group 1 and, again, tile 0's epilogue inputs
+    issue_batch(min(2, n - 1), 2, 2, min(1, n - 1), 1);              // batch "-1"
+    __builtin_amdgcn_sched_barrier(0);
+
+    // lane-constant part of the fragment addresses: record kx + l31, slot (half + 2*lo) rotated by (c>>2)&3
+    unsigned lrd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = kx + l31;
+            lrd[kx][lo] = c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
+        }
+    const int px = c0 + l31;
+    float* red = reinterpret_cast<float*>(smem + SX_RED);
+    constexpr int kBatch = BWD ? 12 : 6;
+    constexpr int kStores = (YF ? 4 : 16) + (RGB ? 3 : 0);
+    int rb = 18 + wave;      // ring row of image row R0 + 4t - 1 + wave (group g, row j at ring row 4 (g mod 5) + j): group -1 is ring group 4
+    int gs1 = 1;             // ring group of group t + 1
+    int m3 = 0;              // t mod 3
+
+    for (int t = 0; t < n; ++t) {
+        // Issue order so far: ... batch(t-2) [group t+1, tile t's epilogue inputs], stores(t-2), batch(t-1), stores(t-1).
+        // Everything up to batch(t-2) must have landed; wave 0 issues one more store per tile (the dot partial).
+        if (t >= 3) {
+            if (BWD && wave == 0) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores + 2));
+            else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
+        } else if (t == 2) {                         // tile 0 stored no dot partial
+            if (BWD && wave == 0) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores + 1));
+            else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
+        } else if (t == 1) {
+            __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + kStores));     // wave 0's first dot partial is stored in tile 1, after this point
+        } else {
+            __builtin_amdgcn_s_waitcnt(SX_VML(kBatch));
+        }
+        __builtin_amdgcn_s_barrier();                // group t is converted; ring group (t+3) % 5 and the (t % 3) buffers are free
+        __builtin_amdgcn_sched_barrier(0);
+        const int m3n = m3 == 2 ? 0 : m3 + 1;        // (t + 1) % 3
+        {
+            int gs3 = gs1 + 2;
+            if (gs3 >= SX_NG) gs3 -= SX_NG;
+            const int m3p = m3n == 2 ? 0 : m3n + 1;  // (t + 2) % 3
+            if (!(SX_ABL & 8)) issue_batch(min(t + 3, n - 1), gs3, m3, min(t + 2, n - 1), m3p);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (BWD && t > 0 && wave == 0 && lane < 32) {
+            // cross-wave sum of the previous tile's dot partials (written to LDS before the barrier above)
+            a.dot_part[((long)b * M + lane) * a.dot_nparts + (long)(t0 + t - 1) * p.tiles_x + tx] =
+                lds_read_sum4(smem0 + SX_RED + ((t - 1) & 1) * 512 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- matrix phase of tile t with the in-place conversion of group t+1 woven in: one conversion unit (a row of the
+        // thread's pixel, then the halo record) between the nine matrix instructions of each (channel block, tap row) — their
+        // VALU work runs while the matrix pipe is busy.  Past the segment's end the unit converts a dead ring group (a
+        // duplicate of the last group, not counted): no branch inside the region.
+        // Two accumulation chains: hi*hi, and the two cross terms hi*lo + lo*hi (the small terms are summed among themselves
+        // before they meet the large one).
+        const bool cnt_ok = t + 1 < n;
+        const unsigned cring = smem0 + gs1 * SX_GROUP;
+        const unsigned csm = smem0 + SX_SMALL + m3n * SX_SMALL_ONE;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        unsigned rbase[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int row = rb + ky;
+            if (row >= 4 * SX_NG) row -= 4 * SX_NG;
+            rbase[ky] = row * SX_ROW;
+        }
+#pragma unroll
+        for (int kc = 0; kc < ((SX_ABL & 4) ? 0 : 2); ++kc) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int c = kc * 3 + ky;
+                half8 bh[3], bl[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const unsigned char* base = smem + rbase[ky] + kc * (SX_C * 64);
+                    bh[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][0]);
+                    bl[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][1]);
+                }
+                f32x4 rvu = {0.f, 0.f, 0.f, 0.f}, s4u = {0.f, 0.f, 0.f, 0.f}, chl[7];
+                if (!(SX_ABL & 2)) {
+                    if (c < 4) {
+                        // the four quarters of a record read it before any of them writes (one instruction stream per wave; the
+                        // block ends with lgkmcnt(0))
+                        if (BWD) lds_read2(cring + c * SX_ROW + crec + cq * 16, csm + (c * 32 + cpx) * 16, rvu, s4u);
+                        else rvu = lds_read1x4(cring + c * SX_ROW + crec + cq * 16);
+                    } else if (c == 4) {
+                        if (BWD) {
+                            lds_read2(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16, csm + (128 + wave * 2 + hside) * 16, rvu, s4u);
+                            lds_read7_16(smem0 + SX_CST + 128 + (hkc * 4 + cq) * 7 * 16, chl);
+                        } else {
+                            rvu = lds_read1x4(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tp = ky * 3 + kx;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], bh[kx], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], bl[kx], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx][kc], bh[kx], acc1, 0, 0, 0);
+                if (!(SX_ABL & 2)) {
+                    if (c < 4) {
+                        // rows counted in this workgroup's sums: its own 4n rows (the last group all but its last row); the halo
+                        // columns belong to the neighbouring strips
+                        const float fi = (cnt_ok && (t + 1 < n - 1 || c < 3)) ? 1.f : 0.f;
+                        convert_unit(rvu, s4u, cin, xs, fi, cring + c * SX_ROW + cwr, true);
+                    } else if (c == 4) {
+                        convert_unit(rvu, s4u, chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: this wave's row
+        const int py = R0 + 4 * t + wave;
+        f32x4 osc[4], dxv[4];
+        lds_read4_16(smem0 + SX_CST + half * 64, osc[0], osc[1], osc[2], osc[3]);
+        if (BWD) lds_read4(smem0 + SX_DOT + m3 * SX_DOT_ONE + wave * 4096 + lane * 16, dxv[0], dxv[1], dxv[2], dxv[3]);
+        float nz = 0.f;
+        if (!BWD) nz = nwf * lds_read1(smem0 + SX_SMALL + m3 * 1024 + wave * 256 + lane * 4);
+        float o[16], dsum[BWD ? 16 : 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc0[r] + acc1[r];
+            o[r] = v * osc[r >> 2][r & 3];
+            if (BWD) {
+                const float dv = dxv[r >> 2][r & 3];
+                dsum[BWD ? r : 0] = (v * us) * dv;
+                if (PRE) o[r] *= dv > 0.f ? kSqrt2 : 0.2f * kSqrt2;
+            } else {
+                o[r] += nz + bia[BWD ? 0 : r];
+                if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
+            }
+        }
+        if (RGB) {
+            // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
+            float c0s = 0.f, c1s = 0.f, c2s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c0s += wr[0][r] * o[r];
+                c1s += wr[RGB ? 1 : 0][r] * o[r];
+                c2s += wr[RGB ? 2 : 0][r] * o[r];
+            }
+            c0s += __shfl_xor(c0s, 32, 64);
+            c1s += __shfl_xor(c1s, 32, 64);
+            c2s += __shfl_xor(c2s, 32, 64);
+            if (half == 0) {
+                float* rp = a.rgb_y + (long)b * 3 * HW + (long)py * W + px;
+                rp[0] = c0s;
+                rp[HW] = c1s;
+                rp[2 * HW] = c2s;
+            }
+        }
+        if (SX_ABL & 1) {
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q += o[r];
+            if (q == 123456.75f) a.y[0] = q;
+        } else if (YF) {
+            float* yf = a.y + (((long)b * 2 * H + py) * W + px) * 16 + 4 * half;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                *reinterpret_cast<float4*>(yf + (long)(rr >> 1) * HW * 16 + (rr & 1) * 8) =
+                    make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
+        } else {
+            unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + c0) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + (long)(r & 3) * p.out_plane * 4 + moff[YF ? 0 : (r >> 2)]) = o[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (BWD) {
+            // sum over the 32 pixels of the row held by each half wave, then hand the 32 channel sums to LDS
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dsum[BWD ? r : 0] = half_sum_dpp(dsum[BWD ? r : 0]);
+            if (l31 == kHalfSumLane) {
+                const unsigned rp = smem0 + SX_RED + (t & 1) * 512 + wave * 128 + half * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds_write4(rp + ((r & 3) + 8 * (r >> 2)) * 4, dsum[BWD ? r : 0]);
+            }
+        }
+        rb += 4;
+        if (rb >= 4 * SX_NG) rb -= 4 * SX_NG;
+        gs1 = gs1 == SX_NG - 1 ? 0 : gs1 + 1;
+        m3 = m3n;
+    }
+    __builtin_amdgcn_s_waitcnt(SX_VM(0));
+    __syncthreads();
+    if (BWD) {
+        if (wave == 0 && lane < 32) {
+            const float* rp = red + ((n - 1) & 1) * 128;
+            a.dot_part[((long)b * M + lane) * a.dot_nparts + (long)(t0 + n - 1) * p.tiles_x + tx] =
+                rp[lane] + rp[32 + lane] + rp[64 + lane] + rp[96 + lane];
+        }
+        // partial sums of the activation backward: the 16 lanes of a wave with the same quarter (lane bits 2-5); the waves
+        // (ckc = wave >> 1, two waves per channel block) are combined by the first 32 threads
+        const oodgan_actbwd_fuse& f = p.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+                acc_r[BWD ? j : 0] += __shfl_xor(acc_r[BWD ? j : 0], o, 64);
+                acc_t[BWD ? j : 0] += __shfl_xor(acc_t[BWD ? j : 0], o, 64);
+            }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        float* fin = reinterpret_cast<float*>(smem + SX_FIN);         // [wave][quarter*4 + j][r, t]
+        float* finm = fin + 4 * 32 * 2;
+        if (lane < 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fin[(wave * 16 + lane * 4 + j) * 2 + 0] = acc_r[BWD ? j : 0];
+                fin[(wave * 16 + lane * 4 + j) * 2 + 1] = acc_t[BWD ? j : 0];
+            }
+        }
+        if (lane == 0) finm[wave] = amax;
+        __syncthreads();
+        const int part = seg * p.tiles_x + tx;
+        if (tid < 32) {      // channel tid: block tid >> 4 = waves 2 (tid >> 4) and + 1
+            const int wv = 2 * (tid >> 4), cc = tid & 15;
+            const long o = ((long)b * M + tid) * p.nparts + part;
+            f.part_r[o] = fin[(wv * 16 + cc) * 2] + fin[((wv + 1) * 16 + cc) * 2];
+            f.part_t[o] = fin[(wv * 16 + cc) * 2 + 1] + fin[((wv + 1) * 16 + cc) * 2 + 1];
+        }
+        if (tid < 2) f.part_max[((long)b * 2 + tid) * p.nparts + part] = fmaxf(finm[2 * tid], finm[2 * tid + 1]);
+    }
+}
+
+const void* zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+    }
+    return z;
+}
+
+int num_cus() {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        num_cu = prop.multiProcessorCount;
+    }
+    return num_cu;
+}
+
+// strips are cut into segments only when there are fewer strips than CUs (one workgroup per CU: 152 KB of LDS); tiles of 4 rows
+void segments(int B, int H, int W, int& tiles_x, int& tiles_y, int& seg_tiles, int& nseg) {
+    tiles_y = (H + 3) / 4;
+    tiles_x = (W + 31) / 32;
+    const int ncu = num_cus() > 0 ? num_cus() : 256;
+    const long strips = (long)B * tiles_x;
+    int ns = (int)((ncu + strips - 1) / strips);
+    if (ns < 1) ns = 1;
+    seg_tiles = (tiles_y + ns - 1) / ns;
+    if (seg_tiles < 8) seg_tiles = tiles_y < 8 ? tiles_y : 8;
+    nseg = (tiles_y + seg_tiles - 1) / seg_tiles;
+}
+
+}  // namespace
+
+// number of partial sums per (sample, channel) the x_fform == 2 kernel writes to fuse->part_r / part_t (and per (sample,
+// 16-channel block) to part_max)
+extern "C" int oodgan_conv3x3_xf_nparts(int B, int H, int W) {
+    int tx, ty, st, ns;
+    segments(B, H, W, tx, ty, st, ns);
+    return tx * ns;
+}
+
+// dot_nparts of the x_fform == 2 instance: one partial per 4-row tile
+extern "C" int oodgan_conv3x3_xf_dot_nparts(int H, int W) { return ((H + 3) / 4) * ((W + 31) / 32); }
+
+extern "C" int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W) {
+    return (B > 0 && K == 32 && M == 32 && H >= 8 && W >= 32 && H % 4 == 0 && W % 32 == 0 && (long)H * W * 64 * 2 < (1L << 32)) ? 1 : 0;
+}
+
+namespace oodgan {
+
+int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {
+    StripX p;
+    p.a = a_in;
+    oodgan_conv_args& a = p.a;
+    OODGAN_REQUIRE(oodgan_conv3x3_xf_supported(a.B, a.K, a.M, a.Hin, a.Win), "conv3x3 F-form input: needs K == M == 32, H %% 4 == 0, W %% 32 == 0");
+    OODGAN_REQUIRE(a.mode == OODGAN_CONV_S1 && !a.x_sform && a.in_shift == nullptr && a.ys == nullptr && a.y != nullptr && a.groups <= 1,
+                   "conv3x3 F-form input: mode S1, no shift, no S-form output");
+    OODGAN_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0, "conv3x3 F-form input: 16-byte aligned x and y");
+    if (a.out_pitch == 0) a.out_pitch = a.Win;
+    p.out_plane = (long)a.Hin * a.out_pitch;
+    p.w_unscale = unscale;
+    p.zeros = zero_page();
+    OODGAN_REQUIRE(p.zeros != nullptr, "conv3x3 F-form input: cannot allocate the zero page");
+    segments(a.B, a.Hin, a.Win, p.tiles_x, p.tiles_y, p.seg_tiles, p.nseg);
+    p.Mp = (a.M + 63) / 64 * 64;
+    p.nparts = p.tiles_x * p.nseg;
+    const bool bwd = a.x_fform == 2;
+    if (bwd) {
+        OODGAN_REQUIRE(a.fuse != nullptr && a.dotx != nullptr && a.dotx_fform && a.dot_part != nullptr && a.in_scale == nullptr,
+                       "conv3x3 x_fform 2: needs fuse (the activation backward), an F-form dotx, dot_part and no in_scale");
+        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 x_fform 2: dot_nparts %d != %d", a.dot_nparts, p.tiles_x * p.tiles_y);
+        OODGAN_REQUIRE(a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && a.rgb_y == nullptr && !a.y_fform,
+                       "conv3x3 x_fform 2: the input-gradient instance has no noise / bias / activation / ToRGB / F-form output");
+        p.f = *a.fuse;
+        OODGAN_REQUIRE(p.f.part_r && p.f.part_t && p.f.part_max && p.f.dscale && p.f.g_rgb && p.f.w_rgb && p.f.s_rgb,
+                       "conv3x3 x_fform 2: incomplete fuse arguments (the ToRGB branch is mandatory: it is the only gradient source)");
+        OODGAN_REQUIRE(p.f.noise == nullptr || p.f.noise_batch == 1 || p.f.noise_batch == a.B, "conv3x3 x_fform 2: noise_batch");
+        OODGAN_REQUIRE((long)a.M * p.out_plane * 4 < (1L << 32), "conv3x3 x_fform 2: plane too large");
+        a.fuse = nullptr;
+    } else {
+        OODGAN_REQUIRE(a.x_fform == 1 && a.dotx == nullptr && a.fuse == nullptr && a.y_fform && a.out_pitch == a.Win,
+                       "conv3x3 x_fform 1: the forward instance writes a dense F-form y and takes no dotx / fuse");
+        OODGAN_REQUIRE(a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU, "conv3x3 x_fform 1: act must be none or lrelu");
+        OODGAN_REQUIRE(a.rgb_y == nullptr || (a.rgb_w && a.rgb_s), "conv3x3 x_fform 1: the fused ToRGB needs rgb_w and rgb_s");
+        p.f = oodgan_actbwd_fuse{};
+    }
+    const long nblk = (long)a.B * p.tiles_x * p.nseg;
+    OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 F-form input: grid too large");
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM), true);
+    (void)once;
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    const dim3 grid((unsigned)nblk), block(256);
+    if (bwd) {
+        if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false>), grid, block, SX_SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false>), grid, block, SX_SMEM, st, p, w16);
+    } else if (a.rgb_y) hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, true, false, true>), grid, block, SX_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, false, false, true>), grid, block, SX_SMEM, st, p, w16);
+    return check_launch("conv3x3_f16s_stripx");
+}
+
+}  // namespace oodgan

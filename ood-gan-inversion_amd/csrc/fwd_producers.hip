@@ -47,6 +47,7 @@ struct BlurArgs {
     int tiles_x, tiles_y;
     SDims yd;
     unsigned* vmax;          // (B) or null: max |value written to ys| per sample (fwd_range.hip)
+    int y_fform;             // 1: y is written in F-form ([B][C/16][2H][2W][16]) and there is no S-form output; vmax = max |y*ys_scale|
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur_act_sform_kernel(const BlurArgs a) {
@@ -179,13 +180,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float* cell = &lst[cc * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)];
             float t = *cell + nz + cb[0][cc];
             if (a.act == OODGAN_ACT_LRELU) t = (t > 0.f ? t : 0.2f * t) * kSqrt2;
-            if (kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
+            if (!a.y_fform && kc * 16 + cc < a.C) yp[(long)cc * HWo] = t;
             const float v = t * cb[1][cc];
             vm = fmaxf(vm, fabsf(v));
-            *cell = v;
+            *cell = a.y_fform ? t : v;
         }
     }
-    if (a.ys) {
+    if (a.y_fform) {
+        // ---- D': the 64-byte fp32 records, one channel quarter (16 bytes) per thread and pass, the 64 lanes of a store writing 64
+        // consecutive quarters (1 KB contiguous)
+        __syncthreads();
+        float* yf = a.y + ((long)b * KC + kc) * HWo * 16;
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) {
+            const int u = tid + rep * 256;
+            const int pos = u >> 2, q = u & 3;
+            const int Y = Y0 + (pos >> 6), X = X0 + (pos & 63);
+            if (Y >= Ho || X >= Wo) continue;
+            const float* cell = &lst[(4 * q) * LS_CH + (pos >> 6) * LS_ROW + (pos & 63)];
+            *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X) * 16 + 4 * q) = make_float4(cell[0], cell[LS_CH], cell[2 * LS_CH], cell[3 * LS_CH]);
+        }
+    }
+    if (a.ys && !a.y_fform) {
         // ---- D: the 64-byte records, one 16-byte slot per thread and pass (slots 0,1 = hi halves of channels 0-7 / 8-15, slots
         // 2,3 = lo halves), ordered so that the 64 lanes of a store write 64 CONSECUTIVE slots (1 KB contiguous): one thread per
         // record issues four 16-byte pieces at a 64-byte stride, four times the memory transactions
@@ -211,10 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 }  // namespace
 
-extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
-                                     int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
-                                     const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
-                                     void* stream) {
+static int blur_act_launch(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
+                           int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
+                           const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
+                           int y_fform, void* stream) {
     OODGAN_REQUIRE(z && kernel && y && B > 0 && C > 0 && H > 0 && W > 0, "blur_act_sform: bad args");
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "blur_act_sform: noise_batch");
     OODGAN_REQUIRE(act == OODGAN_ACT_NONE || act == OODGAN_ACT_LRELU, "blur_act_sform: act must be none or lrelu");
@@ -228,9 +244,24 @@ extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float*
     a.tiles_x = (2 * W + 63) / 64;
     a.tiles_y = (2 * H + 7) / 8;
     a.yd = sform_dims(C, 2 * H, 2 * W);
-    a.vmax = ys ? vmax : nullptr;
+    a.vmax = (ys || y_fform) ? vmax : nullptr;
+    a.y_fform = y_fform;
+    OODGAN_REQUIRE(!y_fform || (C % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0), "blur_act_fform: C %% 16 == 0 and a 16-byte aligned y");
     const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "blur_act_sform: grid too large");
     hipLaunchKernelGGL(blur_act_sform_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);
     return check_launch("blur_act_sform");
+}
+
+extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
+                                     int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
+                                     const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
+                                     void* stream) {
+    return blur_act_launch(z, kernel, y, ys, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 0, stream);
+}
+
+extern "C" int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const float* ys_scale, int ys_scale_stride,
+                                     const float* bias, const float* noise, int noise_batch, const float* noise_w, int act,
+                                     int B, int C, int H, int W, int in_pitch, unsigned* vmax, void* stream) {
+    return blur_act_launch(z, kernel, y, nullptr, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 1, stream);
 }

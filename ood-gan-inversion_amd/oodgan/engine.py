@@ -91,6 +91,7 @@ class GeneratorEngine:
         self.by_name = {L.name: L for L in layers}
         self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
         self.fused_rgb = True
+        self.fuse_x = True           # 1024² level: F-form activations, the strip convs convert their input themselves (conv_f16s_stripx.hip)
         self.batched_tail = True
         src = 'input'
         for L in layers:            # producer of every layer's input feature
@@ -257,7 +258,10 @@ class GeneratorEngine:
             if L.kind == 'conv':
                 if self.sform:
                     # S-form hand-off: style folded in while splitting, the conv then streams its tiles by LDS-DMA
-                    if pending is not None:     # written by the up-conv tail that produced `out`
+                    xf_in = isinstance(out, ops.FForm)      # the up-conv tail left its activation in F-form: converted inside the conv
+                    if xf_in:
+                        xs = out
+                    elif pending is not None:     # written by the up-conv tail that produced `out`
                         xs, pending = pending, None
                     else:
                         xs = to_s(L, out)
@@ -271,7 +275,7 @@ class GeneratorEngine:
                               and self.bwd_state.get(L.name) is not None and not return_features)
                         out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                                        noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)),
-                                                       y_fform=ff)
+                                                       y_fform=ff or xf_in, in_scale=_Cols(s_use, L.row, L.cin) if xf_in else None)
                     else:
                         out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                           noise_weight=L.noise_w, act=ACT_LRELU)
@@ -299,9 +303,17 @@ class GeneratorEngine:
                     # blur + noise + bias + activation, and the following conv's S-form input (x its style), in one pass
                     Ln = self.next_conv[L.name]
                     Hi = out.shape[2]
-                    pending = ops.sform_scratch(B, L.cout, 2 * Hi, 2 * Hi, self.device, tag=2)
-                    out = ops.blur_act_sform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True, ys=pending,
-                                             ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                    if (save and self.fuse_x and self.fused_bwd and self.fused_rgb and Ln is self.layers_styled_last and not return_features
+                            and self.bwd_state.get(Ln.name) is not None and self.bwd_state.get(L.name) is not None
+                            and ops.xf_supported(B, Ln.cin, Ln.cout, 2 * Hi, 2 * Hi)):
+                        # last level inside the W+ loop: the activation stays in F-form and the conv converts it itself — no
+                        # S-form copy of the largest tensor of the step is written or read
+                        out = ops.blur_act_fform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True,
+                                                 ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                    else:
+                        pending = ops.sform_scratch(B, L.cout, 2 * Hi, 2 * Hi, self.device, tag=2)
+                        out = ops.blur_act_sform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True, ys=pending,
+                                                 ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
                 else:
                     out = ops.blur_bias_act(z, self.k4x4, (1, 1), L.bias, nz, L.noise_w, act=True, in_hw=(H2, H2),
                                             in_pitch=z.shape[3])
@@ -360,8 +372,14 @@ class GeneratorEngine:
                 prev_rgb = L
                 continue
             out, x_in, nz = acts[L.name], acts[L.src], noises[L.noise_idx]
-            if isinstance(out, ops.FForm) and not (carry_scale and self.fused_bwd and self.bwd_state.get(L.name) is not None and g_feat is None):
+            fused_ok = carry_scale and self.fused_bwd and self.bwd_state.get(L.name) is not None
+            # last level: out and x_in in F-form -> the activation backward runs inside the input-gradient conv (ops.ActBwdX)
+            xf_bwd = (fused_ok and g_feat is None and L.kind == 'conv' and isinstance(out, ops.FForm) and isinstance(x_in, ops.FForm)
+                      and prev_rgb is not None and self.fuse_x)
+            if isinstance(out, ops.FForm) and not (fused_ok and (g_feat is None or fused_pre is not None)):
                 out = out.to_nchw()         # the two-pass path reads NCHW
+            if isinstance(x_in, ops.FForm) and not xf_bwd:
+                x_in = x_in.to_nchw()
             s = _Cols(s_all, L.row, L.cin)
             d = _Cols(d_all, L.drow, L.cout)
             Hd = x_in.shape[2]
@@ -374,6 +392,9 @@ class GeneratorEngine:
                 # gradient, partial sums and maxima come from there; g_feat never went to HBM)
                 gin, rsum, tsum, part_m = fused_in.dst, fused_in.r, None, fused_in.part_m
                 fused_in = None
+                mul2, g_pre = st, None
+            elif st is not None and xf_bwd:
+                gin, rsum, tsum, part_m = None, None, None, None        # produced by the conv below (ops.ActBwdX)
                 mul2, g_pre = st, None
             elif st is not None:
                 # fused producer: g_pre goes straight into the next matrix kernel's input layout, scaled with the
@@ -407,6 +428,19 @@ class GeneratorEngine:
                 gs_all[:, Rg.row:Rg.row + Rg.cin] = tsum
             # demodulation gradient
             deferred = st is not None and jobs is not None
+            xa = None
+            if st is not None and xf_bwd:
+                xa = ops.ActBwdX(nz, L.noise_w, L.bias, d, st, gskip[L.res], Rg.w_rgb, _Cols(s_all, Rg.row, Rg.cin),
+                                 t_into=_Cols(gs_all, Rg.row, Rg.cin))
+                pre = None
+                Lp = self.by_name.get(L.src)
+                if (Lp is not None and Lp.kind == 'up' and self.fuse_act_bwd and self.bwd_state.get(L.src) is not None
+                        and ops.s1_actgrad_supported(B, L.cout, L.cin, out.shape[2], out.shape[3])):
+                    pre = ops.DotActGrad()
+                dx, dot = ops.conv3x3(out, L.wpk_bwd, L.cin, CONV_S1, out_scale=s, dotx=x_in, in_mul2=mul2,
+                                      dot_into=_Cols(gs_all, L.row, L.cin), jobs=jobs, dot_actgrad=pre, xf_act=xa)
+                rsum, part_m = xa.r, xa.part_m
+                fused_in, fused_pre = None, pre
             if deferred:        # rsum is filled by the batched reduction at the end of the pass; so is this job's input
                 jobs.add_demod(_Cols(s_all, L.row, L.cin), L.wsq, _Cols(d_all, L.drow, L.cout), rsum, _Cols(gs_all, L.row, L.cin), B, L.cin,
                                L.cout, L.scale)
@@ -415,7 +449,12 @@ class GeneratorEngine:
                                              ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, ctypes.c_void_p(rsum.data_ptr()),
                                              ctypes.c_void_p(gs_all.data_ptr() + 4 * L.row), self.R, B, L.cin, L.cout, L.scale,
                                              ops._stream()), 'demod_bwd')
-            if st is not None:
+            if xa is not None:
+                if deferred:
+                    jobs.add_check(part_m, st)
+                else:
+                    ops.absmax_scale_check(part_m, st, self.bwd_flag)
+            elif st is not None:
                 fz = None
                 Lp = self.by_name.get(L.src)
                 stp = self.bwd_state.get(L.src) if (L.kind == 'up' and Lp is not None and self.fuse_act_bwd) else None

@@ -357,6 +357,25 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     return y
 
 
+def blur_act_fform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys_scale=None, vmax=None):
+    """The same tail with y in F-form and no S-form (include/oodgan.h, oodgan_blur_act_fform): the following conv converts its input
+    itself (``conv3x3(FForm, ..., in_scale=style)``); ``vmax`` still records max |y * ys_scale| for the forward range control."""
+    z = _dev(z)
+    B, C = z.shape[0], z.shape[1]
+    y = torch.empty(B, C, 2 * H, 2 * W, device=z.device, dtype=torch.float32)
+    nz = _opt(noise, 'noise')
+    check(_lib.lib().oodgan_blur_act_fform(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(_opt(ys_scale, 'ys_scale')),
+                                           0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
+                                           1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
+                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), _stream()), 'blur_act_fform')
+    return FForm(y)
+
+
+def xf_supported(B, K, M, H, W):
+    """``conv3x3`` takes an ``FForm`` input of this shape (csrc/conv_f16s_stripx.hip)."""
+    return bool(_lib.lib().oodgan_conv3x3_xf_supported(B, K, M, H, W))
+
+
 VMAX_SLOTS = 64      # OODGAN_VMAX_SLOTS (include/oodgan.h)
 
 
@@ -651,13 +670,17 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
             in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,
-            groups=1, y_fform=False):
+            groups=1, y_fform=False, xf_act=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
     packed weight G*Mg output channels of K inputs (mode S2, fp32 input)."""
     sform_in = isinstance(x, (SForm, SFormPhases))
-    if not sform_in:
+    fform_in = isinstance(x, FForm)      # split-f16 strip kernel with in-kernel conversion (include/oodgan.h, x_fform)
+    if fform_in:
+        assert mode == CONV_S1 and wpk.precision == 'f16s'
+        y_fform = xf_act is None        # forward: F-form out; input gradient (xf_act: the activation backward that makes the input): NCHW
+    elif not sform_in:
         x = _dev(x)
     B, K = x.shape[0], x.shape[1] // max(1, groups)
     H, W = in_hw if in_hw is not None else (x.shape[2], x.shape[3])
@@ -671,7 +694,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         oh, ow = (H - 1) // 2, (W - 1) // 2
     pitch = out_pitch if out_pitch else ow
     if out is None and want_y:
-        out = torch.empty(B, M, oh, pitch, device=x.data.device if sform_in else x.device, dtype=torch.float32)
+        out = torch.empty(B, M, oh, pitch, device=x.data.device if (sform_in or fform_in) else x.device, dtype=torch.float32)
     a = ConvArgs()
     a.x, a.wpk, a.y = _p(x), _p(wpk), _p(out)
     a.in_scale, a.in_shift, a.out_scale = _p(_opt(in_scale, 'in_scale')), _p(_opt(in_shift, 'in_shift')), _p(_opt(out_scale, 'out_scale'))
@@ -684,6 +707,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.mode, a.act = mode, act
     a.in_mul2 = _p(in_mul2)
     a.x_sform = 1 if sform_in else 0
+    a.x_fform = (2 if xf_act is not None else 1) if fform_in else 0
     a.groups = int(groups)
     a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
@@ -698,10 +722,17 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     if fuse is not None:        # ActBwdFusion: the activation backward of the layer below runs in this conv's epilogue
         fz = fuse.struct(B, M, oh, ow)
         a.fuse = ctypes.cast(ctypes.pointer(fz), ctypes.c_void_p)
+    if xf_act is not None:      # ActBwdX: the activation backward of THIS layer produces the conv input inside the kernel
+        fz = xf_act.struct(B, K, H, W)
+        a.fuse = ctypes.cast(ctypes.pointer(fz), ctypes.c_void_p)
     part = None
     if dotx is not None:
-        dx_ = _dev(dotx, 'dotx')
-        if wpk.precision == 'f16s':
+        dot_f = isinstance(dotx, FForm)
+        dx_ = dotx.data if dot_f else _dev(dotx, 'dotx')
+        a.dotx_fform = 1 if dot_f else 0
+        if fform_in:
+            npart = _lib.lib().oodgan_conv3x3_xf_dot_nparts(H, W)
+        elif wpk.precision == 'f16s':
             npart = _lib.lib().oodgan_conv3x3_f16s_nparts2(mode, H, W, 1 if sform_in else 0)
         else:
             npart = _lib.lib().oodgan_conv3x3_nparts(mode, H, W)
@@ -716,6 +747,8 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         check(_lib.lib().oodgan_conv3x3(ctypes.byref(a), _stream()), 'conv3x3')
     if fuse is not None:
         fuse.finish(part, a.dot_nparts, jobs)
+    if xf_act is not None:
+        xf_act.finish(jobs)
     if dotx is not None:
         if dot_into is not None:        # += into the layer's columns of the style-gradient accumulator
             if jobs is not None:
@@ -795,6 +828,51 @@ class ActBwdFusion:
                 _reduce_into(self.part_t, B, M, nparts, self.t_into, False)
             else:
                 self.t = _reduce_parts(self.part_t, B * M, nparts)
+
+
+class ActBwdX:
+    """Arguments and results of the activation backward that runs INSIDE the input-gradient conv of the same layer
+    (``conv3x3(out_fform, wpk_bwd, ..., xf_act=this)``, oodgan_conv_args.x_fform = 2): the quantities ``act_bwd_producer`` returns
+    — (r, t, part_max) — without the S-form gradient ever going to HBM.  Last styled conv only: its gradient comes from ToRGB alone."""
+
+    def __init__(self, noise, noise_weight, bias, dscale, mul2, g_rgb, w_rgb, s_rgb, t_into=None):
+        self.noise, self.noise_weight, self.bias, self.dscale, self.mul2 = _opt(noise, 'noise'), _opt(noise_weight, 'nw'), _opt(bias, 'bias'), dscale, mul2
+        self.g_rgb, self.w_rgb, self.s_rgb, self.t_into = _dev(g_rgb, 'g_rgb'), w_rgb, s_rgb, t_into
+        self.r = self.t = self.part_m = None
+
+    def struct(self, B, C, H, W):
+        dev = self.g_rgb.device
+        self.B, self.C = B, C
+        self.nparts = _lib.lib().oodgan_conv3x3_xf_nparts(B, H, W)
+        self.part_r = torch.empty(B, C, self.nparts, device=dev, dtype=torch.float32)
+        self.part_t = torch.empty(B, C, self.nparts, device=dev, dtype=torch.float32)
+        self.part_m = torch.empty(B * ((C + 15) // 16) * self.nparts, device=dev, dtype=torch.float32)
+        z = _lib.ActBwdFuse()
+        z.g_rgb, z.noise, z.noise_w, z.bias = _p(self.g_rgb), _p(self.noise), _p(self.noise_weight), _p(self.bias)
+        self._w = _dev(self.w_rgb).reshape(3, C)
+        z.w_rgb, z.s_rgb, z.s_rgb_stride = _p(self._w), _p(self.s_rgb), self.s_rgb.shape[1]
+        z.noise_batch = 1 if self.noise is None else self.noise.shape[0]
+        z.dscale, z.dscale_stride, z.mul2, z.ys = _p(self.dscale), self.dscale.shape[1], _p(self.mul2), None
+        z.part_r, z.part_t, z.part_max = _p(self.part_r), _p(self.part_t), _p(self.part_m)
+        z.rgb_scale, z.nmax = 1.0 / math.sqrt(C), self.part_m.numel()
+        return z
+
+    def finish(self, jobs):
+        B, C = self.B, self.C
+        if jobs is not None:
+            self.r = torch.empty(B, C, device=self.part_r.device, dtype=torch.float32)
+            jobs.add_reduce(self.part_r, self.r, B, C, self.nparts, C, False)
+            if self.t_into is not None:
+                jobs.add_reduce(self.part_t, self.t_into, B, C, self.nparts, self.t_into.shape[1], False)
+            else:
+                self.t = torch.empty(B, C, device=self.part_r.device, dtype=torch.float32)
+                jobs.add_reduce(self.part_t, self.t, B, C, self.nparts, C, False)
+            return
+        self.r = _reduce_parts(self.part_r, B * C, self.nparts)
+        if self.t_into is not None:
+            _reduce_into(self.part_t, B, C, self.nparts, self.t_into, False)
+        else:
+            self.t = _reduce_parts(self.part_t, B * C, self.nparts)
 
 
 def rgb_finish(partial, bias=None, skip=None, kernel=None):

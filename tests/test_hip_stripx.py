@@ -1,0 +1,110 @@
+"""The strip conv with in-kernel conversion of an F-form input (csrc/conv_f16s_stripx.hip, oodgan_conv_args.x_fform) against the
+two-pass path it replaces at the 1024² level of the W+ loop: S-form producer + strip conv (conv_f16s_strip.hip), both already
+pinned against the oracle / the reference's float64 generator (test_hip_ops.py, test_hip_wplus_golden.py).  Same arithmetic up to
+the order of the fp32 accumulation of the hi*lo / lo*hi terms."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R_, 'ood-gan-inversion_amd'))
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_fform(x):
+    B, C, H, W = x.shape
+    return x.view(B, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().view(B, C, H, W)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 40, 96), (3, 8, 32), (1, 1024, 1024)])
+def test_forward_with_fform_input(B, H, W):
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(H * 7 + W)
+    C = 32
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, C, generator=g)).abs().to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+    wf = ops.pack_conv3x3(w, precision='f16s')
+    nz = torch.randn(B, 1, H, W, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    w_rgb, s_rgb = torch.randn(3, C, generator=g).to(dev), (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    assert ops.xf_supported(B, C, C, H, W)
+    xs = ops.to_sform(x, s)
+    y0, rgb0 = ops.conv3x3(xs, wf, C, ops.CONV_S1, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, rgb=(w_rgb, s_rgb))
+    y1, rgb1 = ops.conv3x3(ops.FForm(_to_fform(x)), wf, C, ops.CONV_S1, in_scale=s, out_scale=d, bias=bias, noise=nz, noise_weight=nw,
+                           act=ops.ACT_LRELU, rgb=(w_rgb, s_rgb))
+    assert isinstance(y1, ops.FForm)
+    assert _rel(y1.to_nchw(), y0) < 1e-6 and _rel(rgb1, rgb0) < 1e-6
+    y2 = ops.conv3x3(ops.FForm(_to_fform(x)), wf, C, ops.CONV_S1, in_scale=s, out_scale=d, bias=bias, noise=nz[:1], noise_weight=nw, act=ops.ACT_LRELU)
+    y3 = ops.conv3x3(xs, wf, C, ops.CONV_S1, out_scale=d, bias=bias, noise=nz[:1], noise_weight=nw, act=ops.ACT_LRELU)
+    assert _rel(y2.to_nchw(), y3) < 1e-6
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 40, 96), (3, 8, 32), (1, 1024, 1024)])
+@pytest.mark.parametrize('pre', [True, False])
+def test_input_gradient_with_the_activation_backward_inside(B, H, W, pre):
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(H * 5 + W + 1)
+    C = 32
+    out2 = torch.randn(B, C, H, W, generator=g).to(dev)
+    out1 = torch.randn(B, C, H, W, generator=g).to(dev)
+    g_rgb = (1e-3 * torch.randn(B, 3, H, W, generator=g)).to(dev)
+    nz = torch.randn(B, 1, H, W, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    s1 = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    w_rgb, s_rgb = torch.randn(3, C, generator=g).to(dev), (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+    wb = ops.pack_conv3x3(w, transpose=True, flip=True, precision='f16s')
+    mul2 = torch.tensor([2.0 ** -14, 2.0 ** 14], device=dev)
+    o2f, o1f = ops.FForm(_to_fform(out2)), ops.FForm(_to_fform(out1))
+    # two passes: producer -> S-form -> strip conv
+    gin = ops.SForm(B, C, H, W, dev)
+    r0, t0, pm0 = ops.act_bwd_producer(o2f, None, nz, nw, bias, d, mul2, gin, g_rgb=g_rgb, w_rgb=w_rgb, s_rgb=s_rgb)
+    dx0, dot0 = ops.conv3x3(gin, wb, C, ops.CONV_S1, out_scale=s1, dotx=out1, in_mul2=mul2, dot_actgrad=ops.DotActGrad() if pre else None)
+    # one pass
+    xa = ops.ActBwdX(nz, nw, bias, d, mul2, g_rgb, w_rgb, s_rgb)
+    dx1, dot1 = ops.conv3x3(o2f, wb, C, ops.CONV_S1, out_scale=s1, dotx=o1f, in_mul2=mul2, dot_actgrad=ops.DotActGrad() if pre else None, xf_act=xa)
+    assert _rel(dx1, dx0) < 1e-6
+    assert _rel(dot1, dot0) < 2e-5          # sums of +-1e-3 terms over H*W pixels in a different order
+    assert _rel(xa.r, r0) < 2e-5 and _rel(xa.t, t0) < 2e-5
+    assert float(xa.part_m.max()) == float(pm0.max())
+    # no noise / shared noise variants
+    xa2 = ops.ActBwdX(None, None, None, d, mul2, g_rgb, w_rgb, s_rgb)
+    dx2, _ = ops.conv3x3(o2f, wb, C, ops.CONV_S1, out_scale=s1, dotx=o1f, in_mul2=mul2, xf_act=xa2)
+    gin2 = ops.SForm(B, C, H, W, dev)
+    r2, _, _ = ops.act_bwd_producer(o2f, None, None, None, None, d, mul2, gin2, g_rgb=g_rgb, w_rgb=w_rgb, s_rgb=s_rgb)
+    dx3, _ = ops.conv3x3(gin2, wb, C, ops.CONV_S1, out_scale=s1, dotx=out1, in_mul2=mul2)
+    assert _rel(dx2, dx3) < 1e-6 and _rel(xa2.r, r2) < 2e-5
+
+
+def test_blur_act_fform_equals_blur_act_sform():
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(77)
+    B, C, H = 2, 32, 48
+    pitch = (2 * H + 1 + 3) // 4 * 4
+    z = torch.randn(B, C, 2 * H + 1, pitch, generator=g).to(dev)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+    nz = torch.randn(B, 1, 2 * H, 2 * H, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    ys = ops.SForm(B, C, 2 * H, 2 * H, dev)
+    vm0 = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+    vm1 = torch.zeros_like(vm0)
+    y0 = ops.blur_act_sform(z, k, H, H, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm0)
+    y1 = ops.blur_act_fform(z, k, H, H, bias, nz, nw, act=True, ys_scale=s, vmax=vm1)
+    assert torch.equal(y1.to_nchw(), y0)
+    assert torch.equal(vm0.max(dim=1).values, vm1.max(dim=1).values)

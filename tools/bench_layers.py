@@ -36,6 +36,39 @@ def report(tag, ms, flops, byts):
     print(f'{tag:34s} {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF/s  {byts / ms / 1e6:7.1f} GB/s', flush=True)
 
 
+def to_fform(x):
+    B_, C_, H_, W_ = x.shape
+    return ops.FForm(x.view(B_, C_ // 16, 16, H_, W_).permute(0, 1, 3, 4, 2).contiguous().view(B_, C_, H_, W_))
+
+
+if 'SX' in which:               # the 1024² level inside the W+ loop: two-pass path against the strip conv that converts its input itself
+    C, H = 32, 1024
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+    wf = ops.pack_conv3x3(w, precision='f16s')
+    wb = ops.pack_conv3x3(w, transpose=True, flip=True, precision='f16s')
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, C, generator=g)).abs().to(dev)
+    nz = torch.randn(B, 1, H, H, generator=g).to(dev)
+    nw, bias = torch.tensor([0.1], device=dev), torch.zeros(C, device=dev)
+    w_rgb, s_rgb = torch.randn(3, C, generator=g).to(dev), (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    g_rgb = (1e-3 * torch.randn(B, 3, H, H, generator=g)).to(dev)
+    mul2 = torch.tensor([2.0 ** -14, 2.0 ** 14], device=dev)
+    xs, xf = ops.to_sform(x, s), to_fform(x)
+    out2 = torch.randn(B, C, H, H, generator=g).to(dev)
+    o2f = to_fform(out2)
+    del out2
+    fl, by = 2.0 * B * C * C * 9 * H * H, 4.0 * B * C * H * H
+    report('fwd S-form in, F-form out, rgb', timeit(lambda: ops.conv3x3(xs, wf, C, ops.CONV_S1, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, rgb=(w_rgb, s_rgb), y_fform=True)), fl, 2 * by)
+    report('fwd F-form in (x_fform 1), rgb', timeit(lambda: ops.conv3x3(xf, wf, C, ops.CONV_S1, in_scale=s, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU, rgb=(w_rgb, s_rgb))), fl, 2 * by)
+    gin = ops.SForm(B, C, H, H, dev)
+    report('bwd producer act_bwd_sform_f', timeit(lambda: ops.act_bwd_producer(o2f, None, nz, nw, bias, d, mul2, gin, g_rgb=g_rgb, w_rgb=w_rgb, s_rgb=s_rgb)), 0, 2 * by)
+    report('bwd strip conv + dot + act grad', timeit(lambda: ops.conv3x3(gin, wb, C, ops.CONV_S1, out_scale=s, dotx=x, in_mul2=mul2, dot_actgrad=ops.DotActGrad())), fl, 3 * by)
+    report('bwd x_fform 2 (both in one)', timeit(lambda: ops.conv3x3(o2f, wb, C, ops.CONV_S1, out_scale=s, dotx=xf, in_mul2=mul2, dot_actgrad=ops.DotActGrad(),
+                                                                     xf_act=ops.ActBwdX(nz, nw, bias, d, mul2, g_rgb, w_rgb, s_rgb))), fl, 3 * by)
+    sys.exit(0)
+
 for res in (8, 16, 32, 64, 128, 256, 512, 1024):
     if only and res not in only:
         continue
