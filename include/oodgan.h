@@ -182,7 +182,8 @@ typedef struct oodgan_conv_args {
                                   this conv's input; `fuse` describes that backward exactly as for oodgan_act_bwd_sform
                                   (g = s_rgb*t, g_pre = g*act'(out), staged value = g_pre*dscale*mul2[1]; fuse->ys unused) and
                                   receives part_r / part_t (B,32,nparts) and part_max (B*2*nparts floats) with
-                                  nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win); dotx (F-form, dotx_fform = 1) is mandatory, y NCHW. */
+                                  nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win) — also the dot_nparts of this instance; dotx (F-form,
+                                  dotx_fform = 1) is mandatory, y NCHW. */
     int dotx_fform;          /* 1: dotx is in F-form (x_fform == 2 only) */
 } oodgan_conv_args;
 
@@ -240,7 +241,6 @@ int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
  * x_fform == 2 instance writes to fuse->part_r / part_t (per (sample, 16-channel block) to fuse->part_max) */
 int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W);
 int oodgan_conv3x3_xf_nparts(int B, int H, int W);
-int oodgan_conv3x3_xf_dot_nparts(int H, int W);    /* dot_nparts the x_fform == 2 instance expects (one partial per 4-row tile) */
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs

@@ -21,7 +21,7 @@
 //     matrix phase that way.  With no register loads the only vmcnt waits are the explicit counted ones below, which leave two
 //     tiles of prefetch and the newest stores in flight (memory operations of a wave retire in issue order);
 //   * the operation counts per tile and wave are uniform (clamped duplicates instead of branches; H % 4 == 0, W % 32 == 0):
-//     backward 12 DMA + 16 stores (+1 in wave 0), forward 6 DMA + 4 (+3) stores — far below the 64 the 6-bit counter allows.
+//     backward 12 DMA + 16 stores, forward 6 DMA + 4 (+3) stores — far below the 64 the 6-bit counter allows.
 #include "conv_common.hpp"
 #include "sform.hpp"
 #include <cstdint>
@@ -52,7 +52,8 @@ constexpr int SX_DOT_ONE = 16384;
 constexpr int SX_RED = SX_DOT + 3 * SX_DOT_ONE;        // 2 x 4 waves x 32 floats: dot partials of two tiles
 constexpr int SX_FIN = SX_RED + 1024;                  // final sums: [4 waves][32 ch][r,t] + [4][2] maxima
 constexpr int SX_CST = SX_FIN + 4 * 32 * 2 * 4 + 64;   // [2 halves][16] epilogue scales, then [kc 2][quarter 4][7] float4 constants
-constexpr int SX_SMEM = SX_CST + 128 + 8 * 7 * 16;     // 152 KiB
+constexpr int SX_EPC = SX_CST + 128 + 8 * 7 * 16;      // forward: [half 2][rr 4][bias, wr0, wr1, wr2][4 channels] floats
+constexpr int SX_SMEM = SX_EPC + 512;                  // 152 KiB
 
 #define SX_VM(n) ((((n) >> 4) & 3) << 14 | 0x0F70 | ((n) & 15))
 #define SX_VML(n) ((((n) >> 4) & 3) << 14 | 0x0070 | ((n) & 15))      // ... and lgkmcnt(0)
@@ -197,20 +198,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int k = 0; k < 7; ++k) cst[tid * 7 + k] = make_float4(c7[k][0], c7[k][1], c7[k][2], c7[k][3]);
         }
     }
-    float bia[BWD ? 1 : 16];
-    if (!BWD) {
+    if (!BWD && tid < 32) {      // forward epilogue constants of channel m(r): bias and the three modulated ToRGB rows (rgb_scale * w[k,m] * s_rgb[b,m])
+        const int hh = tid >> 4, r = tid & 15, m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float* e = reinterpret_cast<float*>(smem + SX_EPC) + (hh * 4 + (r >> 2)) * 16 + (r & 3);
+        e[0] = a.bias ? a.bias[m] : 0.f;
+        const float sv = RGB ? a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bia[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
-    }
-    float wr[RGB ? 3 : 1][16];
-    if (RGB) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float sv = a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wr[RGB ? k : 0][r] = sv * a.rgb_w[k * M + m];
-        }
+        for (int k = 0; k < 3; ++k) e[4 * (k + 1)] = RGB ? sv * a.rgb_w[k * M + m] : 0.f;
     }
     const float nwf = (!BWD && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     unsigned moff[YF ? 1 : 4];               // NCHW y: byte offset of channel 8 rr + 4 half at this lane's column
@@ -392,8 +386,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     convert(0, 0, 0, true);
     __syncthreads();                                 // every wave is done with small-input buffer 2 before group 2's lands in it
     __builtin_amdgcn_sched_barrier(0);
-    issue_batch(min(1, n - 1), 1, 1, 0, 0);                          // batch "-2": group 1 and, again, tile 0's epilogue inputs
-    issue_batch(min(2, n - 1), 2, 2, min(1, n - 1), 1);              // batch "-1"
+    issue_batch(min(1, n - 1), 1, 1, 0, 2);                          // batch "-2": group 1 (its epilogue inputs are never read)
+    issue_batch(min(2, n - 1), 2, 2, 0, 0);                          // batch "-1": group 2, tile 0's epilogue inputs
     __builtin_amdgcn_sched_barrier(0);
 
     // lane-constant part of the fragment addresses: record kx + l31, slot (half + 2*lo) rotated by (c>>2)&3
@@ -406,53 +400,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lrd[kx][lo] = c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
         }
     const int px = c0 + l31;
-    float* red = reinterpret_cast<float*>(smem + SX_RED);
     constexpr int kBatch = BWD ? 12 : 6;
     constexpr int kStores = (YF ? 4 : 16) + (RGB ? 3 : 0);
     int rb = 18 + wave;      // ring row of image row R0 + 4t - 1 + wave (group g, row j at ring row 4 (g mod 5) + j): group -1 is ring group 4
     int gs1 = 1;             // ring group of group t + 1
     int m3 = 0;              // t mod 3
+    int m3l = 2;             // (t - 1) mod 3
+    float vprev[16], dsum[BWD ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vprev[r] = 0.f;
+    if (BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[BWD ? r : 0] = 0.f;
+    }
 
-    for (int t = 0; t < n; ++t) {
-        // Issue order so far: ... batch(t-2) [group t+1, tile t's epilogue inputs], stores(t-2), batch(t-1), stores(t-1).
-        // Everything up to batch(t-2) must have landed; wave 0 issues one more store per tile (the dot partial).
-        if (t >= 3) {
-            if (BWD && wave == 0) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores + 2));
-            else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
-        } else if (t == 2) {                         // tile 0 stored no dot partial
-            if (BWD && wave == 0) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores + 1));
-            else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
-        } else if (t == 1) {
-            __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + kStores));     // wave 0's first dot partial is stored in tile 1, after this point
-        } else {
-            __builtin_amdgcn_s_waitcnt(SX_VML(kBatch));
-        }
+    // Iteration t: matrix phase of tile t with the in-place conversion of group t+1 AND the epilogue arithmetic of tile t-1 woven in
+    // (a wave64 VALU instruction takes 4 cycles, a matrix instruction keeps its pipe busy for 32: the ~500 VALU instructions of a
+    // tile fit under its 54 matrix instructions only if they sit between them); then the stores of tile t-1.  One more
+    // iteration than tiles; the matrix phase of iteration n works on dead data.
+    for (int t = 0; t <= n; ++t) {
+        // Issue order so far: ... batch(t-2) [group t+1; epilogue inputs of tile t-1], stores(t-3), batch(t-1), stores(t-2).
+        // Everything up to batch(t-2) must have landed.
+        if (t >= 3) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
+        else if (t == 2) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + kStores));
+        else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch));
         __builtin_amdgcn_s_barrier();                // group t is converted; ring group (t+3) % 5 and the (t % 3) buffers are free
         __builtin_amdgcn_sched_barrier(0);
         const int m3n = m3 == 2 ? 0 : m3 + 1;        // (t + 1) % 3
         {
             int gs3 = gs1 + 2;
             if (gs3 >= SX_NG) gs3 -= SX_NG;
-            const int m3p = m3n == 2 ? 0 : m3n + 1;  // (t + 2) % 3
-            if (!(SX_ABL & 8)) issue_batch(min(t + 3, n - 1), gs3, m3, min(t + 2, n - 1), m3p);
+            if (!(SX_ABL & 8)) issue_batch(min(t + 3, n - 1), gs3, m3, min(t + 1, n - 1), m3n);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (BWD && t > 0 && wave == 0 && lane < 32) {
-            // cross-wave sum of the previous tile's dot partials (written to LDS before the barrier above)
-            a.dot_part[((long)b * M + lane) * a.dot_nparts + (long)(t0 + t - 1) * p.tiles_x + tx] =
-                lds_read_sum4(smem0 + SX_RED + ((t - 1) & 1) * 512 + lane * 4);
-        }
+        // The compiler's waitcnt model counts an LDS-DMA as an outstanding LDS access too and, while one is pending, turns every
+        // lgkmcnt wait into lgkmcnt(0) — operand fragments requested a chunk ahead would be drained at every use.  The hardware
+        // counts the DMA in vmcnt only: this wait costs nothing (no LDS operation is outstanding here) and retires the DMAs in
+        // the model, so that the waits below are counted.
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- matrix phase of tile t with the in-place conversion of group t+1 woven in: one conversion unit (a row of the
-        // thread's pixel, then the halo record) between the nine matrix instructions of each (channel block, tap row) — their
-        // VALU work runs while the matrix pipe is busy.  Past the segment's end the unit converts a dead ring group (a
-        // duplicate of the last group, not counted): no branch inside the region.
-        // Two accumulation chains: hi*hi, and the two cross terms hi*lo + lo*hi (the small terms are summed among themselves
-        // before they meet the large one).
         const bool cnt_ok = t + 1 < n;
         const unsigned cring = smem0 + gs1 * SX_GROUP;
         const unsigned csm = smem0 + SX_SMALL + m3n * SX_SMALL_ONE;
+        const float eflag = t >= 1 ? us : 0.f;       // the epilogue of "tile -1" contributes nothing to the sums
+        // epilogue inputs of tile t-1 (landed with batch(t-2))
+        f32x4 osc[4], dxv[4];
+        lds_read4_16(smem0 + SX_CST + half * 64, osc[0], osc[1], osc[2], osc[3]);
+        if (BWD) lds_read4(smem0 + SX_DOT + m3l * SX_DOT_ONE + wave * 4096 + lane * 16, dxv[0], dxv[1], dxv[2], dxv[3]);
+        float nz = 0.f;
+        if (!BWD) nz = nwf * lds_read1(smem0 + SX_SMALL + m3l * 1024 + wave * 256 + lane * 4);
+        float o[16];
+        float c0s = 0.f, c1s = 0.f, c2s = 0.f;
+
+        // two accumulation chains: hi*hi, and the two cross terms hi*lo + lo*hi (the small terms are summed among themselves
+        // before they meet the large one)
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
@@ -463,149 +464,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (row >= 4 * SX_NG) row -= 4 * SX_NG;
             rbase[ky] = row * SX_ROW;
         }
+        // operand fragments of chunk c+1 are requested before the matrix instructions of chunk c (the barrier below lets everything
+        // but LDS instructions move across it: the compiler otherwise sinks every read to just before its use)
+        half8 fb[2][6];
+        auto frag_load = [&](int c, half8 (&f)[6]) {
+            const unsigned char* base = smem + rbase[c % 3] + (c / 3) * (SX_C * 64);
 #pragma unroll
-        for (int kc = 0; kc < ((SX_ABL & 4) ? 0 : 2); ++kc) {
+            for (int kx = 0; kx < 3; ++kx) {
+                f[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][0]);
+                f[3 + kx] = *reinterpret_cast<const half8*>(base + lrd[kx][1]);
+            }
+        };
+        frag_load(0, fb[0]);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int c = kc * 3 + ky;
-                half8 bh[3], bl[3];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const unsigned char* base = smem + rbase[ky] + kc * (SX_C * 64);
-                    bh[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][0]);
-                    bl[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][1]);
-                }
-                f32x4 rvu = {0.f, 0.f, 0.f, 0.f}, s4u = {0.f, 0.f, 0.f, 0.f}, chl[7];
-                if (!(SX_ABL & 2)) {
-                    if (c < 4) {
-                        // the four quarters of a record read it before any of them writes (one instruction stream per wave; the
-                        // block ends with lgkmcnt(0))
-                        if (BWD) lds_read2(cring + c * SX_ROW + crec + cq * 16, csm + (c * 32 + cpx) * 16, rvu, s4u);
-                        else rvu = lds_read1x4(cring + c * SX_ROW + crec + cq * 16);
-                    } else if (c == 4) {
-                        if (BWD) {
-                            lds_read2(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16, csm + (128 + wave * 2 + hside) * 16, rvu, s4u);
-                            lds_read7_16(smem0 + SX_CST + 128 + (hkc * 4 + cq) * 7 * 16, chl);
-                        } else {
-                            rvu = lds_read1x4(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
-                        }
+        for (int c = 0; c < ((SX_ABL & 4) ? 0 : 6); ++c) {
+            const int kc = c / 3, ky = c % 3;
+            f32x4 rvu = {0.f, 0.f, 0.f, 0.f}, s4u = {0.f, 0.f, 0.f, 0.f}, chl[7];
+            if (!(SX_ABL & 2)) {
+                if (c < 4) {
+                    // the four quarters of a record read it before any of them writes (one instruction stream per wave; the
+                    // block ends with lgkmcnt(0)).  Past the segment's end the unit converts a dead ring group (not counted).
+                    if (BWD) lds_read2(cring + c * SX_ROW + crec + cq * 16, csm + (c * 32 + cpx) * 16, rvu, s4u);
+                    else rvu = lds_read1x4(cring + c * SX_ROW + crec + cq * 16);
+                } else if (c == 4) {
+                    if (BWD) {
+                        lds_read2(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16, csm + (128 + wave * 2 + hside) * 16, rvu, s4u);
+                        lds_read7_16(smem0 + SX_CST + 128 + (hkc * 4 + cq) * 7 * 16, chl);
+                    } else {
+                        rvu = lds_read1x4(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
                     }
                 }
+            }
+            // epilogue constants of the slice below
+            const int ec = c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 2 : c == 5 ? 3 : -1;
+            f32x4 eb = {0.f, 0.f, 0.f, 0.f}, ew0 = eb, ew1 = eb, ew2 = eb;
+            if (!BWD && ec >= 0) lds_read4_16(smem0 + SX_EPC + (half * 4 + ec) * 64, eb, ew0, ew1, ew2);
+            if (c < 5) frag_load(c + 1, fb[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0x7ff & ~0x380);          // nothing of the LDS classes crosses
+            const half8 (&f)[6] = fb[c & 1];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int tp = ky * 3 + kx;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], bh[kx], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], bl[kx], acc1, 0, 0, 0);
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tp = ky * 3 + kx;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], f[kx], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], f[3 + kx], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx][kc], f[kx], acc1, 0, 0, 0);
+            if (!(SX_ABL & 2)) {
+                if (c < 4) {
+                    // rows counted in this workgroup's sums: its own 4n rows (the last group all but its last row); the halo
+                    // columns belong to the neighbouring strips
+                    const float fi = (cnt_ok && (t + 1 < n - 1 || c < 3)) ? 1.f : 0.f;
+                    convert_unit(rvu, s4u, cin, xs, fi, cring + c * SX_ROW + cwr, true);
+                } else if (c == 4) {
+                    convert_unit(rvu, s4u, chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
                 }
+            }
+            // ---- a slice of the epilogue arithmetic of tile t-1: channels 4ec .. 4ec+3 after chunks 1, 2, 3, 5 (chunks 0 and 4 carry
+            // the heavier conversion units of the backward / the halo unit)
+            if (ec >= 0) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx][kc], bh[kx], acc1, 0, 0, 0);
-                if (!(SX_ABL & 2)) {
-                    if (c < 4) {
-                        // rows counted in this workgroup's sums: its own 4n rows (the last group all but its last row); the halo
-                        // columns belong to the neighbouring strips
-                        const float fi = (cnt_ok && (t + 1 < n - 1 || c < 3)) ? 1.f : 0.f;
-                        convert_unit(rvu, s4u, cin, xs, fi, cring + c * SX_ROW + cwr, true);
-                    } else if (c == 4) {
-                        convert_unit(rvu, s4u, chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = ec * 4 + e;
+                    const float v = vprev[r];
+                    float ov = v * osc[ec][e];
+                    if (BWD) {
+                        const float dv = dxv[ec][e];
+                        dsum[BWD ? r : 0] += (v * eflag) * dv;
+                        if (PRE) ov *= dv > 0.f ? kSqrt2 : 0.2f * kSqrt2;
+                    } else {
+                        ov += nz + eb[e];
+                        if (a.act == OODGAN_ACT_LRELU) ov = (ov > 0.f ? ov : 0.2f * ov) * kSqrt2;
+                    }
+                    o[r] = ov;
+                    if (RGB) {
+                        c0s += ew0[e] * ov;
+                        c1s += ew1[e] * ov;
+                        c2s += ew2[e] * ov;
                     }
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue: this wave's row
-        const int py = R0 + 4 * t + wave;
-        f32x4 osc[4], dxv[4];
-        lds_read4_16(smem0 + SX_CST + half * 64, osc[0], osc[1], osc[2], osc[3]);
-        if (BWD) lds_read4(smem0 + SX_DOT + m3 * SX_DOT_ONE + wave * 4096 + lane * 16, dxv[0], dxv[1], dxv[2], dxv[3]);
-        float nz = 0.f;
-        if (!BWD) nz = nwf * lds_read1(smem0 + SX_SMALL + m3 * 1024 + wave * 256 + lane * 4);
-        float o[16], dsum[BWD ? 16 : 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc0[r] + acc1[r];
-            o[r] = v * osc[r >> 2][r & 3];
-            if (BWD) {
-                const float dv = dxv[r >> 2][r & 3];
-                dsum[BWD ? r : 0] = (v * us) * dv;
-                if (PRE) o[r] *= dv > 0.f ? kSqrt2 : 0.2f * kSqrt2;
+        for (int r = 0; r < 16; ++r) vprev[r] = acc0[r] + acc1[r];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- stores of tile t-1: this wave's row
+        if (t >= 1) {
+            const int py = R0 + 4 * (t - 1) + wave;
+            if (RGB) {
+                // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
+                c0s += __shfl_xor(c0s, 32, 64);
+                c1s += __shfl_xor(c1s, 32, 64);
+                c2s += __shfl_xor(c2s, 32, 64);
+                if (half == 0) {
+                    float* rp = a.rgb_y + (long)b * 3 * HW + (long)py * W + px;
+                    rp[0] = c0s;
+                    rp[HW] = c1s;
+                    rp[2 * HW] = c2s;
+                }
+            }
+            if (SX_ABL & 1) {
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q += o[r];
+                if (q == 123456.75f) a.y[0] = q;
+            } else if (YF) {
+                float* yf = a.y + (((long)b * 2 * H + py) * W + px) * 16 + 4 * half;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    *reinterpret_cast<float4*>(yf + (long)(rr >> 1) * HW * 16 + (rr & 1) * 8) =
+                        make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
             } else {
-                o[r] += nz + bia[BWD ? 0 : r];
-                if (a.act == OODGAN_ACT_LRELU) o[r] = (o[r] > 0.f ? o[r] : 0.2f * o[r]) * kSqrt2;
+                unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + c0) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + (long)(r & 3) * p.out_plane * 4 + moff[YF ? 0 : (r >> 2)]) = o[r];
             }
-        }
-        if (RGB) {
-            // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
-            float c0s = 0.f, c1s = 0.f, c2s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                c0s += wr[0][r] * o[r];
-                c1s += wr[RGB ? 1 : 0][r] * o[r];
-                c2s += wr[RGB ? 2 : 0][r] * o[r];
-            }
-            c0s += __shfl_xor(c0s, 32, 64);
-            c1s += __shfl_xor(c1s, 32, 64);
-            c2s += __shfl_xor(c2s, 32, 64);
-            if (half == 0) {
-                float* rp = a.rgb_y + (long)b * 3 * HW + (long)py * W + px;
-                rp[0] = c0s;
-                rp[HW] = c1s;
-                rp[2 * HW] = c2s;
-            }
-        }
-        if (SX_ABL & 1) {
-            float q = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q += o[r];
-            if (q == 123456.75f) a.y[0] = q;
-        } else if (YF) {
-            float* yf = a.y + (((long)b * 2 * H + py) * W + px) * 16 + 4 * half;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                *reinterpret_cast<float4*>(yf + (long)(rr >> 1) * HW * 16 + (rr & 1) * 8) =
-                    make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
-        } else {
-            unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + c0) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + (long)(r & 3) * p.out_plane * 4 + moff[YF ? 0 : (r >> 2)]) = o[r];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (BWD) {
-            // sum over the 32 pixels of the row held by each half wave, then hand the 32 channel sums to LDS
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dsum[BWD ? r : 0] = half_sum_dpp(dsum[BWD ? r : 0]);
-            if (l31 == kHalfSumLane) {
-                const unsigned rp = smem0 + SX_RED + (t & 1) * 512 + wave * 128 + half * 16;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lds_write4(rp + ((r & 3) + 8 * (r >> 2)) * 4, dsum[BWD ? r : 0]);
-            }
-        }
         rb += 4;
         if (rb >= 4 * SX_NG) rb -= 4 * SX_NG;
         gs1 = gs1 == SX_NG - 1 ? 0 : gs1 + 1;
+        m3l = m3;
         m3 = m3n;
     }
-    __builtin_amdgcn_s_waitcnt(SX_VM(0));
+    __builtin_amdgcn_s_waitcnt(SX_VML(0));
     __syncthreads();
     if (BWD) {
-        if (wave == 0 && lane < 32) {
-            const float* rp = red + ((n - 1) & 1) * 128;
-            a.dot_part[((long)b * M + lane) * a.dot_nparts + (long)(t0 + n - 1) * p.tiles_x + tx] =
-                rp[lane] + rp[32 + lane] + rp[64 + lane] + rp[96 + lane];
+        const oodgan_actbwd_fuse& f = p.f;
+        const int part = seg * p.tiles_x + tx;
+        float* fin = reinterpret_cast<float*>(smem + SX_FIN);         // [wave][32] dot sums, then [wave][quarter*4 + j][r, t]
+        float* finm = fin + 4 * 32 * 2;
+        // style-gradient dot: the 32 pixels of each half wave, then the four waves (rows)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsum[BWD ? r : 0] = half_sum_dpp(dsum[BWD ? r : 0]);
+        if (l31 == kHalfSumLane) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = dsum[BWD ? r : 0];
         }
+        __syncthreads();
+        if (tid < 32) a.dot_part[((long)b * M + tid) * a.dot_nparts + part] = (fin[tid] + fin[32 + tid]) + (fin[64 + tid] + fin[96 + tid]);
+        __syncthreads();
         // partial sums of the activation backward: the 16 lanes of a wave with the same quarter (lane bits 2-5); the waves
         // (ckc = wave >> 1, two waves per channel block) are combined by the first 32 threads
-        const oodgan_actbwd_fuse& f = p.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) {
-                acc_r[BWD ? j : 0] += __shfl_xor(acc_r[BWD ? j : 0], o, 64);
-                acc_t[BWD ? j : 0] += __shfl_xor(acc_t[BWD ? j : 0], o, 64);
+            for (int o_ = 4; o_ < 64; o_ <<= 1) {
+                acc_r[BWD ? j : 0] += __shfl_xor(acc_r[BWD ? j : 0], o_, 64);
+                acc_t[BWD ? j : 0] += __shfl_xor(acc_t[BWD ? j : 0], o_, 64);
             }
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        float* fin = reinterpret_cast<float*>(smem + SX_FIN);         // [wave][quarter*4 + j][r, t]
-        float* finm = fin + 4 * 32 * 2;
+        for (int o_ = 1; o_ < 64; o_ <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o_, 64));
         if (lane < 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -615,12 +624,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (lane == 0) finm[wave] = amax;
         __syncthreads();
-        const int part = seg * p.tiles_x + tx;
         if (tid < 32) {      // channel tid: block tid >> 4 = waves 2 (tid >> 4) and + 1
             const int wv = 2 * (tid >> 4), cc = tid & 15;
-            const long o = ((long)b * M + tid) * p.nparts + part;
-            f.part_r[o] = fin[(wv * 16 + cc) * 2] + fin[((wv + 1) * 16 + cc) * 2];
-            f.part_t[o] = fin[(wv * 16 + cc) * 2 + 1] + fin[((wv + 1) * 16 + cc) * 2 + 1];
+            const long o_ = ((long)b * M + tid) * p.nparts + part;
+            f.part_r[o_] = fin[(wv * 16 + cc) * 2] + fin[((wv + 1) * 16 + cc) * 2];
+            f.part_t[o_] = fin[(wv * 16 + cc) * 2 + 1] + fin[((wv + 1) * 16 + cc) * 2 + 1];
         }
         if (tid < 2) f.part_max[((long)b * 2 + tid) * p.nparts + part] = fmaxf(finm[2 * tid], finm[2 * tid + 1]);
     }
@@ -668,9 +676,6 @@ extern "C" int oodgan_conv3x3_xf_nparts(int B, int H, int W) {
     return tx * ns;
 }
 
-// dot_nparts of the x_fform == 2 instance: one partial per 4-row tile
-extern "C" int oodgan_conv3x3_xf_dot_nparts(int H, int W) { return ((H + 3) / 4) * ((W + 31) / 32); }
-
 extern "C" int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W) {
     return (B > 0 && K == 32 && M == 32 && H >= 8 && W >= 32 && H % 4 == 0 && W % 32 == 0 && (long)H * W * 64 * 2 < (1L << 32)) ? 1 : 0;
 }
@@ -697,7 +702,7 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
     if (bwd) {
         OODGAN_REQUIRE(a.fuse != nullptr && a.dotx != nullptr && a.dotx_fform && a.dot_part != nullptr && a.in_scale == nullptr,
                        "conv3x3 x_fform 2: needs fuse (the activation backward), an F-form dotx, dot_part and no in_scale");
-        OODGAN_REQUIRE(a.dot_nparts == p.tiles_x * p.tiles_y, "conv3x3 x_fform 2: dot_nparts %d != %d", a.dot_nparts, p.tiles_x * p.tiles_y);
+        OODGAN_REQUIRE(a.dot_nparts == p.nparts, "conv3x3 x_fform 2: dot_nparts %d != %d (oodgan_conv3x3_xf_nparts)", a.dot_nparts, p.nparts);
         OODGAN_REQUIRE(a.noise == nullptr && a.bias == nullptr && a.act == OODGAN_ACT_NONE && a.rgb_y == nullptr && !a.y_fform,
                        "conv3x3 x_fform 2: the input-gradient instance has no noise / bias / activation / ToRGB / F-form output");
         p.f = *a.fuse;

@@ -93,7 +93,7 @@ _SIGS = {
     'oodgan_blur_act_fform': (c_int, [P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     'oodgan_conv3x3_xf_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_xf_nparts': (c_int, [c_int, c_int, c_int]),
-    'oodgan_conv3x3_xf_dot_nparts': (c_int, [c_int, c_int]),
+
     'oodgan_absmax_scaled': (c_int, [P, P, c_int, P, c_int, c_int, c_long, P]),
     'oodgan_fwd_range_update': (c_int, [P, P, P, c_int, P]),
     'oodgan_fwd_range_plan': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

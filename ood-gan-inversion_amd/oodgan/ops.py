@@ -731,7 +731,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
         dx_ = dotx.data if dot_f else _dev(dotx, 'dotx')
         a.dotx_fform = 1 if dot_f else 0
         if fform_in:
-            npart = _lib.lib().oodgan_conv3x3_xf_dot_nparts(H, W)
+            npart = _lib.lib().oodgan_conv3x3_xf_nparts(B, H, W)
         elif wpk.precision == 'f16s':
             npart = _lib.lib().oodgan_conv3x3_f16s_nparts2(mode, H, W, 1 if sform_in else 0)
         else:
