@@ -99,6 +99,23 @@ __device__ __forceinline__ void lds_write16(unsigned a, unsigned x, unsigned y, 
     asm volatile("ds_write_b128 %0, %1" : : "v"(a), "v"(v) : "memory");
 }
 __device__ __forceinline__ void lds_write4(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(v) : "memory"); }
+// Split form: the reads are ISSUED here and WAITED FOR by a later lds_wait*() that names their destinations as in/out operands —
+// every consumer depends on that statement, so the matrix / VALU instructions between the two overlap the LDS latency.  (The
+// destinations must not be touched in between; tools/check_stripx_isa.py verifies that the compiler did not insert a copy.)
+__device__ __forceinline__ void lds_issue(f32x4& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a) : "memory"); }
+__device__ __forceinline__ void lds_issue(half8& d, unsigned a) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a) : "memory"); }
+__device__ __forceinline__ void lds_issue(float& d, unsigned a) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(a) : "memory"); }
+__device__ __forceinline__ void lds_wait(half8 (&f)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : : "memory");
+}
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+__device__ __forceinline__ void lds_wait(f32x4 (&r)[7]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) : : "memory");
+}
+__device__ __forceinline__ void lds_wait(float& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
 __device__ __forceinline__ void lds_read2(unsigned a0, unsigned a1, f32x4& r0, f32x4& r1) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1) : "memory");
 }
@@ -443,64 +460,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned cring = smem0 + gs1 * SX_GROUP;
         const unsigned csm = smem0 + SX_SMALL + m3n * SX_SMALL_ONE;
         const float eflag = t >= 1 ? us : 0.f;       // the epilogue of "tile -1" contributes nothing to the sums
-        // epilogue inputs of tile t-1 (landed with batch(t-2))
-        f32x4 osc[4], dxv[4];
-        lds_read4_16(smem0 + SX_CST + half * 64, osc[0], osc[1], osc[2], osc[3]);
-        if (BWD) lds_read4(smem0 + SX_DOT + m3l * SX_DOT_ONE + wave * 4096 + lane * 16, dxv[0], dxv[1], dxv[2], dxv[3]);
-        float nz = 0.f;
-        if (!BWD) nz = nwf * lds_read1(smem0 + SX_SMALL + m3l * 1024 + wave * 256 + lane * 4);
-        float o[16];
-        float c0s = 0.f, c1s = 0.f, c2s = 0.f;
-
-        // two accumulation chains: hi*hi, and the two cross terms hi*lo + lo*hi (the small terms are summed among themselves
-        // before they meet the large one)
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
         unsigned rbase[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             int row = rb + ky;
             if (row >= 4 * SX_NG) row -= 4 * SX_NG;
-            rbase[ky] = row * SX_ROW;
+            rbase[ky] = smem0 + row * SX_ROW;
         }
-        // operand fragments of chunk c+1 are requested before the matrix instructions of chunk c (the barrier below lets everything
-        // but LDS instructions move across it: the compiler otherwise sinks every read to just before its use)
+        // Every LDS read of the tile is issued one chunk ahead of its use (chunk = the nine matrix instructions of one channel
+        // block and tap row) and waited for at the end of the chunk in between: operand fragments of chunk c+1, the raw record (and
+        // per-pixel inputs) of conversion unit c+1, the constants of the next epilogue slice.
         half8 fb[2][6];
-        auto frag_load = [&](int c, half8 (&f)[6]) {
-            const unsigned char* base = smem + rbase[c % 3] + (c / 3) * (SX_C * 64);
+        f32x4 ru[2], su[2], chl[7], osc[4], dxv[4], ec4[2][4];
+        float nzr = 0.f;
+        auto frag_issue = [&](int c, half8 (&f)[6]) {
+            const unsigned base = rbase[c % 3] + (c / 3) * (SX_C * 64);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                f[kx] = *reinterpret_cast<const half8*>(base + lrd[kx][0]);
-                f[3 + kx] = *reinterpret_cast<const half8*>(base + lrd[kx][1]);
+                lds_issue(f[kx], base + lrd[kx][0]);
+                lds_issue(f[3 + kx], base + lrd[kx][1]);
             }
         };
-        frag_load(0, fb[0]);
+        auto unit_issue = [&](int u, f32x4& r, f32x4& s4) {       // u = 0..3: row u of the thread's pixel; 4: the halo record
+            if (u < 4) {
+                lds_issue(r, cring + u * SX_ROW + crec + cq * 16);
+                if (BWD) lds_issue(s4, csm + (u * 32 + cpx) * 16);
+            } else {
+                lds_issue(r, smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
+                if (BWD) lds_issue(s4, csm + (128 + wave * 2 + hside) * 16);
+            }
+            if (!BWD) s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto slice_of = [](int c) { return c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 2 : c == 5 ? 3 : -1; };
+        // first batch of the tile (its latency is the one exposed per tile): fragments of chunk 0, unit 0, the epilogue inputs of tile t-1
+        frag_issue(0, fb[0]);
+        unit_issue(0, ru[0], su[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_issue(osc[k], smem0 + SX_CST + half * 64 + k * 16);
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_issue(dxv[k], smem0 + SX_DOT + m3l * SX_DOT_ONE + wave * 4096 + lane * 16 + k * 1024);
+        } else {
+            lds_issue(nzr, smem0 + SX_SMALL + m3l * 1024 + wave * 256 + lane * 4);
+        }
+        lds_wait(fb[0]);
+        lds_wait(ru[0], su[0]);
+        lds_wait(osc[0], osc[1], osc[2], osc[3]);
+        if (BWD) lds_wait(dxv[0], dxv[1], dxv[2], dxv[3]);
+        else lds_wait(nzr);
+        const float nz = nwf * nzr;
+        float o[16];
+        float c0s = 0.f, c1s = 0.f, c2s = 0.f;
+
+        // two accumulation chains: hi*hi, and the two cross terms hi*lo + lo*hi (the small terms are summed among themselves before
+        // they meet the large one).  Three chains were slower (16 more registers): the kernel is bound by the ISSUE of its ~700
+        // instructions per tile and wave — one wave per SIMD issues one instruction every 4-5 cycles whatever its kind.
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
         for (int c = 0; c < ((SX_ABL & 4) ? 0 : 6); ++c) {
             const int kc = c / 3, ky = c % 3;
-            f32x4 rvu = {0.f, 0.f, 0.f, 0.f}, s4u = {0.f, 0.f, 0.f, 0.f}, chl[7];
-            if (!(SX_ABL & 2)) {
-                if (c < 4) {
-                    // the four quarters of a record read it before any of them writes (one instruction stream per wave; the
-                    // block ends with lgkmcnt(0)).  Past the segment's end the unit converts a dead ring group (not counted).
-                    if (BWD) lds_read2(cring + c * SX_ROW + crec + cq * 16, csm + (c * 32 + cpx) * 16, rvu, s4u);
-                    else rvu = lds_read1x4(cring + c * SX_ROW + crec + cq * 16);
-                } else if (c == 4) {
-                    if (BWD) {
-                        lds_read2(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16, csm + (128 + wave * 2 + hside) * 16, rvu, s4u);
-                        lds_read7_16(smem0 + SX_CST + 128 + (hkc * 4 + cq) * 7 * 16, chl);
-                    } else {
-                        rvu = lds_read1x4(smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
-                    }
-                }
+            // ---- issue for chunk c+1
+            if (c < 5) frag_issue(c + 1, fb[(c + 1) & 1]);
+            if (c < 4) unit_issue(c + 1, ru[(c + 1) & 1], su[(c + 1) & 1]);
+            if (BWD && c == 3) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) lds_issue(chl[k], smem0 + SX_CST + 128 + ((hkc * 4 + cq) * 7 + k) * 16);
             }
-            // epilogue constants of the slice below
-            const int ec = c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 2 : c == 5 ? 3 : -1;
-            f32x4 eb = {0.f, 0.f, 0.f, 0.f}, ew0 = eb, ew1 = eb, ew2 = eb;
-            if (!BWD && ec >= 0) lds_read4_16(smem0 + SX_EPC + (half * 4 + ec) * 64, eb, ew0, ew1, ew2);
-            if (c < 5) frag_load(c + 1, fb[(c + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0x7ff & ~0x380);          // nothing of the LDS classes crosses
+            const int ecn = c < 5 ? slice_of(c + 1) : -1;
+            if (!BWD && ecn >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_issue(ec4[(c + 1) & 1][k], smem0 + SX_EPC + (half * 4 + ecn) * 64 + k * 16);
+            }
+            // ---- chunk c: nine matrix instructions ...
             const half8 (&f)[6] = fb[c & 1];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -510,18 +543,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx][kc], f[kx], acc1, 0, 0, 0);
+            // ---- ... with conversion unit c (in place: the four quarters of a record have all read it — their reads were waited for
+            // at the end of the previous chunk — before any of them writes; past the segment's end a dead ring group, not counted)
             if (!(SX_ABL & 2)) {
                 if (c < 4) {
                     // rows counted in this workgroup's sums: its own 4n rows (the last group all but its last row); the halo
                     // columns belong to the neighbouring strips
                     const float fi = (cnt_ok && (t + 1 < n - 1 || c < 3)) ? 1.f : 0.f;
-                    convert_unit(rvu, s4u, cin, xs, fi, cring + c * SX_ROW + cwr, true);
+                    convert_unit(ru[c & 1], su[c & 1], cin, xs, fi, cring + c * SX_ROW + cwr, true);
                 } else if (c == 4) {
-                    convert_unit(rvu, s4u, chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
+                    convert_unit(ru[0], su[0], chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
                 }
             }
-            // ---- a slice of the epilogue arithmetic of tile t-1: channels 4ec .. 4ec+3 after chunks 1, 2, 3, 5 (chunks 0 and 4 carry
-            // the heavier conversion units of the backward / the halo unit)
+            // ---- ... and a slice of the epilogue arithmetic of tile t-1: channels 4ec .. 4ec+3 after chunks 1, 2, 3, 5
+            const int ec = slice_of(c);
             if (ec >= 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -533,17 +568,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         dsum[BWD ? r : 0] += (v * eflag) * dv;
                         if (PRE) ov *= dv > 0.f ? kSqrt2 : 0.2f * kSqrt2;
                     } else {
-                        ov += nz + eb[e];
+                        ov += nz + ec4[c & 1][0][e];
                         if (a.act == OODGAN_ACT_LRELU) ov = (ov > 0.f ? ov : 0.2f * ov) * kSqrt2;
                     }
                     o[r] = ov;
                     if (RGB) {
-                        c0s += ew0[e] * ov;
-                        c1s += ew1[e] * ov;
-                        c2s += ew2[e] * ov;
+                        c0s += ec4[c & 1][1][e] * ov;
+                        c1s += ec4[c & 1][2][e] * ov;
+                        c2s += ec4[c & 1][3][e] * ov;
                     }
                 }
             }
+            // ---- what was issued at the top of this chunk has had nine matrix instructions to arrive
+            if (c < 5) lds_wait(fb[(c + 1) & 1]);
+            if (c < 4) lds_wait(ru[(c + 1) & 1], su[(c + 1) & 1]);
+            if (BWD && c == 3) lds_wait(chl);
+            if (!BWD && ecn >= 0) lds_wait(ec4[(c + 1) & 1][0], ec4[(c + 1) & 1][1], ec4[(c + 1) & 1][2], ec4[(c + 1) & 1][3]);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) vprev[r] = acc0[r] + acc1[r];
