@@ -55,3 +55,15 @@ def test_product_path_refuses_cpu_tensors():
         ops.fused_leaky_relu(torch.zeros(1, 3, 4, 4), torch.zeros(3))
     with pytest.raises(RuntimeError):
         ops.upfirdn2d(torch.zeros(1, 3, 4, 4), torch.ones(4, 4))
+
+
+def test_stripx_isa_keeps_its_hand_placed_waits():
+    """csrc/conv_f16s_stripx.hip issues its LDS reads by inline assembly and waits for them later (tools/check_stripx_isa.py): the
+    compiler must not have touched a destination register in between, nor added a full vmcnt drain or scratch access to the tile
+    loop.  Cross-compiles the file for gfx950 (no GPU needed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_stripx_isa.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('inline LDS reads checked') == 4, r.stdout
