@@ -36,24 +36,34 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #ifndef SX_ABL
 #define SX_ABL 0
 #endif
+#ifndef SX_PD_FWD
+#define SX_PD_FWD 4
+#endif
 
 namespace {
 
 constexpr int SX_C = 34;                               // records per ring row and channel block
 constexpr int SX_ROW = 2 * SX_C * 64;                  // 4352 bytes: [kc 2][34 records][64 B]
 constexpr int SX_GROUP = 4 * SX_ROW;                   // 17408: four rows
-constexpr int SX_NG = 5;                               // groups t-1 (its last two rows), t, t+1 (being converted), t+2, t+3 (in flight)
-constexpr int SX_RING = SX_NG * SX_GROUP;              // 87040
-constexpr int SX_HALO = SX_RING;                       // 3 x [4 waves][256 B]: raw halo records (columns 0 / 33) of a group
-constexpr int SX_SMALL = SX_HALO + 3 * 1024;           // backward: 3 x 3072 ([pixel slot][g_rgb 0..2, noise]); forward: 3 x 1 KiB noise rows
 constexpr int SX_SMALL_ONE = 3072;
-constexpr int SX_DOT = SX_SMALL + 3 * SX_SMALL_ONE;    // 3 x 16 KiB: saved forward input of a tile, thread-private slots
 constexpr int SX_DOT_ONE = 16384;
-constexpr int SX_RED = SX_DOT + 3 * SX_DOT_ONE;        // 2 x 4 waves x 32 floats: dot partials of two tiles
-constexpr int SX_FIN = SX_RED + 1024;                  // final sums: [4 waves][32 ch][r,t] + [4][2] maxima
-constexpr int SX_CST = SX_FIN + 4 * 32 * 2 * 4 + 64;   // [2 halves][16] epilogue scales, then [kc 2][quarter 4][7] float4 constants
-constexpr int SX_EPC = SX_CST + 128 + 8 * 7 * 16;      // forward: [half 2][rr 4][bias, wr0, wr1, wr2][4 channels] floats
-constexpr int SX_SMEM = SX_EPC + 512;                  // 152 KiB
+// LDS layout for prefetch distance PD (tiles between the request of a group and its conversion): NG = PD + 3 ring groups — t-1 (its
+// last two rows), t, t+1 (being converted) and PD in flight — and NB = PD + 1 buffers for everything else that travels with a batch.
+// The backward (48 KiB of dot rows) has room for PD = 2, the forward for more: with 2 tiles of 17 KiB in flight per CU the
+// forward was short of memory-level parallelism (793 us with, 552 us without the loads inside the loop; HBM alone 434).
+template <bool BWD>
+struct SXL {
+    static constexpr int PD = BWD ? 2 : SX_PD_FWD;
+    static constexpr int NG = PD + 3, NB = PD + 1;
+    static constexpr int RING = NG * SX_GROUP;
+    static constexpr int HALO = RING;                              // NB x [4 waves][256 B]: raw halo records (columns 0 / 33) of a group
+    static constexpr int SMALL = HALO + NB * 1024;                 // backward: NB x 3072 ([pixel slot][g_rgb 0..2, noise]); forward: NB x 1 KiB noise rows
+    static constexpr int DOT = SMALL + NB * (BWD ? SX_SMALL_ONE : 1024);   // backward: NB x 16 KiB saved forward input of a tile, thread-private slots
+    static constexpr int FIN = DOT + (BWD ? NB * SX_DOT_ONE : 0);  // final sums: [4 waves][32 ch][r,t] + [4][2] maxima
+    static constexpr int CST = FIN + 4 * 32 * 2 * 4 + 64;          // [2 halves][16] epilogue scales, then [kc 2][quarter 4][7] float4 constants
+    static constexpr int EPC = CST + 128 + 8 * 7 * 16;             // forward: [half 2][rr 4][bias, wr0, wr1, wr2][4 channels] floats
+    static constexpr int SMEM = EPC + 512;                         // backward 151 KiB
+};
 
 #define SX_VM(n) ((((n) >> 4) & 3) << 14 | 0x0F70 | ((n) & 15))
 #define SX_VML(n) ((((n) >> 4) & 3) << 14 | 0x0070 | ((n) & 15))      // ... and lgkmcnt(0)
@@ -147,11 +157,16 @@ struct StripX {
 };
 
 // BWD: x_fform == 2 (activation backward in the conversion, style-gradient dot in the epilogue).  RGB: fused ToRGB colour
-// sums (forward).  PRE: y <- dx * act'(dotx) (oodgan_conv_args.dot_actgrad).  YF: y in F-form.
-template <bool BWD, bool RGB, bool PRE, bool YF>
+// sums (forward).  PRE: y <- dx * act'(dotx) (oodgan_conv_args.dot_actgrad).  YF: y in F-form.  SEG: the strips are cut into
+// segments (fewer strips than CUs): rows fetched as another segment's halo must be kept out of the backward's sums; with one
+// segment per strip the only such rows lie outside the image and contribute zeros by themselves.
+template <bool BWD, bool RGB, bool PRE, bool YF, bool SEG = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_stripx_kernel(
     const StripX p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using L = SXL<BWD>;
+    constexpr int SX_NG = L::NG, NB = L::NB, PD = L::PD;
+    constexpr int SX_HALO = L::HALO, SX_SMALL = L::SMALL, SX_DOT = L::DOT, SX_FIN = L::FIN, SX_CST = L::CST, SX_EPC = L::EPC;
     const oodgan_conv_args& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,6 +197,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ah[tp][kc] = wb[(0 * 2 + half) * p.Mp + l31];
             al[tp][kc] = wb[(1 * 2 + half) * p.Mp + l31];
         }
+#if 1
+    // home the weight fragments in accumulation registers: v_mfma reads its A operand from either file, the VALU work of the loop
+    // then has the architectural registers to itself (otherwise the allocator parks them there as spills and copies them back
+    // before every use: 76-204 v_accvgpr_read per tile)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            asm volatile("" : "+a"(ah[tp][kc]));
+            asm volatile("" : "+a"(al[tp][kc]));
+        }
+#endif
 
     // ---- per-workgroup constants in LDS (read back where they are used: they would otherwise occupy registers through the
     // matrix phase): epilogue scale out_scale * unscale of channel m(r) = (r & 3) + 8 (r >> 2) + 4 half; the seven per-channel
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int hh = tid >> 4, r = tid & 15, m = (r & 3) + 8 * (r >> 2) + 4 * hh;
         reinterpret_cast<float*>(smem + SX_CST)[tid] = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
     }
-    float4* cst = reinterpret_cast<float4*>(smem + SX_CST + 128);      // [kc*4 + q][w0, w1, w2 (x rgb_scale), s_rgb, bias, d*scale, |d|]
+    float4* cst = reinterpret_cast<float4*>(smem + SX_CST + 128);      // [kc*4 + q][w0, w1, w2 (x rgb_scale), s_rgb*sqrt2, s_rgb*0.2*sqrt2, bias, d*scale]
     float nwb = 0.f;
     if (BWD) {
         const oodgan_actbwd_fuse& f = p.f;
@@ -205,11 +232,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 c7[0][j] = f.w_rgb[0 * M + c] * f.rgb_scale;
                 c7[1][j] = f.w_rgb[1 * M + c] * f.rgb_scale;
                 c7[2][j] = f.w_rgb[2 * M + c] * f.rgb_scale;
-                c7[3][j] = f.s_rgb[(long)b * f.s_rgb_stride + c];
-                c7[4][j] = f.bias ? f.bias[c] : 0.f;
+                const float srv = f.s_rgb[(long)b * f.s_rgb_stride + c];
+                c7[3][j] = srv * kSqrt2;                       // s_rgb folded into the two slopes of the activation gradient
+                c7[4][j] = srv * (0.2f * kSqrt2);
+                c7[5][j] = f.bias ? f.bias[c] : 0.f;
                 const float dv = f.dscale[(long)b * f.dscale_stride + c];
-                c7[5][j] = dv * m2;
-                c7[6][j] = fabsf(dv);
+                c7[6][j] = dv * m2;
             }
 #pragma unroll
             for (int k = 0; k < 7; ++k) cst[tid * 7 + k] = make_float4(c7[k][0], c7[k][1], c7[k][2], c7[k][3]);
@@ -250,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long row_bytes = (long)W * 64;
 
     float xs[4], xsh[4];                     // forward: staged value = x * in_scale[b,k] * in_mul2[1] (interior / halo role)
-    float acc_r[BWD ? 4 : 1], acc_t[BWD ? 4 : 1], amax = 0.f;
+    float acc_r[BWD ? 4 : 1], acc_t[BWD ? 4 : 1], amax4[BWD ? 4 : 1];
     if (!BWD) {
         const float m2 = a.in_mul2 ? a.in_mul2[1] : 1.f;
 #pragma unroll
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc_r[j] = acc_t[j] = 0.f;
+        for (int j = 0; j < 4; ++j) acc_r[j] = acc_t[j] = amax4[j] = 0.f;
     }
 
     // backward: component lane & 3 of the per-pixel inputs (g_rgb 0..2, noise) of pixel slot (lane >> 2) of a piece
@@ -279,8 +307,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned char* dfb = BWD ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * 2 * HW) * 64 + half * 16 : nullptr;
 
     // ---- one batch of LDS-DMA: raw rows + halo + small inputs of group g (into ring group gs, buffers g3) and, with it, the
-    // epilogue inputs of tile td (dot rows / noise; buffer d3).  Indices past the segment are clamped by the CALLER to valid
-    // groups / tiles (the duplicates land in dead buffers).  12 operations per wave (backward), 6 (forward).
+    // epilogue inputs of tile td (dot rows / noise; buffer d3).  Groups past the image read the page of zeros; the caller clamps
+    // td to a valid tile (the duplicates land in dead buffers).  12 operations per wave (backward), 6 (forward).
     auto issue_batch = [&](int g, int gs, int g3, int td, int d3) {
         const int r0g = R0 + 4 * g + 1;
         unsigned char* ring = smem + gs * SX_GROUP;
@@ -327,25 +355,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- in-place conversion of group g (ring group gs, buffers g3): fp32 records -> rotated hi / lo slots.  `count`: the
     // group's rows enter this workgroup's sums (wave-uniform; the caller excludes duplicates).
-    auto convert_unit = [&](const f32x4 rv, const f32x4 s4, const f32x4 (&cq7)[7], const float* xsc, float fi, unsigned dst, bool wr_ok) {
+    auto convert_unit = [&](const f32x4 rv, const f32x4 s4, const f32x4 (&cq7)[7], const float* xsc, float fi, unsigned dst, bool wr_ok, bool sums) {
         const float ov[4] = {rv[0], rv[1], rv[2], rv[3]};
         float v[4];
         if (!BWD) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ov[j] * xsc[j];
         } else {
-            const f32x4 w0 = cq7[0], w1 = cq7[1], w2 = cq7[2], sr = cq7[3], bv = cq7[4], ds = cq7[5], da = cq7[6];
+            const f32x4 w0 = cq7[0], w1 = cq7[1], w2 = cq7[2], sa = cq7[3], sb = cq7[4], bv = cq7[5], ds = cq7[6];
             const float nz = nwb * s4[3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float o = ov[j];
                 const float t = w0[j] * s4[0] + w1[j] * s4[1] + w2[j] * s4[2];
-                const float gp = (sr[j] * t) * (o > 0.f ? kSqrt2 : 0.2f * kSqrt2);
-                const float ycv = (o > 0.f ? o * kInvPos : o * kInvNeg) - nz - bv[j];
-                const float gi = gp * fi;
-                acc_r[BWD ? j : 0] += gi * ycv;
-                acc_t[BWD ? j : 0] += (o * fi) * t;
-                amax = fmaxf(amax, fabsf(gi) * da[j]);
+                const bool pos = o > 0.f;
+                const float gp = t * (pos ? sa[j] : sb[j]);
+                const float ycv = o * (pos ? kInvPos : kInvNeg) - (nz + bv[j]);
+                if (sums) {          // false for the halo unit: its pixels are counted by the neighbouring strip
+                    const float gi = SEG ? gp * fi : gp;
+                    acc_r[BWD ? j : 0] += gi * ycv;
+                    acc_t[BWD ? j : 0] += (SEG ? o * fi : o) * t;
+                    amax4[BWD ? j : 0] = fmaxf(amax4[BWD ? j : 0], fabsf(gi));     // x |d| at the end
+                }
                 v[j] = gp * ds[j];
             }
         }
@@ -387,24 +418,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // rows counted in this workgroup's sums: its own 4n rows (group -1 contributes its last row, the last group all
             // but its last); the halo columns belong to the neighbouring strips
             const float fi = (count && (g < 0 ? i == 3 : (g < n - 1 || i < 3))) ? 1.f : 0.f;
-            convert_unit(rv[i], s4[i], cin, xs, fi, ring + i * SX_ROW + cwr, true);
+            convert_unit(rv[i], s4[i], cin, xs, fi, ring + i * SX_ROW + cwr, true, true);
         }
-        convert_unit(rv[4], s4[4], chl, xsh, 0.f, ring + wave * SX_ROW + hwr, lane < 16);
+        convert_unit(rv[4], s4[4], chl, xsh, 0.f, ring + wave * SX_ROW + hwr, lane < 16, false);
     };
 
     __builtin_amdgcn_s_waitcnt(SX_VM(0));            // weights, scales: retired here, never inside the loop
-    // ---- prologue: groups -1 (its last two rows are the halo above the first tile) and 0 converted, groups 1 and 2 and the
-    // epilogue inputs of tiles 0 and 1 in flight
-    issue_batch(-1, 4, 2, 0, 0);
-    issue_batch(0, 0, 0, min(1, n - 1), 1);
+    // ---- prologue: groups -1 (its last two rows are the halo above the first tile) and 0 converted, then the batches "-PD" .. "-1":
+    // groups 1 .. PD in flight, with them the epilogue inputs of the tiles up to PD - 2
+    issue_batch(-1, SX_NG - 1, NB - 1, 0, 0);
+    issue_batch(0, 0, 0, 0, 0);
     __builtin_amdgcn_s_waitcnt(SX_VM(0));
     __syncthreads();
-    convert(-1, 4, 2, true);
+    convert(-1, SX_NG - 1, NB - 1, true);
     convert(0, 0, 0, true);
-    __syncthreads();                                 // every wave is done with small-input buffer 2 before group 2's lands in it
+    __syncthreads();                                 // every wave is done with the small-input buffers before later groups land in them
     __builtin_amdgcn_sched_barrier(0);
-    issue_batch(min(1, n - 1), 1, 1, 0, 2);                          // batch "-2": group 1 (its epilogue inputs are never read)
-    issue_batch(min(2, n - 1), 2, 2, 0, 0);                          // batch "-1": group 2, tile 0's epilogue inputs
+#pragma unroll
+    for (int k = PD; k >= 1; --k) {                  // batch(-k): group PD + 1 - k, epilogue inputs of tile PD - 1 - k (k = PD: never read)
+        const int g = PD + 1 - k, td = PD - 1 - k;
+        issue_batch(g, g % SX_NG, g % NB, min(max(td, 0), n - 1), (td + NB) % NB);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // lane-constant part of the fragment addresses: record kx + l31, slot (half + 2*lo) rotated by (c>>2)&3
@@ -419,10 +453,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int px = c0 + l31;
     constexpr int kBatch = BWD ? 12 : 6;
     constexpr int kStores = (YF ? 4 : 16) + (RGB ? 3 : 0);
-    int rb = 18 + wave;      // ring row of image row R0 + 4t - 1 + wave (group g, row j at ring row 4 (g mod 5) + j): group -1 is ring group 4
+    int rb = 4 * SX_NG - 2 + wave;   // ring row of image row R0 + 4t - 1 + wave (group g, row j at ring row 4 (g mod NG) + j): group -1 is the last ring group
     int gs1 = 1;             // ring group of group t + 1
-    int m3 = 0;              // t mod 3
-    int m3l = 2;             // (t - 1) mod 3
+    int m3 = 0;              // t mod NB
+    int m3l = NB - 1;        // (t - 1) mod NB
     float vprev[16], dsum[BWD ? 16 : 1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) vprev[r] = 0.f;
@@ -436,18 +470,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // tile fit under its 54 matrix instructions only if they sit between them); then the stores of tile t-1.  One more
     // iteration than tiles; the matrix phase of iteration n works on dead data.
     for (int t = 0; t <= n; ++t) {
-        // Issue order so far: ... batch(t-2) [group t+1; epilogue inputs of tile t-1], stores(t-3), batch(t-1), stores(t-2).
-        // Everything up to batch(t-2) must have landed.
-        if (t >= 3) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + 2 * kStores));
-        else if (t == 2) __builtin_amdgcn_s_waitcnt(SX_VML(kBatch + kStores));
-        else __builtin_amdgcn_s_waitcnt(SX_VML(kBatch));
-        __builtin_amdgcn_s_barrier();                // group t is converted; ring group (t+3) % 5 and the (t % 3) buffers are free
-        __builtin_amdgcn_sched_barrier(0);
-        const int m3n = m3 == 2 ? 0 : m3 + 1;        // (t + 1) % 3
+        // Issue order so far: ... batch(t-PD) [group t+1; epilogue inputs of tile t-1], stores(t-PD-1), batch(t-PD+1), ... batch(t-1),
+        // stores(t-2).  Everything up to batch(t-PD) must have landed: PD - 1 batches and the stores of up to PD tiles stay in flight.
         {
-            int gs3 = gs1 + 2;
-            if (gs3 >= SX_NG) gs3 -= SX_NG;
-            if (!(SX_ABL & 8)) issue_batch(min(t + 3, n - 1), gs3, m3, min(t + 1, n - 1), m3n);
+            const int ns = min(PD, max(0, t - 1));   // tiles -1 and below stored nothing
+            if (ns >= PD) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + PD * kStores));
+            else if (ns == 3) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 3 * kStores));
+            else if (ns == 2) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 2 * kStores));
+            else if (ns == 1) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + kStores));
+            else __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch));
+        }
+        __builtin_amdgcn_s_barrier();                // group t is converted; ring group (t+PD+1) % NG and the (t % NB) buffers are free
+        __builtin_amdgcn_sched_barrier(0);
+        const int m3n = m3 == NB - 1 ? 0 : m3 + 1;   // (t + 1) % NB
+        {
+            int gsn = gs1 + PD;                      // ring group of group t + PD + 1
+            if (gsn >= SX_NG) gsn -= SX_NG;
+            int md = m3 - 2;                         // buffer of tile t + PD - 1
+            if (md < 0) md += NB;
+            // groups past the segment's end: rows of the next segment (valid memory; kept out of the sums by `cnt_ok`) or rows below
+            // the image (the page of zeros: zero contributions)
+            if (!(SX_ABL & 8)) issue_batch(t + PD + 1, gsn, m3, min(t + PD - 1, n - 1), md);
         }
         // The compiler's waitcnt model counts an LDS-DMA as an outstanding LDS access too and, while one is pending, turns every
         // lgkmcnt wait into lgkmcnt(0) — operand fragments requested a chunk ahead would be drained at every use.  The hardware
@@ -550,9 +593,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // rows counted in this workgroup's sums: its own 4n rows (the last group all but its last row); the halo
                     // columns belong to the neighbouring strips
                     const float fi = (cnt_ok && (t + 1 < n - 1 || c < 3)) ? 1.f : 0.f;
-                    convert_unit(ru[c & 1], su[c & 1], cin, xs, fi, cring + c * SX_ROW + cwr, true);
+                    convert_unit(ru[c & 1], su[c & 1], cin, xs, fi, cring + c * SX_ROW + cwr, true, true);
                 } else if (c == 4) {
-                    convert_unit(ru[0], su[0], chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16);
+                    convert_unit(ru[0], su[0], chl, xsh, 0.f, cring + wave * SX_ROW + hwr, lane < 16, false);
                 }
             }
             // ---- ... and a slice of the epilogue arithmetic of tile t-1: channels 4ec .. 4ec+3 after chunks 1, 2, 3, 5
@@ -653,6 +696,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc_r[BWD ? j : 0] += __shfl_xor(acc_r[BWD ? j : 0], o_, 64);
                 acc_t[BWD ? j : 0] += __shfl_xor(acc_t[BWD ? j : 0], o_, 64);
             }
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, amax4[BWD ? j : 0] * fabsf(f.dscale[(long)b * f.dscale_stride + ckc * 16 + cq * 4 + j]));
 #pragma unroll
         for (int o_ = 1; o_ < 64; o_ <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o_, 64));
         if (lane < 4) {
@@ -760,22 +806,32 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
     }
     const long nblk = (long)a.B * p.tiles_x * p.nseg;
     OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 F-form input: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, false, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX_SMEM), true);
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     const dim3 grid((unsigned)nblk), block(256);
     if (bwd) {
-        if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false>), grid, block, SX_SMEM, st, p, w16);
-        else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false>), grid, block, SX_SMEM, st, p, w16);
-    } else if (a.rgb_y) hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, true, false, true>), grid, block, SX_SMEM, st, p, w16);
-    else hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, false, false, true>), grid, block, SX_SMEM, st, p, w16);
+        const bool seg = p.nseg > 1;
+        if (a.dot_actgrad) {
+            if (seg) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+            else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, false>), grid, block, SXL<true>::SMEM, st, p, w16);
+        } else {
+            if (seg) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+            else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false, false>), grid, block, SXL<true>::SMEM, st, p, w16);
+        }
+    } else if (a.rgb_y) hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, true, false, true>), grid, block, SXL<false>::SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, false, false, true>), grid, block, SXL<false>::SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_stripx");
 }
 

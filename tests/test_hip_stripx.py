@@ -79,7 +79,8 @@ def test_input_gradient_with_the_activation_backward_inside(B, H, W, pre):
     assert _rel(dx1, dx0) < 1e-6
     assert _rel(dot1, dot0) < 2e-5          # sums of +-1e-3 terms over H*W pixels in a different order
     assert _rel(xa.r, r0) < 2e-5 and _rel(xa.t, t0) < 2e-5
-    assert float(xa.part_m.max()) == float(pm0.max())
+    # the recorded maximum feeds a power-of-two range scale: s_rgb is folded into the slope here, one rounding apart from the producer
+    assert abs(float(xa.part_m.max()) - float(pm0.max())) <= 1e-6 * float(pm0.max())
     # no noise / shared noise variants
     xa2 = ops.ActBwdX(None, None, None, d, mul2, g_rgb, w_rgb, s_rgb)
     dx2, _ = ops.conv3x3(o2f, wb, C, ops.CONV_S1, out_scale=s1, dotx=o1f, in_mul2=mul2, xf_act=xa2)
