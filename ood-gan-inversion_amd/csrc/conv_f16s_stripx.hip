@@ -40,6 +40,16 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #define SX_PD_FWD 4
 #endif
 
+#ifdef OODGAN_CLOCK_STAMP
+// Diagnostic build only (make STAMP=1): shader cycles a wave spends in the phases of the tile loop, summed over its tiles —
+// [workgroup][wave][counted wait, barrier, matrix phase with the woven work, stores, whole loop, 100 MHz ticks of the loop]
+__device__ unsigned long long* g_stripx_stamp = nullptr;
+__device__ long g_stripx_stamp_n = 0;
+#define SX_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define SX_STAMP(v)
+#endif
+
 namespace {
 
 constexpr int SX_C = 34;                               // records per ring row and channel block
@@ -309,48 +319,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- one batch of LDS-DMA: raw rows + halo + small inputs of group g (into ring group gs, buffers g3) and, with it, the
     // epilogue inputs of tile td (dot rows / noise; buffer d3).  Groups past the image read the page of zeros; the caller clamps
     // td to a valid tile (the duplicates land in dead buffers).  12 operations per wave (backward), 6 (forward).
-    auto issue_batch = [&](int g, int gs, int g3, int td, int d3) {
+    // The kBatch operations of a batch, one at a time (`op` is a compile-time index after unrolling): the loop issues them spread
+    // over the chunks of the matrix phase.  Issued all at once at the top of the tile the ~140 cache lines a wave requests do not
+    // fit the memory pipeline's queues — the wave sat in the issue of its loads for as long as HBM took to serve them (forward:
+    // 793 us, 552 us without the loads; the difference is the 1.07 GB at the HBM rate), every CU at the same moment.
+    auto issue_op = [&](int op, int g, int gs, int g3, int td, int d3) {
         const int r0g = R0 + 4 * g + 1;
-        unsigned char* ring = smem + gs * SX_GROUP;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0g + i;
+        if (op < 4) {                                // raw row `op` of the thread's pixel
+            const int r = r0g + op;
             const bool rok = r >= 0 && r < H;                        // wave-uniform
             const unsigned char* src = rok ? xfb + (long)r * row_bytes + goff0 : zp;
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(ring + i * SX_ROW + ckc * (SX_C * 64) + (1 + 16 * (wave & 1)) * 64), 16, 0, 0);
-        }
-        {
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + gs * SX_GROUP + op * SX_ROW + ckc * (SX_C * 64) + (1 + 16 * (wave & 1)) * 64), 16, 0, 0);
+        } else if (op == 4) {                        // halo records of row `wave`
             const int r = r0g + wave;
             const unsigned char* src = (hinv || r < 0 || r >= H) ? zp : xfb + (long)r * row_bytes + hgoff;
             if (lane < 16)
                 __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_HALO + g3 * 1024 + wave * 256), 16, 0, 0);
-        }
-        if (BWD) {
-            unsigned char* dst = smem + SX_SMALL + g3 * SX_SMALL_ONE;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {        // pieces 0..7: row q >> 1, pixels 16 (q & 1) .. + 15
-                const int q = wave + 4 * k;
-                const int r = r0g + (q >> 1);
-                const bool rok = r >= 0 && r < H;
-                const float* src = (rok && !nz_zero) ? sbase + (long)r * W + c0 + 16 * (q & 1) + (lane >> 2) : reinterpret_cast<const float*>(zp);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + q * 256), 4, 0, 0);
-            }
-            {                                    // piece 8 (+ duplicates 9..11): halo pixels, slot 128 + row*2 + side
-                const int hs = (lane >> 2) & 7;
-                const int r = r0g + (hs >> 1), gx = c0 - 1 + ((hs & 1) ? 33 : 0);
-                const bool ok = r >= 0 && r < H && gx >= 0 && gx < W && !nz_zero;
-                const float* src = ok ? sbase + (long)r * W + gx : reinterpret_cast<const float*>(zp);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + (8 + wave) * 256), 4, 0, 0);
-            }
-            unsigned char* dd = smem + SX_DOT + d3 * SX_DOT_ONE + wave * 4096;
-            const long pix = (long)(R0 + 4 * td + wave) * W + c0 + l31;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(dfb + ((long)(rr >> 1) * HW + pix) * 64 + (rr & 1) * 32), (lds_void*)(dd + rr * 1024), 16, 0, 0);
-        } else {
+        } else if (!BWD) {                           // op 5: the noise of tile td
             const float* src = nzb ? nzb + (long)(R0 + 4 * td + wave) * W + c0 + l31 : reinterpret_cast<const float*>(zp);
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_SMALL + d3 * 1024 + wave * 256), 4, 0, 0);
+        } else if (op < 7) {                         // per-pixel inputs, pieces 0..7: row q >> 1, pixels 16 (q & 1) .. + 15
+            const int q = wave + 4 * (op - 5);
+            const int r = r0g + (q >> 1);
+            const bool rok = r >= 0 && r < H;
+            const float* src = (rok && !nz_zero) ? sbase + (long)r * W + c0 + 16 * (q & 1) + (lane >> 2) : reinterpret_cast<const float*>(zp);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_SMALL + g3 * SX_SMALL_ONE + q * 256), 4, 0, 0);
+        } else if (op == 7) {                        // piece 8 (+ duplicates 9..11): halo pixels, slot 128 + row*2 + side
+            const int hs = (lane >> 2) & 7;
+            const int r = r0g + (hs >> 1), gx = c0 - 1 + ((hs & 1) ? 33 : 0);
+            const bool ok = r >= 0 && r < H && gx >= 0 && gx < W && !nz_zero;
+            const float* src = ok ? sbase + (long)r * W + gx : reinterpret_cast<const float*>(zp);
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + SX_SMALL + g3 * SX_SMALL_ONE + (8 + wave) * 256), 4, 0, 0);
+        } else {                                     // ops 8..11: the saved forward input of tile td (style-gradient dot)
+            const int rr = op - 8;
+            const long pix = (long)(R0 + 4 * td + wave) * W + c0 + l31;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(dfb + ((long)(rr >> 1) * HW + pix) * 64 + (rr & 1) * 32),
+                                             (lds_void*)(smem + SX_DOT + d3 * SX_DOT_ONE + wave * 4096 + rr * 1024), 16, 0, 0);
         }
+    };
+    auto issue_batch = [&](int g, int gs, int g3, int td, int d3) {
+#pragma unroll
+        for (int op = 0; op < (BWD ? 12 : 6); ++op) issue_op(op, g, gs, g3, td, d3);
     };
 
     // ---- in-place conversion of group g (ring group gs, buffers g3): fp32 records -> rotated hi / lo slots.  `count`: the
@@ -453,6 +462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int px = c0 + l31;
     constexpr int kBatch = BWD ? 12 : 6;
     constexpr int kStores = (YF ? 4 : 16) + (RGB ? 3 : 0);
+    constexpr int kTail = (YF ? 1 : 4) + (RGB ? 3 : 0);         // stores issued after the last operation of the iteration's batch
     int rb = 4 * SX_NG - 2 + wave;   // ring row of image row R0 + 4t - 1 + wave (group g, row j at ring row 4 (g mod NG) + j): group -1 is the last ring group
     int gs1 = 1;             // ring group of group t + 1
     int m3 = 0;              // t mod NB
@@ -469,29 +479,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (a wave64 VALU instruction takes 4 cycles, a matrix instruction keeps its pipe busy for 32: the ~500 VALU instructions of a
     // tile fit under its 54 matrix instructions only if they sit between them); then the stores of tile t-1.  One more
     // iteration than tiles; the matrix phase of iteration n works on dead data.
+#ifdef OODGAN_CLOCK_STAMP
+    unsigned long long st_wait = 0, st_bar = 0, st_mat = 0, st_sto = 0;
+    const unsigned long long st_l0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = 0; t <= n; ++t) {
-        // Issue order so far: ... batch(t-PD) [group t+1; epilogue inputs of tile t-1], stores(t-PD-1), batch(t-PD+1), ... batch(t-1),
-        // stores(t-2).  Everything up to batch(t-PD) must have landed: PD - 1 batches and the stores of up to PD tiles stay in flight.
-        {
-            const int ns = min(PD, max(0, t - 1));   // tiles -1 and below stored nothing
-            if (ns >= PD) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + PD * kStores));
-            else if (ns == 3) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 3 * kStores));
-            else if (ns == 2) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 2 * kStores));
-            else if (ns == 1) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + kStores));
-            else __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch));
-        }
+        SX_STAMP(st_a);
+        // Issue order of an iteration: the batch's operations chunk by chunk, the y stores of a slice after chunks 1, 2, 3 and 5, the
+        // colour stores at the end — so behind the LAST operation of batch(t-PD) come kTail stores of its own iteration and PD - 1
+        // whole iterations (kBatch + kStores each).  Everything up to that operation must have landed.  For t < PD the batch in
+        // question was issued before the loop: behind it come PD - 1 - t more of those and the t iterations so far (iteration 0 stores
+        // like any other — into tile 0's rows, see below).
+        if (t >= PD) __builtin_amdgcn_s_waitcnt(SX_VML(kTail + (PD - 1) * (kBatch + kStores)));
+        else if (t == 3) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 3 * kStores));
+        else if (t == 2) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + 2 * kStores));
+        else if (t == 1) __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch + kStores));
+        else __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * kBatch));
+        static_assert(PD <= 4 && kTail + (PD - 1) * (kBatch + kStores) < 64, "the counted wait fits vmcnt");
+        SX_STAMP(st_b);
         __builtin_amdgcn_s_barrier();                // group t is converted; ring group (t+PD+1) % NG and the (t % NB) buffers are free
+        SX_STAMP(st_c);
         __builtin_amdgcn_sched_barrier(0);
         const int m3n = m3 == NB - 1 ? 0 : m3 + 1;   // (t + 1) % NB
-        {
-            int gsn = gs1 + PD;                      // ring group of group t + PD + 1
-            if (gsn >= SX_NG) gsn -= SX_NG;
-            int md = m3 - 2;                         // buffer of tile t + PD - 1
-            if (md < 0) md += NB;
-            // groups past the segment's end: rows of the next segment (valid memory; kept out of the sums by `cnt_ok`) or rows below
-            // the image (the page of zeros: zero contributions)
-            if (!(SX_ABL & 8)) issue_batch(t + PD + 1, gsn, m3, min(t + PD - 1, n - 1), md);
-        }
+        int gsn = gs1 + PD;                          // ring group of group t + PD + 1
+        if (gsn >= SX_NG) gsn -= SX_NG;
+        int md = m3 - 2;                             // buffer of tile t + PD - 1
+        if (md < 0) md += NB;
+        const int tdn = min(t + PD - 1, n - 1);
+        // batch(t) — group t + PD + 1 (past the segment's end: rows of the next segment, kept out of the sums by `cnt_ok`, or rows
+        // below the image, the page of zeros) and the epilogue inputs of tile t + PD - 1 — is issued in kBatch / 6 operations per chunk
         // The compiler's waitcnt model counts an LDS-DMA as an outstanding LDS access too and, while one is pending, turns every
         // lgkmcnt wait into lgkmcnt(0) — operand fragments requested a chunk ahead would be drained at every use.  The hardware
         // counts the DMA in vmcnt only: this wait costs nothing (no LDS operation is outstanding here) and retires the DMAs in
@@ -503,6 +519,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned cring = smem0 + gs1 * SX_GROUP;
         const unsigned csm = smem0 + SX_SMALL + m3n * SX_SMALL_ONE;
         const float eflag = t >= 1 ? us : 0.f;       // the epilogue of "tile -1" contributes nothing to the sums
+        // row of tile t-1 this wave stores; iteration 0 has nothing to store and writes (garbage) to tile 0's row, which iteration 1
+        // overwrites — same wave, same addresses, in order — instead of branching around the stores inside the matrix phase
+        const int pyp = R0 + 4 * max(t - 1, 0) + wave;
+        float* const yfp = a.y + (((long)b * 2 * H + pyp) * W + px) * 16 + 4 * half;                                   // F-form
+        unsigned char* const yrp = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)pyp * a.out_pitch + c0) * 4;   // NCHW
         unsigned rbase[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -564,7 +585,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int c = 0; c < ((SX_ABL & 4) ? 0 : 6); ++c) {
             const int kc = c / 3, ky = c % 3;
-            // ---- issue for chunk c+1
+            // ---- this chunk's share of batch(t), then the LDS reads for chunk c+1
+            if (!(SX_ABL & 8)) {
+#pragma unroll
+                for (int k = 0; k < kBatch / 6; ++k) issue_op(c * (kBatch / 6) + k, t + PD + 1, gsn, m3, tdn, md);
+            }
             if (c < 5) frag_issue(c + 1, fb[(c + 1) & 1]);
             if (c < 4) unit_issue(c + 1, ru[(c + 1) & 1], su[(c + 1) & 1]);
             if (BWD && c == 3) {
@@ -621,6 +646,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         c2s += ec4[c & 1][3][e] * ov;
                     }
                 }
+                // the slice's four channels leave at once (spread over the tile like the loads: a burst of stores at the end of
+                // the tile stalled in its issue — 1.0 of 3.6 us per tile in the stamp build)
+                if (!(SX_ABL & 1)) {
+                    if (YF) {
+                        *reinterpret_cast<float4*>(yfp + (long)(ec >> 1) * HW * 16 + (ec & 1) * 8) = make_float4(o[4 * ec], o[4 * ec + 1], o[4 * ec + 2], o[4 * ec + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            *reinterpret_cast<float*>(yrp + (long)e * p.out_plane * 4 + moff[YF ? 0 : ec]) = o[4 * ec + e];
+                    }
+                }
             }
             // ---- what was issued at the top of this chunk has had nine matrix instructions to arrive
             if (c < 5) lds_wait(fb[(c + 1) & 1]);
@@ -631,36 +667,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) vprev[r] = acc0[r] + acc1[r];
         __builtin_amdgcn_sched_barrier(0);
-        // ---- stores of tile t-1: this wave's row
-        if (t >= 1) {
-            const int py = R0 + 4 * (t - 1) + wave;
-            if (RGB) {
-                // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
-                c0s += __shfl_xor(c0s, 32, 64);
-                c1s += __shfl_xor(c1s, 32, 64);
-                c2s += __shfl_xor(c2s, 32, 64);
-                if (half == 0) {
-                    float* rp = a.rgb_y + (long)b * 3 * HW + (long)py * W + px;
-                    rp[0] = c0s;
-                    rp[HW] = c1s;
-                    rp[2 * HW] = c2s;
-                }
-            }
-            if (SX_ABL & 1) {
-                float q = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) q += o[r];
-                if (q == 123456.75f) a.y[0] = q;
-            } else if (YF) {
-                float* yf = a.y + (((long)b * 2 * H + py) * W + px) * 16 + 4 * half;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    *reinterpret_cast<float4*>(yf + (long)(rr >> 1) * HW * 16 + (rr & 1) * 8) =
-                        make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
-            } else {
-                unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + c0) * 4;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *reinterpret_cast<float*>(yr + (long)(r & 3) * p.out_plane * 4 + moff[YF ? 0 : (r >> 2)]) = o[r];
+        SX_STAMP(st_d);
+        // ---- the colour sums of tile t-1 (its y stores went out slice by slice above)
+        if (RGB) {
+            // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
+            c0s += __shfl_xor(c0s, 32, 64);
+            c1s += __shfl_xor(c1s, 32, 64);
+            c2s += __shfl_xor(c2s, 32, 64);
+            if (half == 0) {
+                float* rp = a.rgb_y + (long)b * 3 * HW + (long)pyp * W + px;
+                rp[0] = c0s;
+                rp[HW] = c1s;
+                rp[2 * HW] = c2s;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -669,7 +687,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         gs1 = gs1 == SX_NG - 1 ? 0 : gs1 + 1;
         m3l = m3;
         m3 = m3n;
+#ifdef OODGAN_CLOCK_STAMP
+        {
+            const unsigned long long st_e = __builtin_amdgcn_s_memtime();
+            st_wait += st_b - st_a; st_bar += st_c - st_b; st_mat += st_d - st_c; st_sto += st_e - st_d;
+        }
+#endif
     }
+#ifdef OODGAN_CLOCK_STAMP
+    if (lane == 0 && g_stripx_stamp && (long)blockIdx.x < g_stripx_stamp_n) {
+        unsigned long long* q = g_stripx_stamp + ((long)blockIdx.x * 4 + wave) * 6;
+        q[0] = st_wait; q[1] = st_bar; q[2] = st_mat; q[3] = st_sto;
+        q[4] = __builtin_amdgcn_s_memtime() - st_l0; q[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
     __builtin_amdgcn_s_waitcnt(SX_VML(0));
     __syncthreads();
     if (BWD) {
@@ -765,6 +796,19 @@ extern "C" int oodgan_conv3x3_xf_nparts(int B, int H, int W) {
 extern "C" int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W) {
     return (B > 0 && K == 32 && M == 32 && H >= 8 && W >= 32 && H % 4 == 0 && W % 32 == 0 && (long)H * W * 64 * 2 < (1L << 32)) ? 1 : 0;
 }
+
+#ifdef OODGAN_CLOCK_STAMP
+// stamp build only: buf = n x 4 waves x 6 counters of workgroup blockIdx.x (last launch wins)
+extern "C" int oodgan_debug_set_stripx_stamp_buffer(void* buf, long n) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stripx_stamp), &p, sizeof(p)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stripx_stamp_n), &n, sizeof(n)) != hipSuccess) {
+        oodgan::set_error("debug_set_stripx_stamp_buffer: hipMemcpyToSymbol failed");
+        return OODGAN_E_LAUNCH;
+    }
+    return 0;
+}
+#endif
 
 namespace oodgan {
 
