@@ -37,7 +37,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 #define SX_ABL 0
 #endif
 #ifndef SX_PD_FWD
-#define SX_PD_FWD 4
+#define SX_PD_FWD 2
 #endif
 
 #ifdef OODGAN_CLOCK_STAMP
@@ -59,8 +59,9 @@ constexpr int SX_SMALL_ONE = 3072;
 constexpr int SX_DOT_ONE = 16384;
 // LDS layout for prefetch distance PD (tiles between the request of a group and its conversion): NG = PD + 3 ring groups — t-1 (its
 // last two rows), t, t+1 (being converted) and PD in flight — and NB = PD + 1 buffers for everything else that travels with a batch.
-// The backward (48 KiB of dot rows) has room for PD = 2, the forward for more: with 2 tiles of 17 KiB in flight per CU the
-// forward was short of memory-level parallelism (793 us with, 552 us without the loads inside the loop; HBM alone 434).
+// The backward (48 KiB of dot rows) has room for PD = 2; the forward would have room for 4, which measured the same as 2 (the
+// counted wait and the barrier cost 0.1 us per tile in the stamp build: the prefetch is deep enough) — it keeps PD = 2 and
+// leaves 60 KiB of LDS to kernels of the other HIP streams.
 template <bool BWD>
 struct SXL {
     static constexpr int PD = BWD ? 2 : SX_PD_FWD;
