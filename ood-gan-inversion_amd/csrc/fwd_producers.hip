@@ -225,12 +225,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (a.vmax) record_vmax(a.vmax, b, vm);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// STRIP WALK of the same tail for the F-form output (the 1024² level inside the W+ loop, oodgan_blur_act_fform): the tile kernel
+// above fetches an 11 x 72 input tile for every 8 x 64 outputs and loads only during the first of its four phases (623 us for
+// 2.15 GB at B = 8).  Here a workgroup owns (b, 16-channel block, 64 output columns) and walks DOWN a segment of output rows:
+//   * thread = (channel, column quad); one iteration = one output row Y = one NEW z row Y + 2, requested three iterations earlier
+//     (register prefetch: a float4 per thread, the three halo columns by the edge threads of a channel, a float4 of noise);
+//   * the kernel must be rank one (Blur's [1,3,3,1] x [1,3,3,1] is; the caller falls back to the tile kernel otherwise): one
+//     horizontal 4-tap pass of the new row — the neighbours' columns come by DPP inside the channel's 16 lanes — then the
+//     vertical pass over the last four filtered rows kept in registers;
+//   * noise + bias + activation, the 16 channels of a pixel meet through a double-buffered LDS image (one barrier per row) and
+//     leave as 64-byte fp32 records, 16 bytes per lane, 1 KiB contiguous per wave.
+struct BlurStripGeo { int nstrips, nseg, seg_rows; };
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void blur_act_fform_strip_kernel(const BlurArgs a, const BlurStripGeo geo) {
+    constexpr int GP = 68;                                   // LDS pitch of a channel's 64 columns
+    __shared__ __attribute__((aligned(16))) float gat[2][16][GP];
+    __shared__ float ksep[8];
+    const int tid = threadIdx.x;
+    int w;
+    {
+        const int total = gridDim.x, bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int strip = w % geo.nstrips; w /= geo.nstrips;
+    const int seg = w % geo.nseg; w /= geo.nseg;
+    const int KC = a.yd.KC, kc = w % KC, b = w / KC;
+    const int Ho = 2 * a.H, Wo = 2 * a.W, Hz = Ho + 1, Wz = Wo + 1;
+    const int Y0 = seg * geo.seg_rows, Y1 = min(Y0 + geo.seg_rows, Ho);
+    const int X0 = 64 * strip;
+    if (tid < 8) {
+        // kf[ky][kx] = k[3-ky][3-kx] (upfirdn2d flips); rank one: kf[ky][kx] = kv[ky] * kh[kx] with kv[ky] = kf[ky][0] / kf[0][0], kh = kf[0][.]
+        const float k00 = a.kern[15];
+        ksep[tid] = tid < 4 ? a.kern[15 - 4 * tid] / k00 : a.kern[15 - (tid - 4)];
+    }
+    __syncthreads();
+    const float kv0 = ksep[0], kv1 = ksep[1], kv2 = ksep[2], kv3 = ksep[3], kh0 = ksep[4], kh1 = ksep[5], kh2 = ksep[6], kh3 = ksep[7];
+    const int ch = tid >> 4, q = tid & 15, c = kc * 16 + ch;
+    const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
+    const float bv = a.bias ? a.bias[c] : 0.f;
+    const float ysc = a.ys_scale ? a.ys_scale[(long)b * a.ys_scale_stride + c] : 1.f;
+    const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const long HWo = (long)Ho * Wo;
+    const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : nullptr;
+    const int gx = X0 + 4 * q;                               // this thread's output columns gx .. gx+3 = z columns gx-1 .. gx+5 are needed
+    // one z row: own float4 (columns gx .. gx+3), the edge threads' halo (q = 0: column X0-1; q = 15: columns X0+64, X0+65); zero outside
+    // the (2H+1) x (2W+1) support (columns between the valid width and the pitch are not defined)
+    struct Row { float4 m; float e0, e1; float4 n; };
+    auto load_row = [&](int r, int Y, Row& R) {
+        R.m = make_float4(0.f, 0.f, 0.f, 0.f);
+        R.e0 = R.e1 = 0.f;
+        R.n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && r < Hz) {
+            const float* rp = zp + (long)r * a.pitch;
+            if (gx + 3 < a.pitch) R.m = *reinterpret_cast<const float4*>(rp + gx);
+            if (gx + 0 >= Wz) R.m.x = 0.f;
+            if (gx + 1 >= Wz) R.m.y = 0.f;
+            if (gx + 2 >= Wz) R.m.z = 0.f;
+            if (gx + 3 >= Wz) R.m.w = 0.f;
+            if (q == 0 && X0 >= 1) R.e0 = rp[X0 - 1];
+            if (q == 15) {
+                if (X0 + 64 < Wz) R.e0 = rp[X0 + 64];
+                if (X0 + 65 < Wz) R.e1 = rp[X0 + 65];
+            }
+        }
+        if (np && Y >= 0 && Y < Ho && gx + 3 < Wo) R.n = *reinterpret_cast<const float4*>(np + (long)Y * Wo + gx);
+    };
+    // horizontal pass of a row: h[e] = sum_b kh[b] * z[gx + e - 1 + b]
+    auto hpass = [&](const Row& R, float (&h)[4]) {
+        // left neighbour's last column, right neighbour's first two (DPP row_shr / row_shl inside the channel's 16 lanes)
+        float lw = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.w), 0x111, 0xF, 0xF, false));   // row_shr:1
+        float rx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.x), 0x101, 0xF, 0xF, false));   // row_shl:1
+        float ry = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.y), 0x101, 0xF, 0xF, false));
+        if (q == 0) lw = R.e0;
+        if (q == 15) { rx = R.e0; ry = R.e1; }
+        const float x[7] = {lw, R.m.x, R.m.y, R.m.z, R.m.w, rx, ry};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = kh0 * x[e] + kh1 * x[e + 1] + kh2 * x[e + 2] + kh3 * x[e + 3];
+    };
+
+    // out[Y] = kv0 h[Y-1] + kv1 h[Y] + kv2 h[Y+1] + kv3 h[Y+2]: three filtered rows of history, the new one arrives each iteration
+    float h0[4], h1[4], h2[4];
+    Row R0, R1, R2;                                          // rows in flight: z rows Y+2, Y+3, Y+4 of the current iteration
+    {
+        Row T;
+        load_row(Y0 - 1, -1, T); hpass(T, h0);
+        load_row(Y0, -1, T);     hpass(T, h1);
+        load_row(Y0 + 1, -1, T); hpass(T, h2);
+    }
+    load_row(Y0 + 2, Y0, R0);
+    load_row(Y0 + 3, Y0 + 1, R1);
+    load_row(Y0 + 4, Y0 + 2, R2);
+    float vm = 0.f;
+    float* yf = a.y + ((long)b * KC + kc) * HWo * 16;
+    const int pcol = tid >> 2, pq = tid & 3;                 // F-form role: pixel column, channel quarter
+    for (int Y = Y0; Y < Y1; ++Y) {
+        float h3[4];
+        hpass(R0, h3);
+        const float4 n4 = R0.n;
+        R0 = R1;
+        R1 = R2;
+        load_row(Y + 5, Y + 3, R2);
+        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = kv0 * h0[e] + kv1 * h1[e] + kv2 * h2[e] + kv3 * h3[e] + nw * nn[e] + bv;
+            if (a.act == OODGAN_ACT_LRELU) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
+            t[e] = v;
+            if (gx + e < Wo) vm = fmaxf(vm, fabsf(v * ysc));
+            h0[e] = h1[e]; h1[e] = h2[e]; h2[e] = h3[e];
+        }
+        float (*gb)[GP] = gat[Y & 1];
+        *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
+        __syncthreads();
+        if (X0 + pcol < Wo)
+            *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
+                make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
+    }
+    if (a.vmax && c < a.C) record_vmax(a.vmax, b, vm);
+}
+
 }  // namespace
 
 static int blur_act_launch(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
                            int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
                            const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
-                           int y_fform, void* stream) {
+                           int y_fform, int rank_one, void* stream) {
     OODGAN_REQUIRE(z && kernel && y && B > 0 && C > 0 && H > 0 && W > 0, "blur_act_sform: bad args");
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "blur_act_sform: noise_batch");
     OODGAN_REQUIRE(act == OODGAN_ACT_NONE || act == OODGAN_ACT_LRELU, "blur_act_sform: act must be none or lrelu");
@@ -247,6 +369,21 @@ static int blur_act_launch(const float* z, const float* kernel, float* y, void* 
     a.vmax = (ys || y_fform) ? vmax : nullptr;
     a.y_fform = y_fform;
     OODGAN_REQUIRE(!y_fform || (C % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0), "blur_act_fform: C %% 16 == 0 and a 16-byte aligned y");
+    if (y_fform && rank_one == 1 && 2 * W >= 64 && oodgan::tunable(oodgan::OODGAN_TUN_BLUR_STRIP)) {
+        BlurStripGeo geo;
+        geo.nstrips = (2 * W + 63) / 64;
+        const long base = (long)B * a.yd.KC * geo.nstrips;
+        long nseg = (8L * 1024) / base;
+        if (nseg < 1) nseg = 1;
+        int seg_rows = (int)((2 * H + nseg - 1) / nseg);
+        if (seg_rows < 32) seg_rows = 32;
+        geo.seg_rows = seg_rows;
+        geo.nseg = (2 * H + seg_rows - 1) / seg_rows;
+        const long nbs = base * geo.nseg;
+        OODGAN_REQUIRE(nbs < (1L << 31), "blur_act_fform: grid too large");
+        hipLaunchKernelGGL(blur_act_fform_strip_kernel, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
+        return check_launch("blur_act_fform_strip");
+    }
     const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "blur_act_sform: grid too large");
     hipLaunchKernelGGL(blur_act_sform_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);
@@ -257,11 +394,11 @@ extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float*
                                      int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
                                      const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
                                      void* stream) {
-    return blur_act_launch(z, kernel, y, ys, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 0, stream);
+    return blur_act_launch(z, kernel, y, ys, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 0, 0, stream);
 }
 
 extern "C" int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const float* ys_scale, int ys_scale_stride,
                                      const float* bias, const float* noise, int noise_batch, const float* noise_w, int act,
-                                     int B, int C, int H, int W, int in_pitch, unsigned* vmax, void* stream) {
-    return blur_act_launch(z, kernel, y, nullptr, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 1, stream);
+                                     int B, int C, int H, int W, int in_pitch, unsigned* vmax, int kernel_rank_one, void* stream) {
+    return blur_act_launch(z, kernel, y, nullptr, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 1, kernel_rank_one, stream);
 }

@@ -24,6 +24,7 @@ Tunable g_tun[OODGAN_TUN_COUNT] = {
     {"s2_big_min_items", "OODGAN_S2_BIG_MIN_ITEMS", 128, {0}, {0}},
     {"t2_big_min_items", "OODGAN_T2_BIG_MIN_ITEMS", 128, {0}, {0}},
     {"blurt_strip", "OODGAN_BLURT_STRIP", 1, {0}, {0}},
+    {"blur_strip", "OODGAN_BLUR_STRIP", 1, {0}, {0}},
 };
 }  // namespace
 long tunable(int id) {

@@ -42,6 +42,7 @@ class GeneratorEngine:
         self.const_input = g('input.input')
         self.k4x4 = (make_kernel() * 4.0).to(dev)          # Blur(upsample_factor=2) / Upsample kernel
         self.k4x4_flip = torch.flip(self.k4x4, [0, 1]).contiguous()
+        self.k4x4_rank1 = bool(torch.linalg.matrix_rank(make_kernel().double()) == 1)
         layers = []
 
         def styled(name, cin, cout, res, lat, up, nidx):
@@ -309,7 +310,7 @@ class GeneratorEngine:
                         # last level inside the W+ loop: the activation stays in F-form and the conv converts it itself — no
                         # S-form copy of the largest tensor of the step is written or read
                         out = ops.blur_act_fform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True,
-                                                 ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                                                 ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx], rank_one=self.k4x4_rank1)
                     else:
                         pending = ops.sform_scratch(B, L.cout, 2 * Hi, 2 * Hi, self.device, tag=2)
                         out = ops.blur_act_sform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True, ys=pending,

@@ -357,9 +357,10 @@ def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     return y
 
 
-def blur_act_fform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys_scale=None, vmax=None):
+def blur_act_fform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys_scale=None, vmax=None, rank_one=False):
     """The same tail with y in F-form and no S-form (include/oodgan.h, oodgan_blur_act_fform): the following conv converts its input
-    itself (``conv3x3(FForm, ..., in_scale=style)``); ``vmax`` still records max |y * ys_scale| for the forward range control."""
+    itself (``conv3x3(FForm, ..., in_scale=style)``); ``vmax`` still records max |y * ys_scale| for the forward range control.
+    ``rank_one``: the caller knows the kernel to be an outer product (selects the strip-walk kernel)."""
     z = _dev(z)
     B, C = z.shape[0], z.shape[1]
     y = torch.empty(B, C, 2 * H, 2 * W, device=z.device, dtype=torch.float32)
@@ -367,7 +368,8 @@ def blur_act_fform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, ac
     check(_lib.lib().oodgan_blur_act_fform(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(_opt(ys_scale, 'ys_scale')),
                                            0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
                                            1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
-                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), _stream()), 'blur_act_fform')
+                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), 1 if rank_one else 0, _stream()),
+          'blur_act_fform')
     return FForm(y)
 
 

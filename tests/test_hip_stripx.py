@@ -90,22 +90,34 @@ def test_input_gradient_with_the_activation_backward_inside(B, H, W, pre):
     assert _rel(dx2, dx3) < 1e-6 and _rel(xa2.r, r2) < 2e-5
 
 
-def test_blur_act_fform_equals_blur_act_sform():
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 48, 48), (1, 32, 32, 80), (1, 16, 64, 32), (1, 32, 512, 512)])
+@pytest.mark.parametrize('rank_one', [False, True])
+def test_blur_act_fform_equals_blur_act_sform(B, C, H, W, rank_one):
+    """F-form tail of the up-conv (tile kernel, and the strip walk selected by rank_one) against the S-form / NCHW producer."""
     from oodgan import ops
     dev = torch.device('cuda:0')
-    g = torch.Generator().manual_seed(77)
-    B, C, H = 2, 32, 48
-    pitch = (2 * H + 1 + 3) // 4 * 4
+    g = torch.Generator().manual_seed(77 + H + W)
+    pitch = (2 * W + 1 + 3) // 4 * 4
     z = torch.randn(B, C, 2 * H + 1, pitch, generator=g).to(dev)
+    z[..., 2 * W + 1:] = float('nan')                     # columns between the valid width and the pitch are not defined
     k1 = torch.tensor([1., 3., 3., 1.])
     k = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
-    nz = torch.randn(B, 1, 2 * H, 2 * H, generator=g).to(dev)
+    nz = torch.randn(B, 1, 2 * H, 2 * W, generator=g).to(dev)
     nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
     s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
-    ys = ops.SForm(B, C, 2 * H, 2 * H, dev)
+    ys = ops.SForm(B, C, 2 * H, 2 * W, dev)
     vm0 = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
     vm1 = torch.zeros_like(vm0)
-    y0 = ops.blur_act_sform(z, k, H, H, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm0)
-    y1 = ops.blur_act_fform(z, k, H, H, bias, nz, nw, act=True, ys_scale=s, vmax=vm1)
-    assert torch.equal(y1.to_nchw(), y0)
-    assert torch.equal(vm0.max(dim=1).values, vm1.max(dim=1).values)
+    y0 = ops.blur_act_sform(z, k, H, W, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm0)
+    y1 = ops.blur_act_fform(z, k, H, W, bias, nz, nw, act=True, ys_scale=s, vmax=vm1, rank_one=rank_one)
+    if rank_one:        # separable evaluation: another order of the 16 products
+        assert _rel(y1.to_nchw(), y0) < 2e-6
+        a, b_ = vm0.max(dim=1).values.view(torch.float32), vm1.max(dim=1).values.view(torch.float32)
+        assert float(((a - b_).abs() / a).max()) < 2e-6
+    else:
+        assert torch.equal(y1.to_nchw(), y0)
+        assert torch.equal(vm0.max(dim=1).values, vm1.max(dim=1).values)
+    # shared noise, no bias
+    y2 = ops.blur_act_sform(z, k, H, W, None, nz[:1], nw, act=True, ys=ys, ys_scale=s)
+    y3 = ops.blur_act_fform(z, k, H, W, None, nz[:1], nw, act=True, ys_scale=s, rank_one=rank_one)
+    assert _rel(y3.to_nchw(), y2) < 2e-6

@@ -96,3 +96,19 @@ for res in (128, 256, 512):
     byts = 4.0 * B * C * 2 * res * res
     print(f'torgb_fwd_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
     del x, ys
+
+
+# the F-form tail of the 1024² level: tile kernel against the strip walk
+res = 1024
+C, H = CH[res], res // 2
+g = torch.Generator().manual_seed(res)
+pitch = (res + 1 + 3) // 4 * 4
+z = torch.randn(B, C, res + 1, pitch, generator=g).to(dev)
+nz = torch.randn(B, 1, res, res, generator=g).to(dev)
+nw, bias = torch.tensor([0.1], device=dev), torch.zeros(C, device=dev)
+s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+vm = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+for r1 in (False, True):
+    ms = timeit(lambda: ops.blur_act_fform(z, kf, H, H, bias, nz, nw, act=True, ys_scale=s, vmax=vm, rank_one=r1))
+    byts = 4.0 * B * C * (res * res + (res + 1) ** 2)
+    print(f'blur_act_fform {C:3d} ch @{res:4d} rank_one={r1}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
