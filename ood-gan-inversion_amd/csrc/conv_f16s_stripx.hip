@@ -771,6 +771,25 @@ int num_cus() {
     return num_cu;
 }
 
+// everything that must not happen for the first time inside a stream capture (hipMalloc of the zero page, device query, function
+// attributes): done on the first oodgan_conv3x3_xf_supported() call — the engine makes one when it is built — or launch
+bool stripx_init() {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM), true);
+    (void)once;
+    return zero_page() != nullptr && num_cus() > 0;
+}
+
 // strips are cut into segments only when there are fewer strips than CUs (one workgroup per CU: 152 KB of LDS); tiles of 4 rows
 void segments(int B, int H, int W, int& tiles_x, int& tiles_y, int& seg_tiles, int& nseg) {
     tiles_y = (H + 3) / 4;
@@ -795,6 +814,7 @@ extern "C" int oodgan_conv3x3_xf_nparts(int B, int H, int W) {
 }
 
 extern "C" int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W) {
+    if (!stripx_init()) return 0;
     return (B > 0 && K == 32 && M == 32 && H >= 8 && W >= 32 && H % 4 == 0 && W % 32 == 0 && (long)H * W * 64 * 2 < (1L << 32)) ? 1 : 0;
 }
 
@@ -825,7 +845,6 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
     p.out_plane = (long)a.Hin * a.out_pitch;
     p.w_unscale = unscale;
     p.zeros = zero_page();
-    OODGAN_REQUIRE(p.zeros != nullptr, "conv3x3 F-form input: cannot allocate the zero page");
     segments(a.B, a.Hin, a.Win, p.tiles_x, p.tiles_y, p.seg_tiles, p.nseg);
     p.Mp = (a.M + 63) / 64 * 64;
     p.nparts = p.tiles_x * p.nseg;
@@ -851,19 +870,7 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
     }
     const long nblk = (long)a.B * p.tiles_x * p.nseg;
     OODGAN_REQUIRE(nblk < (1L << 31), "conv3x3 F-form input: grid too large");
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, false, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM), true);
-    (void)once;
+    OODGAN_REQUIRE(stripx_init(), "conv3x3 F-form input: initialisation failed (zero page / device query)");
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     const dim3 grid((unsigned)nblk), block(256);
     if (bwd) {

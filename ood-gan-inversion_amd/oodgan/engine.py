@@ -93,6 +93,7 @@ class GeneratorEngine:
         self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
         self.fused_rgb = True
         self.fuse_x = True           # 1024² level: F-form activations, the strip convs convert their input themselves (conv_f16s_stripx.hip)
+        ops.xf_supported(1, 32, 32, 8, 32)      # first call initialises that path (allocations must not fall into a stream capture)
         self.batched_tail = True
         src = 'input'
         for L in layers:            # producer of every layer's input feature

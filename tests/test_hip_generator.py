@@ -217,6 +217,23 @@ def test_three_streams_vs_one_at_full_size(dev):
     assert rel0 <= 1e-5 and rel <= 1e-3 and frac > 0.999 and (l3[-1] < l3[0]).all()
 
 
+def test_graph_replay_at_full_size(dev):
+    """A W+ step captured into a hipGraph and replayed (WPlusInverter.invert(use_graph=True)) at the bench geometry: the F-form path
+    of the 1024² level (conv_f16s_stripx.hip) is first used in step 2, i.e. inside the capture — its one-time allocations and
+    attribute calls must have happened before (done when the engine is built).  Same trajectory as the eager loop."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, B, steps = 1024, 2, 4
+    P = synth.generator_state(size, seed=0)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size)
+    target = torch.cat([synth.make_images(size, 1, seed=1000 + g) for g in range(B)]).to(dev)
+    noises = [torch.cat([synth.make_noises(size, 1, seed=2000 + g)[i] for g in range(B)]).to(dev) for i in range(17)]
+    w0 = torch.cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in range(B)]).to(dev)
+    inv = WPlusInverter(eng)
+    w1, l1 = inv.invert(target, w0, noises, steps=steps, streams=1)
+    w2, l2 = inv.invert(target, w0, noises, steps=steps, streams=1, use_graph=True)
+    assert torch.equal(l1, l2) and torch.equal(w1, w2)
+
+
 def test_torgb_reproducible_beside_matrix_kernels_of_another_stream(dev):
     """Guard for DESIGN.md §10: a ToRGB launch that shares the GPU with the stride-2 / transposed matrix kernels of
     another HIP stream must give the same bits as alone (with packed-fp32 instructions in the kernels 70–85 % of such
