@@ -186,6 +186,11 @@ typedef struct oodgan_conv_args {
                                   nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win) — also the dot_nparts of this instance; dotx (F-form,
                                   dotx_fform = 1) is mandatory, y NCHW. */
     int dotx_fform;          /* 1: dotx is in F-form (x_fform == 2 only) */
+    void* workspace;         /* optional scratch of workspace_bytes >= oodgan_conv3x3_tiny_workspace(...) bytes, zero-initialised once by
+                                the caller and owned by ONE stream: with it the 4x4 / 8x8 layers (mode S1 with S-form input, mode S2
+                                with phase-split S-form input, K >= 64) run as a skinny GEMM over the batch with a K split
+                                (csrc/conv_f16s_tiny.hip); NULL: the tile kernels */
+    long workspace_bytes;
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -242,6 +247,8 @@ int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
  * x_fform == 2 instance writes to fuse->part_r / part_t (per (sample, 16-channel block) to fuse->part_max) */
 int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W);
 int oodgan_conv3x3_xf_nparts(int B, int H, int W);
+/* bytes of oodgan_conv_args.workspace the skinny-GEMM kernel of the 4x4 / 8x8 layers needs for this call (0: not applicable) */
+long oodgan_conv3x3_tiny_workspace(int mode, int B, int K, int M, int Hin, int Win);
 
 /* S-form activations (csrc/sform.hpp): per pixel and 16-channel block one 64-byte record {hi[16], lo[16]} f16 of the
  * value already multiplied by the consumer's scale, with a zero border and tile padding, so that the split-f16 convs

@@ -33,6 +33,8 @@ bool s1_big_eligible(const oodgan_conv_args& a);
 int launch_s1_big(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1_strip(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s1_stripx(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
+bool tiny_eligible(const oodgan_conv_args& a);
+int launch_tiny(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_t2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 int launch_s2v2(const oodgan_conv_args& a, const void* wpk16, const float* unscale, hipStream_t st);
 bool s2_big_eligible(const oodgan_conv_args& a);
@@ -463,6 +465,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:
+            if (tiny_eligible(a)) return launch_tiny(a, a.wpk, unscale2, st);
             if (a.x_sform && s1_strip_eligible(a)) return launch_s1_strip(a, a.wpk, unscale2, st);
             OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32)");
             if (a.x_sform && s1_big_eligible(a)) return launch_s1_big(a, a.wpk, unscale2, st);
@@ -475,6 +478,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
             return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
+            if (tiny_eligible(a)) return launch_tiny(a, a.wpk, unscale2, st);
             if (a.x_sform && s2_big_eligible(a)) return launch_s2_big(a, a.wpk, unscale2, st);
             if (a.x_sform) return launch_s2v2(a, a.wpk, unscale2, st);
             return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);

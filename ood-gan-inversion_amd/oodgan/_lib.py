@@ -25,7 +25,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int), ('workspace', P), ('workspace_bytes', c_long),
     ]
 
 
@@ -93,6 +93,7 @@ _SIGS = {
     'oodgan_blur_act_fform': (c_int, [P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'oodgan_conv3x3_xf_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_xf_nparts': (c_int, [c_int, c_int, c_int]),
+    'oodgan_conv3x3_tiny_workspace': (c_long, [c_int, c_int, c_int, c_int, c_int, c_int]),
 
     'oodgan_absmax_scaled': (c_int, [P, P, c_int, P, c_int, c_int, c_long, P]),
     'oodgan_fwd_range_update': (c_int, [P, P, P, c_int, P]),

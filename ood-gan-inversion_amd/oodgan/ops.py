@@ -319,6 +319,20 @@ def sform_phases_scratch(B, C, H, W, device):
     return buf
 
 
+_WS_POOL = {}
+USE_TINY = True      # the 4x4 / 8x8 layers as a skinny GEMM with a K split (csrc/conv_f16s_tiny.hip); False: the tile kernels
+
+
+def conv_workspace(nbytes, device):
+    """Scratch for ``oodgan_conv_args.workspace``: zero-initialised once (the kernel leaves its counters at zero), one per HIP
+    stream — two streams running the same layer at the same time must not share partial tiles."""
+    key = (nbytes, str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _WS_POOL.get(key)
+    if buf is None:
+        buf = _WS_POOL[key] = torch.zeros(nbytes // 4, device=device, dtype=torch.int32)
+    return buf
+
+
 def sform_scratch(B, C, H, W, device, tag=0):
     """Reusable S-form buffer (zero border written once at allocation; producers only touch the interior, so a
     buffer can be recycled for any tensor of the same logical shape)."""
@@ -710,6 +724,12 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.in_mul2 = _p(in_mul2)
     a.x_sform = 1 if sform_in else 0
     a.x_fform = (2 if xf_act is not None else 1) if fform_in else 0
+    ws = None
+    if sform_in and USE_TINY and wpk.precision == 'f16s' and mode in (CONV_S1, CONV_S2) and min(oh, ow) <= 8:
+        nb = _lib.lib().oodgan_conv3x3_tiny_workspace(mode, B, K, M, H, W)
+        if nb > 0:
+            ws = conv_workspace(nb, x.data.device)
+            a.workspace, a.workspace_bytes = _p(ws), nb
     a.groups = int(groups)
     a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))

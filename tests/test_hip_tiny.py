@@ -1,0 +1,85 @@
+"""The skinny-GEMM kernel of the 4x4 / 8x8 layers (csrc/conv_f16s_tiny.hip: images packed into the N tiles, K split over workgroups,
+fixed-order combine by the last workgroup of a tile) against the tile kernels it replaces — which are pinned against the oracle
+and the reference's golden vectors (test_hip_ops.py) — at the geometries of the W+ loop: stride 1 forward (noise + bias +
+lrelu) and input gradient (style-gradient dot), stride 2 on the phase-split S-form (input gradient of the up-conv)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R_, 'ood-gan-inversion_amd'))
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _both(fn):
+    from oodgan import ops
+    old = ops.USE_TINY
+    try:
+        ops.USE_TINY = False
+        ref = fn()
+        ops.USE_TINY = True
+        new = fn()
+    finally:
+        ops.USE_TINY = old
+    return ref, new
+
+
+@pytest.mark.parametrize('B,C,M,H', [(8, 512, 512, 4), (8, 512, 512, 8), (3, 128, 64, 8), (1, 64, 96, 4), (5, 512, 512, 4)])
+def test_stride1_forward_and_input_gradient(B, C, M, H):
+    from oodgan import _lib, ops
+    dev = torch.device('cuda:0')
+    assert _lib.lib().oodgan_conv3x3_tiny_workspace(ops.CONV_S1, B, C, M, H, H) > 0
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, M, generator=g)).abs().to(dev)
+    w = (torch.randn(M, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+    wf = ops.pack_conv3x3(w, precision='f16s')
+    nz = torch.randn(B, 1, H, H, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(M, generator=g)).to(dev)
+    xs = ops.to_sform(x, s)
+    y0, y1 = _both(lambda: ops.conv3x3(xs, wf, M, ops.CONV_S1, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU))
+    assert _rel(y1, y0) < 5e-6
+    y0, y1 = _both(lambda: ops.conv3x3(xs, wf, M, ops.CONV_S1, out_scale=d, noise=nz[:1], noise_weight=nw, act=ops.ACT_LRELU))
+    assert _rel(y1, y0) < 5e-6
+    # input gradient: transposed weights, dot with the saved forward input, range scale
+    if C == M:
+        wb = ops.pack_conv3x3(w, transpose=True, flip=True, precision='f16s')
+        gsrc = (1e-3 * torch.randn(B, M, H, H, generator=g)).to(dev)
+        mul2 = torch.tensor([2.0 ** -13, 2.0 ** 13], device=dev)
+        gs = ops.to_sform(gsrc, d, mul2)
+        (dx0, dot0), (dx1, dot1) = _both(lambda: ops.conv3x3(gs, wb, C, ops.CONV_S1, out_scale=s, dotx=x, in_mul2=mul2))
+        assert _rel(dx1, dx0) < 5e-6 and _rel(dot1, dot0) < 1e-5       # another order of the 4608-term fp32 sums (K split 8-18 ways)
+    # a second launch on the same workspace (the counters were left at zero)
+    y2 = ops.conv3x3(xs, wf, M, ops.CONV_S1, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU)
+    y3 = ops.conv3x3(xs, wf, M, ops.CONV_S1, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU)
+    assert torch.equal(y2, y3)
+
+
+@pytest.mark.parametrize('B,Cg,Cx,H', [(8, 512, 512, 4), (8, 512, 512, 8), (2, 64, 128, 8), (3, 128, 64, 4)])
+def test_stride2_input_gradient_of_the_up_conv(B, Cg, Cx, H):
+    """g2 (B, Cg, 2H+1, 2H+1) in phase-split S-form -> dx (B, Cx, H, H) with the style-gradient dot."""
+    from oodgan import _lib, ops
+    dev = torch.device('cuda:0')
+    Hin = 2 * H + 1
+    assert _lib.lib().oodgan_conv3x3_tiny_workspace(ops.CONV_S2, B, Cg, Cx, Hin, Hin) > 0
+    g = torch.Generator().manual_seed(B * 10 + H)
+    P2 = (Hin + 3) // 4 * 4
+    g2 = (1e-3 * torch.randn(B, Cg, Hin, P2, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, Cg, generator=g)).to(dev)
+    s = (1 + 0.3 * torch.randn(B, Cx, generator=g)).to(dev)
+    x = torch.randn(B, Cx, H, H, generator=g).to(dev)
+    w = (torch.randn(Cg, Cx, 3, 3, generator=g) / math.sqrt(Cx * 9)).to(dev)
+    wb = ops.pack_conv3x3(w, transpose=True, flip=False, precision='f16s')
+    mul2 = torch.tensor([2.0 ** -13, 2.0 ** 13], device=dev)
+    gp = ops.to_sform_phases(g2, H, H, d, mul2, in_pitch=P2)
+    (dx0, dot0), (dx1, dot1) = _both(lambda: ops.conv3x3(gp, wb, Cx, ops.CONV_S2, out_scale=s, dotx=x, in_mul2=mul2))
+    assert _rel(dx1, dx0) < 5e-6 and _rel(dot1, dot0) < 1e-5       # another order of the 4608-term fp32 sums (K split 8-18 ways)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of an engine switch on the bench workload (B=8, 1024², one stream): alternates the W+ loop with the switch on and
-off, three rounds.  Usage: python tools/ab_engine_flag.py fform [steps]   (switches: fform = F-form hand-off of the last styled conv)"""
+off, three rounds.  Usage: python tools/ab_engine_flag.py fform [steps]   (switches: an engine attribute such as fuse_x; fform = F-form hand-off of the last styled conv; tiny = ops.USE_TINY)"""
 import os
 import sys
 import time
@@ -25,7 +25,9 @@ inv = WPlusInverter(eng)
 
 
 def set_flag(on):
-    if flag == 'fform':
+    if flag == 'tiny':
+        ops.USE_TINY = on
+    elif flag == 'fform':
         eng.layers_styled_last = [L for L in eng.layers if L.kind != 'rgb'][-1] if on else None
     else:
         setattr(eng, flag, on)

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(R_, 'ood-gan-inversion_amd'))
 from oodgan import ops  # noqa: E402
 
 dev = torch.device('cuda:0')
+ops.USE_TINY = os.environ.get('OODGAN_NO_TINY') is None       # the skinny-GEMM kernel of the 4x4 / 8x8 layers
 which = sys.argv[1].split(',') if len(sys.argv) > 1 else ['S1', 'T2', 'S2']
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 only = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else None      # resolutions
@@ -69,10 +70,10 @@ if 'SX' in which:               # the 1024² level inside the W+ loop: two-pass 
                                                                      xf_act=ops.ActBwdX(nz, nw, bias, d, mul2, g_rgb, w_rgb, s_rgb))), fl, 3 * by)
     sys.exit(0)
 
-for res in (8, 16, 32, 64, 128, 256, 512, 1024):
+for res in (4, 8, 16, 32, 64, 128, 256, 512, 1024):
     if only and res not in only:
         continue
-    cin, cout = CH[res // 2], CH[res]
+    cin, cout = CH[max(res // 2, 4)], CH[res]
     g = torch.Generator().manual_seed(res)
     if 'S1' in which:           # plain conv at `res`: cout -> cout
         C, H = cout, res
@@ -89,6 +90,8 @@ for res in (8, 16, 32, 64, 128, 256, 512, 1024):
         report(f'S1 fwd {C}->{C} @{H}', timeit(lambda: ops.conv3x3(xs, wf, C, ops.CONV_S1, out_scale=s, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU)), fl, by)
         report(f'S1 bwd+dot {C}->{C} @{H}', timeit(lambda: ops.conv3x3(xs, wb, C, ops.CONV_S1, out_scale=s, dotx=x)), fl, by * 1.5)
         del x, xs, nz
+    if res == 4:
+        continue
     if 'T2' in which:           # up conv res/2 -> res: cin -> cout
         H = res // 2
         w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev)
