@@ -195,13 +195,26 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
             rel[i] = (int)sform_unit(yd, 0, 0, (int)(po / W), (int)(po % W), t & 3);
         }
     }
-    for (int kc = 0; kc < Ci / 16; ++kc) {
+    // the 16 channel planes of block kc+1 are requested before block kc is processed: one block at a time left every block a
+    // bare round trip to HBM (80 % of the wave time waiting at 3.7 TB/s)
+    float2 nx[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) nx[c] = *reinterpret_cast<const float2*>(xp + (long)c * HW);
+    const int nkc = Ci / 16;
+    for (int kc = 0; kc < nkc; ++kc) {
         unsigned hp[TS_PX][8], lp[TS_PX][8];
+        float2 cx[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cx[c] = nx[c];
+        if (kc + 1 < nkc) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) nx[c] = *reinterpret_cast<const float2*>(xp + (long)((kc + 1) * 16 + c) * HW);
+        }
 #pragma unroll
         for (int cp = 0; cp < 8; ++cp) {
             const int ci = kc * 16 + 2 * cp;
-            const float2 v0 = *reinterpret_cast<const float2*>(xp + (long)ci * HW);
-            const float2 v1 = *reinterpret_cast<const float2*>(xp + (long)(ci + 1) * HW);
+            const float2 v0 = cx[2 * cp];
+            const float2 v1 = cx[2 * cp + 1];
             const float e0[TS_PX] = {v0.x, v0.y}, e1[TS_PX] = {v1.x, v1.y};
             const float w00 = ws[ci], w01 = ws[Ci + ci], w02 = ws[2 * Ci + ci];
             const float w10 = ws[ci + 1], w11 = ws[Ci + ci + 1], w12 = ws[2 * Ci + ci + 1];
