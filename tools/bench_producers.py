@@ -45,6 +45,12 @@ for res in (64, 128, 256, 512, 1024):
     ms = timeit(lambda: ops.act_bwd_producer(out, gf, nz, nw, bias, d, mul2, dst, blur_kernel=k))
     byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
     print(f'act_bwd_blurT {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
+    # the form the loop uses: the conv above already applied act' (one tensor in)
+    dg = ops.DotActGrad()
+    dg.dot_part, dg.scale = torch.zeros(B, C, 4, device=dev), d
+    ms = timeit(lambda: ops.act_bwd_producer(None, gf, nz, nw, bias, d, mul2, dst, blur_kernel=k, dot_of=dg))
+    byts = 4.0 * B * C * (res * res + (res + 1) ** 2)
+    print(f'act_bwd_blurT {C:3d} ch @{res:4d} pre-activated: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
     del out, gf, nz, dst
 
 kf = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
