@@ -753,21 +753,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 const void* zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
-    }
+    static void* const z = [] {          // initialised once, thread-safe (function-local static)
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) q = nullptr;
+        return q;
+    }();
     return z;
 }
 
 int num_cus() {
-    static int num_cu = 0;
-    if (!num_cu) {
+    static const int num_cu = [] {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        num_cu = prop.multiProcessorCount;
-    }
+        return (int)prop.multiProcessorCount;
+    }();
     return num_cu;
 }
 
