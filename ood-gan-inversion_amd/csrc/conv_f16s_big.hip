@@ -61,7 +61,8 @@ struct BigConv {
 // that layer's demodulation gradient are finished by the producer and the dot partials, include/oodgan.h).
 constexpr int BG_ZERO = BG_SMEM;                           // 3.5 KB of zeros (the B operand's second half of the lo*hi product of tap 8)
 constexpr int BG_ZBYTES = 3584;
-constexpr int BG_SMEM16 = BG_SMEM + BG_ZBYTES;            // 159232
+constexpr int BG_CST = BG_SMEM + BG_ZBYTES;                // [3][64] floats: out scale, bias, PReLU slope of the workgroup's channels
+constexpr int BG_SMEM16 = BG_CST + 3 * 64 * 4;             // 160000
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifdef OODGAN_CLOCK_STAMP
@@ -200,8 +201,25 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 #ifdef OODGAN_CLOCK_STAMP
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Per-channel constants of the epilogue, requested before the first stage and parked in LDS.  Loaded where they are used
+    // (`m < M ? out_scale[m] : 0` per accumulator register) each one is a branch around a load followed by vmcnt(0): sixteen
+    // serialised round trips per tile in front of the stores.  The ds_write waits for stage 0 like the loop's first barrier does;
+    // the epilogue reads the table behind the loop's barriers.
+    float cst_o = 0.f, cst_b = 0.f, cst_s = 1.f;
+    if (tid < 64 && m0 + tid < M) {
+        const int m = m0 + tid;
+        cst_o = a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f;
+        if (!DOT && a.bias) cst_b = a.bias[m];
+        if (!DOT && a.act == OODGAN_ACT_PRELU) cst_s = a.slope[m];
+    }
 #pragma unroll
     for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
+    if (tid < 64) {
+        float* cst = reinterpret_cast<float*>(smem + BG_CST);
+        cst[tid] = cst_o;
+        if (!DOT) { cst[64 + tid] = cst_b; cst[128 + tid] = cst_s; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): written before this wave arrives at the loop's first barrier
+    }
     for (int t = 0; t < nchunk; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
@@ -252,13 +270,14 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     unsigned moff[16], doff[16];
     float dsum[16];
     const bool prelu = !DOT && a.act == OODGAN_ACT_PRELU;
+    const float* cst = reinterpret_cast<const float*>(smem + BG_CST);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int m = m0 + 16 * (q >> 2) + 4 * g + (q & 3);
+        const int j = 16 * (q >> 2) + 4 * g + (q & 3), m = m0 + j;
         const bool mok = m < M;
-        osc[q] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
-        bia[q] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
-        slp[q] = (prelu && mok) ? a.slope[m] : 1.f;
+        osc[q] = cst[j] * us;
+        bia[q] = DOT ? 0.f : cst[64 + j];
+        slp[q] = DOT ? 1.f : cst[128 + j];
         moff[q] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
         doff[q] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
         dsum[q] = 0.f;

@@ -41,7 +41,8 @@ constexpr int TB_WPIECES = 36;
 constexpr int TB_PIECES = TB_XPIECES + TB_WPIECES;         // 55 -> 7 per wave (one harmless duplicate)
 constexpr int TB_NPW = 7;
 constexpr int TB_STAGE = (TB_PIECES + 1) * 1024;           // 57344
-constexpr int TB_SMEM = 2 * TB_STAGE;
+constexpr int TB_CST = 2 * TB_STAGE;                       // [64] floats: the out scale of the workgroup's channels
+constexpr int TB_SMEM = TB_CST + 64 * 4;
 
 struct T2Big {
     oodgan_conv_args a;
@@ -169,7 +170,16 @@ __device__ __forceinline__ void t2big_body(const T2Big& p, const uint4* __restri
 #define TB_IC(n) std::integral_constant<int, n>{}
 #define TB_SB() __builtin_amdgcn_sched_barrier(0)
     // taps are visited in an order that alternates the output phase, so two consecutive taps never hit the same accumulators
+    // The epilogue's per-channel scale, requested before the first stage and parked in LDS: loaded where it is used it is a
+    // branch, a load and a vmcnt(0) per accumulator register — 32 serialised round trips per tile, each one also waiting for the
+    // two stores in front of it.  (Written behind stage 0's request; read after the K loop's barriers.)
+    float cst_o = 0.f;
+    if (tid < 64 && m0 + tid < M) cst_o = a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m0 + tid] : 1.f;
     dma_stage(0, 0);
+    if (tid < 64) {
+        reinterpret_cast<float*>(smem + TB_CST)[tid] = cst_o;
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): written before this wave arrives at the loop's first barrier
+    }
     for (int t = 0; t < nchunk; ++t) {
         __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): only stage t is outstanding
         __builtin_amdgcn_s_barrier();
@@ -205,6 +215,7 @@ __device__ __forceinline__ void t2big_body(const T2Big& p, const uint4* __restri
     // ---- epilogue: z rows 2i', 2i'+1; the two x-phases of a position are one aligned float2
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
     float* yb = a.y + (long)b * M * p.out_plane;
+    const float* cst = reinterpret_cast<const float*>(smem + TB_CST);
     if constexpr (EDGE) {
         const int e = e0 + 32 * wave + l31;
         if (e > W + H) return;
@@ -216,7 +227,7 @@ __device__ __forceinline__ void t2big_body(const T2Big& p, const uint4* __restri
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
-                const float sc = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
+                const float sc = cst[m - m0] * us;
                 float* zp = yb + (long)m * p.out_plane;
                 if (rowt) {
                     float* q = zp + (long)(2 * H) * a.out_pitch + 2 * e;
@@ -238,7 +249,7 @@ __device__ __forceinline__ void t2big_body(const T2Big& p, const uint4* __restri
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= M) continue;
-            const float sc = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
+            const float sc = cst[m - m0] * us;
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const int zy = 2 * ip + py;

@@ -270,64 +270,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const long HWo = (long)Ho * Wo;
     const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : nullptr;
     const int gx = X0 + 4 * q;                               // this thread's output columns gx .. gx+3 = z columns gx-1 .. gx+5 are needed
-    // one z row: own float4 (columns gx .. gx+3), the edge threads' halo (q = 0: column X0-1; q = 15: columns X0+64, X0+65); zero outside
-    // the (2H+1) x (2W+1) support (columns between the valid width and the pitch are not defined)
-    struct Row { float4 m; float e0, e1; float4 n; };
+    // one z row: own float4 (columns gx .. gx+3) and the halo of the edge threads (q = 0: column X0-1; q = 15: columns X0+64, X0+65).
+    // A load is ONLY a load here: every lane reads from a clamped address, and what lies outside the (2H+1) x (2W+1) support
+    // (columns between the valid width and the pitch are not defined) is masked where the row is CONSUMED, three iterations later,
+    // with lane masks that do not depend on the row.  Masking a value right behind its load (`if (gx >= Wz) m.x = 0`) is a use: the
+    // compiler waits for the load — vmcnt(0) — at that point, in every iteration, and the rows in flight are worth nothing (that
+    // form of this kernel: 76 % of the wave time waiting at 3.5 TB/s).  For the same reason the three row buffers rotate by NAME
+    // (the loop body is written three times): `R0 = R1` is a read of R1.
+    struct Row { float4 m; float e0, e1; float4 n; float rv; };
+    const int gxc = min(gx, a.pitch - 4);                    // gx + 3 >= pitch <=> gx >= pitch >= Wz: all four columns masked
+    const bool mk0 = gx + 0 < Wz, mk1 = gx + 1 < Wz, mk2 = gx + 2 < Wz, mk3 = gx + 3 < Wz;
+    const bool q0 = q == 0, q15 = q == 15;
+    const int ec0 = q0 ? max(X0 - 1, 0) : min(X0 + 64, a.pitch - 1), ec1 = min(X0 + 65, a.pitch - 1);
+    const bool me0 = q0 ? X0 >= 1 : X0 + 64 < Wz, me1 = X0 + 65 < Wz;
+    const bool mkn = gx + 3 < Wo;
+    const int gxn = min(gx, Wo - 4);
     auto load_row = [&](int r, int Y, Row& R) {
-        R.m = make_float4(0.f, 0.f, 0.f, 0.f);
-        R.e0 = R.e1 = 0.f;
-        R.n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && r < Hz) {
-            const float* rp = zp + (long)r * a.pitch;
-            if (gx + 3 < a.pitch) R.m = *reinterpret_cast<const float4*>(rp + gx);
-            if (gx + 0 >= Wz) R.m.x = 0.f;
-            if (gx + 1 >= Wz) R.m.y = 0.f;
-            if (gx + 2 >= Wz) R.m.z = 0.f;
-            if (gx + 3 >= Wz) R.m.w = 0.f;
-            if (q == 0 && X0 >= 1) R.e0 = rp[X0 - 1];
-            if (q == 15) {
-                if (X0 + 64 < Wz) R.e0 = rp[X0 + 64];
-                if (X0 + 65 < Wz) R.e1 = rp[X0 + 65];
-            }
-        }
-        if (np && Y >= 0 && Y < Ho && gx + 3 < Wo) R.n = *reinterpret_cast<const float4*>(np + (long)Y * Wo + gx);
+        const float* rp = zp + (long)min(max(r, 0), Hz - 1) * a.pitch;
+        R.rv = (r >= 0 && r < Hz) ? 1.f : 0.f;
+        R.m = *reinterpret_cast<const float4*>(rp + gxc);
+        R.e0 = rp[ec0];
+        R.e1 = rp[ec1];
+        if (np) R.n = *reinterpret_cast<const float4*>(np + (long)min(max(Y, 0), Ho - 1) * Wo + gxn);
     };
     // horizontal pass of a row: h[e] = sum_b kh[b] * z[gx + e - 1 + b]
     auto hpass = [&](const Row& R, float (&h)[4]) {
+        const float mx = mk0 ? R.m.x : 0.f, my = mk1 ? R.m.y : 0.f, mz = mk2 ? R.m.z : 0.f, mw = mk3 ? R.m.w : 0.f;
+        const float e0 = me0 ? R.e0 : 0.f, e1 = me1 ? R.e1 : 0.f;
         // left neighbour's last column, right neighbour's first two (DPP row_shr / row_shl inside the channel's 16 lanes)
-        float lw = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.w), 0x111, 0xF, 0xF, false));   // row_shr:1
-        float rx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.x), 0x101, 0xF, 0xF, false));   // row_shl:1
-        float ry = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, R.m.y), 0x101, 0xF, 0xF, false));
-        if (q == 0) lw = R.e0;
-        if (q == 15) { rx = R.e0; ry = R.e1; }
-        const float x[7] = {lw, R.m.x, R.m.y, R.m.z, R.m.w, rx, ry};
+        float lw = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mw), 0x111, 0xF, 0xF, false));   // row_shr:1
+        float rx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x101, 0xF, 0xF, false));   // row_shl:1
+        float ry = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, my), 0x101, 0xF, 0xF, false));
+        if (q0) lw = e0;
+        if (q15) { rx = e0; ry = e1; }
+        const float x[7] = {lw, mx, my, mz, mw, rx, ry};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = kh0 * x[e] + kh1 * x[e + 1] + kh2 * x[e + 2] + kh3 * x[e + 3];
+        for (int e = 0; e < 4; ++e) h[e] = (kh0 * x[e] + kh1 * x[e + 1] + kh2 * x[e + 2] + kh3 * x[e + 3]) * R.rv;
     };
 
     // out[Y] = kv0 h[Y-1] + kv1 h[Y] + kv2 h[Y+1] + kv3 h[Y+2]: three filtered rows of history, the new one arrives each iteration
     float h0[4], h1[4], h2[4];
     Row R0, R1, R2;                                          // rows in flight: z rows Y+2, Y+3, Y+4 of the current iteration
+    R0.n = R1.n = R2.n = make_float4(0.f, 0.f, 0.f, 0.f);
     {
-        Row T;
-        load_row(Y0 - 1, -1, T); hpass(T, h0);
-        load_row(Y0, -1, T);     hpass(T, h1);
-        load_row(Y0 + 1, -1, T); hpass(T, h2);
+        Row T0, T1, T2;                                      // all six rows of the prologue are requested before the first is used
+        T0.n = T1.n = T2.n = make_float4(0.f, 0.f, 0.f, 0.f);
+        load_row(Y0 - 1, -1, T0);
+        load_row(Y0, -1, T1);
+        load_row(Y0 + 1, -1, T2);
+        load_row(Y0 + 2, Y0, R0);
+        load_row(Y0 + 3, Y0 + 1, R1);
+        load_row(Y0 + 4, Y0 + 2, R2);
+        hpass(T0, h0);
+        hpass(T1, h1);
+        hpass(T2, h2);
     }
-    load_row(Y0 + 2, Y0, R0);
-    load_row(Y0 + 3, Y0 + 1, R1);
-    load_row(Y0 + 4, Y0 + 2, R2);
     float vm = 0.f;
     float* yf = a.y + ((long)b * KC + kc) * HWo * 16;
     const int pcol = tid >> 2, pq = tid & 3;                 // F-form role: pixel column, channel quarter
-    for (int Y = Y0; Y < Y1; ++Y) {
+    const bool pok = X0 + pcol < Wo;
+    auto step = [&](int Y, Row& R) {
         float h3[4];
-        hpass(R0, h3);
-        const float4 n4 = R0.n;
-        R0 = R1;
-        R1 = R2;
-        load_row(Y + 5, Y + 3, R2);
-        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        hpass(R, h3);
+        const float nn[4] = {mkn ? R.n.x : 0.f, mkn ? R.n.y : 0.f, mkn ? R.n.z : 0.f, mkn ? R.n.w : 0.f};
+        load_row(Y + 5, Y + 3, R);
         float t[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -340,9 +346,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float (*gb)[GP] = gat[Y & 1];
         *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
         __syncthreads();
-        if (X0 + pcol < Wo)
+        if (pok)
             *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
                 make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
+    };
+    for (int Y = Y0; Y < Y1; Y += 3) {
+        step(Y, R0);
+        if (Y + 1 < Y1) step(Y + 1, R1);
+        if (Y + 2 < Y1) step(Y + 2, R2);
     }
     if (a.vmax && c < a.C) record_vmax(a.vmax, b, vm);
 }
