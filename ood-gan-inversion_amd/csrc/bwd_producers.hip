@@ -12,6 +12,7 @@
 // src/ops/op/fused_act.py:25-58) and of Blur(pad=(1,1)) (src/ops/op/upfirdn2d.py:115-120).
 #include "common.hpp"
 #include "sform.hpp"
+#include <type_traits>
 #include <cstdint>
 #include <cstdlib>
 
@@ -529,14 +530,13 @@ struct StripGeo {
 // Measured alternatives (1024² layer, us): 64-column strips x 16 channels (this kernel) 935; 128 columns x 16 channels with
 // 512 threads 981-1012; 128 columns x 8 channels (256 threads, half records per workgroup) 1092; no halo loads at all 742.
 template <int QN, bool XTRA, bool PRE>
-__global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
+__global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(PRE ? 4 : 3, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
                                                                    int H, int W, SPDims sp, StripGeo geo) {
     constexpr int SW = 4 * QN, NT = 16 * QN, NWV = NT / 64;
     constexpr int BS_RP = SW + 4;       // LDS pitch of a g_pre row: 2 + SW + 1 columns, 16-byte aligned rows
     constexpr int BS_GP = SW + 4;       // gather pitch
-    __shared__ __attribute__((aligned(16))) float raw[2][16][BS_RP];
-    __shared__ __attribute__((aligned(16))) float gat[2][16][BS_GP];
-    __shared__ __attribute__((aligned(16))) float nzl[2][2][SW];      // [iteration parity][row a/b][own column]: the noise rows, loaded once per workgroup
+    static_assert(QN == 16, "a channel row is one DPP row of 16 lanes");
+    __shared__ __attribute__((aligned(16))) float gat[2][2][16][BS_GP];      // [iteration parity][g2 row of the pair][channel][column]
     __shared__ float cst[7][16];
     __shared__ float redm[NWV];
     const int tid = threadIdx.x;
@@ -564,8 +564,33 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
     for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) kp[aa][bb] = kern[(3 - aa) * 4 + (3 - bb)];
+    // A rank-one kernel (make_kernel of a 1-D filter: kp[a][b] = kv[a] * kh[b]) needs 32 instead of 76 multiply-adds per row and
+    // thread — the waves of this kernel are busy 30 % of the time at four per SIMD: it is bound by instruction issue as much as by
+    // memory.  Checked here on the 16 values (uniform), so the result does not depend on a promise by the caller.
+    float kv[4], kh[4];
+    bool rank1 = kp[0][0] != 0.f;
+    {
+        float kmax = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) kmax = fmaxf(kmax, fabsf(kp[aa][bb]));
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            kv[aa] = rank1 ? kp[aa][0] / kp[0][0] : 0.f;
+            kh[aa] = kp[0][aa];
+        }
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) rank1 = rank1 && fabsf(kp[aa][bb] - kv[aa] * kh[bb]) <= 1e-7f * kmax;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa)                       // uniform values: keep them in scalar registers
+            kv[aa] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kv[aa])));
+    }
     const int ch = tid / QN, q = tid % QN, c = kc * 16 + ch;
     const float bv = cst[4][ch], sc_ = cst[5][ch];
+    const int csw = (ch >> 3) & 1;                           // column swizzle of the gather image (see step())
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
     const long cbase = ((long)b * a.C + c) * HW;
@@ -580,48 +605,33 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
     // PRE: g_feat already is g_pre (the conv above applied act' in its epilogue, oodgan_conv_args.dot_actgrad): `out` is not
     // read, and the r sum keeps only its noise / bias term (the caller adds sum dx*out = out_scale * dot of that conv)
-    struct Rows { float4 o[PRE ? 1 : 2], g[2]; float2 oe[PRE ? 1 : 2], ge[2]; };    // [row a/b]; oe/ge: the halo extras (q = 0: two columns, q = 15: .x)
-    auto load_rows = [&](int i, Rows& R) {
+    //
+    // A load is ONLY a load here.  Every lane reads every piece of a row pair from a clamped address — no branch around a load,
+    // no zero written over a loaded value — and what lies outside the image, the channel count or the lane's role is masked in
+    // step(), one iteration later, with masks that do not depend on the row (rok: uniform, recomputed from i).  The compiler can
+    // only COUNT loads it knows are issued: with the loads of iteration i+1 inside `if (rok && vm)` the wait for iteration i's
+    // data came out as vmcnt(0) — the prefetch was waited for right where it was requested (52 % of the wave time waiting at 4.2 TB/s).
+    // The halo extras are one float2 per lane: column pair X0-2 for every lane but the last of a channel row, X0+SW for that one.
+    struct Rows { float4 o[PRE ? 1 : 2], g[2], n[2]; float2 oe[PRE ? 1 : 2], ge[2]; };    // [row a/b]
+    const int gxc = min(gxm, Wg - 4);
+    const int ecol = q == QN - 1 ? min(X0 + SW, Wg - 2) : max(X0 - 2, 0);
+    const long cbase_c = ((long)b * a.C + min(c, a.C - 1)) * HW;
+    const float* gsrc = a.g_feat ? a.g_feat : a.out;        // a valid address when there is no feature gradient (masked below)
+    const bool has_g = a.g_feat != nullptr;
+    const float* nsrc = np ? np : gsrc + cbase_c;
+    const bool has_n = np != nullptr && gxm + 3 < Wg;
+    auto load_rows = [&](int i, Rows& R) __attribute__((always_inline)) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * i + 1 + rr;
-            const bool rok = r >= 0 && r < Hg;
-            const long p = (long)r * Wg + gxm;
-            R.g[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-            R.ge[rr] = make_float2(0.f, 0.f);
+            const int rc = min(max(2 * i + 1 + rr, 0), Hg - 1);
+            const long p = cbase_c + (long)rc * Wg;
             if (!PRE) {
-                R.o[PRE ? 0 : rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-                R.oe[PRE ? 0 : rr] = make_float2(0.f, 0.f);
+                R.o[PRE ? 0 : rr] = *reinterpret_cast<const float4*>(a.out + p + gxc);
+                R.oe[PRE ? 0 : rr] = *reinterpret_cast<const float2*>(a.out + p + ecol);
             }
-            if (rok && vm) {
-                if (!PRE) R.o[PRE ? 0 : rr] = *reinterpret_cast<const float4*>(a.out + cbase + p);
-                if (a.g_feat) R.g[rr] = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
-            }
-            if (rok && vl) {
-                if (!PRE) R.oe[PRE ? 0 : rr] = *reinterpret_cast<const float2*>(a.out + cbase + p - 2);
-                if (a.g_feat) R.ge[rr] = *reinterpret_cast<const float2*>(a.g_feat + cbase + p - 2);
-            }
-            if (rok && vr) {
-                if (!PRE) R.oe[PRE ? 0 : rr].x = a.out[cbase + p + 4];
-                if (a.g_feat) R.ge[rr].x = a.g_feat[cbase + p + 4];
-            }
-        }
-    };
-    // the noise map is shared by all channels: threads 0..15 fetch the 64 own columns of a row TWO iterations ahead and put
-    // them into LDS one iteration ahead; every thread reads them from there (the halo columns do not enter the sums)
-    float4 nn[2];
-    auto load_noise = [&](int i) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * i + 1 + rr, gx = X0 + 4 * tid;
-            nn[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (np && tid < QN && r >= 0 && r < Hg && gx + 3 < Wg) nn[rr] = *reinterpret_cast<const float4*>(np + (long)r * Wg + gx);
-        }
-    };
-    auto put_noise = [&](int i) {
-        if (tid < QN) {
-            *reinterpret_cast<float4*>(&nzl[i & 1][0][4 * tid]) = nn[0];
-            *reinterpret_cast<float4*>(&nzl[i & 1][1][4 * tid]) = nn[1];
+            R.g[rr] = *reinterpret_cast<const float4*>(gsrc + p + gxc);
+            R.ge[rr] = *reinterpret_cast<const float2*>(gsrc + p + ecol);
+            R.n[rr] = *reinterpret_cast<const float4*>(nsrc + (long)rc * Wg + gxc);
         }
     };
 
@@ -634,20 +644,22 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
         for (int e = 0; e < 4; ++e) pend[k][e] = 0.f;
 
-    auto step = [&](int i, const Rows& R) {
-        // the noise rows of this iteration were put into LDS one iteration ago (published by that iteration's barriers)
-        const int par = i & 1;
-        put_noise(i + 1);
-        load_noise(i + 2);
-        // ---- A/B: activation gradient of the two new rows -> LDS
+    auto step = [&](int i, const Rows& R, auto r1_c) __attribute__((always_inline)) {
+        constexpr bool R1 = decltype(r1_c)::value;
+        // ---- A/B: activation gradient of the two new rows
+        float done[2][4];
+        float (*gt)[16][BS_GP] = gat[i & 1];                 // one barrier per iteration: the gather image alternates
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * i + 1 + rr;
+            const bool rok = r >= 0 && r < Hg;
             const bool own = r >= 2 * i0 + 1 || (seg == 0 && r == 0);      // warm-up rows belong to the segment above
-            const float gv[4] = {R.g[rr].x, R.g[rr].y, R.g[rr].z, R.g[rr].w};
+            const bool mg = rok && vm && has_g, mn = rok && has_n;
+            const bool me0 = rok && has_g && (vl || vr), me1 = rok && has_g && vl;      // the right column is the pair's .x
+            const float gv[4] = {mg ? R.g[rr].x : 0.f, mg ? R.g[rr].y : 0.f, mg ? R.g[rr].z : 0.f, mg ? R.g[rr].w : 0.f};
             float gp[4], e0, e1;
-            const float4 n4 = *reinterpret_cast<const float4*>(&nzl[par][rr][4 * q]);
-            const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+            const float nv[4] = {mn ? R.n[rr].x : 0.f, mn ? R.n[rr].y : 0.f, mn ? R.n[rr].z : 0.f, mn ? R.n[rr].w : 0.f};
+            const float ge0 = me0 ? R.ge[rr].x : 0.f, ge1 = me1 ? R.ge[rr].y : 0.f;
             if (PRE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -657,12 +669,13 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         amax = fmaxf(amax, fabsf(gp[e]));
                     }
                 }
-                e0 = R.ge[rr].x;
-                e1 = R.ge[rr].y;
+                e0 = ge0;
+                e1 = ge1;
             } else {
                 const float4 o4 = R.o[PRE ? 0 : rr];
                 const float2 oe = R.oe[PRE ? 0 : rr];
-                const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+                const bool mo = rok && vm;
+                const float ov[4] = {mo ? o4.x : 0.f, mo ? o4.y : 0.f, mo ? o4.z : 0.f, mo ? o4.w : 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float o = ov[e];
@@ -674,73 +687,90 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     }
                 }
                 // halo extras (no sums): q = 0 -> l = 0,1; q = 15 -> l = 66
-                e0 = R.ge[rr].x * (oe.x > 0.f ? kSqrt2 : 0.2f * kSqrt2);
-                e1 = R.ge[rr].y * (oe.y > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                e0 = ge0 * (oe.x > 0.f ? kSqrt2 : 0.2f * kSqrt2);
+                e1 = ge1 * (oe.y > 0.f ? kSqrt2 : 0.2f * kSqrt2);
             }
-            float2* dst = reinterpret_cast<float2*>(&raw[rr][ch][4 * q + 2]);
-            dst[0] = make_float2(gp[0], gp[1]);
-            dst[1] = make_float2(gp[2], gp[3]);
-            if (q == 0) *reinterpret_cast<float2*>(&raw[rr][ch][0]) = make_float2(e0, e1);
-            if (q == QN - 1) raw[rr][ch][SW + 2] = e0;
-        }
-        __syncthreads();
-        // ---- C: the four horizontal 4-tap passes of each new row for columns X0 + 4q .. +3 feed the pending rows; g row 2i+1
-        // completes g2 row 2i, g row 2i+2 completes g2 row 2i+1.  Output column e needs l = 4q+e .. 4q+e+3.
-        float done[2][4];
+            // ---- C: the four horizontal 4-tap passes of each new row for columns X0 + 4q .. +3 feed the pending rows; g row 2i+1
+            // completes g2 row 2i, g row 2i+2 completes g2 row 2i+1.  Output column e needs columns X0 + 4q + e - 2 .. + 1: the left
+            // neighbour's last two values and the right neighbour's first one come by DPP inside the channel's 16 lanes (row_shr:1 /
+            // row_shl:1), the strip's halo from the extras of its first and last lane.
+            float lz = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gp[2]), 0x111, 0xF, 0xF, false));
+            float lw = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gp[3]), 0x111, 0xF, 0xF, false));
+            float rx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gp[0]), 0x101, 0xF, 0xF, false));
+            if (q == 0) { lz = e0; lw = e1; }
+            if (q == QN - 1) rx = e0;
+            const float x[7] = {lz, lw, gp[0], gp[1], gp[2], gp[3], rx};
+            // row r contributes kp[a] to g2 row r + 2 - a: a = 3 completes pend[0], a = 0 opens a new row
+            float dxx = 0.f;
+            if constexpr (R1) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const float* row = &raw[rr][ch][4 * q];
-            const float4 p0 = *reinterpret_cast<const float4*>(row);
-            const float2 p1 = *reinterpret_cast<const float2*>(row + 4);
-            const float p2 = row[6];
-            const float x[7] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p2};
-            float fresh[4];
+                for (int e = 0; e < 4; ++e) {
+                    // explicit fused operations: every instance of the kernel rounds the same way (the tests compare them bit for bit)
+                    const float hr = __builtin_fmaf(kh[3], x[e + 3], __builtin_fmaf(kh[2], x[e + 2], __builtin_fmaf(kh[1], x[e + 1], kh[0] * x[e])));
+                    done[rr][e] = __builtin_fmaf(kv[3], hr, pend[0][e]);
+                    pend[0][e] = __builtin_fmaf(kv[2], hr, pend[1][e]);
+                    pend[1][e] = __builtin_fmaf(kv[1], hr, pend[2][e]);
+                    pend[2][e] = kv[0] * hr;
+                }
+                if (XTRA && xtra && q == QN - 1) {
+                    const float hr = __builtin_fmaf(kh[1], x[5], kh[0] * x[4]);
+                    dxx = __builtin_fmaf(kv[3], hr, pendx[0]);
+                    pendx[0] = __builtin_fmaf(kv[2], hr, pendx[1]);
+                    pendx[1] = __builtin_fmaf(kv[1], hr, pendx[2]);
+                    pendx[2] = kv[0] * hr;
+                }
+            } else {
+                float fresh[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // row r contributes kp[a] to g2 row r + 2 - a: a = 3 completes pend[0], a = 0 opens a new row
-                done[rr][e] = pend[0][e] + (kp[3][0] * x[e] + kp[3][1] * x[e + 1] + kp[3][2] * x[e + 2] + kp[3][3] * x[e + 3]);
-                pend[0][e] = pend[1][e] + (kp[2][0] * x[e] + kp[2][1] * x[e + 1] + kp[2][2] * x[e + 2] + kp[2][3] * x[e + 3]);
-                pend[1][e] = pend[2][e] + (kp[1][0] * x[e] + kp[1][1] * x[e + 1] + kp[1][2] * x[e + 2] + kp[1][3] * x[e + 3]);
-                fresh[e] = kp[0][0] * x[e] + kp[0][1] * x[e + 1] + kp[0][2] * x[e + 2] + kp[0][3] * x[e + 3];
+                for (int e = 0; e < 4; ++e) {
+                    done[rr][e] = pend[0][e] + (kp[3][0] * x[e] + kp[3][1] * x[e + 1] + kp[3][2] * x[e + 2] + kp[3][3] * x[e + 3]);
+                    pend[0][e] = pend[1][e] + (kp[2][0] * x[e] + kp[2][1] * x[e + 1] + kp[2][2] * x[e + 2] + kp[2][3] * x[e + 3]);
+                    pend[1][e] = pend[2][e] + (kp[1][0] * x[e] + kp[1][1] * x[e + 1] + kp[1][2] * x[e + 2] + kp[1][3] * x[e + 3]);
+                    fresh[e] = kp[0][0] * x[e] + kp[0][1] * x[e + 1] + kp[0][2] * x[e + 2] + kp[0][3] * x[e + 3];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pend[2][e] = fresh[e];
+                if (XTRA && xtra && q == QN - 1) {   // output column X0+SW = 2W: its taps b = 0,1 see the last two g columns, b = 2,3 the border
+                    dxx = pendx[0] + (kp[3][0] * x[4] + kp[3][1] * x[5]);
+                    pendx[0] = pendx[1] + (kp[2][0] * x[4] + kp[2][1] * x[5]);
+                    pendx[1] = pendx[2] + (kp[1][0] * x[4] + kp[1][1] * x[5]);
+                    pendx[2] = kp[0][0] * x[4] + kp[0][1] * x[5];
+                }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pend[2][e] = fresh[e];
-            if (XTRA && xtra && q == QN - 1) {       // output column X0+SW = 2W: its taps b = 0,1 see the last two g columns, b = 2,3 the border
-                const float dx_ = pendx[0] + (kp[3][0] * x[4] + kp[3][1] * x[5]);
-                pendx[0] = pendx[1] + (kp[2][0] * x[4] + kp[2][1] * x[5]);
-                pendx[1] = pendx[2] + (kp[1][0] * x[4] + kp[1][1] * x[5]);
-                pendx[2] = kp[0][0] * x[4] + kp[0][1] * x[5];
-                if (i >= i0) gat[rr][ch][SW] = dx_ * sc_;
-            }
+            if (XTRA && xtra && q == QN - 1 && i >= i0) gt[rr][ch][SW ^ csw] = dxx * sc_;
         }
         if (i >= i0) {
-            *reinterpret_cast<float4*>(&gat[0][ch][4 * q]) = make_float4(done[0][0] * sc_, done[0][1] * sc_, done[0][2] * sc_, done[0][3] * sc_);
-            *reinterpret_cast<float4*>(&gat[1][ch][4 * q]) = make_float4(done[1][0] * sc_, done[1][1] * sc_, done[1][2] * sc_, done[1][3] * sc_);
+            // channels 8-15 keep their columns pairwise swapped (column ^ 1): the gather below reads the two channel halves of a
+            // position with lanes 32 banks apart, which the swap turns into the other bank parity
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float d0 = done[rr][0] * sc_, d1 = done[rr][1] * sc_, d2 = done[rr][2] * sc_, d3 = done[rr][3] * sc_;
+                *reinterpret_cast<float4*>(&gt[rr][ch][4 * q]) = csw ? make_float4(d1, d0, d3, d2) : make_float4(d0, d1, d2, d3);
+            }
         }
         __syncthreads();
-        // ---- E: 4 phase rows x SW/2 positions x 4 sixteen-byte slots = 8*SW slot tasks, two per thread, ordered so that the 64
-        // lanes of a store instruction write 64 CONSECUTIVE slots (1 KB contiguous: 16 whole records) — one thread per record
-        // would issue 16-byte pieces at a 64-byte stride, four times the memory transactions
+        // ---- E: 4 phase rows x SW/2 positions x 2 channel halves = 4*SW tasks, one per thread: a wave is a phase row, a lane pair a
+        // record.  The thread converts its 8 channels once and writes the hi slot and the lo slot of its half (two stores of a wave
+        // cover bytes 0-31 and 32-63 of 32 consecutive records); with a task per 16-byte slot every value was converted twice.
         if (i >= i0) {
-            constexpr int TASKS = 2 * SW * 4;                 // 4 phase rows x SW/2 positions x 4 slots
-#pragma unroll
-            for (int k = 0; k < TASKS / NT; ++k) {
-                const int u = tid + NT * k;
-                const int ph = u / (2 * SW), v = u % (2 * SW);
-                const int py = ph >> 1, px = ph & 1, jl = v >> 2, sl = v & 3;       // sl: 0,1 the hi halves, 2,3 the lo halves
-                const int j = j0 + jl, Xl = 2 * jl + px;
-                if (j > W) continue;
+            static_assert(4 * SW == NT, "one gather task per thread");
+            const int ph = tid / SW, v = tid % SW;
+            const int py = ph >> 1, px = ph & 1, jl = v >> 1, hf = v & 1;
+            const int j = j0 + jl, Xl = 2 * jl + px;
+            if (j <= W) {
                 const bool zero = (2 * i + py > 2 * H) || (X0 + Xl > 2 * W);
-                half8 o8;
+                half8 h8, l8;
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) {
-                    float val = gat[py][8 * (sl & 1) + cc][Xl];
+                    float val = gt[py][8 * hf + cc][Xl ^ hf];
                     if (zero) val = 0.f;
                     const _Float16 hh = (_Float16)val;
-                    o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
+                    h8[cc] = hh;
+                    l8[cc] = (_Float16)(val - (float)hh);
                 }
                 half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
-                recp[sl] = o8;
+                recp[hf] = h8;
+                recp[2 + hf] = l8;
             }
             if (XTRA && xtra && tid < 16) {          // the four records of position j = W (px = 1 lies beyond the image: zeros)
                 const int ph = tid >> 2, sl = tid & 3, py = ph >> 1, px = ph & 1;
@@ -748,7 +778,7 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 half8 o8;
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) {
-                    float val = zero ? 0.f : gat[py][8 * (sl & 1) + cc][SW];
+                    float val = zero ? 0.f : gt[py][8 * (sl & 1) + cc][SW ^ (sl & 1)];
                     const _Float16 hh = (_Float16)val;
                     o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
                 }
@@ -761,19 +791,19 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // two warm-up iterations fill the history (rows 2*i0-3 .. 2*i0), then one iteration per position row; the loads of
     // iteration i+1 are in flight while iteration i computes
     Rows ra, rb;
-    load_noise(i0 - 2);
-    put_noise(i0 - 2);
-    load_noise(i0 - 1);
     load_rows(i0 - 2, ra);
-    __syncthreads();
     int i = i0 - 2;
-    for (; i + 1 < i1; i += 2) {
-        load_rows(i + 1, rb);
-        step(i, ra);
-        load_rows(i + 2, ra);
-        step(i + 1, rb);
-    }
-    if (i < i1) step(i, ra);
+    auto walk = [&](auto r1_c) __attribute__((always_inline)) {
+        for (; i + 1 < i1; i += 2) {
+            load_rows(i + 1, rb);
+            step(i, ra, r1_c);
+            load_rows(i + 2, ra);
+            step(i + 1, rb, r1_c);
+        }
+        if (i < i1) step(i, ra, r1_c);
+    };
+    if (rank1) walk(std::true_type{});
+    else walk(std::false_type{});
 
     // ---- per-channel sums and the block maximum -> the tile kernel's slot layout
 #pragma unroll
