@@ -39,7 +39,7 @@ int oodgan_device_count(void);
  *   "s2_big_min_items" OODGAN_S2_BIG_MIN_ITEMS 128   8-wave stride-1 / stride-2 / transposed kernels take a conv (unit tests lower
  *   "t2_big_min_items" OODGAN_T2_BIG_MIN_ITEMS 128   them to reach those kernels with small tensors, or raise them for the A/B)
  *   "blurt_strip"      OODGAN_BLURT_STRIP      1     0: the tile kernel instead of the strip walk in oodgan_act_bwd_blurT_sform_phases
- *   "blur_strip"       OODGAN_BLUR_STRIP       1     0: the tile kernel instead of the strip walk in oodgan_blur_act_fform
+ *   "blur_strip"       OODGAN_BLUR_STRIP       1     0: the tile kernel instead of the strip walk in oodgan_blur_act_fform / _sform_sep
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);
@@ -305,6 +305,10 @@ int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const f
                           int B, int C, int H, int W, int in_pitch, unsigned* vmax, int kernel_rank_one, void* stream);
 /* kernel_rank_one: 1 when the caller knows the 4x4 kernel to be an outer product (Blur's [1,3,3,1] x [1,3,3,1] is): selects the
  * strip-walk kernel (one horizontal and one vertical 4-tap pass); 0: the tile kernel, which tests the taps itself. */
+/* oodgan_blur_act_sform with the same promise about the kernel (C %% 16 == 0 and 2W >= 64 for the strip walk; the tile kernel otherwise) */
+int oodgan_blur_act_sform_sep(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale, int ys_scale_stride,
+                              const float* bias, const float* noise, int noise_batch, const float* noise_w, int act, int B, int C,
+                              int H, int W, int in_pitch, unsigned* vmax, int kernel_rank_one, void* stream);
 
 /* ---- fused backward producers (csrc/bwd_producers.hip): oodgan_act_bwd_fused's arithmetic (autograd of NoiseInjection +
  * FusedLeakyReLU merged with the ToRGB branch, src/ops/StyleGAN/model.py:283-292,343-372) written directly as the

@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //     leave as 64-byte fp32 records, 16 bytes per lane, 1 KiB contiguous per wave.
 struct BlurStripGeo { int nstrips, nseg, seg_rows; };
 
+// SF: instead of the F-form records the kernel writes y as fp32 planes (a float4 per thread and row: its channel's four columns)
+// and the S-form of y * ys_scale (the gather image then holds the scaled values; a thread converts the 8 channels of its slot).
+template <bool SF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void blur_act_fform_strip_kernel(const BlurArgs a, const BlurStripGeo geo) {
     constexpr int GP = 68;                                   // LDS pitch of a channel's 64 columns
     __shared__ __attribute__((aligned(16))) float gat[2][16][GP];
@@ -327,7 +330,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
     float vm = 0.f;
     float* yf = a.y + ((long)b * KC + kc) * HWo * 16;
-    const int pcol = tid >> 2, pq = tid & 3;                 // F-form role: pixel column, channel quarter
+    float* yplane = a.y + ((long)b * a.C + min(c, a.C - 1)) * HWo;          // SF: this thread's channel plane
+    const bool yok = c < a.C && gx + 3 < Wo;
+    const int pcol = tid >> 2, pq = tid & 3;                 // record role: pixel column, channel quarter (F-form) / slot (S-form)
     const bool pok = X0 + pcol < Wo;
     auto step = [&](int Y, Row& R) {
         float h3[4];
@@ -344,11 +349,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             h0[e] = h1[e]; h1[e] = h2[e]; h2[e] = h3[e];
         }
         float (*gb)[GP] = gat[Y & 1];
-        *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
-        __syncthreads();
-        if (pok)
-            *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
-                make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
+        if constexpr (SF) {
+            if (yok) *reinterpret_cast<float4*>(yplane + (long)Y * Wo + gx) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0] * ysc, t[1] * ysc, t[2] * ysc, t[3] * ysc);
+            __syncthreads();
+            if (pok) {
+                // slot pq of the pixel's record: hi (pq < 2) or lo halves of channels 8 (pq & 1) .. + 7; the lanes of a wave write 16 whole records
+                half8 o8;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const float val = gb[8 * (pq & 1) + cc][pcol];
+                    const _Float16 hh = (_Float16)val;
+                    o8[cc] = (pq & 2) ? (_Float16)(val - (float)hh) : hh;
+                }
+                reinterpret_cast<half8*>(a.ys + sform_unit(a.yd, b, kc, Y, X0 + pcol, 0))[pq] = o8;
+            }
+        } else {
+            *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
+            __syncthreads();
+            if (pok)
+                *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
+                    make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
+        }
     };
     for (int Y = Y0; Y < Y1; Y += 3) {
         step(Y, R0);
@@ -380,7 +402,7 @@ static int blur_act_launch(const float* z, const float* kernel, float* y, void* 
     a.vmax = (ys || y_fform) ? vmax : nullptr;
     a.y_fform = y_fform;
     OODGAN_REQUIRE(!y_fform || (C % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0), "blur_act_fform: C %% 16 == 0 and a 16-byte aligned y");
-    if (y_fform && rank_one == 1 && 2 * W >= 64 && oodgan::tunable(oodgan::OODGAN_TUN_BLUR_STRIP)) {
+    if ((y_fform || ys) && rank_one == 1 && 2 * W >= 64 && (C % 16) == 0 && oodgan::tunable(oodgan::OODGAN_TUN_BLUR_STRIP)) {
         BlurStripGeo geo;
         geo.nstrips = (2 * W + 63) / 64;
         const long base = (long)B * a.yd.KC * geo.nstrips;
@@ -392,8 +414,9 @@ static int blur_act_launch(const float* z, const float* kernel, float* y, void* 
         geo.nseg = (2 * H + seg_rows - 1) / seg_rows;
         const long nbs = base * geo.nseg;
         OODGAN_REQUIRE(nbs < (1L << 31), "blur_act_fform: grid too large");
-        hipLaunchKernelGGL(blur_act_fform_strip_kernel, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
-        return check_launch("blur_act_fform_strip");
+        if (y_fform) hipLaunchKernelGGL(blur_act_fform_strip_kernel<false>, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
+        else hipLaunchKernelGGL(blur_act_fform_strip_kernel<true>, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
+        return check_launch("blur_act_strip");
     }
     const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
     OODGAN_REQUIRE(nb < (1L << 31), "blur_act_sform: grid too large");
@@ -406,6 +429,14 @@ extern "C" int oodgan_blur_act_sform(const float* z, const float* kernel, float*
                                      const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
                                      void* stream) {
     return blur_act_launch(z, kernel, y, ys, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 0, 0, stream);
+}
+
+extern "C" int oodgan_blur_act_sform_sep(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale,
+                                         int ys_scale_stride, const float* bias, const float* noise, int noise_batch,
+                                         const float* noise_w, int act, int B, int C, int H, int W, int in_pitch, unsigned* vmax,
+                                         int kernel_rank_one, void* stream) {
+    return blur_act_launch(z, kernel, y, ys, ys_scale, ys_scale_stride, bias, noise, noise_batch, noise_w, act, B, C, H, W, in_pitch, vmax, 0,
+                           kernel_rank_one, stream);
 }
 
 extern "C" int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const float* ys_scale, int ys_scale_stride,

@@ -256,28 +256,42 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     }
     const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
     const int h2 = H >> 1, w2_ = W >> 1;
+    // up-sampled skip: the 2 x 2 taps of both pixels are fetched from clamped positions, all 24 values in flight together, and
+    // a tap outside the image gets a zero weight (a conditional load per tap was a round trip per tap: eight in a row)
+    float sv[TS_PX][4][3], skw[TS_PX][4];
+    if (skip) {
+        const float* sp = skip + (long)b * 3 * h2 * w2_;
 #pragma unroll
-    for (int j = 0; j < TS_PX; ++j) {
-        float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
-        if (skip) {
+        for (int j = 0; j < TS_PX; ++j) {
             const int Y = Y0, X = X0 + j;
-            const float* sp = skip + (long)b * 3 * h2 * w2_;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ky = (Y & 1) + 2 * t;
                 const int iy = (Y + ky - 2) >> 1;
-                if (Y + ky - 2 < 0 || iy >= h2) continue;
+                const bool yok = Y + ky - 2 >= 0 && iy < h2;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int kx = (X & 1) + 2 * u;
                     const int ix = (X + kx - 2) >> 1;
-                    if (X + kx - 2 < 0 || ix >= w2_) continue;
-                    const float kv = kf[ky * 4 + kx];
-                    const long q = (long)iy * w2_ + ix;
-                    o0 += kv * sp[q];
-                    o1 += kv * sp[(long)h2 * w2_ + q];
-                    o2 += kv * sp[2L * h2 * w2_ + q];
+                    const bool ok = yok && X + kx - 2 >= 0 && ix < w2_;
+                    const long q = (long)min(max(iy, 0), h2 - 1) * w2_ + min(max(ix, 0), w2_ - 1);
+                    skw[j][2 * t + u] = ok ? kf[ky * 4 + kx] : 0.f;
+                    sv[j][2 * t + u][0] = sp[q];
+                    sv[j][2 * t + u][1] = sp[(long)h2 * w2_ + q];
+                    sv[j][2 * t + u][2] = sp[2L * h2 * w2_ + q];
                 }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TS_PX; ++j) {
+        float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
+        if (skip) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o0 += skw[j][k] * sv[j][k][0];
+                o1 += skw[j][k] * sv[j][k][1];
+                o2 += skw[j][k] * sv[j][k][2];
             }
         }
         float* yp = y + (long)b * 3 * HW + p + j;

@@ -90,6 +90,7 @@ _SIGS = {
     'oodgan_resize_bicubic_ac': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_avgpool': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_blur_act_sform': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    'oodgan_blur_act_sform_sep': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'oodgan_blur_act_fform': (c_int, [P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'oodgan_conv3x3_xf_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_xf_nparts': (c_int, [c_int, c_int, c_int]),

@@ -357,17 +357,19 @@ def to_sform(x, scale=None, mul2=None, out=None, in_hw=None, in_pitch=0, vmax=No
     return out
 
 
-def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys=None, ys_scale=None, vmax=None):
-    """Tail of the up-sampling StyledConv in one pass (include/oodgan.h, oodgan_blur_act_sform): z (B,C,2H+1,pitch) from
-    conv3x3(mode T2) -> y (B,C,2H,2W) and, into ``ys`` (an SForm), y*ys_scale for the next conv."""
+def blur_act_sform(z, kernel, H, W, bias=None, noise=None, noise_weight=None, act=True, ys=None, ys_scale=None, vmax=None, rank_one=False):
+    """Tail of the up-sampling StyledConv in one pass (include/oodgan.h, oodgan_blur_act_sform / _sform_sep): z (B,C,2H+1,pitch) from
+    conv3x3(mode T2) -> y (B,C,2H,2W) and, into ``ys`` (an SForm), y*ys_scale for the next conv.  ``rank_one``: the caller knows
+    the kernel to be an outer product (selects the strip-walk kernel)."""
     z = _dev(z)
     B, C = z.shape[0], z.shape[1]
     y = torch.empty(B, C, 2 * H, 2 * W, device=z.device, dtype=torch.float32)
     nz = _opt(noise, 'noise')
-    check(_lib.lib().oodgan_blur_act_sform(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
-                                           0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
-                                           1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
-                                           ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), _stream()), 'blur_act_sform')
+    check(_lib.lib().oodgan_blur_act_sform_sep(_p(z), _p(_dev(kernel, 'kernel')), _p(y), _p(ys), _p(_opt(ys_scale, 'ys_scale')),
+                                               0 if ys_scale is None else ys_scale.shape[1], _p(_opt(bias, 'bias')), _p(nz),
+                                               1 if nz is None else nz.shape[0], _p(_opt(noise_weight, 'nw')),
+                                               ACT_LRELU if act else ACT_NONE, B, C, H, W, z.shape[3], _p(vmax), 1 if rank_one else 0,
+                                               _stream()), 'blur_act_sform')
     return y
 
 

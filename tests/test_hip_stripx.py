@@ -121,3 +121,33 @@ def test_blur_act_fform_equals_blur_act_sform(B, C, H, W, rank_one):
     y2 = ops.blur_act_sform(z, k, H, W, None, nz[:1], nw, act=True, ys=ys, ys_scale=s)
     y3 = ops.blur_act_fform(z, k, H, W, None, nz[:1], nw, act=True, ys_scale=s, rank_one=rank_one)
     assert _rel(y3.to_nchw(), y2) < 2e-6
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 32, 48, 48), (1, 32, 32, 80), (1, 16, 64, 32), (1, 64, 40, 100), (1, 32, 512, 512)])
+def test_blur_act_sform_strip_walk_equals_tile_kernel(B, C, H, W):
+    """S-form + NCHW tail of the up-conv: the strip walk (rank_one promise) against the tile kernel; its S-form output is exactly
+    to_sform(its own y, style); partial last strips (2W % 64 != 0), shared noise, no bias."""
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(177 + H + W)
+    pitch = (2 * W + 1 + 3) // 4 * 4
+    z = torch.randn(B, C, 2 * H + 1, pitch, generator=g).to(dev)
+    z[..., 2 * W + 1:] = float('nan')                     # columns between the valid width and the pitch are not defined
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+    nz = torch.randn(B, 1, 2 * H, 2 * W, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    ys0, ys1 = ops.SForm(B, C, 2 * H, 2 * W, dev), ops.SForm(B, C, 2 * H, 2 * W, dev)
+    vm0 = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+    vm1 = torch.zeros_like(vm0)
+    y0 = ops.blur_act_sform(z, k, H, W, bias, nz, nw, act=True, ys=ys0, ys_scale=s, vmax=vm0)
+    y1 = ops.blur_act_sform(z, k, H, W, bias, nz, nw, act=True, ys=ys1, ys_scale=s, vmax=vm1, rank_one=True)
+    assert _rel(y1, y0) < 2e-6                            # separable evaluation in another order
+    assert torch.equal(ys1.data, ops.to_sform(y1, s).data)
+    want = (y1 * s[:, :, None, None]).abs().amax(dim=(1, 2, 3))
+    assert torch.equal(vm1.view(torch.float32).amax(dim=1), want)
+    y2 = ops.blur_act_sform(z, k, H, W, None, nz[:1], nw, act=False, ys=ys0, ys_scale=s)
+    y3 = ops.blur_act_sform(z, k, H, W, None, nz[:1], nw, act=False, ys=ys1, ys_scale=s, rank_one=True)
+    assert _rel(y3, y2) < 2e-6
+    assert torch.equal(ys1.data, ops.to_sform(y3, s).data)

@@ -64,7 +64,8 @@ for res in (64, 128, 256, 512, 1024):
     s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
     ys = ops.SForm(B, C, res, res, dev)
     vm = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
-    ms = timeit(lambda: ops.blur_act_sform(z, kf, H, H, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm))
+    R1 = os.environ.get("OODGAN_BENCH_R1") is not None
+    ms = timeit(lambda: ops.blur_act_sform(z, kf, H, H, bias, nz, nw, act=True, ys=ys, ys_scale=s, vmax=vm, rank_one=R1))
     byts = 4.0 * B * C * (2 * res * res + (res + 1) ** 2)
     print(f'blur_act_sform {C:3d} ch @{res:4d}: {ms * 1e3:8.1f} us  {byts / ms / 1e6:7.1f} GB/s', flush=True)
     del z, nz, ys
