@@ -55,21 +55,52 @@ struct ActArgs {
 
 
 // per-block channel constants in LDS: [0] w0 [1] w1 [2] w2 (already x rgb_scale) [3] s_rgb [4] bias [5] d*scale [6] |d|
-__device__ __forceinline__ void load_consts(const ActArgs& a, int b, int kc, float (*cst)[16]) {
+// fetch_const(): the raw value behind cst[t >> 4][t & 15] for thread t < 112 — ONE unconditional load per thread from a selected,
+// clamped address (part_r: a valid address for the constants that do not exist); a switch over `which` with a load in every arm is
+// one round trip per arm and wave.  put_const() fixes it up (selects only) and stores it; a kernel may request other data in
+// between — the value is not touched before put_const().
+struct ConstSel { int which, c; bool has; };
+__device__ __forceinline__ ConstSel const_sel(const ActArgs& a, int kc) {
+    const int t = threadIdx.x;
+    ConstSel s;
+    s.which = t >> 4;
+    s.c = kc * 16 + (t & 15);
+    s.has = s.which < 4 ? a.g_rgb != nullptr : s.which == 4 ? a.bias != nullptr : a.dscale != nullptr;
+    return s;
+}
+
+__device__ __forceinline__ float fetch_const(const ActArgs& a, int b, int kc) {
+    float raw = 0.f;
+    if (threadIdx.x < 112) {
+        const ConstSel s = const_sel(a, kc);
+        const int cc = min(s.c, a.C - 1);
+        const float* src = a.part_r;
+        if (s.has) {
+            if (s.which < 3) src = a.w_rgb + s.which * a.C + cc;
+            else if (s.which == 3) src = a.s_rgb + (long)b * a.s_rgb_stride + cc;
+            else if (s.which == 4) src = a.bias + cc;
+            else src = a.dscale + (long)b * a.dscale_stride + cc;
+        }
+        raw = *src;
+    }
+    return raw;
+}
+
+__device__ __forceinline__ void put_const(const ActArgs& a, int kc, float (*cst)[16], float raw) {
     const int t = threadIdx.x;
     if (t < 112) {
-        const int which = t >> 4, j = t & 15, c = kc * 16 + j;
-        float v = 0.f;
-        if (c < a.C) {
-            if (which < 3) v = a.g_rgb ? a.w_rgb[which * a.C + c] * a.rgb_scale : 0.f;
-            else if (which == 3) v = a.g_rgb ? a.s_rgb[(long)b * a.s_rgb_stride + c] : 0.f;
-            else if (which == 4) v = a.bias ? a.bias[c] : 0.f;
-            else if (which == 5) v = (a.dscale ? a.dscale[(long)b * a.dscale_stride + c] : 1.f) * (a.mul2 ? a.mul2[1] : 1.f);
-            else v = a.dscale ? fabsf(a.dscale[(long)b * a.dscale_stride + c]) : 1.f;
-        }
-        cst[which][j] = v;
+        const ConstSel s = const_sel(a, kc);
+        const float m2 = a.mul2 ? a.mul2[1] : 1.f;
+        float v;
+        if (s.which < 3) v = s.has ? raw * a.rgb_scale : 0.f;
+        else if (s.which <= 4) v = s.has ? raw : 0.f;
+        else if (s.which == 5) v = (s.has ? raw : 1.f) * m2;
+        else v = s.has ? fabsf(raw) : 1.f;
+        cst[t >> 4][t & 15] = s.c < a.C ? v : 0.f;
     }
 }
+
+__device__ __forceinline__ void load_consts(const ActArgs& a, int b, int kc, float (*cst)[16]) { put_const(a, kc, cst, fetch_const(a, b, kc)); }
 
 constexpr int kP1Chunk = 512;       // pixels of one (b, 16-channel block) per workgroup
 constexpr int kP1Pitch = kP1Chunk + 4;
@@ -556,8 +587,7 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(PRE ? 4
     // position j = W (g2 column 2W, the one beyond the last pair of g columns) would need a strip of its own: the last
     // strip emits it as a 65th / 129th output column from the two g columns it already holds
     const bool xtra = XTRA && strip == geo.nstrips - 1;
-    load_consts(a, b, kc, cst);
-    __syncthreads();
+    const float cval = fetch_const(a, b, kc);               // stored and published behind the first row request (below)
     // the 16 taps (uniform: scalar registers); g2[Y][X] = sum_{a,b} kp[a][b] * g[Y+a-2][X+b-2], kp = the flipped kernel
     float kp[4][4];
 #pragma unroll
@@ -589,7 +619,7 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(PRE ? 4
             kv[aa] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kv[aa])));
     }
     const int ch = tid / QN, q = tid % QN, c = kc * 16 + ch;
-    const float bv = cst[4][ch], sc_ = cst[5][ch];
+    float bv = 0.f, sc_ = 0.f;                               // cst[4][ch], cst[5][ch]: read behind the barrier below
     const int csw = (ch >> 3) & 1;                           // column swizzle of the gather image (see step())
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* np = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
@@ -792,6 +822,10 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(PRE ? 4
     // iteration i+1 are in flight while iteration i computes
     Rows ra, rb;
     load_rows(i0 - 2, ra);
+    put_const(a, kc, cst, cval);
+    __syncthreads();
+    bv = cst[4][ch];
+    sc_ = cst[5][ch];
     int i = i0 - 2;
     auto walk = [&](auto r1_c) __attribute__((always_inline)) {
         for (; i + 1 < i1; i += 2) {

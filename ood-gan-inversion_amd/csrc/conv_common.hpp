@@ -61,12 +61,20 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& p, f32x16 (&acc)[MT][
         const int jp = c0 + l31;           // j'
         const int zx = 2 * jp;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            // the 16 scales of the M-tile from clamped channels, all in flight together: a load inside the store loop is a branch, a
+            // load and a vmcnt(0) per value, which also waits for the two stores in front of it
+            float scv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+                scv[r] = osc ? osc[m] : 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= a.M || zx >= p.Wout) continue;
-                const float sc = (osc ? osc[m] : 1.f) * us;
+                const float sc = scv[r] * us;
 #pragma unroll
                 for (int py = 0; py < 2; ++py) {
                     const int zy = 2 * ip + py;
@@ -76,6 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& p, f32x16 (&acc)[MT][
                     *reinterpret_cast<float2*>(yb + (long)m * p.out_plane + (long)zy * a.out_pitch + zx) = v;
                 }
             }
+        }
     } else {
     const int px = c0 + l31;
     const float* db = a.dotx ? a.dotx + (long)b * a.M * ((long)p.Hout * p.Wout) : nullptr;

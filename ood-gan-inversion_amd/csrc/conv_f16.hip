@@ -93,11 +93,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // (oodgan_modconv_f16_pack) and is folded into bias and noise weight here: sqrt2*lrelu(v) = lrelu(sqrt2*v), and
     // lrelu(u) = max(u, 0.2u), so the activation costs two VALU operations per value.
     const float gain = LRELU ? kSqrt2 : 1.f;
+    const float* bias_p = p.bias ? p.bias : reinterpret_cast<const float*>(p.wpk);
     float bias_g[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+        // an unconditional load from a clamped channel (a valid address when there is no bias), masked by a select: `m < M ? bias[m]
+        // : 0` is a branch, a load and a vmcnt(0) per value — sixteen round trips in a row before the first tile is requested
         const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias_g[r] = (p.bias && m < p.M) ? gain * p.bias[m] : 0.f;
+        const float bv = bias_p[min(m, p.M - 1)];
+        bias_g[r] = (p.bias && m < p.M) ? gain * bv : 0.f;
     }
     const float nwg = p.noise ? gain * (p.noise_w ? p.noise_w[0] : 1.f) : 0.f;
     const int MC = (p.M + 15) / 16;
@@ -282,11 +286,14 @@ __global__ __launch_bounds__(256) void modconv_f16_strip_kernel(const StripArgs 
 
     // ---- epilogue constants (see modconv_f16_kernel)
     const float gain = LRELU ? kSqrt2 : 1.f;
+    const float* bias_p = p.bias ? p.bias : reinterpret_cast<const float*>(p.wpk);
     float bias_g[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+        // unconditional loads, masked by a select (see modconv_f16_kernel): one round trip together with the weights
         const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-        bias_g[r] = (p.bias && m < p.M) ? gain * p.bias[m] : 0.f;
+        const float bv = bias_p[min(m, p.M - 1)];
+        bias_g[r] = (p.bias && m < p.M) ? gain * bv : 0.f;
     }
     const float nwg = p.noise ? gain * (p.noise_w ? p.noise_w[0] : 1.f) : 0.f;
     const int MC = (p.M + 15) / 16;

@@ -71,9 +71,9 @@ struct S2Cfg {
     static constexpr int NA = 5 + WA, NB = 5 + WB;         // loads per wave in flight for a stage
     static constexpr int OFF_XA = 0, OFF_WA = SB_XBYTES, OFF_XB = OFF_WA + 6 * TAPB, OFF_WB = OFF_XB + SB_XBYTES;
     static constexpr int SMEM = OFF_WB + 3 * TAPB;         // 155648 (MH = 2) / 118784 (MH = 1)
-    // FUSE: [7][MBW] floats of channel constants.  MH = 1 stages them BEFORE the K loop: outside the stage buffers
-    static constexpr int OFF_CST = MH == 1 ? SMEM : 8192;
-    static constexpr int SMEM_FUSE = MH == 1 ? SMEM + 7 * MBW * 4 : SMEM;
+    // FUSE: [7][MBW] floats of channel constants, staged BEFORE the K loop: outside the stage buffers (159232 bytes for MH = 2)
+    static constexpr int OFF_CST = SMEM;
+    static constexpr int SMEM_FUSE = SMEM + 7 * MBW * 4;
 };
 
 constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15); }
@@ -218,18 +218,6 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     if constexpr (EARLY) {
         static_assert(!EARLY || RW == 1, "one row per wave");
         const oodgan_actbwd_fuse& f = p.f;
-        float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);
-        if (tid < C::MBW) {
-            const int m = m0 + tid;
-            const bool mok = m < M;
-            cst[0 * C::MBW + tid] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f;
-            cst[1 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[0 * M + m] * f.rgb_scale : 0.f;
-            cst[2 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[1 * M + m] * f.rgb_scale : 0.f;
-            cst[3 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[2 * M + m] * f.rgb_scale : 0.f;
-            cst[4 * C::MBW + tid] = (mok && f.g_rgb) ? f.s_rgb[(long)b * f.s_rgb_stride + m] : 0.f;
-            cst[5 * C::MBW + tid] = (mok && f.bias) ? f.bias[m] : 0.f;
-            cst[6 * C::MBW + tid] = mok ? f.dscale[(long)b * f.dscale_stride + m] * f.mul2[1] : 0.f;
-        }
         const int px = c0 + l31, py_ = r0 + rg;
         const long HW = (long)H * W, pix = (long)py_ * W + px;
         eok = py_ < H && px < W;
@@ -251,9 +239,43 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         }
     }
 
+    // FUSE: the seven per-channel constants of the fused epilogue, requested here from clamped channels — all in flight together and
+    // under the first stage's fetch — and parked in LDS.  (`mok ? ptr[m] : 0` where it is used is a branch, a load and a vmcnt(0) per
+    // constant: seven serialised round trips per workgroup, 3-4 us of the 21 us a tile of the 1024² -> 512² layer takes.)
+    float cv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSE) {
+        const oodgan_actbwd_fuse& f = p.f;
+        if (tid < C::MBW) {
+            const int m = min(m0 + tid, M - 1);
+            cv[0] = a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f;
+            if (f.g_rgb) {
+                cv[1] = f.w_rgb[0 * M + m];
+                cv[2] = f.w_rgb[1 * M + m];
+                cv[3] = f.w_rgb[2 * M + m];
+                cv[4] = f.s_rgb[(long)b * f.s_rgb_stride + m];
+            }
+            if (f.bias) cv[5] = f.bias[m];
+            cv[6] = f.dscale[(long)b * f.dscale_stride + m];
+        }
+    }
     // single barrier per stage: after it every wave has finished stage st-1 (its slot is free) and stage st has landed
     // (each wave waited for its own loads); the fetch of stage st+1 is issued first and runs under this stage's MFMAs
     dma_stage(0);
+    if constexpr (FUSE) {
+        if (tid < C::MBW) {
+            const oodgan_actbwd_fuse& f = p.f;
+            float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);
+            const bool mok = m0 + tid < M;
+            cst[0 * C::MBW + tid] = mok ? cv[0] : 0.f;
+            cst[1 * C::MBW + tid] = mok ? cv[1] * f.rgb_scale : 0.f;
+            cst[2 * C::MBW + tid] = mok ? cv[2] * f.rgb_scale : 0.f;
+            cst[3 * C::MBW + tid] = mok ? cv[3] * f.rgb_scale : 0.f;
+            cst[4 * C::MBW + tid] = mok ? cv[4] : 0.f;
+            cst[5 * C::MBW + tid] = mok ? cv[5] : 0.f;
+            cst[6 * C::MBW + tid] = mok ? cv[6] * f.mul2[1] : 0.f;
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): written before this wave arrives at the loop's first barrier
+        }
+    }
     for (int st = 0; st < nstage; ++st) {
         const int py = st & 1;
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
@@ -298,18 +320,6 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);        // [7][MBW]: a*us->g_feat scale, w0, w1, w2, s_rgb, bias, d*scale
         const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
         const float rscale = f.mul2[1];
-        if (!EARLY && tid < C::MBW) {
-            const int m = m0 + tid;
-            const bool mok = m < M;
-            cst[0 * C::MBW + tid] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) : 0.f;
-            cst[1 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[0 * M + m] * f.rgb_scale : 0.f;
-            cst[2 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[1 * M + m] * f.rgb_scale : 0.f;
-            cst[3 * C::MBW + tid] = (mok && f.g_rgb) ? f.w_rgb[2 * M + m] * f.rgb_scale : 0.f;
-            cst[4 * C::MBW + tid] = (mok && f.g_rgb) ? f.s_rgb[(long)b * f.s_rgb_stride + m] : 0.f;
-            cst[5 * C::MBW + tid] = (mok && f.bias) ? f.bias[m] : 0.f;
-            cst[6 * C::MBW + tid] = mok ? f.dscale[(long)b * f.dscale_stride + m] * rscale : 0.f;
-        }
-        if (!EARLY) __syncthreads();
         const int px = c0 + l31;
         const long HW = (long)H * W;
         const float nw = f.noise ? (f.noise_w ? f.noise_w[0] : 1.f) : 0.f;

@@ -241,11 +241,13 @@ struct BlurStripGeo { int nstrips, nseg, seg_rows; };
 
 // SF: instead of the F-form records the kernel writes y as fp32 planes (a float4 per thread and row: its channel's four columns)
 // and the S-form of y * ys_scale (the gather image then holds the scaled values; a thread converts the 8 channels of its slot).
-template <bool SF>
+// FULL: 2W % 64 == 0 — every lane of every strip stores, so the stores (and the noise load, from a valid address when there is no
+// noise) sit in straight-line code: the compiler can count what is in flight only through code without branches around memory
+// operations; with an `if` around a store it drained everything (vmcnt(0)) twice per three rows.
+template <bool SF, bool FULL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void blur_act_fform_strip_kernel(const BlurArgs a, const BlurStripGeo geo) {
     constexpr int GP = 68;                                   // LDS pitch of a channel's 64 columns
     __shared__ __attribute__((aligned(16))) float gat[2][16][GP];
-    __shared__ float ksep[8];
     const int tid = threadIdx.x;
     int w;
     {
@@ -258,13 +260,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int Ho = 2 * a.H, Wo = 2 * a.W, Hz = Ho + 1, Wz = Wo + 1;
     const int Y0 = seg * geo.seg_rows, Y1 = min(Y0 + geo.seg_rows, Ho);
     const int X0 = 64 * strip;
-    if (tid < 8) {
-        // kf[ky][kx] = k[3-ky][3-kx] (upfirdn2d flips); rank one: kf[ky][kx] = kv[ky] * kh[kx] with kv[ky] = kf[ky][0] / kf[0][0], kh = kf[0][.]
-        const float k00 = a.kern[15];
-        ksep[tid] = tid < 4 ? a.kern[15 - 4 * tid] / k00 : a.kern[15 - (tid - 4)];
-    }
-    __syncthreads();
-    const float kv0 = ksep[0], kv1 = ksep[1], kv2 = ksep[2], kv3 = ksep[3], kh0 = ksep[4], kh1 = ksep[5], kh2 = ksep[6], kh3 = ksep[7];
+    // kf[ky][kx] = k[3-ky][3-kx] (upfirdn2d flips); rank one: kf[ky][kx] = kv[ky] * kh[kx] with kv[ky] = kf[ky][0] / kf[0][0], kh = kf[0][.]
+    // (uniform loads, no LDS table and no barrier in front of the first row request)
+    const float k00 = a.kern[15];
+    const float kv0 = 1.f, kv1 = a.kern[11] / k00, kv2 = a.kern[7] / k00, kv3 = a.kern[3] / k00;
+    const float kh0 = k00, kh1 = a.kern[14], kh2 = a.kern[13], kh3 = a.kern[12];
     const int ch = tid >> 4, q = tid & 15, c = kc * 16 + ch;
     const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
     const float bv = a.bias ? a.bias[c] : 0.f;
@@ -286,15 +286,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const bool q0 = q == 0, q15 = q == 15;
     const int ec0 = q0 ? max(X0 - 1, 0) : min(X0 + 64, a.pitch - 1), ec1 = min(X0 + 65, a.pitch - 1);
     const bool me0 = q0 ? X0 >= 1 : X0 + 64 < Wz, me1 = X0 + 65 < Wz;
-    const bool mkn = gx + 3 < Wo;
+    const bool mkn = np != nullptr && gx + 3 < Wo;
     const int gxn = min(gx, Wo - 4);
+    const float* nsrc = np ? np : zp;                        // no noise: any valid address (2H x 2W floats lie inside the z plane)
     auto load_row = [&](int r, int Y, Row& R) {
         const float* rp = zp + (long)min(max(r, 0), Hz - 1) * a.pitch;
         R.rv = (r >= 0 && r < Hz) ? 1.f : 0.f;
         R.m = *reinterpret_cast<const float4*>(rp + gxc);
         R.e0 = rp[ec0];
         R.e1 = rp[ec1];
-        if (np) R.n = *reinterpret_cast<const float4*>(np + (long)min(max(Y, 0), Ho - 1) * Wo + gxn);
+        R.n = *reinterpret_cast<const float4*>(nsrc + (long)min(max(Y, 0), Ho - 1) * Wo + gxn);
     };
     // horizontal pass of a row: h[e] = sum_b kh[b] * z[gx + e - 1 + b]
     auto hpass = [&](const Row& R, float (&h)[4]) {
@@ -334,7 +335,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const bool yok = c < a.C && gx + 3 < Wo;
     const int pcol = tid >> 2, pq = tid & 3;                 // record role: pixel column, channel quarter (F-form) / slot (S-form)
     const bool pok = X0 + pcol < Wo;
-    auto step = [&](int Y, Row& R) {
+    auto step = [&](int Y, Row& R) __attribute__((always_inline)) {
+        // the three steps of a loop trip are one basic block: without a fence the scheduler gathers the masking of all three rows
+        // at its top, and the wait for the youngest request (vmcnt(0)) with it
+        __builtin_amdgcn_sched_barrier(0);
         float h3[4];
         hpass(R, h3);
         const float nn[4] = {mkn ? R.n.x : 0.f, mkn ? R.n.y : 0.f, mkn ? R.n.z : 0.f, mkn ? R.n.w : 0.f};
@@ -350,10 +354,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         float (*gb)[GP] = gat[Y & 1];
         if constexpr (SF) {
-            if (yok) *reinterpret_cast<float4*>(yplane + (long)Y * Wo + gx) = make_float4(t[0], t[1], t[2], t[3]);
+            if (FULL || yok) *reinterpret_cast<float4*>(yplane + (long)Y * Wo + gx) = make_float4(t[0], t[1], t[2], t[3]);
             *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0] * ysc, t[1] * ysc, t[2] * ysc, t[3] * ysc);
             __syncthreads();
-            if (pok) {
+            if (FULL || pok) {
                 // slot pq of the pixel's record: hi (pq < 2) or lo halves of channels 8 (pq & 1) .. + 7; the lanes of a wave write 16 whole records
                 half8 o8;
 #pragma unroll
@@ -367,16 +371,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         } else {
             *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
             __syncthreads();
-            if (pok)
+            if (FULL || pok)
                 *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
                     make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
         }
     };
-    for (int Y = Y0; Y < Y1; Y += 3) {
+    int Y = Y0;
+    for (; Y + 2 < Y1; Y += 3) {
         step(Y, R0);
-        if (Y + 1 < Y1) step(Y + 1, R1);
-        if (Y + 2 < Y1) step(Y + 2, R2);
+        step(Y + 1, R1);
+        step(Y + 2, R2);
     }
+    if (Y < Y1) step(Y, R0);
+    if (Y + 1 < Y1) step(Y + 1, R1);
     if (a.vmax && c < a.C) record_vmax(a.vmax, b, vm);
 }
 
@@ -414,8 +421,12 @@ static int blur_act_launch(const float* z, const float* kernel, float* y, void* 
         geo.nseg = (2 * H + seg_rows - 1) / seg_rows;
         const long nbs = base * geo.nseg;
         OODGAN_REQUIRE(nbs < (1L << 31), "blur_act_fform: grid too large");
-        if (y_fform) hipLaunchKernelGGL(blur_act_fform_strip_kernel<false>, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
-        else hipLaunchKernelGGL(blur_act_fform_strip_kernel<true>, dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo);
+        const bool full = ((2 * W) % 64) == 0;
+#define OODGAN_BLUR_STRIP_LAUNCH(SF, FULL) \
+    hipLaunchKernelGGL((blur_act_fform_strip_kernel<SF, FULL>), dim3((unsigned)nbs), dim3(256), 0, as_stream(stream), a, geo)
+        if (y_fform) { if (full) OODGAN_BLUR_STRIP_LAUNCH(false, true); else OODGAN_BLUR_STRIP_LAUNCH(false, false); }
+        else { if (full) OODGAN_BLUR_STRIP_LAUNCH(true, true); else OODGAN_BLUR_STRIP_LAUNCH(true, false); }
+#undef OODGAN_BLUR_STRIP_LAUNCH
         return check_launch("blur_act_strip");
     }
     const long nb = (long)a.tiles_x * a.tiles_y * a.yd.KC * B;
