@@ -26,16 +26,22 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable t) 
     const oodgan_reduce_job& q = t.j[k];
     const long row = wv - t.first_wave[k];
     const int lane = threadIdx.x & 63;
-    const float* p = q.part + row * q.nparts;
-    float s = 0.f;
-    for (int i = lane; i < q.nparts; i += 64) s += p[i];
-    s = wave_sum(s);
-    if (q.part2) {
-        const float* p2 = q.part2 + row * q.nparts2;
-        float s2 = 0.f;
-        for (int i = lane; i < q.nparts2; i += 64) s2 += p2[i];
-        s += q.scale2[(row / q.C) * q.scale2_stride + (row % q.C)] * wave_sum(s2);
-    }
+    // eight unconditional loads (clamped index, masked by a select) in flight per lane and trip: `for (i = lane; i < n; i += 64)
+    // s += p[i]` is one round trip per 64 partials — 64 in a row for the 4096 partials of the 1024² layers (42 us per launch)
+    auto row_sum = [&](const float* p, int n) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i0 = lane; i0 < n; i0 += 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + 64 * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + 64 * u < n ? v[u] : 0.f;
+            a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+        }
+        return wave_sum((a0 + a1) + (a2 + a3));
+    };
+    float s = row_sum(q.part + row * q.nparts, q.nparts);
+    if (q.part2) s += q.scale2[(row / q.C) * q.scale2_stride + (row % q.C)] * row_sum(q.part2 + row * q.nparts2, q.nparts2);
     if (lane == 0) {
         float* o = q.out + (row / q.C) * q.out_stride + (row % q.C);
         *o = q.accumulate ? *o + s : s;

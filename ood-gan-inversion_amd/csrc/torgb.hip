@@ -9,6 +9,40 @@ using namespace oodgan;
 
 namespace {
 
+// upfirdn2d(skip, k, up=2, pad=(2,1)) at pixel (Y, X): the 2 x 2 taps with (Y+ky-2), (X+kx-2) even.  fetch(): the 12 values from
+// clamped positions, all in flight together; a tap outside the image gets a zero weight.  (A conditional load per tap is a round
+// trip per tap: `if (inside) o += k * sp[q]` four times in a row.)  add(): same order of the sums as the conditional form.
+struct SkipTaps {
+    float v[4][3], w[4];
+    template <class KF>
+    __device__ __forceinline__ void fetch(const float* __restrict__ sp, int h2, int w2, int Y, int X, KF kf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ky = (Y & 1) + 2 * t;
+            const int iy = (Y + ky - 2) >> 1;
+            const bool yok = Y + ky - 2 >= 0 && iy < h2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kx = (X & 1) + 2 * u;
+                const int ix = (X + kx - 2) >> 1;
+                const bool ok = yok && X + kx - 2 >= 0 && ix < w2;
+                const long q = (long)min(max(iy, 0), h2 - 1) * w2 + min(max(ix, 0), w2 - 1);
+                w[2 * t + u] = ok ? kf(ky, kx) : 0.f;
+                v[2 * t + u][0] = sp[q];
+                v[2 * t + u][1] = sp[(long)h2 * w2 + q];
+                v[2 * t + u][2] = sp[2L * h2 * w2 + q];
+            }
+        }
+    }
+    __device__ __forceinline__ void add(float& o0, float& o1, float& o2) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (w[k] != 0.f) { o0 += w[k] * v[k][0]; o1 += w[k] * v[k][1]; o2 += w[k] * v[k][2]; }
+        }
+    }
+};
+
+
 constexpr int kMaxCi = 1024;
 
 // grid (ceil(HW/1024), B); thread = 4 consecutive pixels
@@ -58,25 +92,9 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
         float o0 = a0[j] + b0, o1 = a1[j] + b1, o2 = a2[j] + b2;
         if (skip) {
             const int Y = (int)((p + j) / W), X = (int)((p + j) % W);
-            const float* sp = skip + (long)b * 3 * h2 * w2_;
-            // upfirdn2d(skip, k, up=2, pad=(2,1)): taps with (Y+ky-2) even
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ky = (Y & 1) + 2 * t;
-                const int iy = (Y + ky - 2) >> 1;
-                if (Y + ky - 2 < 0 || iy >= h2) continue;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kx = (X & 1) + 2 * u;
-                    const int ix = (X + kx - 2) >> 1;
-                    if (X + kx - 2 < 0 || ix >= w2_) continue;
-                    const float kv = kf[ky * 4 + kx];
-                    const long q = (long)iy * w2_ + ix;
-                    o0 += kv * sp[q];
-                    o1 += kv * sp[(long)h2 * w2_ + q];
-                    o2 += kv * sp[2L * h2 * w2_ + q];
-                }
-            }
+            SkipTaps st;
+            st.fetch(skip + (long)b * 3 * h2 * w2_, h2, w2_, Y, X, [&](int ky, int kx) { return kf[ky * 4 + kx]; });
+            st.add(o0, o1, o2);
         }
         float* yp = y + (long)b * 3 * HW + p + j;
         yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
@@ -97,7 +115,8 @@ __global__ __launch_bounds__(256) void torgb_fwd_small_kernel(const float* __res
     if (p >= HW) return;
     const float* xp = x + (long)b * Ci * HW + p;
     float a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (int ci = lane; ci < Ci; ci += 64) {
+#pragma unroll 4
+    for (int ci = lane; ci < Ci; ci += 64) {         // unrolled: the loads of four trips in flight (one trip was a bare round trip)
         const float4 v = *reinterpret_cast<const float4*>(xp + (long)ci * HW);
         const float sv = scale * s[(long)b * s_stride + ci];
         const float w0 = sv * w[ci], w1 = sv * w[Ci + ci], w2 = sv * w[2 * Ci + ci];
@@ -123,24 +142,9 @@ __global__ __launch_bounds__(256) void torgb_fwd_small_kernel(const float* __res
     if (skip) {
         const int h2 = H >> 1, w2_ = W >> 1;
         const int Y = (int)((p + j) / W), X = (int)((p + j) % W);
-        const float* sp = skip + (long)b * 3 * h2 * w2_;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int ky = (Y & 1) + 2 * t;
-            const int iy = (Y + ky - 2) >> 1;
-            if (Y + ky - 2 < 0 || iy >= h2) continue;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int kx = (X & 1) + 2 * u;
-                const int ix = (X + kx - 2) >> 1;
-                if (X + kx - 2 < 0 || ix >= w2_) continue;
-                const float kv = kern[(3 - ky) * 4 + (3 - kx)];       // flipped
-                const long q = (long)iy * w2_ + ix;
-                o0 += kv * sp[q];
-                o1 += kv * sp[(long)h2 * w2_ + q];
-                o2 += kv * sp[2L * h2 * w2_ + q];
-            }
-        }
+        SkipTaps st;
+        st.fetch(skip + (long)b * 3 * h2 * w2_, h2, w2_, Y, X, [&](int ky, int kx) { return kern[(3 - ky) * 4 + (3 - kx)]; });      // flipped
+        st.add(o0, o1, o2);
     }
     float* yp = y + (long)b * 3 * HW + p + j;
     yp[0] = o0; yp[HW] = o1; yp[2 * HW] = o2;
@@ -320,24 +324,9 @@ __global__ __launch_bounds__(256) void rgb_finish_kernel(const float* __restrict
         float o1 = part[(long)b * 3 * HW + HW + p] + (bias ? bias[1] : 0.f);
         float o2 = part[(long)b * 3 * HW + 2 * HW + p] + (bias ? bias[2] : 0.f);
         if (skip) {
-            const float* sp = skip + (long)b * 3 * h2 * w2_;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ky = (Y & 1) + 2 * t;
-                const int iy = (Y + ky - 2) >> 1;
-                if (Y + ky - 2 < 0 || iy >= h2) continue;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kx = (X & 1) + 2 * u;
-                    const int ix = (X + kx - 2) >> 1;
-                    if (X + kx - 2 < 0 || ix >= w2_) continue;
-                    const float kv = kf[ky * 4 + kx];
-                    const long q = (long)iy * w2_ + ix;
-                    o0 += kv * sp[q];
-                    o1 += kv * sp[(long)h2 * w2_ + q];
-                    o2 += kv * sp[2L * h2 * w2_ + q];
-                }
-            }
+            SkipTaps st;
+            st.fetch(skip + (long)b * 3 * h2 * w2_, h2, w2_, Y, X, [&](int ky, int kx) { return kf[ky * 4 + kx]; });
+            st.add(o0, o1, o2);
         }
         y[(long)b * 3 * HW + p] = o0;
         y[(long)b * 3 * HW + HW + p] = o1;

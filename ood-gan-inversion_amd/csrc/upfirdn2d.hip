@@ -76,22 +76,22 @@ __global__ __launch_bounds__(256) void down2_k4_kernel(const UfdArgs a) {
         const long pl = e / ((long)a.out_w * a.out_h);
         const float* xp = a.x + pl * in_plane;
         const int y0 = 2 * oy - a.pad_y0, x0 = 2 * ox - a.pad_x0;
+        // the 16 taps from clamped positions, all in flight together, a tap outside the image masked by a select (a conditional load
+        // per tap is a round trip per tap; the launches of this kernel are latency-bound: 3 x B planes)
+        float v[16];
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+                v[ky * 4 + kx] = xp[(long)min(max(y0 + ky, 0), a.in_h - 1) * a.in_pitch + min(max(x0 + kx, 0), a.in_w - 1)];
         float acc = 0.f;
-        if (y0 >= 0 && y0 + 3 < a.in_h && x0 >= 0 && x0 + 3 < a.in_w) {
-            const float* r = xp + (long)y0 * a.in_pitch + x0;
 #pragma unroll
-            for (int ky = 0; ky < 4; ++ky)
+        for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 4; ++kx) acc += kf[ky * 4 + kx] * r[(long)ky * a.in_pitch + kx];
-        } else {
-#pragma unroll
-            for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const int iy = y0 + ky, ix = x0 + kx;
-                    if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) acc += kf[ky * 4 + kx] * xp[(long)iy * a.in_pitch + ix];
-                }
-        }
+            for (int kx = 0; kx < 4; ++kx) {
+                const int iy = y0 + ky, ix = x0 + kx;
+                if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) acc += kf[ky * 4 + kx] * v[ky * 4 + kx];
+            }
         a.y[pl * out_plane + (long)oy * a.out_pitch + ox] = acc;
     }
 }
