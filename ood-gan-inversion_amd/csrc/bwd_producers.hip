@@ -369,6 +369,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int ch = tid >> 4, c = kc * 16 + ch;
         const float w0 = cst[0][ch], w1 = cst[1][ch], w2 = cst[2][ch], sr = cst[3][ch], bv = cst[4][ch];
         const long cbase = ((long)b * a.C + c) * HW;
+        const long cbase_c = ((long)b * a.C + min(c, a.C - 1)) * HW;
+        const bool has_g = a.g_feat != nullptr, has_n = np != nullptr, has_r = gr != nullptr;
+        const float* gsrc = has_g ? a.g_feat : a.out;
+        const float* nsrc = has_n ? np : a.out + cbase_c;
+        const float* rsrc = has_r ? gr : a.out;                 // (the RGB instance is only launched with g_rgb)
         float acc_r = 0.f, acc_t = 0.f;
         // loads are issued in two batches of 7 / 6 tile elements before anything depends on them (a load per iteration
         // would serialise the fill into 13 HBM latencies)
@@ -383,20 +388,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 int r, c4;
                 const bool act = tile_elem(k0 + kk, tid & 15, r, c4);
                 const int gy = gy0 + r, gx = gx0 + 4 * c4;
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                o4[kk] = g4[kk] = nz4[kk] = z4;
-                if (RGB) r04[kk] = r14[kk] = r24[kk] = z4;
                 okv[kk] = k0 + kk < NE && act && c < a.C && gy >= 0 && gy < Hg && gx >= 0 && gx + 3 < Wg;
-                if (okv[kk]) {
-                    const long p = (long)gy * Wg + gx;
-                    o4[kk] = *reinterpret_cast<const float4*>(a.out + cbase + p);
-                    if (a.g_feat) g4[kk] = *reinterpret_cast<const float4*>(a.g_feat + cbase + p);
-                    if (np) nz4[kk] = *reinterpret_cast<const float4*>(np + p);
-                    if (RGB && gr) {
-                        r04[kk] = *reinterpret_cast<const float4*>(gr + p);
-                        r14[kk] = *reinterpret_cast<const float4*>(gr + HW + p);
-                        r24[kk] = *reinterpret_cast<const float4*>(gr + 2 * HW + p);
-                    }
+                // unconditional loads from a clamped position (absent tensors: a valid address, masked by has_*): the values are
+                // only touched inside `if (okv)` below.  A load inside `if (okv)` is waited for with vmcnt(0) at the merge — the
+                // batch was 13 round trips in a row
+                const long p = (long)min(max(gy, 0), Hg - 1) * Wg + min(max(gx, 0), Wg - 4);
+                o4[kk] = *reinterpret_cast<const float4*>(a.out + cbase_c + p);
+                g4[kk] = *reinterpret_cast<const float4*>(gsrc + cbase_c + p);
+                nz4[kk] = *reinterpret_cast<const float4*>(nsrc + p);
+                if (RGB) {
+                    r04[kk] = *reinterpret_cast<const float4*>(rsrc + p);
+                    r14[kk] = *reinterpret_cast<const float4*>(rsrc + HW + p);
+                    r24[kk] = *reinterpret_cast<const float4*>(rsrc + 2 * HW + p);
                 }
             }
 #pragma unroll
@@ -406,10 +409,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const int gy = gy0 + r, gx = gx0 + 4 * c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (okv[kk]) {
-                    const float ov[4] = {o4[kk].x, o4[kk].y, o4[kk].z, o4[kk].w}, gv[4] = {g4[kk].x, g4[kk].y, g4[kk].z, g4[kk].w};
-                    const float nzv[4] = {nz4[kk].x, nz4[kk].y, nz4[kk].z, nz4[kk].w};
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 gq = has_g ? g4[kk] : z4, nq = has_n ? nz4[kk] : z4;
+                    const float ov[4] = {o4[kk].x, o4[kk].y, o4[kk].z, o4[kk].w}, gv[4] = {gq.x, gq.y, gq.z, gq.w};
+                    const float nzv[4] = {nq.x, nq.y, nq.z, nq.w};
                     constexpr int ri = RGB ? 1 : 0;
-                    const float4 q0 = RGB ? r04[kk * ri] : make_float4(0.f, 0.f, 0.f, 0.f), q1 = RGB ? r14[kk * ri] : q0, q2 = RGB ? r24[kk * ri] : q0;
+                    const float4 q0 = (RGB && has_r) ? r04[kk * ri] : z4, q1 = (RGB && has_r) ? r14[kk * ri] : z4, q2 = (RGB && has_r) ? r24[kk * ri] : z4;
                     const float r0v[4] = {q0.x, q0.y, q0.z, q0.w}, r1v[4] = {q1.x, q1.y, q1.z, q1.w}, r2v[4] = {q2.x, q2.y, q2.z, q2.w};
                     // every g pixel is reduced by exactly one block: the one whose 8x64 interior contains it
                     const bool own = gy >= 2 * i0 && gy < 2 * i0 + 8 && gx >= 2 * j0 && gx < 2 * j0 + 64;
