@@ -18,30 +18,36 @@ struct ReduceTable {
     int n;
 };
 
+// rows with at most 64 partials (every layer below 128²) take 16 lanes each, four rows per wave: one wave per row made the launch
+// 69 000 waves of one or two loads — bound by the rate at which waves start (41 us)
+__host__ __device__ __forceinline__ bool reduce_quad(const oodgan_reduce_job& q) { return q.nparts <= 64 && (!q.part2 || q.nparts2 <= 64); }
+
 __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable t) {
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= t.first_wave[t.n]) return;
     int k = 0;
     while (k + 1 < t.n && wv >= t.first_wave[k + 1]) ++k;
     const oodgan_reduce_job& q = t.j[k];
-    const long row = wv - t.first_wave[k];
     const int lane = threadIdx.x & 63;
-    // eight unconditional loads (clamped index, masked by a select) in flight per lane and trip: `for (i = lane; i < n; i += 64)
-    // s += p[i]` is one round trip per 64 partials — 64 in a row for the 4096 partials of the 1024² layers (42 us per launch)
-    auto row_sum = [&](const float* p, int n) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int i0 = lane; i0 < n; i0 += 512) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + 64 * u, n - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = i0 + 64 * u < n ? v[u] : 0.f;
-            a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+    const bool quad = reduce_quad(q);
+    const long nrows = (long)q.B * q.C;
+    const long row_raw = quad ? (wv - t.first_wave[k]) * 4 + (lane >> 4) : wv - t.first_wave[k];
+    const bool live = row_raw < nrows;
+    const long row = live ? row_raw : nrows - 1;
+    // quad: 16 lanes per row, four rows per wave; otherwise one row per wave — the order of a row's sum depends only on its length
+    float s = quad ? row_sum16(q.part + row * q.nparts, q.nparts, lane & 15) : row_sum(q.part + row * q.nparts, q.nparts, lane);
+    if (q.part2) {
+        const float* p2 = q.part2 + row * q.nparts2;
+        const float s2 = quad ? row_sum16(p2, q.nparts2, lane & 15) : row_sum(p2, q.nparts2, lane);
+        s += q.scale2[(row / q.C) * q.scale2_stride + (row % q.C)] * s2;
+    }
+    if (quad) {
+        if (live && (lane & 15) == 0) {
+            float* o = q.out + (row / q.C) * q.out_stride + (row % q.C);
+            *o = q.accumulate ? *o + s : s;
         }
-        return wave_sum((a0 + a1) + (a2 + a3));
-    };
-    float s = row_sum(q.part + row * q.nparts, q.nparts);
-    if (q.part2) s += q.scale2[(row / q.C) * q.scale2_stride + (row % q.C)] * row_sum(q.part2 + row * q.nparts2, q.nparts2);
+        return;
+    }
     if (lane == 0) {
         float* o = q.out + (row / q.C) * q.out_stride + (row % q.C);
         *o = q.accumulate ? *o + s : s;
@@ -102,9 +108,7 @@ __global__ __launch_bounds__(256) void demod_fwd_batch_kernel(const DemodFwdTabl
     const long idx = wv - t.first_wave[k];
     const int lane = threadIdx.x & 63;
     const int b = (int)(idx / q.Co), co = (int)(idx % q.Co);
-    float acc = 0.f;
-    for (int ci = lane; ci < q.Ci; ci += 64) { const float sv = q.s[(long)b * q.s_stride + ci]; acc += sv * sv * q.wsq[(long)co * q.Ci + ci]; }
-    acc = wave_sum(acc);
+    const float acc = demod_dot(q.s + (long)b * q.s_stride, q.wsq + (long)co * q.Ci, q.Ci, lane);
     if (lane == 0) q.d[(long)b * q.d_stride + co] = rsqrtf(acc * (q.scale * q.scale) + 1e-8f);
 }
 
@@ -163,7 +167,7 @@ extern "C" int oodgan_reduce_batch(const oodgan_reduce_job* jobs, int njobs, voi
             OODGAN_REQUIRE(q.part && q.out && q.B > 0 && q.C > 0 && q.nparts > 0 && q.out_stride >= q.C, "reduce_batch: bad job %d", base + i);
             t.j[i] = q;
             t.first_wave[i] = (int)waves;
-            waves += (long)q.B * q.C;
+            waves += reduce_quad(q) ? ((long)q.B * q.C + 3) / 4 : (long)q.B * q.C;
         }
         OODGAN_REQUIRE(waves < (1L << 31), "reduce_batch: too many rows");
         t.first_wave[t.n] = (int)waves;

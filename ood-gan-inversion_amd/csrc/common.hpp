@@ -50,6 +50,62 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Row sums of partials, shared by the per-layer and the batched kernels (they must agree bit for bit: tests/test_hip_generator.py).
+// Loads are unconditional from a clamped index and masked by a select, eight (four) in flight per lane: `for (i = lane; i < n;
+// i += 64) s += p[i]` is one round trip per trip.  n <= 64: 16 lanes per row (row_sum16; every 16-lane group of a wave may own a
+// row of its own); longer rows: the whole wave.
+__device__ __forceinline__ float row_sum16(const float* __restrict__ p, int n, int l) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[min(l + 16 * u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = l + 16 * u < n ? v[u] : 0.f;
+    float r = (v[0] + v[1]) + (v[2] + v[3]);
+    r += __shfl_xor(r, 8, 64);
+    r += __shfl_xor(r, 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
+__device__ __forceinline__ float row_sum_wave(const float* __restrict__ p, int n, int lane) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i0 = lane; i0 < n; i0 += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + 64 * u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + 64 * u < n ? v[u] : 0.f;
+        a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+    }
+    return wave_sum((a0 + a1) + (a2 + a3));
+}
+
+// one row per wave, in the order the row's length selects (all lanes return the sum)
+__device__ __forceinline__ float row_sum(const float* __restrict__ p, int n, int lane) {
+    return n <= 64 ? row_sum16(p, n, lane & 15) : row_sum_wave(p, n, lane);
+}
+
+// sum_ci s[ci]^2 * wsq[ci] over a wave (demodulation, model.py:236-241): eight channel groups in flight per trip
+__device__ __forceinline__ float demod_dot(const float* __restrict__ sp, const float* __restrict__ wp, int Ci, int lane) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c0 = lane; c0 < Ci; c0 += 512) {
+        float sv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ci = min(c0 + 64 * u, Ci - 1);
+            sv[u] = sp[ci];
+            wv[u] = wp[ci];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float pr = c0 + 64 * u < Ci ? sv[u] * sv[u] * wv[u] : 0.f;
+            if ((u & 3) == 0) a0 += pr; else if ((u & 3) == 1) a1 += pr; else if ((u & 3) == 2) a2 += pr; else a3 += pr;
+        }
+    }
+    return wave_sum((a0 + a1) + (a2 + a3));
+}
+
 // Sum over the 32 lanes of each half of the wave with DPP operands (VALU only): quad swaps, row_half_mirror, row_mirror and
 // row_bcast:15 — the total of lanes 0-31 lands in lanes 16-31 (read it in lane 31), that of lanes 32-63 in lanes 48-63 (lane
 // 63).  A __shfl_xor butterfly is five ds_bpermute_b32 per value: the fused epilogue of the stride-2 conv issued 486 of them

@@ -176,10 +176,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float* p = part + row * nparts;
-    float s = 0.f;
-    for (int j = lane; j < nparts; j += 64) s += p[j];
-    s = wave_sum(s);
+    const float s = row_sum(part + row * nparts, nparts, lane);        // common.hpp: the order oodgan_reduce_batch uses
     if (lane == 0) out[row] = accumulate ? out[row] + s : s;
 }
 

@@ -158,9 +158,7 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(const float* __restrict_
     const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= (long)B * Co) return;
     const int b = (int)(idx / Co), co = (int)(idx % Co);
-    float acc = 0.f;
-    for (int ci = lane; ci < Ci; ci += 64) { const float sv = s[(long)b * s_stride + ci]; acc += sv * sv * wsq[(long)co * Ci + ci]; }
-    acc = wave_sum(acc);
+    const float acc = demod_dot(s + (long)b * s_stride, wsq + (long)co * Ci, Ci, lane);       // common.hpp: shared with the batched kernel
     if (lane == 0) d[(long)b * d_stride + co] = rsqrtf(acc * scale2 + 1e-8f);
 }
 
