@@ -56,7 +56,7 @@ extern "C" long oodgan_get_tunable(const char* name) {
     return -1;
 }
 
-extern "C" int oodgan_version(void) { return 102; }      // 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes
+extern "C" int oodgan_version(void) { return 103; }      // 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;
