@@ -93,24 +93,49 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& p, f32x16 (&acc)[MT][
         float dsum[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dsum[r] = 0.f;
+        // the per-channel constants of the M-tile, the noise and the dot operand of a row: unconditional loads from clamped channels /
+        // pixels (`yb`: a valid address for an absent tensor), all of a row in flight together.  `if (bias) v += bias[m]` inside the
+        // store loop is a branch, a load and a vmcnt(0) per value — up to 64 serialised round trips per M-tile, each waiting for the
+        // store before it
+        const float* oscp = osc ? osc : yb;
+        const float* biasp = a.bias ? a.bias : yb;
+        const float* slopep = (a.act == OODGAN_ACT_PRELU && a.slope) ? a.slope : yb;
+        float oscv[16], biav[16], slpv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mc = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+            oscv[r] = oscp[mc];
+            biav[r] = biasp[mc];
+            slpv[r] = slopep[mc];
+        }
+        const long HWo = (long)p.Hout * p.Wout;
+        const float* nzp = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HWo : yb;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int py = r0 + wave * NT + nt;
             const bool pix_ok = (py < p.Hout) && (px < p.Wout);
-            float nz = 0.f;
-            if (a.noise && pix_ok)
-                nz = nw * a.noise[(long)(a.noise_batch > 1 ? b : 0) * p.Hout * p.Wout + (long)py * p.Wout + px];
+            const long pixc = (long)min(py, p.Hout - 1) * p.Wout + min(px, p.Wout - 1);
+            const float nzr = nzp[a.noise ? pixc : 0];
+            float dv[16];
+            if (db) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mc = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+                    dv[r] = db[(long)mc * HWo + pixc];
+                }
+            }
+            const float nz = (a.noise && pix_ok) ? nw * nzr : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (!pix_ok || m >= a.M) continue;
                 float v = acc[mt][nt][r] * us;
-                if (db) dsum[r] += v * db[(long)m * p.Hout * p.Wout + (long)py * p.Wout + px];
-                if (osc) v *= osc[m];
+                if (db) dsum[r] += v * dv[r];
+                if (osc) v *= oscv[r];
                 v += nz;
-                if (a.bias) v += a.bias[m];
+                if (a.bias) v += biav[r];
                 if (a.act == OODGAN_ACT_LRELU) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
-                else if (a.act == OODGAN_ACT_PRELU) v = v > 0.f ? v : a.slope[m] * v;
+                else if (a.act == OODGAN_ACT_PRELU) v = v > 0.f ? v : slpv[r] * v;
                 yb[(long)m * p.out_plane + (long)py * a.out_pitch + px] = v;
             }
         }

@@ -120,37 +120,45 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     const int nchunk = (a.K + CK - 1) / CK;
     const long wchunk = (long)WROWS * p.Mp;          // 16-byte units per K chunk in the packed weights
 
+    // load_x() only loads: every item reads from a clamped address (plane offset 0 and the last channel for what does not exist)
+    // and the raw values stay untouched in xr until store_x() — one K chunk later, behind the MFMAs — scales, masks and converts
+    // them.  With the loads inside `if (ld)` and the scaling right behind them every load was waited for where it was issued
+    // (vmcnt(0)): 20 round trips per chunk in the stride-2 instance, none of them under the matrix instructions.
+    float xsc[4], xsh[4];
+    const float* iscp = isc ? isc : xb;
+    const float* ishp = ish ? ish : xb;
     auto load_x = [&](int t) {
         const int k0 = t * CK + 4 * (tid & 3);
 #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kc = min(k0 + j, a.K - 1);
+            xsc[j] = iscp[kc];
+            xsh[j] = ishp[kc];
+        }
+#pragma unroll
         for (int i = 0; i < XPT; ++i) {
+            const int off = max(xoff[i], 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + j;
-                const bool ld = xoff[i] >= 0 && k < a.K && !(p.ablate & 2);
-                const float sc = ((ld && isc) ? isc[k] : 1.f) * in_mul;
-                const float sh = ((ld && ish) ? ish[k] : 0.f) * in_mul;
+                const float* src = xb + (long)min(k0 + j, a.K - 1) * p.in_plane + off;
                 if (VEC) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ld) {
-                        v = *reinterpret_cast<const float4*>(xb + (long)k * p.in_plane + xoff[i]);
-                        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-                        // elements beyond the logical width (pitch padding / S2 odd width) are zero
-                        if (xgx[i] + 1 >= a.Win) v.y = 0.f;
-                        if (xgx[i] + 2 >= a.Win) v.z = 0.f;
-                        if (xgx[i] + 3 >= a.Win) v.w = 0.f;
-                    }
+                    const float4 v = *reinterpret_cast<const float4*>(src);
                     xr[i][j * 4 + 0] = v.x; xr[i][j * 4 + 1] = v.y; xr[i][j * 4 + 2] = v.z; xr[i][j * 4 + 3] = v.w;
                 } else {
-                    float v = 0.f;
-                    if (ld) v = xb[(long)k * p.in_plane + xoff[i]] * sc + sh;
-                    xr[i][j] = v;
+                    xr[i][j] = *src;
                 }
             }
         }
     };
-    auto store_x = [&]() {
-        const int q = tid & 3;
+    // value (i, channel j, element px) of the chunk whose first channel is k0: scaled, zero where nothing exists
+    auto x_value = [&](int i, int j, int px, int k0) {
+        const bool ld = xoff[i] >= 0 && k0 + j < a.K && !(p.ablate & 2) && (px == 0 || xgx[i] + px < a.Win);
+        const float sc = (isc ? xsc[j] : 1.f) * in_mul, sh = (ish ? xsh[j] : 0.f) * in_mul;
+        const float raw = VEC ? xr[i][j * 4 + px] : xr[i][j];
+        return ld ? raw * sc + sh : 0.f;
+    };
+    auto store_x = [&](int t) {
+        const int q = tid & 3, k0 = t * CK + 4 * q;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int e = tid + i * 256;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
                 half4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v = VEC ? xr[i][j * 4 + px] : xr[i][j];
+                    const float v = x_value(i, j, px, k0);
                     const _Float16 h = (_Float16)v;
                     hi[j] = h;
                     lo[j] = (_Float16)(v - (float)h);
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_f16s_kernel(const KArgs p, const uin
     for (int t = 0; t < nchunk; ++t) {
         __syncthreads();                       // previous chunk fully consumed (first pass: the zero fill is complete)
         dma_w(t);                              // async global->LDS, lands while x is converted
-        if (!(p.ablate & 8)) store_x();
+        if (!(p.ablate & 8)) store_x(t);
         __syncthreads();                       // (hipcc drains vmcnt before the barrier: DMA complete)
         if (t + 1 < nchunk) load_x(t + 1);     // in flight during the MFMA loop
         if (p.ablate & 1) continue;
