@@ -70,7 +70,61 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, const SConv& sc, f
     const float* db = a.dotx ? a.dotx + (long)b * a.M * HWo : nullptr;
     float* yb = a.y ? a.y + (long)b * a.M * p.out_plane : nullptr;
     const bool vec = (p.Wout % 4 == 0) && (a.out_pitch % 4 == 0);
-    {
+    if (vec) {
+        // Aligned rows (every layer of the generator and the encoder): the constants, the noise quad and the dot operands of EIGHT
+        // channels are requested together from clamped channels / pixels (`lo`-independent; an absent tensor reads the workgroup's
+        // own output row, a valid address) and masked where they are used.  The loop below — a conditional load per constant and
+        // operand, each one waited for with vmcnt(0) behind the previous channel's store — was 120 loads with 125 full waits:
+        // 25-40 round trips per tile in kernels of 40-75 us.
+        const int c4 = tid & 63;
+        const int prow = c4 >> 3, pcol = (c4 & 7) * 4;
+        const int py = r0 + prow, px = c0 + pcol;
+        const bool pix_ok = py < p.Hout && px + 3 < p.Wout;
+        const long pixc = (long)min(py, p.Hout - 1) * p.Wout + min(px, p.Wout - 4);
+        const float* dummy = reinterpret_cast<const float*>(sc.xs);      // the S-form input: always there, 16-byte aligned
+        const float4 n4 = *reinterpret_cast<const float4*>(nzp ? nzp + pixc : dummy);
+        const float nn[4] = {nzp ? n4.x : 0.f, nzp ? n4.y : 0.f, nzp ? n4.z : 0.f, nzp ? n4.w : 0.f};
+#pragma unroll
+        for (int i0 = 0; i0 < MB / 4; i0 += 8) {
+            float sclv[8], bvv[8], slv[8];
+            float4 d4v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int mc = min(m0 + (tid >> 6) + 4 * (i0 + u), a.M - 1);
+                sclv[u] = *(osc ? osc + mc : dummy);
+                bvv[u] = *(a.bias ? a.bias + mc : dummy);
+                slv[u] = *((a.act == OODGAN_ACT_PRELU && a.slope) ? a.slope + mc : dummy);
+                d4v[u] = *reinterpret_cast<const float4*>(db ? db + (long)mc * HWo + pixc : dummy);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ml = (tid >> 6) + 4 * (i0 + u);
+                const int m = m0 + ml;
+                const float4 v = *reinterpret_cast<const float4*>(lo + ml * OP + c4 * 4);
+                float vv[4] = {v.x, v.y, v.z, v.w};
+                float dsum = 0.f;
+                const bool m_ok = m < a.M;
+                if (m_ok && pix_ok && (yb || db)) {
+                    const float scl = osc ? sclv[u] : 1.f, bv = a.bias ? bvv[u] : 0.f, sl = slv[u];
+                    if (db) dsum = vv[0] * d4v[u].x + vv[1] * d4v[u].y + vv[2] * d4v[u].z + vv[3] * d4v[u].w;
+                    if (yb) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float o = vv[j] * scl + nw * nn[j] + bv;
+                            if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                            else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                            vv[j] = o;
+                        }
+                        *reinterpret_cast<float4*>(yb + (long)m * p.out_plane + (long)py * a.out_pitch + px) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
+                if (db) {
+                    dsum = wave_sum(dsum);
+                    if (lane == 0 && m_ok) a.dot_part[((long)b * a.M + m) * a.dot_nparts + ctx.tile] = dsum;
+                }
+            }
+        }
+    } else {
         const int c4 = tid & 63;
         const int prow = c4 >> 3, pcol = (c4 & 7) * 4;
         const int py = r0 + prow, px = c0 + pcol;
@@ -136,17 +190,30 @@ __device__ __forceinline__ void tile_epilogue(const KArgs& p, const SConv& sc, f
             const int pxl = u & 255, g16 = u >> 8;
             const int py = r0 + (pxl >> 5), px = c0 + (pxl & 31);
             if (py >= p.Hout || px >= p.Wout || (m0 >> 4) + g16 >= sc.yd.KC) continue;   // last M block may be partial
-            const float nz = nzp ? nw * nzp[(long)py * p.Wout + px] : 0.f;
+            // the constants of the unit's 16 channels in one request (clamped channel; the S-form input as a valid address for an absent
+            // tensor): loaded where they are used they are up to 64 conditional loads, each waited for with vmcnt(0)
+            const float* dmy = reinterpret_cast<const float*>(sc.xs);
+            const float nzr = *(nzp ? nzp + (long)py * p.Wout + px : dmy);
+            float c_osc[16], c_bia[16], c_slp[16], c_ysc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int mc = min(m0 + g16 * 16 + j, a.M - 1);
+                c_osc[j] = *(osc ? osc + mc : dmy);
+                c_bia[j] = *(a.bias ? a.bias + mc : dmy);
+                c_slp[j] = *((a.act == OODGAN_ACT_PRELU && a.slope) ? a.slope + mc : dmy);
+                c_ysc[j] = *(ysc ? ysc + mc : dmy);
+            }
+            const float nz = nzp ? nw * nzr : 0.f;
             half8 hv[2], lv[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int ml = g16 * 16 + j, m = m0 + ml;
                 float o = 0.f;
                 if (m < a.M) {
-                    o = lo[ml * OP + pxl] * (osc ? osc[m] : 1.f) + nz + (a.bias ? a.bias[m] : 0.f);
+                    o = lo[ml * OP + pxl] * (osc ? c_osc[j] : 1.f) + nz + (a.bias ? c_bia[j] : 0.f);
                     if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
-                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : a.slope[m] * o;
-                    if (ysc) o *= ysc[m];
+                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : c_slp[j] * o;
+                    if (ysc) o *= c_ysc[j];
                 }
                 const _Float16 h = (_Float16)o;
                 hv[j >> 3][j & 7] = h;

@@ -107,10 +107,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         __syncthreads();
         if (p < HW) {
             const int kn = (K - k0) < C1_KC ? (K - k0) : C1_KC;
-            for (int kk = 0; kk < kn; ++kk) {
-                const float v = xp[(long)(k0 + kk) * HW];
+            // eight input planes in flight per trip (clamped channel, masked by a select); one plane per trip was a round trip per
+            // input channel.  Same order of the sums as before.
+            for (int kk0 = 0; kk0 < kn; kk0 += 8) {
+                float v[8];
 #pragma unroll
-                for (int j = 0; j < C1_MT; ++j) acc[j] += ws[j * C1_KC + kk] * v;
+                for (int u = 0; u < 8; ++u) v[u] = xp[(long)(k0 + min(kk0 + u, kn - 1)) * HW];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float vu = kk0 + u < kn ? v[u] : 0.f;
+                    const int kk = min(kk0 + u, C1_KC - 1);
+#pragma unroll
+                    for (int j = 0; j < C1_MT; ++j) acc[j] += ws[j * C1_KC + kk] * vu;
+                }
             }
         }
     }
