@@ -816,11 +816,21 @@ __global__ __launch_bounds__(256) void to_sform_phases_kernel(const float* __res
         const int yy = 2 * i + (ph >> 1), xx = 2 * j + (ph & 1);
         const bool inb = yy < Hin && xx < Win;
         half8 h0, h1, l0, l1;
+        // one request for the record's 16 channels and scales (clamped pixel and channel), masked below — see to_sform_kernel
+        float xv[16], scv[16];
+        const float* scp = scale ? scale + (long)b * scale_stride : x;
+        const long pofs = (long)min(yy, Hin - 1) * in_pitch + min(xx, Win - 1);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int cc = min(kc * 16 + jj, C - 1);
+            xv[jj] = x[((long)b * C + cc) * in_plane + pofs];
+            scv[jj] = scp[cc];
+        }
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
             const int c = kc * 16 + jj;
             float v = 0.f;
-            if (inb && c < C) v = x[((long)b * C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) * gm;
+            if (inb && c < C) v = xv[jj] * (scale ? scv[jj] : 1.f) * gm;
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);
             if (jj < 8) { h0[jj] = h; l0[jj] = l; } else { h1[jj - 8] = h; l1[jj - 8] = l; }
@@ -950,13 +960,23 @@ __global__ __launch_bounds__(256) void to_sform_kernel(const float* __restrict__
         }
         if (!live) continue;
         half8 h0, h1, l0, l1;
+        // the 16 channels of the record and their scales in one request (clamped channel; x as a valid address for absent scales):
+        // `if (c < C) v = x[..] * scale[c]` is a branch and a wait per channel — sixteen round trips per record
+        float xv[16], scv[16], shv[16];
+        const float* scp = scale ? scale + (long)b * scale_stride : x;
+        const float* shp = shift ? shift + (long)b * shift_stride : x;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int cc = min(kc * 16 + j, d.C - 1);
+            xv[j] = x[((long)b * d.C + cc) * in_plane + (long)yy * in_pitch + xx];
+            scv[j] = scp[cc];
+            shv[j] = shp[cc];
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int c = kc * 16 + j;
             float v = 0.f;
-            if (c < d.C)
-                v = (x[((long)b * d.C + c) * in_plane + (long)yy * in_pitch + xx] * (scale ? scale[(long)b * scale_stride + c] : 1.f) +
-                     (shift ? shift[(long)b * shift_stride + c] : 0.f)) * gm;
+            if (c < d.C) v = (xv[j] * (scale ? scv[j] : 1.f) + (shift ? shv[j] : 0.f)) * gm;
             vm = fmaxf(vm, fabsf(v));
             const _Float16 h = (_Float16)v;
             const _Float16 l = (_Float16)(v - (float)h);

@@ -117,12 +117,25 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const UfdArgs a, int tile
         kf[threadIdx.x] = (ky < a.kh && kx < a.kw) ? a.k[(a.kh - 1 - ky) * a.kw + (a.kw - 1 - kx)] : 0.f;
     }
     const int iy0 = oy0 - a.pad_y0, ix0 = ox0 - a.pad_x0;
-    for (int e = threadIdx.x; e < FL_H * FL_W; e += 256) {
-        const int r = e / FL_W, c = e % FL_W;
-        const int iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) v = xp[(long)iy * a.in_pitch + ix];
-        t[r * FL_P + c] = v;
+    {
+        // the whole fill of the tile in one request: every element from a clamped position, masked when it goes to LDS (a conditional
+        // load per trip, stored right away, is a round trip per trip: ten in a row)
+        constexpr int NF = (FL_H * FL_W + 255) / 256;
+        float fv[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int e = min((int)threadIdx.x + 256 * i, FL_H * FL_W - 1);
+            const int iy = iy0 + e / FL_W, ix = ix0 + e % FL_W;
+            fv[i] = xp[(long)min(max(iy, 0), a.in_h - 1) * a.in_pitch + min(max(ix, 0), a.in_w - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            if (e >= FL_H * FL_W) continue;
+            const int r = e / FL_W, c = e % FL_W;
+            const int iy = iy0 + r, ix = ix0 + c;
+            t[r * FL_P + c] = (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) ? fv[i] : 0.f;
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -133,6 +146,16 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const UfdArgs a, int tile
     const float bv = a.bias ? a.bias[pl % a.C] : 0.f;
     const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
     const float* np = a.noise ? a.noise + (a.noise_batch > 1 ? b : 0) * (long)a.out_h * a.out_w : nullptr;
+    // the noise of this thread's eight outputs, requested before the filter runs (clamped pixel; the input plane as a valid address
+    // when there is no noise)
+    float nzv[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = min(oy0 + ty + rr * 16, a.out_h - 1), ox = min(ox0 + 4 * tx + j, a.out_w - 1);
+            nzv[rr][j] = *(np ? np + (long)oy * a.out_w + ox : xp);
+        }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int r = ty + rr * 16;
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const UfdArgs a, int tile
             const int ox = ox0 + 4 * tx + j;
             if (ox >= a.out_w) continue;
             float v = o[j];
-            if (np) v += nw * np[(long)oy * a.out_w + ox];
+            if (np) v += nw * nzv[rr][j];
             v += bv;
             if (a.act == OODGAN_ACT_LRELU) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
             a.y[pl * out_plane + (long)oy * a.out_pitch + ox] = v;
