@@ -461,13 +461,27 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     for (int mt = 0; mt < 2; ++mt) {
         float osc[16], bia[16], slp[16];
         unsigned moff[16], doff[16];
+        // the constants of the M-tile from clamped channels, all in flight together (the packed weights as a valid address for an absent
+        // tensor), masked by selects: `mok ? ptr[m] : 0` per register was a branch, a load and a vmcnt(0) each
+        const float* dmy = reinterpret_cast<const float*>(wpk16);
+        const float* oscp = a.out_scale ? a.out_scale + (long)b * a.out_scale_stride : dmy;
+        const float* biap = (!DOT && a.bias) ? a.bias : dmy;
+        const float* slpp = (!DOT && a.act == OODGAN_ACT_PRELU) ? a.slope : dmy;
+        float c_o[16], c_b[16], c_s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mc = min(m0 + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, M - 1);
+            c_o[r] = oscp[a.out_scale ? mc : 0];
+            c_b[r] = biap[(!DOT && a.bias) ? mc : 0];
+            c_s[r] = slpp[(!DOT && a.act == OODGAN_ACT_PRELU) ? mc : 0];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mh * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool mok = m < M;
-            osc[r] = mok ? (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us : 0.f;
-            bia[r] = (!DOT && a.bias && mok) ? a.bias[m] : 0.f;
-            slp[r] = (!DOT && a.act == OODGAN_ACT_PRELU && mok) ? a.slope[m] : 1.f;
+            osc[r] = mok ? (a.out_scale ? c_o[r] : 1.f) * us : 0.f;
+            bia[r] = (!DOT && a.bias && mok) ? c_b[r] : 0.f;
+            slp[r] = (!DOT && a.act == OODGAN_ACT_PRELU && mok) ? c_s[r] : 1.f;
             moff[r] = mok ? (unsigned)((long)m * p.out_plane * 4) : 0xFFFFFFFFu;
             doff[r] = mok ? (unsigned)((long)m * H * W * 4) : 0u;
         }
