@@ -18,10 +18,20 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
     const float* p = x + (long)blockIdx.x * HW;
     float s = 0.f;
     if ((HW & 3) == 0) {
-        for (long i = threadIdx.x; i < (HW >> 2); i += 256) {
-            const float4 v = reinterpret_cast<const float4*>(p)[i];
-            s += (v.x + v.y) + (v.z + v.w);
+        // four float4 per thread in flight per trip (clamped index, masked by a select): one per trip was a round trip per trip
+        const long n4 = HW >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(p)[min(i + 256 * u, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = i + 256 * u < n4 ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.f;
+                if (u == 0) s0 += t; else if (u == 1) s1 += t; else if (u == 2) s2 += t; else s3 += t;
+            }
         }
+        s = (s0 + s1) + (s2 + s3);
     } else {
         for (long i = threadIdx.x; i < HW; i += 256) s += p[i];
     }
@@ -31,11 +41,20 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
     const float mean = mean_s;
     float q = 0.f;
     if ((HW & 3) == 0) {
-        for (long i = threadIdx.x; i < (HW >> 2); i += 256) {
-            const float4 v = reinterpret_cast<const float4*>(p)[i];
-            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+        const long n4 = HW >> 2;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(p)[min(i + 256 * u, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+                const float t = i + 256 * u < n4 ? (a * a + b * b) + (c * c + d * d) : 0.f;
+                if (u == 0) q0 += t; else if (u == 1) q1 += t; else if (u == 2) q2 += t; else q3 += t;
+            }
         }
+        q = (q0 + q1) + (q2 + q3);
     } else {
         for (long i = threadIdx.x; i < HW; i += 256) { const float a = p[i] - mean; q += a * a; }
     }
