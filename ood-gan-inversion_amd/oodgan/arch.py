@@ -119,7 +119,8 @@ class ood_faceGAN_e4e(nn.Module):
             self.cycle_align = kwargs.get('cycle_align', 1)
             for i in range(self.log_outsize, 4, -1):
                 chn = self.channels[2 ** i]
-                self.modulation.append(samm.StyledscaleNshfitBlock(chn, chn, style_dim, scale=warp_scale,
+                chn_mul = 2 if modulation_type == 'SFT' else 1      # reference :110-112 (only matters with a mod_btn extractor)
+                self.modulation.append(samm.StyledscaleNshfitBlock(chn, chn * chn_mul, style_dim, scale=warp_scale,
                                                                    btn=kwargs.get('mod_btn', None),
                                                                    cycle_align=self.cycle_align,
                                                                    diff_fAndg=kwargs.get('diff_fAndg', True)))

@@ -170,11 +170,18 @@ class StyledConv(nn.Module):
         super().__init__()
         self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
                                     blur_kernel=blur_kernel, demodulate=demodulate)
-        self.noise = NoiseInjection()
-        self.activate = FusedLeakyReLU(out_channel)
+        # noiseInjection=False / activation=False (model.py:332-341; used by SAMM's styleBlock, helpers.py:43-57): the reference
+        # puts a lambda there, so the state dict has no noise.weight / activate.bias either
+        self.noise = NoiseInjection() if kwargs.get('noiseInjection', True) else None
+        self.activate = FusedLeakyReLU(out_channel) if kwargs.get('activation', True) else None
 
     def forward(self, input, style, noise=None, **kwargs):
         out = self.conv(input, style)
+        if self.noise is None:
+            return out if self.activate is None else self.activate(out)
+        if self.activate is None:
+            kwargs.update({'style': style})
+            return self.noise(out, noise=noise, **kwargs)
         if noise is None:
             b, _, h, w = out.shape
             noise = torch.randn(b, 1, h, w, device=out.device, dtype=out.dtype)

@@ -224,9 +224,10 @@ class bottleneck_IR(nn.Module):
 
     def __init__(self, in_channel, depth, stride=1, bn='InstanceNorm', bias=False):
         super().__init__()
-        if stride != 1 or bias or bn != 'InstanceNorm':
-            raise NotImplementedError('SAMM uses stride-1, bias-free, InstanceNorm bottlenecks only')
+        if stride != 1 or bias or bn not in ('InstanceNorm', False, None):
+            raise NotImplementedError('SAMM uses stride-1, bias-free bottlenecks with InstanceNorm (AlignNet) or without a norm (mod_btn)')
         self.in_channel, self.depth = in_channel, depth
+        self.norm = bn == 'InstanceNorm'                # bn=False: BN() is nn.Identity (e4e helpers.py:93-99), style_bottleneck_IR
         if in_channel == depth:
             self.shortcut_layer = nn.MaxPool2d(1, stride)
         else:
@@ -239,6 +240,9 @@ class bottleneck_IR(nn.Module):
         w1, w2 = self.res_layer[1].weight, self.res_layer[3].weight
         key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version)
         if key != self._key:
+            if not self.norm:
+                self._key, self._prep = key, {'w1': ops.pack_conv3x3(w1.detach()), 'w2': ops.pack_conv3x3(w2.detach())}
+                return self._prep
             if self.depth <= 4 and self.in_channel > 8:
                 self._key, self._prep = key, {}          # conv3x3_fewout / conv3x3_small take the raw weights
                 return self._prep
@@ -251,6 +255,14 @@ class bottleneck_IR(nn.Module):
     def forward(self, x):
         prep = self._prepared()
         rl = self.res_layer
+        if not self.norm:
+            # res_layer = conv3x3 -> PReLU -> conv3x3, plain residual sum (e4e helpers.py:426-452 with BN = Identity)
+            r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight)
+            r = ops.conv3x3(r, prep['w2'], self.depth, CONV_S1)
+            shortcut = x if self.in_channel == self.depth else conv1x1(x, self.shortcut_layer[0].weight)
+            B = x.shape[0]
+            one = torch.ones(B, self.depth, device=r.device, dtype=torch.float32)
+            return affine_apply(r, one, torch.zeros_like(one), res=shortcut)
         sc, sh = instnorm_coeffs(instnorm_stats(x), rl[0].weight, rl[0].bias)
         if self.in_channel >= 64 and self.depth >= 64:
             # the AlignNet convs (2C -> 2C channels, 7x the generator's FLOPs per image): through the S-form and
@@ -342,20 +354,64 @@ class _NoiseInj(nn.Module):
         self.weight = nn.Parameter(torch.zeros(1))
 
 
+class style_bottleneck_IR(nn.Module):
+    """``mod_btn='style_bottleneck_IR'`` (reference src/ops/SAMM/helpers.py:22-40): two norm-free bottlenecks, a ModulatedConv2d on the
+    layer's style and a FusedLeakyReLU.  Parameter names follow the reference's state dict."""
+
+    def __init__(self, in_channel, depth, style_dim, stride=1, upsample=False, downsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True, bn=False):
+        super().__init__()
+        from .modules import FusedLeakyReLU, ModulatedConv2d
+        self.btn = nn.Sequential(bottleneck_IR(in_channel, in_channel, stride, bn), bottleneck_IR(in_channel, depth, stride, bn))
+        self.final_conv = ModulatedConv2d(depth, depth, 3, style_dim, demodulate=demodulate, upsample=upsample, downsample=downsample,
+                                          blur_kernel=blur_kernel)
+        self.act = FusedLeakyReLU(depth)
+
+    def forward(self, x, style):
+        return self.act(self.final_conv(self.btn(x), style))
+
+
+class styleBlock(nn.Module):
+    """``mod_btn='styleBlock'`` (reference src/ops/SAMM/helpers.py:43-57): two StyledConv, the first without noise, the second with the
+    noise / activation flags the caller passes (StyledscaleNshfitBlock: neither)."""
+
+    def __init__(self, in_channel, depth, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1], demodulate=True, noiseInjection=True,
+                 activation=False):
+        super().__init__()
+        from .modules import StyledConv
+        self.conv1 = StyledConv(in_channel, depth, 3, style_dim, demodulate=demodulate, upsample=upsample, blur_kernel=blur_kernel,
+                                noiseInjection=False, activation=True)
+        self.conv2 = StyledConv(depth, depth, 3, style_dim, demodulate=demodulate, upsample=upsample, blur_kernel=blur_kernel,
+                                noiseInjection=noiseInjection, activation=activation)
+
+    def forward(self, x, style):
+        return self.conv2(self.conv1(x, style), style)
+
+
 class StyledscaleNshfitBlock(nn.Module):
-    """btn=None (identity feature extractor: every shipped YAML)."""
+    """reference src/ops/SAMM/helpers.py:182-216.  btn=None: identity feature extractor (every shipped YAML, SURVEY.md §0 fact 3);
+    'style_bottleneck_IR' / 'styleBlock': the modulated extractors (``mod_btn``), after which the alignment works on out_chn channels."""
 
     def __init__(self, in_chn, out_chn, style_dim, alignment=True, btn=None, **kwargs):
         super().__init__()
-        if btn is not None:
-            raise NotImplementedError("mod_btn is never set by the shipped option files; only btn=None is implemented")
+        if btn == 'style_bottleneck_IR':
+            self.btn1 = style_bottleneck_IR(in_chn, out_chn, style_dim, bn=False)
+        elif btn == 'styleBlock':
+            self.btn1 = styleBlock(in_chn, out_chn, style_dim, noiseInjection=False, activation=False)
+        else:
+            self.btn1 = None
+            out_chn = in_chn
         if not alignment:
             raise NotImplementedError('alignment=False')
-        self.alignment = SPM_Warp(in_chn, **kwargs)
+        self.alignment = SPM_Warp(out_chn, **kwargs)
         self.weight = nn.Parameter(torch.ones(1), requires_grad=False)
         self.noiseInj = _NoiseInj()
 
     def forward(self, x, styles, **kwargs):
+        res = x if self.btn1 is None else self.btn1(x, styles)
+        transform = kwargs.get('transform', None)           # training-time augmentation hook of the reference (:207-208)
+        if transform is not None:
+            res = transform(res)
         gen_feat = kwargs.get('image', None)
         assert gen_feat is not None
-        return self.alignment(x, gen_feat, styles, kwargs.get('aligned', None))
+        return self.alignment(res, gen_feat, styles, kwargs.get('aligned', None))

@@ -289,6 +289,39 @@ def gold_samm():
     save('samm.npz', **g)
 
 
+def gold_modbtn():
+    """The `mod_btn` feature extractors of StyledscaleNshfitBlock (reference src/ops/SAMM/helpers.py:22-57,182-216): the reference
+    modules with their own (seeded) initialisation, state dict + input + style + output.  C = 16 -> 16 and 16 -> 32 channels, 24x24."""
+    from src.ops.SAMM.helpers import style_bottleneck_IR, styleBlock, StyledscaleNshfitBlock
+    g = {}
+    B, C, H, SD = 2, 16, 24, 32
+    x = synth.normal('modbtn.x', (B, C, H, H), 41)
+    style = synth.normal('modbtn.style', (B, SD), 41)
+    gen = synth.normal('modbtn.gen', (B, C, H, H), 41)
+    g.update(x=x, style=style, gen=gen)
+    for tag, mk in (('sb', lambda: style_bottleneck_IR(C, C, SD, bn=False)), ('sb2', lambda: style_bottleneck_IR(C, 2 * C, SD, bn=False)),
+                    ('blk', lambda: styleBlock(C, C, SD, noiseInjection=False, activation=False))):
+        torch.manual_seed(1234)
+        m = mk().eval()
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():      # zero biases / unit PReLU slopes would hide a wrong wiring
+                if n_.endswith('bias') or 'res_layer.2' in n_:
+                    p_.add_(0.1 * torch.randn_like(p_))
+            y = m(x, style)
+        for k, v in m.state_dict().items():
+            g[f'{tag}.sd.{k}'] = v
+        g[f'{tag}.y'] = y
+    for tag, btn in (('blockA', 'style_bottleneck_IR'), ('blockB', 'styleBlock')):
+        torch.manual_seed(4321)
+        m = StyledscaleNshfitBlock(C, C, SD, btn=btn, scale=0.08, cycle_align=1, diff_fAndg=True).eval()
+        with torch.no_grad():
+            y, f = m(x, style, image=gen, aligned=None)
+        for k, v in m.state_dict().items():
+            g[f'{tag}.sd.{k}'] = v
+        g[f'{tag}.y'], g[f'{tag}.field'] = y, f
+    save('modbtn.npz', **g)
+
+
 class _NoiseFeed:
     """Make every NoiseInjection of the reference draw a PRESET noise map instead of a fresh
     RNG sample (the OOD path never exposes ``noise=`` — passing it would bypass the SAMM
@@ -478,6 +511,8 @@ def main():
         gold_encoder()
     if 'restyle' in which:
         gold_restyle()
+    if 'modbtn' in which:
+        gold_modbtn()
     if 'fs' in which:
         gold_featurestyle()
     if 'featin' in which:

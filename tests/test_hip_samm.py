@@ -126,6 +126,30 @@ def test_alignnet_and_spm_warp_vs_golden(dev, golden):
     close(f, g['warp_field_prev'], 3e-4)
 
 
+def test_mod_btn_feature_extractors_vs_reference(dev, golden):
+    """`mod_btn` = 'style_bottleneck_IR' / 'styleBlock' (reference src/ops/SAMM/helpers.py:22-57): the extractors alone (16 -> 16 and
+    16 -> 32 channels: identity and 1x1 shortcut) and inside StyledscaleNshfitBlock in front of the alignment, state dicts loaded strictly
+    from the reference modules' own (tests/golden/make_golden.py modbtn)."""
+    from oodgan import samm
+    g = golden('modbtn.npz')
+    x, style, gen = g['x'].to(dev), g['style'].to(dev), g['gen'].to(dev)
+
+    def state(tag):
+        pre = tag + '.sd.'
+        return {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+
+    for tag, mod in (('sb', samm.style_bottleneck_IR(16, 16, 32, bn=False)), ('sb2', samm.style_bottleneck_IR(16, 32, 32, bn=False)),
+                     ('blk', samm.styleBlock(16, 16, 32, noiseInjection=False, activation=False))):
+        mod.load_state_dict(state(tag), strict=True)
+        close(mod.to(dev)(x, style), g[tag + '.y'], 2e-4)
+    for tag, btn in (('blockA', 'style_bottleneck_IR'), ('blockB', 'styleBlock')):
+        blk = samm.StyledscaleNshfitBlock(16, 16, 32, btn=btn, scale=0.08, cycle_align=1, diff_fAndg=True)
+        blk.load_state_dict(state(tag), strict=True)
+        y, f = blk.to(dev)(x, style, image=gen, aligned=None)
+        close(y, g[tag + '.y'], 3e-4)
+        close(f, g[tag + '.field'], 3e-4)
+
+
 @pytest.mark.parametrize('wscale', [1.0, 1e-3, 3e5])
 def test_bottleneck_8wave_path_range_and_batch(dev, wscale):
     """The AlignNet bottleneck on the S-form + 8-wave kernels (>= 64 channels), batch 3, against the oracle — with the first
