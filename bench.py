@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--roofline-steps', type=int, default=10, help='W+ steps of the exclusive single-stream pass that times the dominant kernel')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the extra leg that times the inversion including the e4e encoder')
     ap.add_argument('--no-forward-only', action='store_true', help="skip the leg that times the reference's own path: encoder + OOD forward, no W+ steps")
+    ap.add_argument('--no-generator-fwd', action='store_true', help='skip the BASELINE configs[1] leg: plain generator forward at batch 4')
     ap.add_argument('--no-single-stream', action='store_true', help='skip the extra leg that times the same job on ONE HIP stream')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
@@ -94,6 +95,16 @@ class ConvProbe:
         n = len(self.recs)
         return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n,
                     bytes_per_launch=byts / n)
+
+
+def pmc_traffic_instances(a):
+    """The same PMC measurement per template instance (forward / input gradient) with each instance's own algorithmic bytes:
+    the blended `traffic` over the blended `alg_bytes_per_launch` overstates the re-fetch (the input gradient also reads dotx)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            return json.load(f).get(f'{a.precision}_b{a.batch}_s{a.size}', {}).get('instances')
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(a):
@@ -164,10 +175,9 @@ def modconv_roofline(iters=30, warmup=3):
     torch.cuda.synchronize()
     ms_serial = e0.elapsed_time(e1) / iters
 
-    # The same sequence as a two-stage pipeline over the iterations (independent samples of the op): the weight preparation of
-    # iteration i+1 (one small launch) runs on a second HIP stream under the conv of iteration i, into the other of two weight
-    # buffers.  Every iteration still performs both launches inside the timed region; what disappears is the launch gap
-    # between two dependent kernels (~55 us of the 570).
+    # SECONDARY figures (named as such in the line, never the headline): the same sequence as a two-stage pipeline over the
+    # iterations (independent samples of the op) — the weight preparation of iteration i+1 (one small launch) on a second HIP
+    # stream under the conv of iteration i, into the other of two weight buffers — launched eagerly and replayed from a hipGraph.
     side = torch.cuda.Stream(device=dev)
     wb2 = [None, None]
     ev_pack = [torch.cuda.Event(), torch.cuda.Event()]
@@ -202,10 +212,7 @@ def modconv_roofline(iters=30, warmup=3):
     e1.record()
     torch.cuda.synchronize()
     ms_eager = e0.elapsed_time(e1) / iters
-    # ... and replayed from a hipGraph of the same two-stream sequence: the host (two launches, two event records and two stream waits
-    # per iteration from Python) is then out of the measurement — on a busy host the eager form is bound by it
-    ms = ms_eager
-    graphed = False
+    ms_graph = None
     try:
         g = torch.cuda.CUDAGraph()
         cap = torch.cuda.Stream(device=dev)
@@ -219,9 +226,8 @@ def modconv_roofline(iters=30, warmup=3):
         g.replay()
         e1.record()
         torch.cuda.synchronize()
-        ms = min(ms_eager, e0.elapsed_time(e1) / iters)
-        graphed = ms < ms_eager
-    except Exception as ex:       # the eager figure stands
+        ms_graph = e0.elapsed_time(e1) / iters
+    except Exception as ex:
         sys.stderr.write('modconv2d: graph replay of the pipelined sequence not available (%s)\n' % (str(ex).splitlines()[0] if str(ex) else type(ex).__name__))
     e0.record()
     for _ in range(iters):
@@ -237,16 +243,60 @@ def modconv_roofline(iters=30, warmup=3):
             traffic = json.load(f).get('modconv_f16_b16_s1024', {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         pass
-    gbps = alg / ms / 1e6
+    gbps = alg / ms_serial / 1e6
+    frac_of = lambda t: None if t is None else round(alg / t / 1e6 / HBM_PEAK_GBPS, 4)
     return dict(workload='fp16 ModulatedConv2d 3x3 32->32 @1024x1024, batch 16: style affine + modulate/demodulate/pack + conv (+noise, bias, lrelu)',
                 kernel='modconv_f16_strip_kernel', bound='hbm', achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s',
-                frac=round(gbps / HBM_PEAK_GBPS, 4), ms=round(ms, 4), ms_single_stream=round(ms_serial, 4),
-                frac_single_stream=round(alg / ms_serial / 1e6 / HBM_PEAK_GBPS, 4), kernel_ms=round(kms, 4), alg_bytes=alg, traffic=traffic,
-                tflops=round(flops / ms / 1e9, 1),
-                ms_pipelined_eager=round(ms_eager, 4), graph_replay=graphed,
-                note='ms: weight preparation of iteration i+1 on a second HIP stream under the conv of iteration i (two weight buffers), '
-                     'the faster of eager launches and a hipGraph replay of that sequence (graph_replay); '
-                     'ms_single_stream: the two launches back to back on one stream')
+                frac=round(gbps / HBM_PEAK_GBPS, 4), ms=round(ms_serial, 4), kernel_ms=round(kms, 4), frac_kernel_alone=frac_of(kms),
+                alg_bytes=alg, traffic=traffic, tflops=round(flops / ms_serial / 1e9, 1),
+                ms_pipelined_eager=round(ms_eager, 4), frac_pipelined_eager=frac_of(ms_eager),
+                ms_pipelined_graph=None if ms_graph is None else round(ms_graph, 4), frac_pipelined_graph=frac_of(ms_graph),
+                note='ms / achieved / frac: ONE ModulatedConv2d.forward at a time — the two launches (weight preparation, conv) back to back '
+                     'on one stream, HIP events around the iterations (the BASELINE definition; rounds 1-2 reported this, round 3 '
+                     'reported the pipelined figure as `frac` and this one as `frac_single_stream`).  ms_pipelined_*: secondary — the '
+                     'weight preparation of iteration i+1 on a second stream under the conv of iteration i, eager / hipGraph replay')
+
+
+def generator_fwd_b4(a, dev, reps=9):
+    """BASELINE configs[1]: StyleGAN2 1024² generator forward, batch 4 — the reference call
+    ``Generator([z], noise=<list>)`` (model.py:483-585: mapping MLP, 17 styled convs, 9 ToRGB) on recipe weights, inputs of
+    tests/make_golden_params.py (the parity run of this exact workload is tests/test_hip_generator.py::
+    test_generator_1024_batch4_vs_reference).  Latency = median host wall time incl. synchronize; GB/s on the algorithmic bytes of
+    SURVEY.md Appendix B (Σ(W + in + out) over the 26 convs = 1 291 MB per image in fp32, 148.5 GFLOP)."""
+    import statistics
+    from oodgan import ops, synth
+    from oodgan.modules import Generator
+    size, B = a.size, 4
+    out = {}
+    z = synth.normal('gen_b4.z', (B, 512), 21).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=2100)]
+    sd = synth.generator_state(size, seed=0)
+    saved = ops.PRECISION
+    try:
+        for prec in ('f16s', 'f32'):
+            ops.PRECISION = prec
+            G = Generator(size, 512, 8)
+            G.load_state_dict(sd, strict=True)
+            G = G.to(dev).eval()
+            for _ in range(2):
+                G([z], noise=noises)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                img, _ = G([z], noise=noises)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t = statistics.median(ts)
+            out[prec] = dict(latency_ms=round(t * 1e3, 3), images_per_s=round(B / t, 2), gbps=round(B * 1291e6 / t / 1e9, 1),
+                             frac_hbm=round(B * 1291e6 / t / 1e9 / HBM_PEAK_GBPS, 4), tflops=round(B * 148.5e9 / t / 1e12, 1))
+            del G, img
+    finally:
+        ops.PRECISION = saved
+    out.update(batch=B, alg_bytes_per_image=1291e6, alg_flops_per_image=148.5e9,
+               note=f'Generator([z], noise=list) at {size}x{size}, batch {B}: median of {reps} host-timed calls incl. synchronize; f16s = the '
+                    'split-f16 matrix-core arithmetic (fp32-class, default), f32 = the exact-fp32 MFMA variant')
+    return out
 
 
 def cpu_baseline(size):
@@ -364,6 +414,7 @@ def forward_only(a, m, x, noises, reps=7):
 
 def main():
     a = parse()
+    t_proc = time.perf_counter()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -419,6 +470,8 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_proc      # input synthesis + model build + warm-up of THIS rank, before the first barrier
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -434,13 +487,14 @@ def main():
     probe.on = False
     per_rank = None
     if dist_on:
-        mine = torch.tensor([dt, float(len(cpus) if cpus else 0)], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt, float(len(cpus) if cpus else 0), t_setup, float(torch.get_num_threads())], device=dev, dtype=torch.float64)
         tmax = mine[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         if world > 1:                                   # launch skew / a slow rank must be visible in the line
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
-            per_rank = dict(seconds=[round(float(t[0].item()), 4) for t in allr], cpus_bound=[int(t[1].item()) for t in allr])
+            per_rank = dict(seconds=[round(float(t[0].item()), 4) for t in allr], cpus_bound=[int(t[1].item()) for t in allr],
+                            setup_seconds=[round(float(t[2].item()), 2) for t in allr], torch_threads=[int(t[3].item()) for t in allr])
         dt = tmax.item()
     def roofline_of(ps, where):
         if not ps:
@@ -448,7 +502,7 @@ def main():
         f16s = a.precision == 'f16s'
         peak = MFMA_F16_PEAK_TFLOPS if f16s else MFMA_F32_PEAK_TFLOPS
         return dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
-                    frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a),
+                    frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a), traffic_per_instance=pmc_traffic_instances(a),
                     kernel=('conv_f16s_s1big_kernel<false|true, *>' if f16s else 'conv_mfma_kernel<0, 2>') +
                            ' (plain 3x3 stride-1 implicit GEMM, >=64 input channels: forward + input gradient)',
                     measured_on=where,
@@ -490,6 +544,9 @@ def main():
             t2 = time.perf_counter()
             single = dict(streams=1, value=round(B / (t2 - t1), 4), unit='images/s', ms_per_step=round((t2 - t1) * 1e3, 2),
                           final_loss_mean=float(ml[-1].mean().item()), note='same workload on one HIP stream')
+        gen_b4 = None
+        if not a.no_generator_fwd and world == 1 and size == 1024:
+            gen_b4 = generator_fwd_b4(a, dev)
         e2e = fwd_only = None
         if not (a.no_end_to_end and a.no_forward_only) and world == 1 and size == 1024:
             full = build_full_model(a, dev)
@@ -519,6 +576,7 @@ def main():
             'single_stream': single,
             'end_to_end': e2e,
             'forward_only': fwd_only,
+            'generator_fwd_b4': gen_b4,
             'per_rank': per_rank,
             'cpu_baseline': cpu,
         }

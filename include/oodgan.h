@@ -12,7 +12,10 @@
  *   - return value: OODGAN_OK (0) or a negative OODGAN_E_* code; no C++ exception crosses the
  *     boundary; oodgan_last_error() returns a thread-local message for the last failure;
  *   - a NULL optional pointer means "term absent" (the reference encodes that as an empty tensor,
- *     fused_bias_act_kernel.cu:62-63).
+ *     fused_bias_act_kernel.cu:62-63);
+ *   - ONE HIP device per process (batch sharding = one process per GPU): per-kernel setup is done once, for the device that is
+ *     current at the first conv call; a conv entry point (oodgan_conv3x3, oodgan_conv3x3_f16s, oodgan_modconv_f16,
+ *     oodgan_conv3x3_xf_supported) called later with another device current returns OODGAN_E_ARG.
  *
  * Each entry names the reference interface it replaces (paths relative to /root/reference).
  */
@@ -43,6 +46,13 @@ int oodgan_device_count(void);
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);
+/* Dispatch counters of oodgan_conv3x3_f16s: how many calls since load (or oodgan_dispatch_reset) went to the kernel family
+ * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
+ * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen".  Host-side, one relaxed atomic increment per call; the reference has no
+ * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
+ * Returns -1 for an unknown name. */
+long oodgan_dispatch_count(const char* name);
+int oodgan_dispatch_reset(void);
 
 /* ------------------------------------------------------------------ L1 custom ops ---------- */
 
@@ -186,8 +196,8 @@ typedef struct oodgan_conv_args {
                                   nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win) — also the dot_nparts of this instance; dotx (F-form,
                                   dotx_fform = 1) is mandatory, y NCHW. */
     int dotx_fform;          /* 1: dotx is in F-form (x_fform == 2 only) */
-    void* workspace;         /* optional scratch of workspace_bytes >= oodgan_conv3x3_tiny_workspace(...) bytes, zero-initialised once by
-                                the caller and owned by ONE stream: with it the 4x4 / 8x8 layers (mode S1 with S-form input, mode S2
+    void* workspace;         /* optional scratch of workspace_bytes >= oodgan_conv3x3_tiny_workspace(...) bytes (the K-split partial tiles:
+                                written by the first launch, read by the finishing one — uninitialised is fine) owned by ONE stream: with it the 4x4 / 8x8 layers (mode S1 with S-form input, mode S2
                                 with phase-split S-form input, K >= 64) run as a skinny GEMM over the batch with a K split
                                 (csrc/conv_f16s_tiny.hip); NULL: the tile kernels */
     long workspace_bytes;

@@ -13,6 +13,17 @@ void set_error(const char* fmt, ...);
 enum { OODGAN_TUN_S1_BIG_MIN_ITEMS = 0, OODGAN_TUN_S2_BIG_MIN_ITEMS, OODGAN_TUN_T2_BIG_MIN_ITEMS, OODGAN_TUN_BLURT_STRIP, OODGAN_TUN_BLUR_STRIP, OODGAN_TUN_COUNT };
 long tunable(int id);
 
+// dispatch counters (runtime.hip, oodgan_dispatch_count): which kernel family a conv call was routed to — tests assert that the
+// kernel they mean to pin is the one that ran
+enum { OODGAN_DC_STRIPX = 0, OODGAN_DC_STRIP, OODGAN_DC_S1BIG, OODGAN_DC_S1V2, OODGAN_DC_S1PP, OODGAN_DC_TINY, OODGAN_DC_T2BIG,
+       OODGAN_DC_T2V2, OODGAN_DC_T2GEN, OODGAN_DC_S2BIG, OODGAN_DC_S2V2, OODGAN_DC_S2GEN, OODGAN_DC_COUNT };
+void count_dispatch(int id);
+
+// One process per GPU: per-kernel setup (dynamic-LDS attributes, the zero page and CU count of the F-form strip
+// conv) is done once per process, for the device that is current at first use.  bound_device_ok() records that device and makes
+// every later conv call fail with OODGAN_E_ARG when another device is current, instead of launching with state of device 0.
+bool bound_device_ok(const char* what);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

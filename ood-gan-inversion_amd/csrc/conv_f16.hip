@@ -597,6 +597,7 @@ extern "C" int oodgan_modconv_f16(const void* x, const void* wpk, const float* n
     OODGAN_REQUIRE(x && wpk && y && B > 0 && H > 0 && W > 0, "modconv_f16: bad args");
     OODGAN_REQUIRE(M >= 1 && M <= 32 && K >= 1 && K <= 32, "modconv_f16: supports up to 32 -> 32 channels (got %d -> %d)", K, M);
     OODGAN_REQUIRE(act == OODGAN_ACT_NONE || act == OODGAN_ACT_LRELU, "modconv_f16: act must be none or lrelu");
+    if (!oodgan::bound_device_ok("modconv_f16")) return OODGAN_E_ARG;
     MCArgs p;
     p.x = reinterpret_cast<const uint4*>(x);
     p.wpk = reinterpret_cast<const uint4*>(wpk);

@@ -457,8 +457,10 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.B > 0 && a.K > 0 && a.M > 0 && a.Hin > 0 && a.Win > 0, "conv3x3_f16s: bad shape");
     OODGAN_REQUIRE(a.act != OODGAN_ACT_PRELU || a.slope, "conv3x3_f16s: PReLU without slopes");
     OODGAN_REQUIRE(a.noise == nullptr || a.noise_batch == 1 || a.noise_batch == a.B, "conv3x3_f16s: noise_batch");
+    if (!bound_device_ok("conv3x3_f16s")) return OODGAN_E_ARG;
     if (a.x_fform) {
         OODGAN_REQUIRE(a.x_fform == 1 || a.x_fform == 2, "conv3x3_f16s: x_fform must be 0, 1 or 2");
+        count_dispatch(OODGAN_DC_STRIPX);
         return launch_s1_stripx(a, a.wpk, unscale2, as_stream(stream));
     }
     OODGAN_REQUIRE(!a.dotx_fform, "conv3x3_f16s: an F-form dotx exists only with x_fform == 2");
@@ -473,22 +475,25 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:
-            if (tiny_eligible(a)) return launch_tiny(a, a.wpk, unscale2, st);
-            if (a.x_sform && s1_strip_eligible(a)) return launch_s1_strip(a, a.wpk, unscale2, st);
+            if (tiny_eligible(a)) { count_dispatch(OODGAN_DC_TINY); return launch_tiny(a, a.wpk, unscale2, st); }
+            if (a.x_sform && s1_strip_eligible(a)) { count_dispatch(OODGAN_DC_STRIP); return launch_s1_strip(a, a.wpk, unscale2, st); }
             OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32)");
-            if (a.x_sform && s1_big_eligible(a)) return launch_s1_big(a, a.wpk, unscale2, st);
-            if (a.x_sform) return launch_s1v2(a, a.wpk, unscale2, st);
+            if (a.x_sform && s1_big_eligible(a)) { count_dispatch(OODGAN_DC_S1BIG); return launch_s1_big(a, a.wpk, unscale2, st); }
+            if (a.x_sform) { count_dispatch(OODGAN_DC_S1V2); return launch_s1v2(a, a.wpk, unscale2, st); }
             OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");
+            count_dispatch(OODGAN_DC_S1PP);
             return launch_s1pp(a, a.wpk, unscale2, st);
         case OODGAN_CONV_T2:
-            if (a.x_sform && t2_big_eligible(a)) return launch_t2_big(a, a.wpk, unscale2, st);
-            if (a.x_sform) return launch_t2v2(a, a.wpk, unscale2, st);
+            if (a.x_sform && t2_big_eligible(a)) { count_dispatch(OODGAN_DC_T2BIG); return launch_t2_big(a, a.wpk, unscale2, st); }
+            if (a.x_sform) { count_dispatch(OODGAN_DC_T2V2); return launch_t2v2(a, a.wpk, unscale2, st); }
+            count_dispatch(OODGAN_DC_T2GEN);
             return launch_mode<OODGAN_CONV_T2>(a, a.wpk, unscale2, st);
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
-            if (tiny_eligible(a)) return launch_tiny(a, a.wpk, unscale2, st);
-            if (a.x_sform && s2_big_eligible(a)) return launch_s2_big(a, a.wpk, unscale2, st);
-            if (a.x_sform) return launch_s2v2(a, a.wpk, unscale2, st);
+            if (tiny_eligible(a)) { count_dispatch(OODGAN_DC_TINY); return launch_tiny(a, a.wpk, unscale2, st); }
+            if (a.x_sform && s2_big_eligible(a)) { count_dispatch(OODGAN_DC_S2BIG); return launch_s2_big(a, a.wpk, unscale2, st); }
+            if (a.x_sform) { count_dispatch(OODGAN_DC_S2V2); return launch_s2v2(a, a.wpk, unscale2, st); }
+            count_dispatch(OODGAN_DC_S2GEN);
             return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);
         default: break;
     }

@@ -814,7 +814,7 @@ extern "C" int oodgan_conv3x3_xf_nparts(int B, int H, int W) {
 }
 
 extern "C" int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W) {
-    if (!stripx_init()) return 0;
+    if (!oodgan::bound_device_ok("conv3x3_xf_supported") || !stripx_init()) return 0;
     return (B > 0 && K == 32 && M == 32 && H >= 8 && W >= 32 && H % 4 == 0 && W % 32 == 0 && (long)H * W * 64 * 2 < (1L << 32)) ? 1 : 0;
 }
 

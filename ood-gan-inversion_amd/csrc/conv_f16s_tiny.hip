@@ -37,7 +37,6 @@ __host__ __device__ inline SPDimsT sp_dims_t(int C, int H, int W) {    // must m
 constexpr int TY_NT = 4;                 // N tiles per workgroup
 constexpr int TY_STEPS = 5;              // K steps per wave (all of them in registers at once)
 constexpr int TY_OP = 132;               // LDS pitch of the epilogue image [32 channels][128 positions]
-constexpr int TY_CNT_BYTES = 4096;       // counters at the head of the workspace (up to 1024 tiles)
 
 struct TinyArgs {
     oodgan_conv_args a;
@@ -272,11 +271,10 @@ int launch_tiny(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     p.xd = sform_dims(a.K, a.Hin, a.Win);
     p.sp = sp_dims_t(a.K, H, H);
     const long ntiles = (long)p.ngroups * p.mblocks;
-    OODGAN_REQUIRE(ntiles * 4 <= TY_CNT_BYTES, "conv3x3 tiny: too many tiles");
     OODGAN_REQUIRE((p.nsteps + p.KS - 1) / p.KS <= 4 * TY_STEPS, "conv3x3 tiny: K split");
-    OODGAN_REQUIRE(a.workspace_bytes >= TY_CNT_BYTES + ntiles * p.KS * (TY_NT * 16 * 64) * 4, "conv3x3 tiny: workspace too small (oodgan_conv3x3_tiny_workspace)");
+    OODGAN_REQUIRE(a.workspace_bytes >= ntiles * p.KS * (TY_NT * 16 * 64) * 4, "conv3x3 tiny: workspace too small (oodgan_conv3x3_tiny_workspace)");
     OODGAN_REQUIRE(!a.dotx || a.dot_part, "conv3x3: dotx without dot_part");
-    p.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.workspace) + TY_CNT_BYTES);
+    p.ws = reinterpret_cast<float*>(a.workspace);
     const dim3 grid((unsigned)(ntiles * p.KS)), block(256);
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     if (a.mode == OODGAN_CONV_S1) hipLaunchKernelGGL((conv_f16s_tiny_kernel<OODGAN_CONV_S1>), grid, block, 0, st, p, w16);
@@ -287,7 +285,7 @@ int launch_tiny(const oodgan_conv_args& a, const void* wpk16, const float* unsca
 
 }  // namespace oodgan
 
-// bytes of workspace (counters + partial tiles) the skinny-GEMM kernel needs for this call, 0 when it does not apply
+// bytes of workspace (the K-split partial tiles) the skinny-GEMM kernel needs for this call, 0 when it does not apply
 extern "C" long oodgan_conv3x3_tiny_workspace(int mode, int B, int K, int M, int Hin, int Win) {
     oodgan_conv_args a = {};
     a.mode = mode; a.B = B; a.K = K; a.M = M; a.Hin = Hin; a.Win = Win; a.x_sform = 1;
@@ -295,5 +293,5 @@ extern "C" long oodgan_conv3x3_tiny_workspace(int mode, int B, int K, int M, int
     if (!tiny_shape(a, H)) return 0;
     int ng, mb, KS;
     oodgan::tiny_split(a, H, ng, mb, KS);
-    return TY_CNT_BYTES + (long)ng * mb * KS * (TY_NT * 16 * 64) * 4;
+    return (long)ng * mb * KS * (TY_NT * 16 * 64) * 4;
 }

@@ -266,6 +266,7 @@ extern "C" int oodgan_conv3x3(const oodgan_conv_args* args, void* stream) {
     OODGAN_REQUIRE(args != nullptr, "conv3x3: null args");
     const oodgan_conv_args& a = *args;
     OODGAN_REQUIRE(a.x && a.wpk && a.y, "conv3x3: null tensor");
+    if (!oodgan::bound_device_ok("conv3x3")) return OODGAN_E_ARG;
     OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3: the fused ToRGB output exists only in the split-f16 strip kernel");
     OODGAN_REQUIRE(a.fuse == nullptr, "conv3x3: the fused activation backward exists only in the split-f16 stride-2 kernel");
     OODGAN_REQUIRE(!a.dot_actgrad, "conv3x3: dot_actgrad exists only in the split-f16 stride-1 kernels");

@@ -260,11 +260,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int Ho = 2 * a.H, Wo = 2 * a.W, Hz = Ho + 1, Wz = Wo + 1;
     const int Y0 = seg * geo.seg_rows, Y1 = min(Y0 + geo.seg_rows, Ho);
     const int X0 = 64 * strip;
-    // kf[ky][kx] = k[3-ky][3-kx] (upfirdn2d flips); rank one: kf[ky][kx] = kv[ky] * kh[kx] with kv[ky] = kf[ky][0] / kf[0][0], kh = kf[0][.]
+    // kf[ky][kx] = k[3-ky][3-kx] (upfirdn2d flips); rank one: kf[ky][kx] = kv[ky] * kh[kx] with kv[ky] = kf[ky][j] / kf[i][j], kh = kf[i][.] for a pivot (i, j)
     // (uniform loads, no LDS table and no barrier in front of the first row request)
-    const float k00 = a.kern[15];
-    const float kv0 = 1.f, kv1 = a.kern[11] / k00, kv2 = a.kern[7] / k00, kv3 = a.kern[3] / k00;
-    const float kh0 = k00, kh1 = a.kern[14], kh2 = a.kern[13], kh3 = a.kern[12];
+    // The pivot is the corner tap when it is non-zero (the usual case, and the one the parity tests pin bit for bit); a rank-one kernel
+    // with a zero corner ([0,1,1,0] x [0,1,1,0]) takes its largest tap as pivot instead — no division by zero, no NaN.
+    int pr = 3, pc = 3;
+    float k00 = a.kern[15];
+    if (!(fabsf(k00) > 0.f)) {
+        float best = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const float v = fabsf(a.kern[i]);
+            if (v > best) { best = v; pr = i >> 2; pc = i & 3; }
+        }
+        k00 = a.kern[pr * 4 + pc];
+    }
+    const bool piv = fabsf(k00) > 0.f;
+    const float kv0 = piv ? a.kern[12 + pc] / k00 : 0.f, kv1 = piv ? a.kern[8 + pc] / k00 : 0.f, kv2 = piv ? a.kern[4 + pc] / k00 : 0.f,
+                kv3 = piv ? a.kern[pc] / k00 : 0.f;
+    const float kh0 = a.kern[pr * 4 + 3], kh1 = a.kern[pr * 4 + 2], kh2 = a.kern[pr * 4 + 1], kh3 = a.kern[pr * 4];
     const int ch = tid >> 4, q = tid & 15, c = kc * 16 + ch;
     const float* zp = a.z + ((long)b * a.C + c) * Hz * a.pitch;
     const float bv = a.bias ? a.bias[c] : 0.f;
@@ -334,6 +347,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     float* yplane = a.y + ((long)b * a.C + min(c, a.C - 1)) * HWo;          // SF: this thread's channel plane
     const bool yok = c < a.C && gx + 3 < Wo;
     const int pcol = tid >> 2, pq = tid & 3;                 // record role: pixel column, channel quarter (F-form) / slot (S-form)
+    // Gather image: channels 8-15 keep their columns XOR 8 (the two 8-column halves of every 16 swapped).  ds_read_b32 is served in
+    // two groups of 32 lanes with bank = dword address mod 32 (MI355X_MICROARCH.md, LDS): with the 68-dword pitch channel rows c and
+    // c + 8 start on the same bank, and the 32 lanes of a group read 8 consecutive columns of channels {q, q + 8} (F-form quarters
+    // 0 / 2 and 1 / 3; S-form halves) — a 2-way conflict on every read (30-39 % of the LDS-active cycles in round 3's counters).
+    // With the swap the 32 lanes touch 32 different banks; the float4 writes (8 contiguous lanes per group) stay conflict free.
+    const int sw = ch & 8;
     const bool pok = X0 + pcol < Wo;
     auto step = [&](int Y, Row& R) __attribute__((always_inline)) {
         // the three steps of a loop trip are one basic block: without a fence the scheduler gathers the masking of all three rows
@@ -355,25 +374,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float (*gb)[GP] = gat[Y & 1];
         if constexpr (SF) {
             if (FULL || yok) *reinterpret_cast<float4*>(yplane + (long)Y * Wo + gx) = make_float4(t[0], t[1], t[2], t[3]);
-            *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0] * ysc, t[1] * ysc, t[2] * ysc, t[3] * ysc);
+            *reinterpret_cast<float4*>(&gb[ch][(4 * q) ^ sw]) = make_float4(t[0] * ysc, t[1] * ysc, t[2] * ysc, t[3] * ysc);
             __syncthreads();
             if (FULL || pok) {
                 // slot pq of the pixel's record: hi (pq < 2) or lo halves of channels 8 (pq & 1) .. + 7; the lanes of a wave write 16 whole records
                 half8 o8;
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) {
-                    const float val = gb[8 * (pq & 1) + cc][pcol];
+                    const float val = gb[8 * (pq & 1) + cc][pcol ^ (8 * (pq & 1))];
                     const _Float16 hh = (_Float16)val;
                     o8[cc] = (pq & 2) ? (_Float16)(val - (float)hh) : hh;
                 }
                 reinterpret_cast<half8*>(a.ys + sform_unit(a.yd, b, kc, Y, X0 + pcol, 0))[pq] = o8;
             }
         } else {
-            *reinterpret_cast<float4*>(&gb[ch][4 * q]) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4*>(&gb[ch][(4 * q) ^ sw]) = make_float4(t[0], t[1], t[2], t[3]);
             __syncthreads();
-            if (FULL || pok)
+            if (FULL || pok) {
+                const int pc_ = pcol ^ ((pq & 2) << 2);            // channels 8-15 (pq >= 2): column ^ 8
                 *reinterpret_cast<float4*>(yf + ((long)Y * Wo + X0 + pcol) * 16 + 4 * pq) =
-                    make_float4(gb[4 * pq][pcol], gb[4 * pq + 1][pcol], gb[4 * pq + 2][pcol], gb[4 * pq + 3][pcol]);
+                    make_float4(gb[4 * pq][pc_], gb[4 * pq + 1][pc_], gb[4 * pq + 2][pc_], gb[4 * pq + 3][pc_]);
+            }
         }
     };
     int Y = Y0;

@@ -56,7 +56,44 @@ extern "C" long oodgan_get_tunable(const char* name) {
     return -1;
 }
 
-extern "C" int oodgan_version(void) { return 103; }      // 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
+// ---- one device per process
+namespace oodgan {
+bool bound_device_ok(const char* what) {
+    static std::atomic<int> bound{-1};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: no current HIP device", what);
+        return false;
+    }
+    int expected = -1;
+    if (bound.compare_exchange_strong(expected, dev, std::memory_order_acq_rel) || expected == dev) return true;
+    set_error("%s: liboodgan_hip.so is bound to HIP device %d (its first use in this process) but device %d is current — one process per GPU "
+              "(select the device with HIP_VISIBLE_DEVICES or torch.cuda.set_device before the first call)", what, expected, dev);
+    return false;
+}
+}  // namespace oodgan
+
+// ---- dispatch counters: one relaxed atomic increment per conv call, on the host
+namespace oodgan {
+namespace {
+const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen"};
+std::atomic<long> g_dc[OODGAN_DC_COUNT];
+}  // namespace
+void count_dispatch(int id) { g_dc[id].fetch_add(1, std::memory_order_relaxed); }
+}  // namespace oodgan
+extern "C" long oodgan_dispatch_count(const char* name) {
+    if (name)
+        for (int i = 0; i < oodgan::OODGAN_DC_COUNT; ++i)
+            if (strcmp(name, oodgan::g_dc_name[i]) == 0) return oodgan::g_dc[i].load(std::memory_order_relaxed);
+    return -1;
+}
+extern "C" int oodgan_dispatch_reset(void) {
+    for (int i = 0; i < oodgan::OODGAN_DC_COUNT; ++i) oodgan::g_dc[i].store(0, std::memory_order_relaxed);
+    return OODGAN_OK;
+}
+
+extern "C" int oodgan_version(void) { return 104; }      // 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;

@@ -61,6 +61,8 @@ _SIGS = {
     'oodgan_device_count': (c_int, []),
     'oodgan_set_tunable': (c_int, [c_char_p, c_long]),
     'oodgan_get_tunable': (c_long, [c_char_p]),
+    'oodgan_dispatch_count': (c_long, [c_char_p]),
+    'oodgan_dispatch_reset': (c_int, []),
     'oodgan_bias_act_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_int, c_float, c_float, P]),
     'oodgan_bias_act_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, c_float, c_float, P]),
     'oodgan_upfirdn2d': (c_int, [P, P, P] + [c_int] * 15 + [P]),
@@ -177,6 +179,18 @@ def set_tunable(name, value):
     old = h.oodgan_get_tunable(name.encode())
     check(h.oodgan_set_tunable(name.encode(), int(value)), 'set_tunable')
     return old
+
+
+def dispatch_count(name):
+    """Calls of oodgan_conv3x3_f16s routed to kernel family ``name`` since load / dispatch_reset() (include/oodgan.h)."""
+    n = lib().oodgan_dispatch_count(name.encode())
+    if n < 0:
+        raise RuntimeError(f'unknown dispatch counter {name!r}')
+    return n
+
+
+def dispatch_reset():
+    check(lib().oodgan_dispatch_reset(), 'dispatch_reset')
 
 
 def exported_symbols():

@@ -289,10 +289,15 @@ class GraphedForward:
     Works for the three variants (their forwards make no host-side decisions on tensor values)."""
 
     def __init__(self, model):
-        self.model, self._cache = model, {}
+        self.model, self._cache, self._side = model, {}, None
 
     def reset(self):
+        """Drop the captured graphs (and, with them, their private pools); the scratch buffers the library-side pools keep per
+        stream handle (ops.sform_scratch / conv_workspace) are released too — they were created for this object's side stream."""
         self._cache = {}
+        if self._side is not None:
+            from . import ops
+            ops.drop_stream_scratch(self._side.cuda_stream)
 
     @torch.no_grad()
     def __call__(self, x, noise=None):
@@ -301,7 +306,12 @@ class GraphedForward:
         if ent is None:
             sx = x.clone()
             sn = None if noise is None else [n.clone() for n in noise]
-            side = torch.cuda.Stream(device=x.device)
+            # ONE side stream per object, used for the warm-up AND the capture: the S-form scratch buffers and conv workspaces are
+            # keyed by the stream handle (ops.sform_scratch), so the buffers the warm-up creates are the ones the captured launches
+            # use — nothing is allocated (or zero-filled) inside the graph, and nothing is left behind under another handle
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=x.device)
+            side = self._side
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):                  # packs weights, fills the memo caches, grows the allocator pools
@@ -309,7 +319,7 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):
                 out, lats = self.model(sx, noise=sn) if sn is not None else self.model(sx)
             ent = self._cache[key] = dict(graph=graph, x=sx, noise=sn, out=out, lats=lats, aligns=dict(self.model.aligns))
         ent['x'].copy_(x)

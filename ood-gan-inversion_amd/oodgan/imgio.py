@@ -120,8 +120,10 @@ def _prepare(img, img2, crop_border, input_order, test_y_channel):
         if crop_border != 0:
             a = a[crop_border:-crop_border, crop_border:-crop_border, ...]
         if test_y_channel and a.shape[2] == 3:      # ITU-R BT.601 luma of a BGR image, [0,255] in and out
-            a = ((a.astype(np.float32) / 255.0) @ np.array([24.966, 128.553, 65.481], dtype=np.float32) + 16.0)[..., None]
-            a = a.astype(np.float64)
+            # metric_util.py:32-46 + matlab_functions.py:236-244,353-359 with their roundings: float32 image / 255, the dot in
+            # float64 (the coefficient list is a Python list), / 255 -> float32, x 255 in float32
+            y = np.dot(a.astype(np.float32) / 255.0, [24.966, 128.553, 65.481]) + 16.0
+            a = ((y / 255.0).astype(np.float32) * 255.0)[..., None]        # stays float32: PSNR's mean / log then run in float32
         out.append(a)
     return out
 
@@ -131,7 +133,7 @@ def calculate_psnr(img, img2, crop_border, input_order='HWC', test_y_channel=Fal
     mse = np.mean((a - b) ** 2)
     if mse == 0:
         return float('inf')
-    return 20.0 * math.log10(255.0 / math.sqrt(mse))
+    return float(20.0 * np.log10(255.0 / np.sqrt(mse)))        # numpy scalar arithmetic in the arrays' dtype, as psnr_ssim.py:43-46
 
 
 def _gauss_window(n=11, sigma=1.5):
@@ -148,6 +150,7 @@ def _filter_valid(a, g):
 
 
 def _ssim(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
     c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
     g = _gauss_window()
     mu1, mu2 = _filter_valid(a, g), _filter_valid(b, g)

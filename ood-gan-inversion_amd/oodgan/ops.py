@@ -324,13 +324,22 @@ USE_TINY = True      # the 4x4 / 8x8 layers as a skinny GEMM with a K split (csr
 
 
 def conv_workspace(nbytes, device):
-    """Scratch for ``oodgan_conv_args.workspace``: zero-initialised once (the kernel leaves its counters at zero), one per HIP
-    stream — two streams running the same layer at the same time must not share partial tiles."""
+    """Scratch for ``oodgan_conv_args.workspace`` (the K-split partial tiles of csrc/conv_f16s_tiny.hip: written, then read by the
+    finishing launch — no counters, no initialisation needed), one per HIP stream — two streams running the same layer at the
+    same time must not share partial tiles."""
     key = (nbytes, str(device), torch.cuda.current_stream().cuda_stream)
     buf = _WS_POOL.get(key)
     if buf is None:
-        buf = _WS_POOL[key] = torch.zeros(nbytes // 4, device=device, dtype=torch.int32)
+        buf = _WS_POOL[key] = torch.empty(nbytes // 4, device=device, dtype=torch.int32)
     return buf
+
+
+def drop_stream_scratch(stream_handle):
+    """Release the pooled S-form buffers and conv workspaces created for one HIP stream (pools are keyed by the raw stream handle:
+    an owner that retires its stream — ``GraphedForward.reset`` — must not leave them behind)."""
+    for pool in (_SFORM_POOL, _WS_POOL):
+        for key in [k for k in pool if k[-1] == stream_handle]:
+            del pool[key]
 
 
 def sform_scratch(B, C, H, W, device, tag=0):

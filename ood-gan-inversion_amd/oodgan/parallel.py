@@ -153,7 +153,8 @@ def _gpu_numa_nodes():
 def bind_rank_to_cpus(local_rank=None, local_world=None):
     """Pin this process to host CPUs near its GPU, chosen from LOCAL_RANK — call BEFORE ``torch.cuda.set_device`` (it is a
     plain ``sched_setaffinity``: no re-exec, nothing touches the GPU).  Eight ranks launching ~170 kernels per W+ step
-    each otherwise migrate across sockets.  Returns the CPU list (or None where affinity is not supported)."""
+    each otherwise migrate across sockets; torch's intra-op thread pool is then sized to the slice (``torch.set_num_threads``).
+    Returns the CPU list (or None where affinity is not supported)."""
     import os
     if not hasattr(os, 'sched_setaffinity'):
         return None
@@ -184,6 +185,13 @@ def bind_rank_to_cpus(local_rank=None, local_world=None):
         os.sched_setaffinity(0, chosen)
     except OSError:
         return None
+    # torch sized its intra-op pool from the whole host when it was imported: eight ranks x 128 default threads would
+    # oversubscribe the cores during the synthetic-input generation and the host-side bookkeeping — size it to the slice
+    try:
+        import torch
+        torch.set_num_threads(max(1, len(chosen)))
+    except Exception:                                      # noqa: BLE001
+        pass
     return chosen
 
 

@@ -236,6 +236,37 @@ def gold_wplus_1024():
     save('wplus_1024.npz', **g)
 
 
+sys.path.insert(0, os.path.dirname(HERE))
+from make_golden_params import GEN_B4  # noqa: E402
+
+
+def gold_generator_1024_b4():
+    """BASELINE configs[1] (C2): the StyleGAN2 1024² generator forward at batch 4 in the reference's own fp32 —
+    ``Generator([z], noise=<list>)``: mapping MLP (model.py:391-400) -> broadcast latent -> model.py:483-585 — on the bench
+    recipe's weights (seed 0).  Stored per image: a ::16 sub-sample, one 64x64 crop, per-channel mean / std, absmax, and
+    the latent after the mapping network (inputs are rebuilt from the seeds by the test)."""
+    from src.ops.StyleGAN.model import Generator
+    size, B = GEN_B4['size'], GEN_B4['batch']
+    sd = synth.generator_state(size, seed=0)
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(sd, strict=True)
+    z = synth.normal('gen_b4.z', (B, 512), GEN_B4['z_seed'])
+    noises = synth.make_noises(size, B, seed=GEN_B4['noise_seed'])
+    g = {}
+    with torch.no_grad():
+        img, lat = G([z], noise=noises, return_latents=True)
+        img64, _ = G.double()([z.double()], noise=[n.double() for n in noises])
+    g['latent'] = lat[:, 0]
+    g['image_sub'] = img[:, :, ::16, ::16]
+    g['image_crop'] = img[:, :, 448:512, 512:576]
+    g['image_mean'] = img.double().mean(dim=(2, 3))
+    g['image_std'] = img.double().std(dim=(2, 3))
+    g['image_absmax'] = img.abs().amax()
+    g['ref_f32_vs_f64'] = (img.double() - img64).abs().max()
+    print(f'generator_1024_b4: absmax {g["image_absmax"].item():.3f}; reference fp32 vs its own float64: {g["ref_f32_vs_f64"].item():.2e}')
+    save('generator_1024_b4.npz', **g)
+
+
 def gold_wplus_256(steps=5):
     """5-step W+ Adam trajectory at 256² (B=2) through the reference Generator autograd (fp32, as shipped)."""
     from src.ops.StyleGAN.model import Generator
@@ -453,8 +484,19 @@ def gold_imgio():
     (BasicSR/basicsr/utils/img_util.py:9-94) and ``calculate_psnr`` (basicsr/metrics/psnr_ssim.py:9-46 with
     metric_util.py / matlab_functions.py).  cv2 is absent from the image: an EMPTY module stands in for the import, and only
     code paths that never call it are exercised (no channel swap: rgb2bgr / bgr2rgb = False; single-channel masks).
-    ``calculate_ssim`` needs cv2.filter2D / getGaussianKernel: it stays unpinned."""
-    _stub('cv2')
+    ``calculate_ssim`` (psnr_ssim.py:49-128) calls two cv2 primitives; numpy stand-ins with their documented semantics are put on
+    the stub — ``getGaussianKernel(n, sigma)`` = exp(-(i-(n-1)/2)^2 / (2 sigma^2)) normalised to sum 1 as an (n,1) float64 column
+    (OpenCV's closed form for n > 7), ``filter2D(src, -1, k)`` = correlation with BORDER_REFLECT_101 (scipy ``mode='mirror'``;
+    the reference crops the 5-pixel border anyway) — so everything of the real ``calculate_ssim`` / ``_ssim`` except those two
+    primitives is what produces the stored values."""
+    from scipy import ndimage
+
+    def _gauss(n, sigma):
+        i = np.arange(n, dtype=np.float64) - (n - 1) / 2.0
+        k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(n, 1)
+
+    _stub('cv2', getGaussianKernel=_gauss, filter2D=lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror'))
     sys.modules['torchvision.utils'].make_grid = None
     _load_real('basicsr.utils.matlab_functions', 'BasicSR/basicsr/utils/matlab_functions.py')
     sys.modules['basicsr.utils'].bgr2ycbcr = sys.modules['basicsr.utils.matlab_functions'].bgr2ycbcr
@@ -486,6 +528,10 @@ def gold_imgio():
                                ps.calculate_psnr(a, b, crop_border=4, test_y_channel=True),
                                ps.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
                                ps.calculate_psnr(a.astype(np.float64), b.astype(np.float64), crop_border=0, test_y_channel=True)])
+    g['ssim_vals'] = np.array([ps.calculate_ssim(a, b, crop_border=0), ps.calculate_ssim(a, b, crop_border=4),
+                               ps.calculate_ssim(a, b, crop_border=4, test_y_channel=True),
+                               ps.calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
+                               ps.calculate_ssim(a, a, crop_border=0)])
     save('imgio.npz', **g)
 
 
@@ -501,6 +547,8 @@ def main():
         gold_wplus(32, 5)
     if 'wplus1024' in which:
         gold_wplus_1024()
+    if 'genb4' in which:
+        gold_generator_1024_b4()
     if 'wplus256' in which:
         gold_wplus_256()
     if 'samm' in which:

@@ -388,3 +388,31 @@ def test_cond_types_sft_add_fuse_vs_golden(dev, golden):
     assert maxdiff(img, g['image_ADD_callback']) <= 1e-4 * max(1.0, g['image_ADD_callback'].abs().max().item())
     with pytest.raises(NotImplementedError):
         G2(lat, input_is_latent=True, noise=noises, conditions=conds(), cond_layers=[1, 3], cond_type='NOISE')
+
+
+@pytest.mark.parametrize('prec', ['f16s', 'f32'])
+def test_generator_1024_batch4_vs_reference(dev, golden, prec, monkeypatch):
+    """BASELINE configs[1] (C2) literally: StyleGAN2 1024² generator forward, batch 4 — ``Generator([z], noise=<list>)``, mapping
+    MLP included — against the reference Generator's own fp32 output on the bench recipe's weights (tests/golden/make_golden.py
+    gold_generator_1024_b4; the reference's fp32 is 2e-5 from its own float64).  Both arithmetic variants of the conv kernels."""
+    from oodgan import ops
+    from oodgan.modules import Generator
+    from make_golden_params import GEN_B4
+    g = golden('generator_1024_b4.npz')
+    size, B = GEN_B4['size'], GEN_B4['batch']
+    monkeypatch.setattr(ops, 'PRECISION', prec)
+    G = Generator(size, 512, 8)
+    G.load_state_dict(synth.generator_state(size, seed=0), strict=True)
+    G = G.to(dev).eval()
+    z = synth.normal('gen_b4.z', (B, 512), GEN_B4['z_seed']).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=GEN_B4['noise_seed'])]
+    img, lat = G([z], noise=noises, return_latents=True)
+    assert G.engine().precision == prec and img.shape == (B, 3, size, size)
+    assert maxdiff(lat[:, 0], g['latent']) < 1e-4 and torch.equal(lat[:, 0], lat[:, 17])
+    im = img.double().cpu()
+    e_sub = (im[:, :, ::16, ::16] - g['image_sub']).abs().max().item()
+    e_crop = (im[:, :, 448:512, 512:576] - g['image_crop']).abs().max().item()
+    e_mom = max((im.mean(dim=(2, 3)) - g['image_mean']).abs().max().item(), (im.std(dim=(2, 3)) - g['image_std']).abs().max().item())
+    print(f'[{prec}] C2 generator forward 1024² B=4 vs reference fp32: sub-sample {e_sub:.2e}, crop {e_crop:.2e}, moments {e_mom:.2e} '
+          f'(absmax {g["image_absmax"].item():.2f}; reference fp32 vs f64 {g["ref_f32_vs_f64"].item():.1e})')
+    assert e_sub < 1e-3 and e_crop < 1e-3 and e_mom < 1e-5

@@ -151,3 +151,27 @@ def test_blur_act_sform_strip_walk_equals_tile_kernel(B, C, H, W):
     y3 = ops.blur_act_sform(z, k, H, W, None, nz[:1], nw, act=False, ys=ys1, ys_scale=s, rank_one=True)
     assert _rel(y3, y2) < 2e-6
     assert torch.equal(ys1.data, ops.to_sform(y3, s).data)
+
+
+@pytest.mark.parametrize('taps', [[0., 1., 1., 0.], [0., 2., 1., 0.5], [1., 0., 0., 3.]])
+def test_blur_strip_walk_with_a_zero_corner_kernel(taps):
+    """A rank-one blur kernel whose corner tap is zero (the strip walk divided the column taps by kern[15] and
+    produced NaN): the strip walk picks its largest tap as pivot and still equals the tile kernel."""
+    from oodgan import ops
+    dev = torch.device('cuda:0')
+    B, C, H, W = 1, 32, 48, 64
+    g = torch.Generator().manual_seed(5)
+    pitch = (2 * W + 1 + 3) // 4 * 4
+    z = torch.randn(B, C, 2 * H + 1, pitch, generator=g).to(dev)
+    k1 = torch.tensor(taps)
+    k2 = torch.tensor(taps[::-1]) * 0.5 if taps[0] else k1
+    k = (k1[:, None] * k2[None, :]).contiguous().to(dev)
+    nz = torch.randn(B, 1, 2 * H, 2 * W, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    s = (1 + 0.3 * torch.randn(B, C, generator=g)).to(dev)
+    ys0, ys1 = ops.SForm(B, C, 2 * H, 2 * W, dev), ops.SForm(B, C, 2 * H, 2 * W, dev)
+    y0 = ops.blur_act_sform(z, k, H, W, bias, nz, nw, act=True, ys=ys0, ys_scale=s)
+    y1 = ops.blur_act_sform(z, k, H, W, bias, nz, nw, act=True, ys=ys1, ys_scale=s, rank_one=True)
+    y2 = ops.blur_act_fform(z, k, H, W, bias, nz, nw, act=True, ys_scale=s, rank_one=True)
+    assert torch.isfinite(y1).all() and torch.isfinite(y2.to_nchw()).all()
+    assert _rel(y1, y0) < 2e-6 and _rel(y2.to_nchw(), y0) < 2e-6

@@ -34,9 +34,12 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
     """loss, image and dL/dW+ of one W+ step at 1024² vs the reference Generator evaluated in float64; every production
     kernel instance of the bench (strip kernel, 16x32-tile kernel at 512², stride-2 / transposed kernels at 512²<->1024²,
     fused producers) is on the checked path.  'image3of8': the golden image sits at index 3 of a batch of 8, and the
-    SECOND backward of the loop is checked too (carried range scales, fused producers)."""
+    In both cases the SECOND step of the loop is checked too (carried range scales, fused producers): with the split-f16
+    arithmetic that step must keep the 1024² activations in F-form and run conv_f16s_stripx (forward + input gradient) —
+    asserted through the layout of the saved activations and the library's dispatch counters, so that a changed eligibility
+    rule cannot silently move this test back onto the S-form strip kernel."""
     from oodgan.engine import GeneratorEngine
-    from oodgan import ops
+    from oodgan import ops, _lib
     g = golden('wplus_1024.npz')
     size, gi = 1024, int(g['image_index'])
     gidx = [gi] if batch == 'alone' else [0, 1, 2, gi, 4, 5, 6, 7]
@@ -47,12 +50,23 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
     gref = g['grad_f64'][0]
     eng.reset_bwd_state()
     eng.reset_fwd_state()
-    for rep in range(2 if batch != 'alone' else 1):
+    for rep in range(2):
         # rep 0: exact range scales (first step of the loop); rep 1: the same latents again through the carried-scale
         # forward and the fused backward producers — must reproduce the same gradient
+        _lib.dispatch_reset()
         img = eng.forward(w0, noises, save=True, range_mode='carry')
+        fform = [n for n in ('convs.14', 'convs.15') if isinstance(eng.saved['acts'][n], ops.FForm)]
         loss, gimg = ops.mse_loss_grad(img, target, gmul)
         glat = eng.backward(gimg, gmul, carry_scale=True)
+        nx, ns = _lib.dispatch_count('stripx'), _lib.dispatch_count('strip')
+        if prec == 'f16s' and rep == 1:
+            # steady state of the loop: up-conv tail and last conv in F-form, both 1024² convs in conv_f16s_stripx
+            assert fform == ['convs.14', 'convs.15'], fform
+            assert (nx, ns) == (2, 0), (nx, ns)
+        elif prec == 'f16s':
+            assert fform == [] and (nx, ns) == (0, 2), (fform, nx, ns)      # first step: S-form strip kernel, exact scales
+        else:
+            assert fform == [] and nx == 0
         im = img[k:k + 1].double().cpu()
         e_img = max((im[:, :, ::16, ::16] - g['image_sub']).abs().max().item(), (im[:, :, 480:544, 480:544] - g['image_crop']).abs().max().item())
         e_mom = max((im.mean(dim=(2, 3)) - g['image_mean']).abs().max().item(), (im.std(dim=(2, 3)) - g['image_std']).abs().max().item())

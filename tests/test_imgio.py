@@ -88,8 +88,9 @@ def test_tensor2img_img2tensor_psnr_vs_reference_vectors(golden):
     """Vectors produced by the REAL BasicSR functions (tests/golden/make_golden.py gold_imgio): the uint8 rounding rule of
     ``tensor2img`` (x255 then numpy round = half to even, after the clamp), its float and batch-of-one paths, the
     single-channel mask path of the CLI, ``img2tensor`` and ``calculate_psnr`` (crop, CHW order, BT.601 Y channel of a
-    BGR image, uint8 and float inputs).  The channel swap itself (cv2.cvtColor) and SSIM (cv2.filter2D) cannot be run
-    here — cv2 is absent — and stay unpinned."""
+    BGR image, uint8 and float inputs), and ``calculate_ssim`` from the real psnr_ssim.py:49-128 with numpy stand-ins for its two
+    cv2 primitives (getGaussianKernel / filter2D, see make_golden.py).  The channel swap itself (cv2.cvtColor) cannot be run here
+    — cv2 is absent — and stays unpinned."""
     import numpy as np
     z = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'imgio.npz'))
     t = torch.from_numpy(z['t'])
@@ -105,4 +106,11 @@ def test_tensor2img_img2tensor_psnr_vs_reference_vectors(golden):
             imgio.calculate_psnr(a, b, crop_border=4, test_y_channel=True),
             imgio.calculate_psnr(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
             imgio.calculate_psnr(a.astype(np.float64), b.astype(np.float64), crop_border=0, test_y_channel=True)]
-    assert np.allclose(mine, v, rtol=1e-7, atol=0), (mine, v.tolist())
+    assert np.allclose(mine, v, rtol=1e-12, atol=0), (mine, v.tolist())
+    sv = z['ssim_vals']
+    ssim = [imgio.calculate_ssim(a, b, crop_border=0), imgio.calculate_ssim(a, b, crop_border=4),
+            imgio.calculate_ssim(a, b, crop_border=4, test_y_channel=True),
+            imgio.calculate_ssim(a.transpose(2, 0, 1), b.transpose(2, 0, 1), crop_border=2, input_order='CHW'),
+            imgio.calculate_ssim(a, a, crop_border=0)]
+    assert np.allclose(ssim, sv, rtol=1e-10, atol=0), (ssim, sv.tolist())
+    assert 0.5 < sv[0] < 1.0 and sv[4] == pytest.approx(1.0, abs=1e-12)

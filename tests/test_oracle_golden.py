@@ -169,3 +169,22 @@ def test_cond_types_vs_reference(golden):
                                              post_hook=lambda k, out, ct=ct: R.feature_modulation(out, conds[k], ct))
             close(img, g[f'image_{ct}'], 1e-4)
             close(feats[-1][:, ::16], g[f'feat_{ct}_sub'], 1e-4)
+
+
+def test_generator_1024_b4_oracle_vs_reference(golden):
+    """BASELINE configs[1] (C2): the oracle's mapping network + 1024² generator forward on image 2 of the reference's batch of 4
+    (generator_1024_b4.npz, produced by the reference Generator in fp32; one image keeps the CPU suite short — images of a
+    batch are independent in every op of the path)."""
+    from make_golden_params import GEN_B4
+    g = golden('generator_1024_b4.npz')
+    size, B, k = GEN_B4['size'], GEN_B4['batch'], 2
+    P = synth.generator_state(size, seed=0)
+    z = synth.normal('gen_b4.z', (B, 512), GEN_B4['z_seed'])
+    noises = [n[k:k + 1] for n in synth.make_noises(size, B, seed=GEN_B4['noise_seed'])]
+    with torch.no_grad():
+        w = R.mapping_network(P, z)
+        close(w, g['latent'], 2e-5)
+        img = R.generator_forward(P, w[k:k + 1].unsqueeze(1).repeat(1, 18, 1), noises, size)
+    close(img[:, :, ::16, ::16], g['image_sub'][k:k + 1], 5e-5)
+    close(img[:, :, 448:512, 512:576], g['image_crop'][k:k + 1], 5e-5)
+    assert (img.double().mean(dim=(2, 3)) - g['image_mean'][k:k + 1]).abs().max().item() < 1e-5

@@ -113,11 +113,15 @@ def test_cpu_slices_for_ranks():
     assert _parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
     assert bind_rank_to_cpus(0, 1) is None                                                  # single process: not bound
     before = sorted(os.sched_getaffinity(0))
+    import torch
+    nt = torch.get_num_threads()
     try:
         got = bind_rank_to_cpus(1, 2)
         assert got and set(got) <= set(before) and sorted(os.sched_getaffinity(0)) == sorted(got)
+        assert torch.get_num_threads() == len(got)          # the intra-op pool follows the slice (8 ranks x all cores otherwise)
     finally:
         os.sched_setaffinity(0, before)
+        torch.set_num_threads(nt)
 
 
 @pytest.mark.parametrize('gB', [4, 5, 1])
