@@ -117,6 +117,57 @@ __device__ __forceinline__ float demod_dot(const float* __restrict__ sp, const f
     return wave_sum((a0 + a1) + (a2 + a3));
 }
 
+// Streaming (non-temporal) accesses for tensors that are read or written ONCE per pass and are far larger than the caches (the
+// activations / gradients of the >= 256² levels: 0.27-1.07 GB at batch 8).  tools/probes/copy_probe.hip, (8,32,1024,1024) fp32 read +
+// write: plain 16-byte accesses 5.4-5.5 TB/s, `nt` loads and stores 5.7-5.9 TB/s (profiles/r4_copy_probe.txt).  -DOODGAN_NT_STREAM=0
+// builds the plain forms (A/B).
+#ifndef OODGAN_NT_STREAM
+#define OODGAN_NT_STREAM 1
+#endif
+typedef float oodgan_f4v __attribute__((ext_vector_type(4)));
+typedef float oodgan_f2v __attribute__((ext_vector_type(2)));
+typedef unsigned oodgan_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#if OODGAN_NT_STREAM
+    const oodgan_f4v v = __builtin_nontemporal_load(reinterpret_cast<const oodgan_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ float2 ld2_stream(const float* p) {
+#if OODGAN_NT_STREAM
+    const oodgan_f2v v = __builtin_nontemporal_load(reinterpret_cast<const oodgan_f2v*>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *reinterpret_cast<const float2*>(p);
+#endif
+}
+__device__ __forceinline__ float ld1_stream(const float* p) {
+#if OODGAN_NT_STREAM
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+#if OODGAN_NT_STREAM
+    __builtin_nontemporal_store(oodgan_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<oodgan_f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+// a 16-byte slot of an S-form / phase-split record
+template <typename T16>
+__device__ __forceinline__ void st16_stream(void* p, const T16& v) {
+    static_assert(sizeof(T16) == 16, "16-byte value");
+#if OODGAN_NT_STREAM
+    __builtin_nontemporal_store(__builtin_bit_cast(oodgan_u4v, v), reinterpret_cast<oodgan_u4v*>(p));
+#else
+    *reinterpret_cast<T16*>(p) = v;
+#endif
+}
+
 // Sum over the 32 lanes of each half of the wave with DPP operands (VALU only): quad swaps, row_half_mirror, row_mirror and
 // row_bcast:15 — the total of lanes 0-31 lands in lanes 16-31 (read it in lane 31), that of lanes 32-63 in lanes 48-63 (lane
 // 63).  A __shfl_xor butterfly is five ds_bpermute_b32 per value: the fused epilogue of the stride-2 conv issued 486 of them

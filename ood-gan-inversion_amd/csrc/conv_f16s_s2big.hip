@@ -368,16 +368,20 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                 }
             }
             unsigned hi[RW][8], lo[RW][8];
-            float sd[16], sr_[16], st_[16];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
                 float vv[RW][2];
+                // registers 2 r2 and 2 r2 + 1 are two consecutive channels: their seven constants come as seven 8-byte LDS reads
+                const int ch0 = chb + ((2 * r2) & 3) + 8 * ((2 * r2) >> 2) + 4 * half;
+                float2 k7[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) k7[i] = *reinterpret_cast<const float2*>(cst + i * C::MBW + ch0);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int r = 2 * r2 + e;
-                    const int ch = chb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float c_g = cst[0 * C::MBW + ch], w0 = cst[1 * C::MBW + ch], w1 = cst[2 * C::MBW + ch], w2 = cst[3 * C::MBW + ch];
-                    const float srg = cst[4 * C::MBW + ch], bv = cst[5 * C::MBW + ch], ds = cst[6 * C::MBW + ch];
+                    const int ch = ch0 + e;
+                    const float c_g = e ? k7[0].y : k7[0].x, w0 = e ? k7[1].y : k7[1].x, w1 = e ? k7[2].y : k7[2].x, w2 = e ? k7[3].y : k7[3].x;
+                    const float srg = e ? k7[4].y : k7[4].x, bv = e ? k7[5].y : k7[5].x, ds = e ? k7[6].y : k7[6].x;
                     float ad = 0.f, ar = 0.f, at = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < RW; ++nt) {
@@ -394,7 +398,14 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                         vmaxv = fmaxf(vmaxv, fabsf(v));
                         vv[nt][e] = v;
                     }
-                    sd[r] = ad; sr_[r] = ar; st_[r] = at;
+                    // the three per-channel sums of this register: lanes -> row group -> LDS, right away (held in sd / sr / st arrays
+                    // until the end of the M-tile they were 48 live registers: the MH = 2 instance spilled 7 of them, round 3)
+                    const float v0 = half_sum_dpp(ad), v1 = half_sum_dpp(ar), v2 = half_sum_dpp(at);
+                    if (l31 == kHalfSumLane) {
+                        red[(rg * 3 + 0) * C::MBW + ch] = v0;
+                        red[(rg * 3 + 1) * C::MBW + ch] = v1;
+                        red[(rg * 3 + 2) * C::MBW + ch] = v2;
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < RW; ++nt) split_pair(vv[nt][0], vv[nt][1], hi[nt][r2], lo[nt][r2]);
@@ -416,17 +427,6 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                         rec[half] = make_uint4(h0[0], h1[0], h0[1], h1[1]);
                         rec[2 + half] = make_uint4(l0[0], l1[0], l0[1], l1[1]);
                     }
-                }
-            }
-            // the three per-channel sums of this M-tile: lanes -> row group -> LDS
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v0 = half_sum_dpp(sd[r]), v1 = half_sum_dpp(sr_[r]), v2 = half_sum_dpp(st_[r]);
-                if (l31 == kHalfSumLane) {
-                    const int ch = chb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    red[(rg * 3 + 0) * C::MBW + ch] = v0;
-                    red[(rg * 3 + 1) * C::MBW + ch] = v1;
-                    red[(rg * 3 + 2) * C::MBW + ch] = v2;
                 }
             }
         }

@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     auto load_row = [&](int r, int Y, Row& R) {
         const float* rp = zp + (long)min(max(r, 0), Hz - 1) * a.pitch;
         R.rv = (r >= 0 && r < Hz) ? 1.f : 0.f;
-        R.m = *reinterpret_cast<const float4*>(rp + gxc);
-        R.e0 = rp[ec0];
+        R.m = *reinterpret_cast<const float4*>(rp + gxc);    // plain loads and stores: with `nt` hints (common.hpp, ld4_stream) this
+        R.e0 = rp[ec0];                                      // kernel is 7-25 % SLOWER at every level (profiles/r4_ab_nt_swizzle.txt)
         R.e1 = rp[ec1];
         R.n = *reinterpret_cast<const float4*>(nsrc + (long)min(max(Y, 0), Ho - 1) * Wo + gxn);
     };

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
     // bare round trip to HBM (80 % of the wave time waiting at 3.7 TB/s)
     float2 nx[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) nx[c] = *reinterpret_cast<const float2*>(xp + (long)c * HW);
+    for (int c = 0; c < 16; ++c) nx[c] = ld2_stream(xp + (long)c * HW);
     const int nkc = Ci / 16;
     for (int kc = 0; kc < nkc; ++kc) {
         unsigned hp[TS_PX][8], lp[TS_PX][8];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
         for (int c = 0; c < 16; ++c) cx[c] = nx[c];
         if (kc + 1 < nkc) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) nx[c] = *reinterpret_cast<const float2*>(xp + (long)((kc + 1) * 16 + c) * HW);
+            for (int c = 0; c < 16; ++c) nx[c] = ld2_stream(xp + (long)((kc + 1) * 16 + c) * HW);
         }
 #pragma unroll
         for (int cp = 0; cp < 8; ++cp) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int t = i * 64 + lane, lo_ = t >> 3, k = t & 7;
-                ysb[rel[i] + (long)kc * yd.plane] = xb[lo_ * 8 + (k ^ (lo_ & 7))];
+                st16_stream(ysb + rel[i] + (long)kc * yd.plane, xb[lo_ * 8 + (k ^ (lo_ & 7))]);
             }
             __builtin_amdgcn_wave_barrier();
         } else {

@@ -7,7 +7,7 @@ TAG=${2:-abprof}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--streams 1 --wsteps 20 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-roofline-events"
+ARGS="--streams 1 --wsteps 20 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd --no-roofline-events"
 for lib in product variant; do
   if [ $lib = variant ]; then export OODGAN_LIB=$V; else unset OODGAN_LIB; fi
   rocprofv3 --kernel-trace -d $OUT/$lib -o k -- python3 bench.py $ARGS > $OUT/$lib.json 2> $OUT/$lib.err

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-mall}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for b in 1 2 8; do
-  rocprofv3 --kernel-trace -d $OUT/b$b -o k -- python3 bench.py --batch $b --streams 1 --wsteps 12 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-roofline-events > $OUT/b$b.json 2> $OUT/b$b.err
+  rocprofv3 --kernel-trace -d $OUT/b$b -o k -- python3 bench.py --batch $b --streams 1 --wsteps 12 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd --no-roofline-events > $OUT/b$b.json 2> $OUT/b$b.err
   python3 tools/rocpd_stats.py $OUT/b$b/k_results.db --per-grid --csv $OUT/b$b.csv > /dev/null
 done
 find $OUT -name "*.db" -delete

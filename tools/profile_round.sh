@@ -7,9 +7,9 @@ TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-SHORT="--wsteps 10 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --streams 1"
-rocprofv3 --kernel-trace -d $OUT/stats_s1 -o k -- python3 bench.py --streams 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only > $OUT/bench_s1.json 2> $OUT/bench_s1.err
-rocprofv3 --kernel-trace -d $OUT/stats_s2 -o k -- python3 bench.py --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only > $OUT/bench_s3.json 2> $OUT/bench_s3.err
+SHORT="--wsteps 10 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd --streams 1"
+rocprofv3 --kernel-trace -d $OUT/stats_s1 -o k -- python3 bench.py --streams 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd > $OUT/bench_s1.json 2> $OUT/bench_s1.err
+rocprofv3 --kernel-trace -d $OUT/stats_s2 -o k -- python3 bench.py --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd > $OUT/bench_s3.json 2> $OUT/bench_s3.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_sq1.err
