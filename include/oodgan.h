@@ -43,12 +43,14 @@ int oodgan_device_count(void);
  *   "t2_big_min_items" OODGAN_T2_BIG_MIN_ITEMS 128   them to reach those kernels with small tensors, or raise them for the A/B)
  *   "blurt_strip"      OODGAN_BLURT_STRIP      1     0: the tile kernel instead of the strip walk in oodgan_act_bwd_blurT_sform_phases
  *   "blur_strip"       OODGAN_BLUR_STRIP       1     0: the tile kernel instead of the strip walk in oodgan_blur_act_fform / _sform_sep
+ *   "upvb_waves"       OODGAN_UPVB_WAVES       12    form of oodgan_upconv_vblur_fform: 12 = one persistent 12-wave workgroup per CU, 6 / 4 = tile
+ *                                                    kernels with two / three workgroups per CU (csrc/conv_f16s_upvb.hip)
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);
 /* Dispatch counters of oodgan_conv3x3_f16s: how many calls since load (or oodgan_dispatch_reset) went to the kernel family
  * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
- * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen".  Host-side, one relaxed atomic increment per call; the reference has no
+ * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", and "upvb" (oodgan_upconv_vblur_fform).  Host-side, one relaxed atomic increment per call; the reference has no
  * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
  * Returns -1 for an unknown name. */
 long oodgan_dispatch_count(const char* name);
@@ -315,6 +317,24 @@ int oodgan_blur_act_fform(const float* z, const float* kernel, float* y, const f
                           int B, int C, int H, int W, int in_pitch, unsigned* vmax, int kernel_rank_one, void* stream);
 /* kernel_rank_one: 1 when the caller knows the 4x4 kernel to be an outer product (Blur's [1,3,3,1] x [1,3,3,1] is): selects the
  * strip-walk kernel (one horizontal and one vertical 4-tap pass); 0: the tile kernel, which tests the taps itself. */
+/* ---- the whole up-sampling StyledConv in ONE pass (csrc/conv_f16s_upvb.hip, round 4): conv_transpose2d(stride 2, pad 0) of the S-form
+ * input xs (K channels, H x W: x * style, split) -> Blur(pad = (1,1)) -> * out_scale[b,m] (demodulation) + noise_w*noise + bias ->
+ * leaky-ReLU*sqrt2 -> y in F-form ([B][M/16][2H][2W][16] fp32).  replaces: ModulatedConv2d.forward's upsample branch + Blur +
+ * NoiseInjection + FusedLeakyReLU of one StyledConv (src/ops/StyleGAN/model.py:199-205,247-258,283-292,343-350) — i.e.
+ * oodgan_conv3x3_f16s(mode T2) followed by oodgan_blur_act_fform, without the (2H+1) x (2W+1) intermediate in memory.
+ * The blur kernel must be rank one, kf[a][b] = kv[a]*kh[b] (kf = the FLIPPED 4x4 kernel, as upfirdn2d applies it).  Its vertical pass
+ * is folded into the weights by the caller — two 3x3 weight sets, one per output-row parity py:
+ *     Wv[py][d+1][kx] = sum over (a, ky) with py + a - 1 - ky == 2d of kv[a] * W[ky][kx],  d = -1, 0, 1
+ * each packed with oodgan_pack_conv3x3_f16s (transpose = flip = 0) into ONE buffer, the second set wset_bytes behind the first;
+ * unscale4 = the two {2^-e, 2^e} pairs of the packs; kh4 = the four horizontal taps kh[0..3] (device).  The horizontal pass runs on
+ * the accumulators.  ys_scale / vmax as in oodgan_blur_act_fform (forward range control of the following conv).
+ * Shapes: K %% 16 == 0, M %% 32 == 0, H >= 4, W >= 30 (oodgan_upconv_vblur_supported).  Twice the matrix work of the transposed conv:
+ * meant for the highest level (64 -> 32 channels, 512² -> 1024²), where the two passes it replaces are bound by memory. */
+int oodgan_upconv_vblur_supported(int B, int K, int M, int H, int W);
+int oodgan_upconv_vblur_fform(const void* xs, const void* wpk2, long wset_bytes, const float* unscale4, const float* kh4,
+                              const float* out_scale, int out_scale_stride, const float* bias, const float* noise, int noise_batch,
+                              const float* noise_w, int act, const float* ys_scale, int ys_scale_stride, unsigned* vmax, float* y,
+                              int B, int K, int M, int H, int W, void* stream);
 /* oodgan_blur_act_sform with the same promise about the kernel (C %% 16 == 0 and 2W >= 64 for the strip walk; the tile kernel otherwise) */
 int oodgan_blur_act_sform_sep(const float* z, const float* kernel, float* y, void* ys, const float* ys_scale, int ys_scale_stride,
                               const float* bias, const float* noise, int noise_batch, const float* noise_w, int act, int B, int C,

@@ -10,13 +10,13 @@ namespace oodgan {
 void set_error(const char* fmt, ...);
 
 // dispatch tunables (runtime.hip): environment default read once, then oodgan_set_tunable
-enum { OODGAN_TUN_S1_BIG_MIN_ITEMS = 0, OODGAN_TUN_S2_BIG_MIN_ITEMS, OODGAN_TUN_T2_BIG_MIN_ITEMS, OODGAN_TUN_BLURT_STRIP, OODGAN_TUN_BLUR_STRIP, OODGAN_TUN_COUNT };
+enum { OODGAN_TUN_S1_BIG_MIN_ITEMS = 0, OODGAN_TUN_S2_BIG_MIN_ITEMS, OODGAN_TUN_T2_BIG_MIN_ITEMS, OODGAN_TUN_BLURT_STRIP, OODGAN_TUN_BLUR_STRIP, OODGAN_TUN_UPVB_WAVES, OODGAN_TUN_COUNT };
 long tunable(int id);
 
 // dispatch counters (runtime.hip, oodgan_dispatch_count): which kernel family a conv call was routed to — tests assert that the
 // kernel they mean to pin is the one that ran
 enum { OODGAN_DC_STRIPX = 0, OODGAN_DC_STRIP, OODGAN_DC_S1BIG, OODGAN_DC_S1V2, OODGAN_DC_S1PP, OODGAN_DC_TINY, OODGAN_DC_T2BIG,
-       OODGAN_DC_T2V2, OODGAN_DC_T2GEN, OODGAN_DC_S2BIG, OODGAN_DC_S2V2, OODGAN_DC_S2GEN, OODGAN_DC_COUNT };
+       OODGAN_DC_T2V2, OODGAN_DC_T2GEN, OODGAN_DC_S2BIG, OODGAN_DC_S2V2, OODGAN_DC_S2GEN, OODGAN_DC_UPVB, OODGAN_DC_COUNT };
 void count_dispatch(int id);
 
 // One process per GPU: per-kernel setup (dynamic-LDS attributes, the zero page and CU count of the F-form strip

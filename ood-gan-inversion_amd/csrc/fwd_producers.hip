@@ -430,7 +430,9 @@ static int blur_act_launch(const float* z, const float* kernel, float* y, void* 
     a.vmax = (ys || y_fform) ? vmax : nullptr;
     a.y_fform = y_fform;
     OODGAN_REQUIRE(!y_fform || (C % 16 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0), "blur_act_fform: C %% 16 == 0 and a 16-byte aligned y");
-    if ((y_fform || ys) && rank_one == 1 && 2 * W >= 64 && (C % 16) == 0 && oodgan::tunable(oodgan::OODGAN_TUN_BLUR_STRIP)) {
+    // (W even: a thread owns four output columns and masks its noise / plane store per quad — with 2W %% 4 != 0 the last two columns of a row
+    // would get neither; odd widths take the tile kernel.  Found by the one-pass up-conv's parity test, round 4.)
+    if ((y_fform || ys) && rank_one == 1 && 2 * W >= 64 && (W % 2) == 0 && (C % 16) == 0 && oodgan::tunable(oodgan::OODGAN_TUN_BLUR_STRIP)) {
         BlurStripGeo geo;
         geo.nstrips = (2 * W + 63) / 64;
         const long base = (long)B * a.yd.KC * geo.nstrips;

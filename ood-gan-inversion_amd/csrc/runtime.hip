@@ -25,6 +25,7 @@ Tunable g_tun[OODGAN_TUN_COUNT] = {
     {"t2_big_min_items", "OODGAN_T2_BIG_MIN_ITEMS", 128, {0}, {0}},
     {"blurt_strip", "OODGAN_BLURT_STRIP", 1, {0}, {0}},
     {"blur_strip", "OODGAN_BLUR_STRIP", 1, {0}, {0}},
+    {"upvb_waves", "OODGAN_UPVB_WAVES", 12, {0}, {0}},
 };
 }  // namespace
 long tunable(int id) {
@@ -77,7 +78,7 @@ bool bound_device_ok(const char* what) {
 // ---- dispatch counters: one relaxed atomic increment per conv call, on the host
 namespace oodgan {
 namespace {
-const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen"};
+const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb"};
 std::atomic<long> g_dc[OODGAN_DC_COUNT];
 }  // namespace
 void count_dispatch(int id) { g_dc[id].fetch_add(1, std::memory_order_relaxed); }

@@ -95,6 +95,8 @@ _SIGS = {
     'oodgan_blur_act_sform_sep': (c_int, [P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'oodgan_blur_act_fform': (c_int, [P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'oodgan_conv3x3_xf_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'oodgan_upconv_vblur_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'oodgan_upconv_vblur_fform': (c_int, [P, P, c_long, P, P, P, c_int, P, P, c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_conv3x3_xf_nparts': (c_int, [c_int, c_int, c_int]),
     'oodgan_conv3x3_tiny_workspace': (c_long, [c_int, c_int, c_int, c_int, c_int, c_int]),
 

@@ -22,7 +22,7 @@ _Cols = ops.Cols
 
 class _Layer:
     __slots__ = ('name', 'kind', 'cin', 'cout', 'res', 'lat', 'row', 'drow', 'wpk', 'wpk_bwd', 'wsq', 'w_rgb',
-                 'bias', 'noise_w', 'scale', 'noise_idx', 'src', 'sidx')
+                 'bias', 'noise_w', 'scale', 'noise_idx', 'src', 'sidx', 'wpk_vb')
 
 
 class GeneratorEngine:
@@ -53,6 +53,7 @@ class GeneratorEngine:
             L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False, precision=self.precision)
             L.wpk_bwd = ops.pack_conv3x3(w, L.scale, transpose=True, flip=not up, precision=self.precision) if with_backward else None
             L.wsq = ops.weight_sqsum(w)
+            L.wpk_vb = None
             L.bias = g(f'{name}.activate.bias')
             L.noise_w = g(f'{name}.noise.weight')
             layers.append(L)
@@ -93,6 +94,13 @@ class GeneratorEngine:
         self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
         self.fused_rgb = True
         self.fuse_x = True           # 1024² level: F-form activations, the strip convs convert their input themselves (conv_f16s_stripx.hip)
+        # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
+        # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
+        self.fuse_up = True
+        Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
+        if (Lup is not None and self.precision == 'f16s' and self.sform and with_backward and Lup.cout % 32 == 0 and Lup.cin % 16 == 0
+                and Lup.cout <= 32 and size >= 64):
+            Lup.wpk_vb = ops.pack_upconv_vblur(g(f'{Lup.name}.conv.weight')[0], Lup.scale, self.k4x4)
         ops.xf_supported(1, 32, 32, 8, 32)      # first call initialises that path (allocations must not fall into a stream capture)
         self.batched_tail = True
         src = 'input'
@@ -286,30 +294,41 @@ class GeneratorEngine:
                     out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,
                                       noise_weight=L.noise_w, act=ACT_LRELU)
             else:
+                Hi = out.shape[2]
+                Ln = self.next_conv.get(L.name)
+                # last level inside the W+ loop: the activation stays in F-form and the conv converts it itself — no S-form copy of
+                # the largest tensor of the step is written or read
+                ff_tail = (self.sform and carry and self.fused_fwd and Ln is not None and save and self.fuse_x and self.fused_bwd and self.fused_rgb
+                           and Ln is self.layers_styled_last and not return_features
+                           and self.bwd_state.get(Ln.name) is not None and self.bwd_state.get(L.name) is not None
+                           and ops.xf_supported(B, Ln.cin, Ln.cout, 2 * Hi, 2 * Hi))
+                one_pass = ff_tail and self.fuse_up and L.wpk_vb is not None and ops.upconv_vblur_supported(B, L.cin, L.cout, Hi, Hi)
+                z = None
                 if self.sform:
                     if pending is not None:
                         xs, pending = pending, None
                     else:
                         xs = to_s(L, out)
-                    z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
+                    if one_pass:
+                        # ... and the (2H+1)² transposed-conv result is not written either: conv + blur + noise + bias + activation in ONE kernel
+                        out = ops.upconv_vblur_fform(xs, L.wpk_vb, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w, act=True,
+                                                     ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                    else:
+                        z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
                     del xs
                 else:
                     z = ops.conv3x3(out, L.wpk, L.cout, CONV_T2, in_scale=s, out_scale=d)
-                H2 = 2 * out.shape[2] + 1
+                H2 = 2 * Hi + 1
                 lat_idx = L.lat
-                if cond_hook is not None and cond_layers is not None and lat_idx in cond_layers:
+                if one_pass:
+                    pass
+                elif cond_hook is not None and cond_layers is not None and lat_idx in cond_layers:
                     raw = ops.blur_bias_act(z, self.k4x4, (1, 1), act=False, in_hw=(H2, H2), in_pitch=z.shape[3])
                     cond = cond_hook(cond_layers.index(lat_idx), raw, latent[:, lat_idx], nz, L.noise_w)
                     out = ops.bias_noise_act(cond, L.bias, nz, L.noise_w)
                 elif carry and self.fused_fwd and L.name in self.next_conv:
                     # blur + noise + bias + activation, and the following conv's S-form input (x its style), in one pass
-                    Ln = self.next_conv[L.name]
-                    Hi = out.shape[2]
-                    if (save and self.fuse_x and self.fused_bwd and self.fused_rgb and Ln is self.layers_styled_last and not return_features
-                            and self.bwd_state.get(Ln.name) is not None and self.bwd_state.get(L.name) is not None
-                            and ops.xf_supported(B, Ln.cin, Ln.cout, 2 * Hi, 2 * Hi)):
-                        # last level inside the W+ loop: the activation stays in F-form and the conv converts it itself — no
-                        # S-form copy of the largest tensor of the step is written or read
+                    if ff_tail:
                         out = ops.blur_act_fform(z, self.k4x4, Hi, Hi, L.bias, nz, L.noise_w, act=True,
                                                  ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx], rank_one=self.k4x4_rank1)
                     else:

@@ -694,6 +694,77 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
     return PackedConv(out, unscale, 'f16s', M)
 
 
+class PackedUpVB:
+    """Composite weights of ``upconv_vblur_fform``: two packed 3x3 sets (one per output-row parity) in one buffer."""
+    __slots__ = ('data', 'unscale4', 'kh', 'wset_bytes', 'M', 'K')
+
+    def __init__(self, data, unscale4, kh, wset_bytes, M, K):
+        self.data, self.unscale4, self.kh, self.wset_bytes, self.M, self.K = data, unscale4, kh, wset_bytes, M, K
+
+
+def rank_one_factors(k2d):
+    """kf = the FLIPPED 4x4 blur kernel as upfirdn2d applies it (src/ops/op/upfirdn2d.py:160-193); returns (kv, kh) with
+    kf[a][b] == kv[a] * kh[b], or None if the kernel is not an outer product.  Host values (float64)."""
+    kf = torch.flip(k2d.detach().double().cpu(), [0, 1])
+    if kf.shape != (4, 4) or not torch.isfinite(kf).all() or float(kf.abs().max()) == 0.0:
+        return None
+    i, j = divmod(int(kf.abs().argmax()), 4)
+    kv, kh = kf[:, j] / kf[i, j], kf[i, :].clone()
+    if float((torch.outer(kv, kh) - kf).abs().max()) > 1e-12 * float(kf.abs().max()):
+        return None
+    return kv, kh
+
+
+def pack_upconv_vblur(weight, scale, k2d):
+    """(Co,Ci,3,3) transposed-conv weight + the 4x4 blur kernel of ``Blur(pad=(1,1))`` -> ``PackedUpVB`` (include/oodgan.h,
+    oodgan_upconv_vblur_fform): the vertical blur pass folded into two 3x3 weight sets,
+    Wv[py][d+1][kx] = sum_{a,ky: py+a-1-ky == 2d} kv[a] * W[ky][kx]; None if the kernel is not rank one.  One-time weight preparation."""
+    f = rank_one_factors(k2d)
+    if f is None:
+        return None
+    kv, kh = f
+    w = _dev(weight, 'weight')
+    Co, Ci = w.shape[0], w.shape[1]
+    wv = torch.zeros(2, Co, Ci, 3, 3, device=w.device, dtype=torch.float64)
+    for py in range(2):
+        for a in range(4):
+            for ky in range(3):
+                t = py + a - 1 - ky
+                if t % 2 == 0 and -1 <= t // 2 <= 1:
+                    wv[py, :, :, t // 2 + 1, :] += float(kv[a]) * w[:, :, ky, :].double()
+    wv = wv.float().contiguous()
+    L = _lib.lib()
+    nbytes = L.oodgan_pack_conv3x3_f16s_bytes(Co, Ci, 0)
+    data = torch.empty(nbytes, device=w.device, dtype=torch.float16)          # 2 sets x nbytes / 2 halves
+    unscale4 = torch.empty(4, device=w.device, dtype=torch.float32)
+    for py in range(2):
+        check(L.oodgan_pack_conv3x3_f16s(_p(wv[py]), ctypes.c_void_p(data.data_ptr() + py * nbytes),
+                                         ctypes.c_void_p(unscale4.data_ptr() + 8 * py), Co, Ci, float(scale), 0, 0, _stream()), 'pack_f16s')
+    return PackedUpVB(data, unscale4, kh.float().to(w.device).contiguous(), nbytes, Co, Ci)
+
+
+def upconv_vblur_supported(B, K, M, H, W):
+    return bool(_lib.lib().oodgan_upconv_vblur_supported(B, K, M, H, W))
+
+
+def upconv_vblur_fform(xs, wvb, out_scale=None, bias=None, noise=None, noise_weight=None, act=True, ys_scale=None, vmax=None):
+    """The up-sampling StyledConv in one pass (include/oodgan.h, oodgan_upconv_vblur_fform): S-form x (B,K,H,W) -> F-form
+    act(Blur(conv_transpose2d(x, W)) * out_scale + noise_w * noise + bias) (B,M,2H,2W), without the (2H+1)² intermediate."""
+    assert isinstance(xs, SForm) and isinstance(wvb, PackedUpVB)
+    B, K, H, W = xs.shape
+    assert K == wvb.K
+    M = wvb.M
+    y = torch.empty(B, M, 2 * H, 2 * W, device=xs.data.device, dtype=torch.float32)
+    nz = _opt(noise, 'noise')
+    check(_lib.lib().oodgan_upconv_vblur_fform(_p(xs), _p(wvb.data), wvb.wset_bytes, _p(wvb.unscale4), _p(wvb.kh),
+                                               _p(_opt(out_scale, 'out_scale')), 0 if out_scale is None else out_scale.shape[1],
+                                               _p(_opt(bias, 'bias')), _p(nz), 1 if nz is None else nz.shape[0],
+                                               _p(_opt(noise_weight, 'nw')), ACT_LRELU if act else ACT_NONE,
+                                               _p(_opt(ys_scale, 'ys_scale')), 0 if ys_scale is None else ys_scale.shape[1], _p(vmax),
+                                               _p(y), B, K, M, H, W, _stream()), 'upconv_vblur_fform')
+    return FForm(y)
+
+
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
             in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,

@@ -175,3 +175,45 @@ def test_blur_strip_walk_with_a_zero_corner_kernel(taps):
     y2 = ops.blur_act_fform(z, k, H, W, bias, nz, nw, act=True, ys_scale=s, rank_one=True)
     assert torch.isfinite(y1).all() and torch.isfinite(y2.to_nchw()).all()
     assert _rel(y1, y0) < 2e-6 and _rel(y2.to_nchw(), y0) < 2e-6
+
+
+@pytest.mark.parametrize('waves', [12, 6, 4])
+@pytest.mark.parametrize('B,K,M,H,W', [(2, 64, 32, 32, 32), (1, 32, 32, 20, 45), (1, 16, 64, 7, 30), (2, 64, 32, 64, 100), (1, 64, 32, 512, 512)])
+def test_upconv_vblur_one_pass_equals_transposed_conv_then_blur(B, K, M, H, W, waves, tunable):
+    """conv_f16s_upvb.hip (transposed conv + Blur + noise + bias + lrelu in one pass, the blur's vertical pass folded into the weights)
+    against the two-pass path it replaces — conv3x3(mode T2) then blur_act_fform — on the same S-form input: image, recorded range
+    maximum, shared noise / no bias / no activation; ragged sizes (partial last tiles in both directions), two channel blocks."""
+    from oodgan import ops, _lib
+    tunable('upvb_waves', waves)        # the persistent 12-wave form and the two tile forms
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(500 + H + W + K)
+    x = torch.randn(B, K, H, W, generator=g).to(dev)
+    s = (1 + 0.3 * torch.randn(B, K, generator=g)).to(dev)
+    d = (1 + 0.3 * torch.randn(B, M, generator=g)).abs().to(dev)
+    w = (torch.randn(M, K, 3, 3, generator=g)).to(dev)
+    scale = 1.0 / math.sqrt(K * 9)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+    nz = torch.randn(B, 1, 2 * H, 2 * W, generator=g).to(dev)
+    nw, bias = torch.tensor([0.3], device=dev), (0.1 * torch.randn(M, generator=g)).to(dev)
+    ysc = (1 + 0.3 * torch.randn(B, M, generator=g)).to(dev)
+    xs = ops.to_sform(x, s)
+    wpk = ops.pack_conv3x3(w, scale, transpose=False, flip=False, precision='f16s')
+    wvb = ops.pack_upconv_vblur(w, scale, k)
+    assert wvb is not None and ops.upconv_vblur_supported(B, K, M, H, W)
+    for (b_, n_, act) in ((bias, nz, True), (None, nz[:1], False), (bias, None, True)):
+        vm0 = torch.zeros(B, ops.VMAX_SLOTS, dtype=torch.int32, device=dev)
+        vm1 = torch.zeros_like(vm0)
+        z = ops.conv3x3(xs, wpk, M, ops.CONV_T2, out_scale=d)
+        y0 = ops.blur_act_fform(z, k, H, W, b_, n_, nw, act=act, ys_scale=ysc, vmax=vm0, rank_one=True).to_nchw()
+        _lib.dispatch_reset()
+        y1 = ops.upconv_vblur_fform(xs, wvb, out_scale=d, bias=b_, noise=n_, noise_weight=nw, act=act, ys_scale=ysc, vmax=vm1)
+        assert _lib.dispatch_count('upvb') == 1
+        y1 = y1.to_nchw()
+        assert torch.isfinite(y1).all()
+        err = (y1 - y0).abs().max().item() / y0.abs().max().item()
+        assert err < 3e-6, (err, act)
+        a, b2 = vm0.max(dim=1).values.view(torch.float32), vm1.max(dim=1).values.view(torch.float32)
+        assert float(((a - b2).abs() / a).max()) < 3e-6
+    # a kernel that is not an outer product has no one-pass form
+    assert ops.pack_upconv_vblur(w, scale, torch.eye(4, device=dev)) is None

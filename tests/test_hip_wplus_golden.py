@@ -63,6 +63,7 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
             # steady state of the loop: up-conv tail and last conv in F-form, both 1024² convs in conv_f16s_stripx
             assert fform == ['convs.14', 'convs.15'], fform
             assert (nx, ns) == (2, 0), (nx, ns)
+            assert _lib.dispatch_count('upvb') == 1          # ... and its up-conv in one pass (conv_f16s_upvb.hip)
         elif prec == 'f16s':
             assert fform == [] and (nx, ns) == (0, 2), (fform, nx, ns)      # first step: S-form strip kernel, exact scales
         else:
