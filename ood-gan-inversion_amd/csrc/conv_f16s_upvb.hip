@@ -129,11 +129,25 @@ __device__ __forceinline__ void upvb_dma(const UpVB& p, int wave, const unsigned
     }
 }
 
+// one piece of a stage (persistent form: the pieces of stage t+1 are issued one at a time BETWEEN the tap steps of stage t — a burst of
+// seven global_load_lds right after the barrier keeps every wave of the CU in the issue of its loads at the same moment)
+template <int NW>
+__device__ __forceinline__ void upvb_dma_piece(const UpVB& p, int wave, const unsigned char* xb, const unsigned (&off)[UVCfg<NW>::NPW], int t,
+                                               unsigned char* dst, int i) {
+    using C = UVCfg<NW>;
+    const int pc = wave + NW * i;
+    if (pc < C::PIECES) {
+        const long wchunk_bytes = (long)UV_WROWS * p.Mp * 16;
+        const unsigned char* src = (pc < C::XPIECES ? xb + (long)t * p.xd.plane * 16 : reinterpret_cast<const unsigned char*>(p.wpk) + (long)t * wchunk_bytes) + off[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
+    }
+}
+
 // 18 taps of one 16-channel chunk, row by row of the x tile: row tap d = ky' - 1 (x rows I-1, I, I+1 = tile rows wave .. wave+2), weight set py,
 // column tap kx -> phase py*2 + (kx & 1), x column j - (kx >> 1) (tile columns l31 + 1 - (kx >> 1)).  The fragments of step i+1 are read
 // under the matrix instructions of step i (two register sets, order pinned); one x row (4 fragments) is live at a time.
-template <int NW>
-__device__ __forceinline__ void upvb_stage(const unsigned char* lx, int wave, int l31, int half, f32x16 (&acc)[4]) {
+template <int NW, typename Between>
+__device__ __forceinline__ void upvb_stage(const unsigned char* lx, int wave, int l31, int half, f32x16 (&acc)[4], Between between) {
     using C = UVCfg<NW>;
     const unsigned char* lwh = lx + C::XBYTES + (half * UV_MB + l31) * 16;
     const unsigned char* lxh = lx + (wave * UV_C + l31) * UV_REC + half * 16;
@@ -167,6 +181,7 @@ __device__ __forceinline__ void upvb_stage(const unsigned char* lx, int wave, in
                 bl[rb ^ 1][cc] = XFRAG((kyp + 1) * UV_C + cc, 1);
             }
         }
+        between(i);
         __builtin_amdgcn_sched_barrier(0);
         MFMA3(acc[py * 2 + (kx & 1)], ah[cur], al[cur], bh[rb][1 - (kx >> 1)], bl[rb][1 - (kx >> 1)]);
         __builtin_amdgcn_sched_barrier(0);
@@ -329,9 +344,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
             __builtin_amdgcn_s_barrier();
             const bool last = t + 1 == nchunk;
             if (last && has_next) set_dma_tile(itn);         // from here on the DMA state describes the NEXT tile
-            if ((!last || has_next) && !(UPVB_ABL & 2)) upvb_dma<NW>(p, wave, xb_dma, off, last ? 0 : t + 1, smem + ((gs + 1) & 1) * C::STAGE);
-            if (UPVB_ABL & 1) continue;
-            upvb_stage<NW>(smem + (gs & 1) * C::STAGE, wave, l31, half, acc);
+            const bool pf = (!last || has_next) && !(UPVB_ABL & 2);
+            const int tn = last ? 0 : t + 1;
+            unsigned char* nbuf = smem + ((gs + 1) & 1) * C::STAGE;
+            if (UPVB_ABL & 1) {
+                if (pf) upvb_dma<NW>(p, wave, xb_dma, off, tn, nbuf);
+                continue;
+            }
+            upvb_stage<NW>(smem + (gs & 1) * C::STAGE, wave, l31, half, acc, [&](int i) {
+                if (pf && i < C::NPW) upvb_dma_piece<NW>(p, wave, xb_dma, off, tn, nbuf, i);
+            });
         }
         if (!(UPVB_ABL & 4)) {
             // the range maximum is recorded per sample: flush when the walk moves on to another image
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
         __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         if (UPVB_ABL & 1) continue;
-        upvb_stage<NW>(smem, wave, l31, half, acc);
+        upvb_stage<NW>(smem, wave, l31, half, acc, [](int) {});
     }
     if (UPVB_ABL & 4) return;
     float vm = 0.f;
