@@ -89,9 +89,15 @@ __device__ __forceinline__ float wave_dpp(float v) {
 
 // per-lane DMA source offsets (bytes) of this wave's pieces for tile (r0, c0, m0).  x: tile origin = image (r0-1, c0-1) = padded
 // (r0, c0); indices clamped into the padded plane (row 0 / column 0 and the last row / column are zeros: what lies outside the image
-// contributes nothing)
+// contributes nothing).  The lane's place inside the tile (row, column, slot of each x piece; row and channel of each weight piece) does
+// not depend on the tile: `upvb_lane_pieces` computes it ONCE per workgroup (integer divisions by 5 and 33 per piece: ~60 vector
+// instructions each — recomputed per tile they were a quarter of the kernel's vector instructions, profiles/r4_upvb_pmc.csv);
+// `upvb_offsets` then costs ~8 per piece.
 template <int NW>
-__device__ __forceinline__ void upvb_offsets(const UpVB& p, int wave, int lane, int r0, int c0, int m0, unsigned (&off)[UVCfg<NW>::NPW]) {
+struct UVLane { int a[UVCfg<NW>::NPW]; };                    // x piece: r << 16 | c << 4 | s; weight piece: 16-byte units of (set, row, j)
+
+template <int NW>
+__device__ __forceinline__ void upvb_lane_pieces(const UpVB& p, int wave, int lane, UVLane<NW>& L) {
     using C = UVCfg<NW>;
 #pragma unroll
     for (int i = 0; i < C::NPW; ++i) {
@@ -102,14 +108,27 @@ __device__ __forceinline__ void upvb_offsets(const UpVB& p, int wave, int lane, 
             const int pos = P / 5;
             int s = P % 5;
             if (s == 4) s = 0;
-            const int r = pos / UV_C, c = pos % UV_C;
-            const int rr = min(max(r0 + r, 0), p.xd.Hp - 1), cc = min(max(c0 + c, 0), p.xd.Wp - 1);
-            off[i] = (unsigned)((((long)rr * p.xd.Wp + cc) * 4 + s) * 16);
+            L.a[i] = (pos / UV_C) << 16 | (pos % UV_C) << 4 | s;
         } else {
             const int pw = pc - C::XPIECES;                  // 0..35: set = pw / 18
             const int set = pw / 18, u = (pw % 18) * 64 + lane;
-            const int row = u / UV_MB, j = u % UV_MB;
-            off[i] = (unsigned)(((long)set * p.wset_units + (long)row * p.Mp + m0 + j) * 16);
+            L.a[i] = (int)((long)set * p.wset_units + (long)(u / UV_MB) * p.Mp + u % UV_MB);
+        }
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void upvb_offsets(const UpVB& p, int wave, const UVLane<NW>& L, int r0, int c0, int m0, unsigned (&off)[UVCfg<NW>::NPW]) {
+    using C = UVCfg<NW>;
+#pragma unroll
+    for (int i = 0; i < C::NPW; ++i) {
+        const int pc = wave + NW * i;
+        if (pc < C::XPIECES) {
+            const int r = L.a[i] >> 16, c = (L.a[i] >> 4) & 0xFFF, s = L.a[i] & 15;
+            const int rr = min(max(r0 + r, 0), p.xd.Hp - 1), cc = min(max(c0 + c, 0), p.xd.Wp - 1);
+            off[i] = (unsigned)(((rr * p.xd.Wp + cc) * 4 + s) * 16);
+        } else {
+            off[i] = (unsigned)((L.a[i] + m0) * 16);
         }
     }
 }
@@ -218,6 +237,7 @@ __device__ __forceinline__ bool upvb_epilogue(const UpVB& p, f32x16 (&acc)[4], i
     }
     const int KC = (p.M + 15) / 16;
     float* yb = p.y + (long)b * KC * HWo * 16;
+    float tvm = 0.f;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {                        // registers 4 g4 .. 4 g4 + 3: four consecutive channels = one 16-byte piece
         float o[2][2][4];                                    // [py][px][channel of the quad]
@@ -242,9 +262,9 @@ __device__ __forceinline__ bool upvb_epilogue(const UpVB& p, f32x16 (&acc)[4], i
                 }
                 o[py][0][e] = y0;
                 o[py][1][e] = y1;
-                mr = fmaxf(mr, fmaxf(fabsf(y0), fabsf(y1)));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mr) : "v"(y0), "v"(y1));       // one instruction per pair for the range maximum
             }
-            if (lane_ok && m0 + cl < p.M) vm = fmaxf(vm, mr * ys);
+            tvm = fmaxf(tvm, mr * ys);                       // (M %% 32 == 0: every channel of the block exists; lanes masked once, below)
         }
         const int mq = m0 + 8 * g4 + 4 * half;               // first channel of the quad
         if (lane_ok && mq < p.M) {
@@ -264,6 +284,7 @@ __device__ __forceinline__ bool upvb_epilogue(const UpVB& p, f32x16 (&acc)[4], i
                 }
         }
     }
+    vm = fmaxf(vm, lane_ok ? tvm : 0.f);
     return I < H;
 }
 
@@ -289,12 +310,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int nchunk = (p.K + 15) / 16;
     unsigned off[C::NPW];                                    // DMA state of the tile whose stages are being REQUESTED
     const unsigned char* xb_dma;
+    UVLane<NW> LP;
+    upvb_lane_pieces<NW>(p, wave, lane, LP);
     auto set_dma_tile = [&](int item) {
         int w = item;
         const int mblk_ = w % p.mblocks;
         w /= p.mblocks;
         const int tile_ = w % ntile, b_ = w / ntile;
-        upvb_offsets<NW>(p, wave, lane, (tile_ / p.tiles_x) * NW, (tile_ % p.tiles_x) * UV_STRIDE - 1, mblk_ * UV_MB, off);
+        upvb_offsets<NW>(p, wave, LP, (tile_ / p.tiles_x) * NW, (tile_ % p.tiles_x) * UV_STRIDE - 1, mblk_ * UV_MB, off);
         xb_dma = reinterpret_cast<const unsigned char*>(p.xs) + (long)b_ * p.xd.KC * p.xd.plane * 16;
     };
     float* ctab = reinterpret_cast<float*>(smem + 2 * C::STAGE);
@@ -387,7 +410,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int r0 = (tile / p.tiles_x) * NW, c0 = (tile % p.tiles_x) * UV_STRIDE - 1, m0 = mblk * UV_MB;
     const int nchunk = (p.K + 15) / 16;
     unsigned off[C::NPW];
-    upvb_offsets<NW>(p, wave, lane, r0, c0, m0, off);
+    UVLane<NW> LP;
+    upvb_lane_pieces<NW>(p, wave, lane, LP);
+    upvb_offsets<NW>(p, wave, LP, r0, c0, m0, off);
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + (long)b * p.xd.KC * p.xd.plane * 16;
     float* ctab = reinterpret_cast<float*>(smem + C::STAGE);      // [3][32]: out scale, bias, ys scale of this tile's channels
     float cv[3] = {1.f, 0.f, 1.f};
