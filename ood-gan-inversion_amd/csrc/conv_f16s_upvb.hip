@@ -394,295 +394,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (p.vmax && vb >= 0) record_vmax(p.vmax, vb, vm);
 }
 
-// ---- row-parity passes (12 waves, persistent): the OVERLAPPED form.  Counters of the form above (profiles/r4_upvb_pmc.csv): per tile and
-// SIMD 20.7 k cycles of matrix instructions and 17 k cycles of vector-instruction issue (1424 vector instructions per wave and tile
-// against 216 matrix instructions), one after the other: all twelve waves of the CU are in the K loop or in the epilogue at the same
-// time.  Deferring the epilogue into the next tile's K loop needs a second accumulator set (tried with 8 waves: 256 registers, spills,
-// slower).  Here a tile is computed as TWO passes, one per output-row parity py: a pass needs only the weight set of its parity and two of
-// the four phase accumulators (32 registers), so the finished pass's pair stays in registers next to the running pass's pair at the
-// SAME register count — and its epilogue (one of four register groups per K stage: vector work + two stores) is independent of the
-// stage's matrix instructions, so the waves of a SIMD run one beside the other.  Price: the x tile is fetched once per pass (LDS-DMA
-// bytes x1.5) and eight barriers per tile instead of four.  No register load inside the loop (noise rows by LDS-DMA with the pass), so
-// the only vmcnt waits are the counted ones at the stage barriers.
-constexpr int RP_NW = 12;
-constexpr int RP_XP = UVCfg<RP_NW>::XPIECES;                  // 37
-constexpr int RP_PIECES = RP_XP + UV_WPIECES / 2;             // 55: x tile + ONE weight set
-constexpr int RP_STAGE = RP_PIECES * 1024;
-constexpr int RP_NPW = (RP_PIECES + RP_NW - 1) / RP_NW;       // 5
-constexpr int RP_TAB = 2 * RP_STAGE, RP_NZ = RP_TAB + UV_CST_MAX * 4;      // noise: [pass parity 2][wave 12][64] floats
-constexpr int RP_SMEM = RP_NZ + 2 * RP_NW * 256;              // 131072
-
-__global__ __launch_bounds__(64 * RP_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_f16s_upvb_rp_kernel(const UpVB p) {
-    constexpr int NW = RP_NW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const bool late = (wave >> 2) & 1;                       // waves 4-7: epilogue group after the stage's matrix instructions
-    const int ntile = p.tiles_x * p.tiles_y;
-    int it, it_end, it_step;
-    {
-        const int xcd = blockIdx.x & 7, q = p.total >> 3, r = p.total & 7;
-        const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        it = first + (int)(blockIdx.x >> 3);
-        it_end = first + q + (xcd < r ? 1 : 0);
-        it_step = (int)(gridDim.x >> 3);
-    }
-    if (it >= it_end) return;
-    const int nchunk = (p.K + 15) / 16;
-    const int Ho = 2 * p.H, Wo = 2 * p.W;
-    const long HWo = (long)Ho * Wo;
-    const long wchunk_bytes = (long)UV_WROWS * p.Mp * 16;
-    // ---- DMA state of the tile being requested: x piece offsets (per tile), weight piece offsets (set 0; the pass adds its set)
-    int lp[RP_NPW];                                           // once per workgroup: x piece r << 16 | c << 4 | s; weight piece 16-byte units
-#pragma unroll
-    for (int i = 0; i < RP_NPW; ++i) {
-        const int pc = wave + NW * i;
-        if (pc < RP_XP) {
-            int P = pc * 64 + lane;
-            if (P >= UVCfg<NW>::NPOS * 5) P = UVCfg<NW>::NPOS * 5 - 1;
-            const int pos = P / 5;
-            int sl = P % 5;
-            if (sl == 4) sl = 0;
-            lp[i] = (pos / UV_C) << 16 | (pos % UV_C) << 4 | sl;
-        } else {
-            const int u = (pc - RP_XP) * 64 + lane;           // 0..17 pieces of one set
-            lp[i] = (int)((long)(u / UV_MB) * p.Mp + u % UV_MB);
-        }
-    }
-    unsigned off[RP_NPW];
-    const unsigned char* xb_dma;
-    const float* nz_dma;                                     // this lane's noise element of row 2I of the tile being requested (clamped)
-    auto set_dma_tile = [&](int item) {
-        int w = item;
-        const int mblk_ = w % p.mblocks;
-        w /= p.mblocks;
-        const int tile_ = w % ntile, b_ = w / ntile;
-        const int r0_ = (tile_ / p.tiles_x) * NW, c0_ = (tile_ % p.tiles_x) * UV_STRIDE - 1, m0_ = mblk_ * UV_MB;
-#pragma unroll
-        for (int i = 0; i < RP_NPW; ++i) {
-            const int pc = wave + NW * i;
-            if (pc < RP_XP) {
-                const int r = lp[i] >> 16, c = (lp[i] >> 4) & 0xFFF, sl = lp[i] & 15;
-                const int rr = min(max(r0_ + r, 0), p.xd.Hp - 1), cc = min(max(c0_ + c, 0), p.xd.Wp - 1);
-                off[i] = (unsigned)(((rr * p.xd.Wp + cc) * 4 + sl) * 16);
-            } else {
-                off[i] = (unsigned)((lp[i] + m0_) * 16);
-            }
-        }
-        xb_dma = reinterpret_cast<const unsigned char*>(p.xs) + (long)b_ * p.xd.KC * p.xd.plane * 16;
-        const int I_ = min(r0_ + wave, p.H - 1), X_ = min(max(2 * c0_ + lane, 0), Wo - 1);
-        nz_dma = (p.noise ? p.noise + (long)(p.noise_batch > 1 ? b_ : 0) * HWo : p.kh) + (p.noise ? (long)(2 * I_) * Wo + X_ : 0);
-    };
-    auto dma_piece = [&](int t, int py, unsigned char* dst, int i) {
-        const int pc = wave + NW * i;
-        if (pc < RP_PIECES) {
-            const unsigned char* src = (pc < RP_XP ? xb_dma + (long)t * p.xd.plane * 16
-                                                   : reinterpret_cast<const unsigned char*>(p.wpk) + (long)py * p.wset_units * 16 + (long)t * wchunk_bytes) + off[i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
-        }
-    };
-    float* ctab = reinterpret_cast<float*>(smem + RP_TAB);
-    set_dma_tile(it);
-#pragma unroll
-    for (int i = 0; i < RP_NPW; ++i) dma_piece(0, 0, smem, i);
-    {
-        const int BM = p.B * p.M;
-        for (int i = tid; i < 2 * BM + p.M; i += 64 * NW) {
-            float v;
-            if (i < BM) v = p.out_scale ? p.out_scale[(long)(i / p.M) * p.out_scale_stride + i % p.M] : 1.f;
-            else if (i < 2 * BM) v = p.ys_scale ? p.ys_scale[(long)((i - BM) / p.M) * p.ys_scale_stride + (i - BM) % p.M] : 1.f;
-            else v = p.bias ? p.bias[i - 2 * BM] : 0.f;
-            ctab[i] = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0)
-    }
-    // constants of the epilogue (uniform)
-    const float kh0 = p.kh[0], kh1 = p.kh[1], kh2 = p.kh[2], kh3 = p.kh[3];
-    const bool lrelu = p.act == OODGAN_ACT_LRELU;
-    const float gsc = lrelu ? kSqrt2 : 1.f;
-    const float usg[2] = {p.unscale4[0] * gsc, p.unscale4[2] * gsc};
-    const float nwg = (p.noise ? (p.noise_w ? p.noise_w[0] : 1.f) : 0.f) * gsc;
-    const int KC = (p.M + 15) / 16;
-
-    f32x16 acc[2], prv[2];                                   // running pass / finished pass: column phases px = 0, 1 of one row parity
-    struct { int b, m0, I, J, py; bool ok; } T;              // the finished pass
-    T.b = 0; T.m0 = 0; T.I = 0; T.J = 0; T.py = 0; T.ok = false;
-    bool have_prev = false;
-    float vm = 0.f, tvm = 0.f;
-    int vb = -1;
-    int young = 0, gs = 0, ppar = 0;                         // ppar: parity of the running pass (noise buffer)
-
-    // one register group (4 g4 .. 4 g4 + 3 = four consecutive channels) of the finished pass: 2 stores
-    auto group = [&](int g4) {
-        const float* nzl = reinterpret_cast<const float*>(smem + RP_NZ) + ((ppar ^ 1) * NW + wave) * 64;
-        const float2 nzr = *reinterpret_cast<const float2*>(nzl + 2 * l31);
-        const float n0 = nzr.x * nwg, n1 = nzr.y * nwg;
-        const float* c_o = ctab + T.b * p.M + T.m0;
-        const float* c_y = ctab + p.B * p.M + T.b * p.M + T.m0;
-        const float* c_b = ctab + 2 * p.B * p.M + T.m0;
-        const float us = usg[T.py];
-        float o0[4], o1[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g4 + e;
-            const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float sc = c_o[cl] * us, bv = c_b[cl] * gsc, ys = fabsf(c_y[cl]);
-            const float v0 = prv[0][r] * sc, v1 = prv[1][r] * sc;
-            const float l1 = wave_dpp<0x138>(v1);
-            const float r0_ = wave_dpp<0x130>(v0);
-            const float r1_ = wave_dpp<0x130>(v1);
-            float y0 = kh0 * l1 + kh1 * v0 + kh2 * v1 + kh3 * r0_ + (n0 + bv);
-            float y1 = kh0 * v0 + kh1 * v1 + kh2 * r0_ + kh3 * r1_ + (n1 + bv);
-            if (lrelu) {
-                y0 = fmaxf(y0, 0.2f * y0);
-                y1 = fmaxf(y1, 0.2f * y1);
-            }
-            o0[e] = y0;
-            o1[e] = y1;
-            float mr = 0.f;
-            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(mr) : "v"(y0), "v"(y1));
-            tvm = fmaxf(tvm, mr * ys);
-        }
-        if (T.ok) {          // always two store instructions per wave whose row exists (the counted vmcnt relies on it)
-            const int mq = T.m0 + 8 * g4 + 4 * half;
-            const bool st = l31 >= 1 && l31 <= UV_STRIDE && 2 * T.J + 1 < Wo && T.J >= 0 && mq < p.M;
-            const int kc = min(mq, p.M - 1) >> 4, qd = (mq & 15) >> 2;
-            const int Jc = min(max(T.J, 0), p.W - 1);
-            float* dst = p.y + (long)T.b * KC * HWo * 16 + (((long)kc * Ho + 2 * T.I + T.py) * Wo + 2 * Jc) * 16 + 4 * qd;
-            if (st) {
-                *reinterpret_cast<float4*>(dst) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-                *reinterpret_cast<float4*>(dst + 16) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-            }
-        }
-    };
-    auto groups_of_stage = [&](int t) {
-        if (!have_prev || (UPVB_ABL & 4)) return;
-        const int ns = nchunk < 4 ? nchunk : 4;
-        if (t >= ns) return;
-        const int g_lo = (t * 4) / ns, g_hi = ((t + 1) * 4) / ns;
-        if (t == 0 && vb != T.b) {                           // (wave-uniform) the range maximum is recorded per sample
-            if (p.vmax && vb >= 0) record_vmax(p.vmax, vb, vm);
-            vm = 0.f;
-            vb = T.b;
-        }
-        for (int g4 = g_lo; g4 < g_hi; ++g4) {
-            switch (g4) {                                    // compile-time register indices
-                case 0: group(0); break;
-                case 1: group(1); break;
-                case 2: group(2); break;
-                default: group(3); break;
-            }
-            if (T.ok) young += 2;
-        }
-        if (t == ns - 1) {                                   // the pass is complete: mask the lanes outside its 60 columns once
-            const bool lane_ok = T.ok && l31 >= 1 && l31 <= UV_STRIDE && 2 * T.J + 1 < Wo && T.J >= 0;
-            vm = fmaxf(vm, lane_ok ? tvm : 0.f);
-            tvm = 0.f;
-        }
-    };
-    // 9 taps of one 16-channel chunk for the running pass's weight set (alone in this stage's buffer)
-    auto stage = [&](const unsigned char* lx) {
-        const unsigned char* lwh = lx + RP_XP * 1024 + (half * UV_MB + l31) * 16;
-        const unsigned char* lxh = lx + (wave * UV_C + l31) * UV_REC + half * 16;
-#define XFRAG(posoff, lo_) (*reinterpret_cast<const half8*>(lxh + (posoff) * UV_REC + (lo_) * 32))
-#define WFRAG(tap, lo_) (*reinterpret_cast<const half8*>(lwh + ((((tap) * 2 + (lo_)) * 2) * UV_MB) * 16))
-        half8 ah[2], al[2], bh[2], bl[2];                    // one x row (columns j-1, j) live at a time
-        ah[0] = WFRAG(0, 0);
-        al[0] = WFRAG(0, 1);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int kyp = i / 3, kx = i % 3, cur = i & 1;
-            if (kx == 0) {
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    bh[cc] = XFRAG(kyp * UV_C + cc, 0);
-                    bl[cc] = XFRAG(kyp * UV_C + cc, 1);
-                }
-            }
-            if (i + 1 < 9) {
-                ah[cur ^ 1] = WFRAG(i + 1, 0);
-                al[cur ^ 1] = WFRAG(i + 1, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[kx & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[1 - (kx >> 1)], acc[kx & 1], 0, 0, 0);
-            acc[kx & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[1 - (kx >> 1)], acc[kx & 1], 0, 0, 0);
-            acc[kx & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[1 - (kx >> 1)], acc[kx & 1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef XFRAG
-#undef WFRAG
-    };
-
-    for (;;) {
-        const int itn = it + it_step;
-        const bool has_next = itn < it_end;
-        int mblk, tile, b;
-        {
-            int w = it;
-            mblk = w % p.mblocks;
-            w /= p.mblocks;
-            tile = w % ntile;
-            b = w / ntile;
-        }
-        const int r0 = (tile / p.tiles_x) * NW, c0 = (tile % p.tiles_x) * UV_STRIDE - 1, m0 = mblk * UV_MB;
-        for (int py = 0; py < 2; ++py) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-            for (int t = 0; t < nchunk; ++t, ++gs) {
-                // counted wait: everything but the `young` newest operations (the stores of the previous stage's epilogue groups)
-                if (young == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
-                else if (young == 4) __builtin_amdgcn_s_waitcnt(0x0F74);
-                else if (young == 8) __builtin_amdgcn_s_waitcnt(0x0F78);
-                else __builtin_amdgcn_s_waitcnt(0x0F70);
-                __builtin_amdgcn_s_barrier();
-                young = 0;
-                // this pass's noise row, into the buffer of its parity (the finished pass reads the other one)
-                if (t == 0) {
-                    unsigned char* d = smem + RP_NZ + (ppar * NW + wave) * 256;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nz_dma + (p.noise ? (long)py * Wo : 0)), (lds_void*)d, 4, 0, 0);
-                }
-                // next stage: t + 1 of this pass, or the first stage of the next pass (the other parity of this tile, or the next tile)
-                const bool last = t + 1 == nchunk;
-                const bool next_tile = last && py == 1;
-                const bool pf = (!last || py == 0 || has_next) && !(UPVB_ABL & 2);
-                if (next_tile && has_next) set_dma_tile(itn);
-                const int tn = last ? 0 : t + 1, pyn = last ? (py ^ 1) : py;
-                unsigned char* nbuf = smem + ((gs + 1) & 1) * RP_STAGE;
-#pragma unroll
-                for (int i = 0; i < RP_NPW; ++i)
-                    if (pf) dma_piece(tn, pyn, nbuf, i);
-                if (!late) groups_of_stage(t);
-                if (!(UPVB_ABL & 1)) stage(smem + (gs & 1) * RP_STAGE);
-                if (late) groups_of_stage(t);
-            }
-            // the running pass becomes the finished one
-            prv[0] = acc[0];
-            prv[1] = acc[1];
-            T.b = b; T.m0 = m0; T.I = r0 + wave; T.J = c0 + l31; T.py = py; T.ok = r0 + wave < p.H;
-            have_prev = true;
-            ppar ^= 1;
-        }
-        if (!has_next) break;
-        it = itn;
-    }
-    // the last pass's epilogue
-    if (!(UPVB_ABL & 4)) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // its noise row has landed
-        if (vb != T.b) {
-            if (p.vmax && vb >= 0) record_vmax(p.vmax, vb, vm);
-            vm = 0.f;
-            vb = T.b;
-        }
-        group(0); group(1); group(2); group(3);
-        const bool lane_ok = T.ok && l31 >= 1 && l31 <= UV_STRIDE && 2 * T.J + 1 < Wo && T.J >= 0;
-        vm = fmaxf(vm, lane_ok ? tvm : 0.f);
-    }
-    if (p.vmax && vb >= 0) record_vmax(p.vmax, vb, vm);
-}
-
 // ---- tile form: one tile per NW-wave workgroup, ONE stage in LDS, several workgroups per CU cover each other's DMA waits and epilogues
 template <int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_f16s_upvb_tile_kernel(const UpVB p) {
@@ -743,7 +454,6 @@ static int upvb_num_cus() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_upvb_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, UVCfg<12>::SMEM_PERSIST) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_upvb_rp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RP_SMEM) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_upvb_tile_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, UVCfg<6>::SMEM_TILE) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_upvb_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, UVCfg<4>::SMEM_TILE) != hipSuccess)
             return 0;
@@ -770,7 +480,7 @@ extern "C" int oodgan_upconv_vblur_fform(const void* xs, const void* wpk2, long 
     OODGAN_REQUIRE(noise == nullptr || noise_batch == 1 || noise_batch == B, "upconv_vblur_fform: noise_batch");
     OODGAN_REQUIRE((wset_bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "upconv_vblur_fform: alignment");
     const int nw = (int)oodgan::tunable(oodgan::OODGAN_TUN_UPVB_WAVES);
-    OODGAN_REQUIRE(nw == 24 || nw == 12 || nw == 6 || nw == 4, "upconv_vblur_fform: tunable upvb_waves must be 24 (12 waves, row-parity passes), 12, 6 or 4");
+    OODGAN_REQUIRE(nw == 12 || nw == 6 || nw == 4, "upconv_vblur_fform: tunable upvb_waves must be 12, 6 or 4");
     UpVB p;
     p.xs = reinterpret_cast<const uint4*>(xs);
     p.xd = sform_dims(K, H, W);
@@ -782,8 +492,7 @@ extern "C" int oodgan_upconv_vblur_fform(const void* xs, const void* wpk2, long 
     p.ys_scale = ys_scale; p.ys_scale_stride = ys_scale_stride; p.vmax = vmax; p.y = y;
     p.B = B; p.K = K; p.M = M; p.H = H; p.W = W; p.act = act;
     p.tiles_x = (2 * W + 2 * UV_STRIDE - 1) / (2 * UV_STRIDE);
-    const int rows = nw == 24 ? 12 : nw;
-    p.tiles_y = (H + rows - 1) / rows;
+    p.tiles_y = (H + nw - 1) / nw;
     p.mblocks = M / UV_MB;
     p.Mp = (M + 63) / 64 * 64;
     const long total = (long)p.tiles_x * p.tiles_y * B * p.mblocks;
@@ -794,11 +503,7 @@ extern "C" int oodgan_upconv_vblur_fform(const void* xs, const void* wpk2, long 
     OODGAN_REQUIRE(upvb_num_cus() > 0, "upconv_vblur_fform: no device");
     oodgan::count_dispatch(oodgan::OODGAN_DC_UPVB);
     hipStream_t st = oodgan::as_stream(stream);
-    if (nw == 24) {
-        long per_xcd = (total + 7) / 8;
-        if (per_xcd > upvb_num_cus() / 8) per_xcd = upvb_num_cus() / 8 > 0 ? upvb_num_cus() / 8 : 1;
-        hipLaunchKernelGGL(conv_f16s_upvb_rp_kernel, dim3((unsigned)(8 * per_xcd)), dim3(64 * RP_NW), RP_SMEM, st, p);
-    } else if (nw == 12) {
+    if (nw == 12) {
         // persistent grid: one workgroup per CU, a multiple of 8 so that every XCD owns a contiguous chunk of tiles
         long per_xcd = (total + 7) / 8;
         if (per_xcd > upvb_num_cus() / 8) per_xcd = upvb_num_cus() / 8 > 0 ? upvb_num_cus() / 8 : 1;

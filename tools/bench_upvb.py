@@ -43,7 +43,7 @@ def timeit(fn, n=20):
 
 
 from oodgan import _lib  # noqa: E402
-for nwv in (24, 12, 6, 4):
+for nwv in (12, 6, 4):
     _lib.set_tunable('upvb_waves', nwv)
     t1 = timeit(lambda: ops.upconv_vblur_fform(xs, wvb, out_scale=d, bias=bias, noise=nz, noise_weight=nw, act=True, ys_scale=d, vmax=vm))
     print(f'lib {os.environ.get("OODGAN_LIB", "product")}: one pass, upvb_waves {nwv}: {t1:.1f} us', flush=True)
