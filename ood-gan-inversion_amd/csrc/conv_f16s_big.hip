@@ -62,7 +62,8 @@ struct BigConv {
 constexpr int BG_ZERO = BG_SMEM;                           // 3.5 KB of zeros (the B operand's second half of the lo*hi product of tap 8)
 constexpr int BG_ZBYTES = 3584;
 constexpr int BG_CST = BG_SMEM + BG_ZBYTES;                // [3][64] floats: out scale, bias, PReLU slope of the workgroup's channels
-constexpr int BG_SMEM16 = BG_CST + 3 * 64 * 4;             // 160000
+constexpr int BG_NZ = BG_CST + 3 * 64 * 4;                 // forward: the tile's 16 x 32 noise values, by LDS-DMA before the K loop (2 KB)
+constexpr int BG_SMEM16 = BG_NZ + 2048;                    // 162048
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifdef OODGAN_CLOCK_STAMP
@@ -212,6 +213,15 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         if (!DOT && a.bias) cst_b = a.bias[m];
         if (!DOT && a.act == OODGAN_ACT_PRELU) cst_s = a.slope[m];
     }
+    // Forward: the noise of this wave's two rows, one dword per lane (lanes 0-31 row 0, 32-63 row 1) from clamped pixels, straight into
+    // LDS with the first stage.  In the epilogue `if (ok) nz = noise[...]` was a branch around a load followed by its use, once per
+    // N-tile: four serialised round trips per tile in front of the stores (round 4: 620 -> see DESIGN 13.6 for the 512² layer).
+    const bool has_nz = !DOT && a.noise != nullptr;
+    if (has_nz) {
+        const int ry = min(r0 + wave * NT + (lane >> 5), H - 1), rx = min(c0 + (lane & 31), W - 1);
+        const float* src = a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W + (long)ry * W + rx;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(smem + BG_NZ + wave * 256), 4, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
     if (tid < 64) {
@@ -264,7 +274,6 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     // pixel (row nt = n >> 1, column 16*(n & 1) + n16): 64-byte runs per channel and store
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
     const float nw = (!DOT && a.noise) ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
-    const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * H * W : nullptr;
     float* red = reinterpret_cast<float*>(smem + BG_RED);
     float osc[16], bia[16], slp[16];
     unsigned moff[16], doff[16];
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         const int py = r0 + wave * NT + (n >> 1), px = c0 + 16 * (n & 1) + n16;
         const bool ok = py < H && px < W;
         float nz = 0.f;
-        if (!DOT && nzb && ok) nz = nw * nzb[(long)py * W + px];
+        if (has_nz) nz = nw * reinterpret_cast<const float*>(smem + BG_NZ)[wave * 64 + (n >> 1) * 32 + 16 * (n & 1) + n16];
         unsigned char* yr = reinterpret_cast<unsigned char*>(a.y) + ((long)b * M * p.out_plane + (long)py * a.out_pitch + px) * 4;
         const unsigned char* dr = DOT ? reinterpret_cast<const unsigned char*>(a.dotx) + ((long)b * M * H * W + (long)py * W + px) * 4 : nullptr;
         float o[16], dv[16];
