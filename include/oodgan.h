@@ -55,6 +55,9 @@ long oodgan_get_tunable(const char* name);
  * Returns -1 for an unknown name. */
 long oodgan_dispatch_count(const char* name);
 int oodgan_dispatch_reset(void);
+/* Zero `bytes` bytes of device memory on `stream` (hipMemsetAsync): the accumulators / atomic-max slots the kernels expect zeroed.  The
+ * host mirror uses it instead of torch.zeros inside the W+ loop, so that no torch kernel runs on the hot path. */
+int oodgan_zero(void* p, long bytes, void* stream);
 
 /* ------------------------------------------------------------------ L1 custom ops ---------- */
 

@@ -94,7 +94,17 @@ extern "C" int oodgan_dispatch_reset(void) {
     return OODGAN_OK;
 }
 
-extern "C" int oodgan_version(void) { return 104; }      // 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
+extern "C" int oodgan_zero(void* p, long bytes, void* stream) {
+    OODGAN_REQUIRE(p != nullptr && bytes >= 0, "zero: bad args");
+    if (bytes == 0) return OODGAN_OK;
+    if (hipMemsetAsync(p, 0, (size_t)bytes, oodgan::as_stream(stream)) != hipSuccess) {
+        oodgan::set_error("zero: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+        return OODGAN_E_LAUNCH;
+    }
+    return OODGAN_OK;
+}
+
+extern "C" int oodgan_version(void) { return 105; }      // 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;

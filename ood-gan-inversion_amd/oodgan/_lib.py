@@ -63,6 +63,7 @@ _SIGS = {
     'oodgan_get_tunable': (c_long, [c_char_p]),
     'oodgan_dispatch_count': (c_long, [c_char_p]),
     'oodgan_dispatch_reset': (c_int, []),
+    'oodgan_zero': (c_int, [P, c_long, P]),
     'oodgan_bias_act_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_int, c_float, c_float, P]),
     'oodgan_bias_act_bwd': (c_int, [P, P, P, P, c_int, c_int, c_long, c_float, c_float, P]),
     'oodgan_upfirdn2d': (c_int, [P, P, P] + [c_int] * 15 + [P]),

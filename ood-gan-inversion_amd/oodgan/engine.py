@@ -376,7 +376,7 @@ class GeneratorEngine:
         if sv is None:
             raise RuntimeError('backward() without forward(save=True)')
         acts, s_all, d_all, noises, B = sv['acts'], sv['s_all'], sv['d_all'], sv['noises'], sv['B']
-        gs_all = torch.zeros(B, self.R, device=self.device, dtype=torch.float32)
+        gs_all = ops.zeros(B, self.R, device=self.device)
         # gradient of the skip chain: gskip[res] for every ToRGB level
         gskip = {self.size: gimg.contiguous()}
         r = self.size

@@ -20,6 +20,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def zeros(*shape, device, dtype=torch.float32):
+    """A zeroed device tensor without a torch kernel: ``torch.empty`` + ``oodgan_zero`` (hipMemsetAsync on the current stream).  Used
+    for the accumulators of the W+ loop (torch tensors are containers only on the hot path)."""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    check(_lib.lib().oodgan_zero(_p(t), t.numel() * t.element_size(), _stream()), 'zero')
+    return t
+
+
 class Cols:
     """A column block [off, off+n) of a dense (B, R) matrix, passed by pointer + row stride (no copy)."""
 
@@ -412,7 +420,7 @@ def absmax_mul2(x):
     e = 0 for an all-zero or non-finite tensor."""
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
-    vm = torch.zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)     # float bit patterns, atomic max
+    vm = zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)     # float bit patterns, atomic max
     mul2 = torch.empty(2, device=x.device, dtype=torch.float32)
     L = _lib.lib()
     check(L.oodgan_absmax_scaled(_p(x), None, 0, _p(vm), B, C, x.numel() // (B * C), _stream()), 'absmax_scaled')
@@ -906,7 +914,7 @@ class ActBwdFusion:
         self.B, self.M = B, M
         self.part_r = torch.empty(B, M, ntile, device=dev, dtype=torch.float32)
         self.part_t = torch.empty(B, M, ntile, device=dev, dtype=torch.float32) if self.g_rgb is not None else None
-        self.part_m = torch.zeros(B * ntile * ((M + 63) // 64) * 8, device=dev, dtype=torch.float32)
+        self.part_m = zeros(B * ntile * ((M + 63) // 64) * 8, device=dev)
         z = _lib.ActBwdFuse()
         z.g_rgb, z.noise, z.noise_w, z.bias = _p(self.g_rgb), _p(self.noise), _p(self.noise_weight), _p(self.bias)
         self._w = None if self.w_rgb is None else _dev(self.w_rgb).reshape(3, M)
