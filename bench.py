@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline-events', action='store_true')
     ap.add_argument('--no-modconv', action='store_true', help='skip the fp16 modulated-conv roofline leg (BASELINE configs[4])')
-    ap.add_argument('--streams', type=int, default=3, help='independent sub-batches of the per-GPU batch advanced on separate HIP streams (DESIGN.md §10)')
+    ap.add_argument('--streams', type=int, default=2, help='independent sub-batches of the per-GPU batch advanced on separate HIP streams (DESIGN.md §10)')
     ap.add_argument('--roofline-steps', type=int, default=10, help='W+ steps of the exclusive single-stream pass that times the dominant kernel')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the extra leg that times the inversion including the e4e encoder')
     ap.add_argument('--no-forward-only', action='store_true', help="skip the leg that times the reference's own path: encoder + OOD forward, no W+ steps")

@@ -258,7 +258,7 @@ class ood_faceGAN_e4e(nn.Module):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
         latents (masks + blend).  Returns (out, lats, losses[steps,B]).
-        ``streams`` (opt-in; ``bench.py`` and the CLI's ``inversion.streams`` use 3): the W+ loop advances the batch as
+        ``streams`` (opt-in; ``bench.py`` uses 2, the CLI's ``inversion.streams`` sets it): the W+ loop advances the batch as
         that many independent sub-batches on concurrent HIP streams (images are independent; the HBM-bound layout
         kernels of one sub-batch run beside the matrix kernels of the other: +4 % at batch 8).  The
         default 1 keeps every kernel alone on the GPU: concurrent queues are only exact for kernels built without

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 SHORT="--wsteps 10 --steps 1 --warmup 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd --streams 1"
 rocprofv3 --kernel-trace -d $OUT/stats_s1 -o k -- python3 bench.py --streams 1 --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd > $OUT/bench_s1.json 2> $OUT/bench_s1.err
-rocprofv3 --kernel-trace -d $OUT/stats_s2 -o k -- python3 bench.py --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd > $OUT/bench_s3.json 2> $OUT/bench_s3.err
+rocprofv3 --kernel-trace -d $OUT/stats_s2 -o k -- python3 bench.py --no-cpu-baseline --no-modconv --no-single-stream --no-end-to-end --no-forward-only --no-generator-fwd > $OUT/bench_sN.json 2> $OUT/bench_sN.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_sq1.err
@@ -23,7 +23,7 @@ find $OUT -name "*.db" | head -20
 # keep summaries only (the merge back is limited to 64 MiB)
 python3 tools/rocpd_stats.py $OUT/stats_s1/k_results.db --csv $OUT/kernel_stats_streams1.csv
 python3 tools/rocpd_stats.py $OUT/stats_s1/k_results.db --per-grid --csv $OUT/kernel_stats_streams1_per_grid.csv
-python3 tools/rocpd_stats.py $OUT/stats_s2/k_results.db --csv $OUT/kernel_stats_streams3.csv
+python3 tools/rocpd_stats.py $OUT/stats_s2/k_results.db --csv $OUT/kernel_stats_streamsN.csv
 python3 tools/rocpd_stats.py $OUT/m2_stats/k_results.db --csv $OUT/m2_kernel_stats.csv
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write --csv $OUT/pmc_fetch_write.csv
 python3 tools/pmc_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm --csv $OUT/pmc_sq.csv
