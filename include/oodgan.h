@@ -55,7 +55,7 @@ long oodgan_get_tunable(const char* name);
  * Returns -1 for an unknown name. */
 long oodgan_dispatch_count(const char* name);
 int oodgan_dispatch_reset(void);
-/* Zero `bytes` bytes of device memory on `stream` (hipMemsetAsync): the accumulators / atomic-max slots the kernels expect zeroed.  The
+/* Zero `bytes` bytes of device memory on `stream` (a fill kernel — graph-capture safe, unlike a memset node here): the accumulators / atomic-max slots the kernels expect zeroed.  The
  * host mirror uses it instead of torch.zeros inside the W+ loop, so that no torch kernel runs on the hot path. */
 int oodgan_zero(void* p, long bytes, void* stream);
 
@@ -255,6 +255,10 @@ int oodgan_conv3x3_f16s_nparts(int mode, int Hin, int Win);   /* dot_nparts expe
 int oodgan_conv3x3_f16s_nparts2(int mode, int Hin, int Win, int x_sform);   /* same, for an S-form input */
 /* 1 when mode S2 with an S-form input of this shape accepts oodgan_conv_args.fuse (the 8-wave kernel of csrc/conv_f16s_s2big.hip) */
 int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, int Win);
+/* 1 when mode S2 with a PHASE-SPLIT S-form input of G*K channels accepts oodgan_conv_args.groups = G (K inputs per group, M = G*Mg outputs,
+ * Mg % 128 == 0): the 8-wave kernel, whose channel block picks its group's K channels; plain epilogue (bias / activation) only.
+ * Outputs of 8x8 and below (down to 1x1) with a workspace (oodgan_conv3x3_tiny_workspace) take groups too: the skinny-GEMM kernel. */
+int oodgan_conv3x3_s2_grouped_supported(int B, int K, int M, int groups, int Hin, int Win);
 /* 1 when mode S1 with an S-form input and dotx of this shape accepts oodgan_conv_args.dot_actgrad (strip / 8-wave kernels)
  * and oodgan_act_bwd_blurT_sform_phases(out = NULL) exists for the (H/2, W/2) layer below */
 int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);

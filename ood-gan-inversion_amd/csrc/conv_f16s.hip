@@ -467,7 +467,9 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
     OODGAN_REQUIRE(a.rgb_y == nullptr || (a.mode == OODGAN_CONV_S1 && a.x_sform), "conv3x3_f16s: fused ToRGB output only for mode S1 with S-form input");
     OODGAN_REQUIRE(a.fuse == nullptr || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.M >= 64),
                    "conv3x3_f16s: the fused activation backward exists only for mode S2 with S-form input and M >= 64");
-    OODGAN_REQUIRE(a.groups <= 1 || (a.mode == OODGAN_CONV_S2 && !a.x_sform), "conv3x3_f16s: groups > 1 only for mode S2 with fp32 NCHW input");
+    OODGAN_REQUIRE(a.groups <= 1 || (a.mode == OODGAN_CONV_S2 && (!a.x_sform || tiny_eligible(a) || s2_big_eligible(a))),
+                   "conv3x3_f16s: groups > 1 only for mode S2 with fp32 NCHW input, or a phase-split S-form input of a shape the 8-wave or the skinny-GEMM kernel "
+                   "takes (oodgan_conv3x3_s2_grouped_supported; oodgan_conv3x3_tiny_workspace > 0 with a workspace)");
     OODGAN_REQUIRE(!a.y_fform || (a.mode == OODGAN_CONV_S1 && a.x_sform && s1_strip_eligible(a)),
                    "conv3x3_f16s: the F-form output exists only in the strip kernel (mode S1, S-form input, 16 < K,M <= 32)");
     OODGAN_REQUIRE(!a.dot_actgrad || (a.mode == OODGAN_CONV_S1 && a.x_sform && a.dotx && (s1_strip_eligible(a) || s1_big_eligible(a))),

@@ -111,8 +111,11 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         const int c = q >> 2, s = ((q & 3) - ((c >> 2) & 3)) & 3;
         offx[i] = (unsigned)(((long)px * p.sp.plane + ((long)(r0 + row) * p.sp.Wq + (c0 + c)) * 4 + s) * 16);
     }
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + (long)b * p.sp.KC * 4 * p.sp.plane * 16;
     const long plane_bytes = p.sp.plane * 16;
+    // grouped convolution (oodgan_conv_args.groups, plain epilogue only): the channel block selects its group's K input channels
+    // of the G*K the S-form holds (p.sp.KC counts all of them)
+    const int grp = a.groups > 1 ? m0 / (M / a.groups) : 0;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.xs) + ((long)b * p.sp.KC + (long)grp * ((a.K + 15) / 16)) * 4 * plane_bytes;
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk16) + (long)m0 * 16;     // uniform; the lane adds lane16
     const unsigned lane16 = lane * 16;
     const long wchunk_bytes = (long)36 * p.Mp * 16;
@@ -561,6 +564,7 @@ bool s2_big_eligible(const oodgan_conv_args& a) {
         return false;
     // bias / activation: only in the plain (no dot, no fused backward) epilogue — the forward use by the encoder
     if ((a.bias != nullptr || a.act != OODGAN_ACT_NONE) && (a.dotx != nullptr || a.fuse != nullptr || a.y == nullptr)) return false;
+    if (a.groups > 1 && (a.dotx != nullptr || a.fuse != nullptr || a.K % 16 != 0 || a.M % a.groups != 0 || (a.M / a.groups) % 128 != 0)) return false;
     if (a.fuse) return true;                // the fused epilogue exists only here (the caller checked s2_fuse_supported)
     // enough 8x32 tiles x 64-channel blocks to fill the chip; the low-resolution layers keep their latency-oriented instance
     const int Hn = (a.Hin - 1) / 2, Wn = (a.Win - 1) / 2;
@@ -580,6 +584,13 @@ extern "C" int oodgan_conv3x3_s2_fuse_supported(int B, int K, int M, int Hin, in
     return (M % 32) == 0 && oodgan::s2_big_eligible(a) ? 1 : 0;
 }
 
+extern "C" int oodgan_conv3x3_s2_grouped_supported(int B, int K, int M, int groups, int Hin, int Win) {
+    oodgan_conv_args a = {};
+    a.mode = OODGAN_CONV_S2; a.x_sform = 1; a.B = B; a.K = K; a.M = M; a.Hin = Hin; a.Win = Win; a.groups = groups;
+    a.y = reinterpret_cast<float*>(1);
+    return groups > 1 && oodgan::s2_big_eligible(a) ? 1 : 0;
+}
+
 namespace oodgan {
 
 int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* unscale, hipStream_t st) {
@@ -591,7 +602,7 @@ int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     if (a.out_pitch == 0) a.out_pitch = p.Wout;
     p.out_plane = (long)p.Hout * a.out_pitch;
     p.xs = reinterpret_cast<const uint4*>(a.x);
-    p.sp = sp_dims2(a.K, p.Hout, p.Wout);
+    p.sp = sp_dims2(a.K * (a.groups > 1 ? a.groups : 1), p.Hout, p.Wout);
     p.w_unscale = unscale;
     p.tiles_y = (p.Hout + 7) / 8;
     p.tiles_x = (p.Wout + 31) / 32;

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else xb[nt] = ((long)b * p.sp.KC * 4) * p.sp.plane + ((long)y * p.sp.Wq + x) * 4;                           // G_ph[i + a][j + b]
     }
     const uint4* xs = reinterpret_cast<const uint4*>(a.x);
+    // grouped convolution (oodgan_conv_args.groups): the channel block selects its group's K/16 chunks of the G*K/16 the S-form holds
+    const int gk = a.groups > 1 ? (m0 / (a.M / a.groups)) * (a.K / 16) : 0;
     const int slot_hi = half, slot_lo = 2 + half;            // channels 8*half .. +7 of the 16-channel block: hi / lo slot
 
     // K steps of this wave: the workgroup's slice [ks*per, ...) cut in four
@@ -86,10 +88,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         alo = wb[(1 * 2 + half) * p.Mp];
         long off;
         if (MODE == OODGAN_CONV_S1) {
-            off = (long)kc * p.xd.plane + ((long)(tap / 3) * p.xd.Wp + (tap % 3)) * 4;
+            off = (long)(kc + gk) * p.xd.plane + ((long)(tap / 3) * p.xd.Wp + (tap % 3)) * 4;
         } else {
             const int ky = tap / 3, kx = tap % 3;
-            off = ((long)kc * 4 + (ky & 1) * 2 + (kx & 1)) * p.sp.plane + ((long)(ky >> 1) * p.sp.Wq + (kx >> 1)) * 4;
+            off = ((long)(kc + gk) * 4 + (ky & 1) * 2 + (kx & 1)) * p.sp.plane + ((long)(ky >> 1) * p.sp.Wq + (kx >> 1)) * 4;
         }
 #pragma unroll
         for (int nt = 0; nt < TY_NT; ++nt) {
@@ -187,13 +189,32 @@ __global__ __launch_bounds__(256) void conv_f16s_tiny_finish_kernel(const TinyAr
     const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
     float dsum = 0.f;
     const bool live = n0 < p.N && m < a.M;
-    {
+    if (p.H < 4) {
+        // 1x1 / 2x2 outputs (the last steps of the e4e style heads): a chunk of four positions spans rows or images — every position
+        // on its own; no noise, no dot (tiny_eligible)
+        if (m < a.M) {
+            const int pitch = a.out_pitch ? a.out_pitch : p.H;
+            const float bv = a.bias ? a.bias[m] : 0.f, sl = a.act == OODGAN_ACT_PRELU ? a.slope[m] : 0.2f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j;
+                if (n < p.N) {
+                    const int b = n / p.npix, pix = n % p.npix;
+                    float o = lo[cl * TY_OP + chunk * 4 + j] * us * (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) + bv;
+                    if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : sl * o;
+                    a.y[((long)b * a.M + m) * ((long)p.H * pitch) + (pix / p.H) * pitch + pix % p.H] = o;
+                }
+            }
+        }
+    } else {
         // every thread loads (clamped chunk and channel; the workspace as a valid address for an absent tensor), one round trip for
         // the four inputs; only live threads use and store
         const int n0c = min(n0, p.N - 4), mc = min(m, a.M - 1);
         const int b = n0c / p.npix, pix0 = n0c % p.npix;
         const float scl = *(a.out_scale ? a.out_scale + (long)b * a.out_scale_stride + mc : p.ws);
         const float bvl = *(a.bias ? a.bias + mc : p.ws);
+        const float slp = *(a.act == OODGAN_ACT_PRELU ? a.slope + mc : p.ws);
         const float4 nz4 = *reinterpret_cast<const float4*>(a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * p.npix + pix0 : p.ws);
         const float4 d4 = *reinterpret_cast<const float4*>(a.dotx ? a.dotx + ((long)b * a.M + mc) * p.npix + pix0 : p.ws);
         const float nw = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
@@ -210,6 +231,7 @@ __global__ __launch_bounds__(256) void conv_f16s_tiny_finish_kernel(const TinyAr
                 if (yb) {
                     float o = t * sc1 + (a.noise ? nw * nzv[j] : 0.f) + bv;
                     if (a.act == OODGAN_ACT_LRELU) o = (o > 0.f ? o : 0.2f * o) * kSqrt2;
+                    else if (a.act == OODGAN_ACT_PRELU) o = o > 0.f ? o : slp * o;
                     yb[py * pitch + px0 + j] = o;
                 }
             }
@@ -231,7 +253,9 @@ bool tiny_shape(const oodgan_conv_args& a, int& H) {
     else if (a.mode == OODGAN_CONV_S2) H = (a.Hin - 1) / 2;
     else return false;
     const int Wd = a.mode == OODGAN_CONV_S1 ? a.Win : (a.Win - 1) / 2;
-    return a.x_sform && H == Wd && (H == 4 || H == 8) && a.K % 16 == 0 && a.K >= 64 && a.M % 32 == 0 && a.B * H * H <= 16384;
+    // 1x1 / 2x2: only the stride-2 chains of the style heads end there (no noise, no dot: tiny_eligible)
+    return a.x_sform && H == Wd && (H == 4 || H == 8 || (a.mode == OODGAN_CONV_S2 && (H == 1 || H == 2))) && a.K % 16 == 0 && a.K >= 64 &&
+           a.M % 32 == 0 && a.B * H * H <= 16384;
 }
 
 }  // namespace
@@ -243,9 +267,11 @@ namespace oodgan {
 bool tiny_eligible(const oodgan_conv_args& a) {
     int H;
     return a.workspace != nullptr && tiny_shape(a, H) && a.ys == nullptr && a.rgb_y == nullptr && a.fuse == nullptr && !a.dot_actgrad &&
-           !a.y_fform && !a.x_fform && a.groups <= 1 && a.in_scale == nullptr && a.in_shift == nullptr &&
-           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU) && (a.y != nullptr || a.dotx != nullptr) &&
-           (a.dotx == nullptr || a.dot_nparts == 1);
+           !a.y_fform && !a.x_fform && a.in_scale == nullptr && a.in_shift == nullptr &&
+           (a.groups <= 1 || (a.mode == OODGAN_CONV_S2 && a.M % a.groups == 0 && (a.M / a.groups) % 32 == 0)) &&
+           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU || (a.act == OODGAN_ACT_PRELU && a.slope != nullptr)) &&
+           (a.y != nullptr || a.dotx != nullptr) && (a.dotx == nullptr || a.dot_nparts == 1) &&
+           (H >= 4 || (a.noise == nullptr && a.dotx == nullptr && a.y != nullptr));
 }
 
 static void tiny_split(const oodgan_conv_args& a, int H, int& ngroups, int& mblocks, int& KS) {
@@ -268,8 +294,9 @@ int launch_tiny(const oodgan_conv_args& a, const void* wpk16, const float* unsca
     tiny_split(a, H, p.ngroups, p.mblocks, p.KS);
     p.Mp = (a.M + 63) / 64 * 64;
     p.nsteps = 9 * (a.K / 16);
-    p.xd = sform_dims(a.K, a.Hin, a.Win);
-    p.sp = sp_dims_t(a.K, H, H);
+    const int G = a.groups > 1 ? a.groups : 1;
+    p.xd = sform_dims(a.K * G, a.Hin, a.Win);
+    p.sp = sp_dims_t(a.K * G, H, H);
     const long ntiles = (long)p.ngroups * p.mblocks;
     OODGAN_REQUIRE((p.nsteps + p.KS - 1) / p.KS <= 4 * TY_STEPS, "conv3x3 tiny: K split");
     OODGAN_REQUIRE(a.workspace_bytes >= ntiles * p.KS * (TY_NT * 16 * 64) * 4, "conv3x3 tiny: workspace too small (oodgan_conv3x3_tiny_workspace)");

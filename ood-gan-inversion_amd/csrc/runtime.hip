@@ -94,14 +94,29 @@ extern "C" int oodgan_dispatch_reset(void) {
     return OODGAN_OK;
 }
 
+namespace {
+// zero fill as a plain kernel: a hipMemsetAsync captured into a hipGraph did not reproduce the eager result on replay (the memset node
+// of this ROCm on private-pool memory; tests/test_encoder.py::test_graphed_forward_equals_eager) — a kernel node does
+__global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p, long bytes) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;        // bytes before the first 16-byte boundary
+    const long h = head < bytes ? head : bytes;
+    const long n16 = (bytes - h) >> 4;
+    if (i < n16) reinterpret_cast<uint4*>(p + h)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < h) p[i] = 0;
+    const long tail = h + (n16 << 4);
+    if (i < bytes - tail) p[tail + i] = 0;
+}
+}  // namespace
+
 extern "C" int oodgan_zero(void* p, long bytes, void* stream) {
     OODGAN_REQUIRE(p != nullptr && bytes >= 0, "zero: bad args");
     if (bytes == 0) return OODGAN_OK;
-    if (hipMemsetAsync(p, 0, (size_t)bytes, oodgan::as_stream(stream)) != hipSuccess) {
-        oodgan::set_error("zero: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
-        return OODGAN_E_LAUNCH;
-    }
-    return OODGAN_OK;
+    const long items = (bytes >> 4) + 16;
+    OODGAN_REQUIRE((items + 255) / 256 < (1L << 31), "zero: too large");
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, oodgan::as_stream(stream),
+                       reinterpret_cast<unsigned char*>(p), bytes);
+    return oodgan::check_launch("zero");
 }
 
 extern "C" int oodgan_version(void) { return 105; }      // 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep

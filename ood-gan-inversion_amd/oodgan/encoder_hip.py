@@ -16,6 +16,8 @@ The encoder runs once per image at 256² and is not part of the measured loop.""
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import _lib, ops, samm
@@ -63,16 +65,29 @@ class _Packed:
         return self.val
 
 
+HEADS_TINY = int(os.environ.get('OODGAN_HEADS_TINY', '1'))
+HEADS_TINY_MAX_OUT = int(os.environ.get('OODGAN_HEADS_TINY_MAX_OUT', '8'))
+HEADS_SFORM_MIN_IN = int(os.environ.get('OODGAN_HEADS_SFORM_MIN_IN', '16'))      # grouped head steps with input maps of at least this size go through the S-form (A/B: tools/forward_only.py)
+
+
 def _conv3x3(x, pk, M, stride=1, **kw):
     if stride == 1:
         return ops.conv3x3(x, pk, M, CONV_S1, **kw)
     assert stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
     xp, pitch = _pad_tl(x)
     B, K, H, W = x.shape
-    if kw.get('groups', 1) == 1 and 'in_scale' not in kw and ops.s2_fuse_supported(B, K, M, H + 1, W + 1):
-        # enough work for the 8-wave stride-2 kernel (the stacked first convs of the style heads: 512 -> 11 x 512 channels at
-        # 64² -> 32²): phase-split S-form of the padded input with a measured power-of-two range scale, bias + slope in the
-        # kernel's epilogue.  The fp32-input kernel ran this conv at 105 TFLOP/s (4.0 ms at batch 8).
+    G = kw.get('groups', 1)
+    tiny = HEADS_TINY and min(H, W) // 2 <= HEADS_TINY_MAX_OUT and ops.tiny_workspace_bytes(CONV_S2, B, K // G, M, H + 1, W + 1) > 0
+    big = ops.s2_fuse_supported(B, K, M, H + 1, W + 1) if G == 1 else \
+        (min(H, W) >= HEADS_SFORM_MIN_IN and ops.s2_grouped_supported(B, K // G, M, G, H + 1, W + 1))
+    if 'in_scale' not in kw and (tiny or big):
+        # through the phase-split S-form (measured power-of-two range scale; bias + slope in the kernel's epilogue):
+        #  * enough work for the 8-wave stride-2 kernel — the stacked first convs of the style heads (512 -> 11 x 512 channels at
+        #    64² -> 32²) and the grouped steps that follow while the maps fill a useful part of its 8 x 32 tile.  The fp32-input kernel
+        #    ran the stacked conv at 105 TFLOP/s (4.0 ms at batch 8);
+        #  * outputs of 8 x 8 and below: the skinny-GEMM kernel (conv_f16s_tiny.hip) — all images' positions packed into the N tiles,
+        #    K split over the chip, every weight read once per 128 positions.  The fp32-input kernel spent 0.83 ms on each of the
+        #    4² / 2² / 1² steps of the 18 heads at batch 8 (170 MB of weights per step, re-streamed by every image's workgroups).
         mul2 = ops.absmax_mul2(x)
         gp = ops.to_sform_phases(xp, H // 2, W // 2, mul2=mul2, in_pitch=pitch,
                                  out=ops.sform_phases_scratch(B, K, H // 2, W // 2, x.device))

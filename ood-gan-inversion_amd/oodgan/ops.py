@@ -21,7 +21,7 @@ def _stream():
 
 
 def zeros(*shape, device, dtype=torch.float32):
-    """A zeroed device tensor without a torch kernel: ``torch.empty`` + ``oodgan_zero`` (hipMemsetAsync on the current stream).  Used
+    """A zeroed device tensor without a torch kernel: ``torch.empty`` + ``oodgan_zero`` (a fill kernel of the library on the current stream).  Used
     for the accumulators of the W+ loop (torch tensors are containers only on the hot path)."""
     t = torch.empty(*shape, device=device, dtype=dtype)
     check(_lib.lib().oodgan_zero(_p(t), t.numel() * t.element_size(), _stream()), 'zero')
@@ -780,7 +780,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
-    packed weight G*Mg output channels of K inputs (mode S2, fp32 input)."""
+    packed weight G*Mg output channels of K inputs (mode S2; fp32 input, or phase-split S-form where ``s2_grouped_supported``)."""
     sform_in = isinstance(x, (SForm, SFormPhases))
     fform_in = isinstance(x, FForm)      # split-f16 strip kernel with in-kernel conversion (include/oodgan.h, x_fform)
     if fform_in:
@@ -880,6 +880,16 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
 
 def s2_fuse_supported(B, K, M, Hin, Win):
     return bool(_lib.lib().oodgan_conv3x3_s2_fuse_supported(B, K, M, Hin, Win))
+
+
+def tiny_workspace_bytes(mode, B, K, M, Hin, Win):
+    """> 0 when the skinny-GEMM kernel (outputs of 8 x 8 and below) takes an S-form input of this shape; K per group."""
+    return int(_lib.lib().oodgan_conv3x3_tiny_workspace(mode, B, K, M, Hin, Win)) if USE_TINY else 0
+
+
+def s2_grouped_supported(B, K, M, groups, Hin, Win):
+    """mode S2 with ``groups`` > 1 takes a phase-split S-form input (K channels per group, M = groups * Mg outputs)."""
+    return bool(_lib.lib().oodgan_conv3x3_s2_grouped_supported(B, K, M, groups, Hin, Win))
 
 
 def s1_actgrad_supported(B, K, M, H, W):

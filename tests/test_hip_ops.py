@@ -526,6 +526,35 @@ def test_conv3x3_s2_grouped(dev, B, G, K, Mg, H, W):
         ops.conv3x3(xp.to(dev), wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, groups=G * 4)
 
 
+@pytest.mark.parametrize('B,G,K,Mg,H,W', [(2, 3, 64, 128, 20, 20), (1, 5, 48, 128, 8, 20), (2, 2, 32, 256, 34, 32)])
+def test_conv3x3_s2_grouped_sform(dev, B, G, K, Mg, H, W, tunable):
+    """The grouped stride-2 conv on the 8-wave kernel (round 4): phase-split S-form of all G*K input channels, every channel block
+    of the kernel reading its own group's K channels.  Same result as the fp32-input grouped kernel to rounding, dispatch counted."""
+    import torch.nn.functional as F
+    from oodgan import _lib, ops
+    tunable('s2_big_min_items', 0)
+    x = synth.normal('grs.x', (B, G * K, H, W), 1, 20.0)
+    w = synth.normal('grs.w', (G * Mg, K, 3, 3), 2, 1.0 / math.sqrt(K * 9))
+    bias = synth.normal('grs.b', (G * Mg,), 3)
+    slope = synth.normal('grs.sl', (G * Mg,), 4, 0.05, 0.1)
+    ref = F.prelu(F.conv2d(x, w, bias, stride=2, padding=1, groups=G), slope)
+    pitch = (W + 1 + 3) // 4 * 4
+    xp = torch.zeros(B, G * K, H + 1, pitch)
+    xp[:, :, 1:, 1:W + 1] = x
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    assert ops.s2_grouped_supported(B, K, G * Mg, G, H + 1, W + 1)
+    assert not ops.s2_grouped_supported(B, K, G * 64, G, H + 1, W + 1)            # Mg % 128
+    mul2 = ops.absmax_mul2(x.to(dev))
+    gp = ops.to_sform_phases(xp.to(dev), H // 2, W // 2, mul2=mul2, in_pitch=pitch)
+    _lib.dispatch_reset()
+    y = ops.conv3x3(gp, wpk, G * Mg, ops.CONV_S2, bias=bias.to(dev), in_mul2=mul2, act=ops.ACT_PRELU, slope=slope.to(dev), groups=G)
+    assert _lib.dispatch_count('s2big') == 1
+    close(y, ref, 2e-5)
+    y2 = ops.conv3x3(xp.to(dev), wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, bias=bias.to(dev), act=ops.ACT_PRELU,
+                     slope=slope.to(dev), groups=G)
+    assert (y - y2).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('B,K,M,H,W,act', [(2, 64, 128, 16, 32, 'prelu'), (1, 48, 192, 10, 40, 'lrelu'), (2, 32, 64, 24, 34, 'none')])
 def test_conv3x3_s2_big_kernel_forward_use(dev, B, K, M, H, W, act, tunable):
     """The 8-wave stride-2 kernel as a FORWARD conv (nn.Conv2d(K, M, 3, stride 2, padding 1) of the e4e encoder's

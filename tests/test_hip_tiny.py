@@ -83,3 +83,39 @@ def test_stride2_input_gradient_of_the_up_conv(B, Cg, Cx, H):
     gp = ops.to_sform_phases(g2, H, H, d, mul2, in_pitch=P2)
     (dx0, dot0), (dx1, dot1) = _both(lambda: ops.conv3x3(gp, wb, Cx, ops.CONV_S2, out_scale=s, dotx=x, in_mul2=mul2))
     assert _rel(dx1, dx0) < 5e-6 and _rel(dot1, dot0) < 1e-5       # another order of the 4608-term fp32 sums (K split 8-18 ways)
+
+
+@pytest.mark.parametrize('B,G,K,Mg,Ho', [(8, 3, 64, 64, 4), (8, 18, 128, 32, 1), (1, 4, 64, 96, 2), (3, 5, 96, 64, 8), (2, 2, 512, 512, 1),
+                                         (5, 1, 64, 64, 2)])
+def test_stride2_grouped_forward_down_to_1x1(B, G, K, Mg, Ho):
+    """Round 4: the style heads of the e4e encoder (GradualStyleBlock, psp_encoders.py:14-34 — chains of Conv2d(512, 512, 3, 2, 1) +
+    LeakyReLU(0.01) down to 1x1, all heads as one grouped conv per step) on the skinny-GEMM kernel: groups, PReLU slopes and bias in the
+    finishing pass, 2x2 and 1x1 outputs — against nn.functional.conv2d(groups=G) and against the fp32-input grouped kernel."""
+    import torch.nn.functional as F
+    from oodgan import _lib, ops
+    dev = torch.device('cuda:0')
+    H = 2 * Ho
+    g = torch.Generator().manual_seed(B * 1000 + G * 10 + Ho)
+    x = (20.0 * torch.randn(B, G * K, H, H, generator=g))
+    w = torch.randn(G * Mg, K, 3, 3, generator=g) / math.sqrt(K * 9)
+    bias = torch.randn(G * Mg, generator=g)
+    slope = 0.05 + 0.1 * torch.rand(G * Mg, generator=g)
+    ref = F.prelu(F.conv2d(x, w, bias, stride=2, padding=1, groups=G), slope)
+    pitch = (H + 1 + 3) // 4 * 4
+    xp = torch.zeros(B, G * K, H + 1, pitch)
+    xp[:, :, 1:, 1:H + 1] = x
+    xp = xp.to(dev)
+    wpk = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    assert ops.tiny_workspace_bytes(ops.CONV_S2, B, K, G * Mg, H + 1, H + 1) > 0
+    mul2 = ops.absmax_mul2(x.to(dev))
+    gp = ops.to_sform_phases(xp, Ho, Ho, mul2=mul2, in_pitch=pitch)
+    kw = dict(bias=bias.to(dev), act=ops.ACT_PRELU, slope=slope.to(dev), groups=G)
+    _lib.dispatch_reset()
+    y = ops.conv3x3(gp, wpk, G * Mg, ops.CONV_S2, in_mul2=mul2, **kw)
+    assert _lib.dispatch_count('tiny') == 1
+    assert y.shape == ref.shape
+    assert _rel(y.cpu(), ref) < 2e-5
+    if Mg % 64 == 0:
+        y2 = ops.conv3x3(xp, wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, H + 1), in_pitch=pitch, **kw)      # fp32-input grouped kernel
+        assert _rel(y, y2) < 2e-5
+    assert torch.equal(ops.conv3x3(gp, wpk, G * Mg, ops.CONV_S2, in_mul2=mul2, **kw), y)

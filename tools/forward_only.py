@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--streams', type=int, default=3)
     ap.add_argument('--wsteps', type=int, default=100)
+    ap.add_argument('--only-full', action='store_true', help='skip the B=1 leg (kernel statistics of the full batch alone)')
     a = ap.parse_args()
     import bench
     from oodgan import synth
@@ -32,7 +33,7 @@ def main():
     x = torch.cat([synth.make_images(a.size, 1, seed=1000 + g) for g in range(a.batch)]).to(dev)
     per = [synth.make_noises(a.size, 1, seed=2000 + g) for g in range(a.batch)]
     noises = [torch.cat([n[i] for n in per]).to(dev) for i in range(17)]
-    r = bench.forward_only(a, m, x, noises, reps=a.reps)
+    r = bench.forward_only(a, m, x, noises, reps=a.reps, only_full=a.only_full)
     print(json.dumps(r[f'b{a.batch}']))
 
 
