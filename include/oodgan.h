@@ -262,6 +262,9 @@ int oodgan_conv3x3_s2_grouped_supported(int B, int K, int M, int groups, int Hin
 /* 1 when mode S1 with an S-form input and dotx of this shape accepts oodgan_conv_args.dot_actgrad (strip / 8-wave kernels)
  * and oodgan_act_bwd_blurT_sform_phases(out = NULL) exists for the (H/2, W/2) layer below */
 int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, int W);
+/* 1 when mode S1 with an S-form input of this shape writes `ys` from the 8-wave kernel's registers; `y` may then be NULL (only the S-form
+ * of the activated output x ys_scale is produced: conv -> activation -> conv chains without the fp32 tensor in between) */
+int oodgan_conv3x3_s1_ys_supported(int B, int K, int M, int H, int W);
 /* oodgan_conv_args.x_fform: 1 when the shape is supported, and the number of partial sums per (sample, channel) that the
  * x_fform == 2 instance writes to fuse->part_r / part_t (per (sample, 16-channel block) to fuse->part_max) */
 int oodgan_conv3x3_xf_supported(int B, int K, int M, int H, int W);

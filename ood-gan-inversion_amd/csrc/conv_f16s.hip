@@ -450,6 +450,14 @@ extern "C" int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, i
     return (s1_strip_eligible(a) || s1_big_eligible(a)) && oodgan_act_bwd_blurT_pre_supported(H / 2, W / 2) && !(H & 1) && !(W & 1) ? 1 : 0;
 }
 
+// 1 when mode S1 with an S-form input of this shape writes oodgan_conv_args.ys from the 8-wave kernel's registers (y may then be NULL)
+extern "C" int oodgan_conv3x3_s1_ys_supported(int B, int K, int M, int H, int W) {
+    oodgan_conv_args a = {};
+    a.mode = OODGAN_CONV_S1; a.x_sform = 1; a.B = B; a.K = K; a.M = M; a.Hin = H; a.Win = W;
+    a.ys = reinterpret_cast<void*>(1);
+    return s1_big_eligible(a) ? 1 : 0;
+}
+
 extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* unscale2, void* stream) {
     OODGAN_REQUIRE(args != nullptr, "conv3x3_f16s: null args");
     const oodgan_conv_args& a = *args;

@@ -41,6 +41,7 @@ struct BigConv {
     const float* w_unscale;
     int tiles_x, tiles_y, mblocks, Mp;
     long out_plane;
+    SDims yd;                // YS instance: S-form of the (M, H, W) output
 };
 
 // The matrix instruction is v_mfma_f32_16x16x32_f16: under a dense MFMA stream the chip holds a higher clock with this shape
@@ -74,7 +75,11 @@ __device__ unsigned long long* g_s1big_stamp = nullptr;
 __device__ long g_s1big_stamp_n = 0;
 #endif
 
-template <bool DOT, bool PRE>
+// YS (forward only, oodgan_conv_args.ys): the activated output x ys_scale[b,m] is ALSO (y != NULL) or ONLY (y == NULL) written as the
+// S-form input of the next conv — lane (n16, g) holds channels 4g .. 4g+3 of a 16-channel block of its pixel: 8 bytes of the hi slot
+// and 8 bytes of the lo slot of that pixel's record, 16 lanes = 16 consecutive records (SAMM's AlignNet: conv -> PReLU -> conv
+// without the fp32 tensor, its range measurement and its conversion pass in between)
+template <bool DOT, bool PRE, bool YS = false>
 __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, const uint4* __restrict__ wpk16) {
     constexpr int NW = 8, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -292,6 +297,14 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         dsum[q] = 0.f;
     }
     const bool mfull = m0 + 64 <= M;
+    float ysc[16];
+    if (YS) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + 16 * (q >> 2) + 4 * g + (q & 3);
+            ysc[q] = a.ys_scale ? a.ys_scale[(long)b * a.ys_scale_stride + min(m, M - 1)] : 1.f;
+        }
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int py = r0 + wave * NT + (n >> 1), px = c0 + 16 * (n & 1) + n16;
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
                 else if (prelu) o[q] = o[q] > 0.f ? o[q] : slp[q] * o[q];
             }
         }
-        if (ok) {
+        if (ok && (!YS || a.y != nullptr)) {
             if (mfull) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) *reinterpret_cast<float*>(yr + moff[q]) = o[q];
@@ -336,6 +349,19 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (moff[q] != 0xFFFFFFFFu) *reinterpret_cast<float*>(yr + moff[q]) = o[q];
+            }
+        }
+        if (YS && !DOT && ok) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (m0 + 16 * mt < M) {          // M % 16 == 0 (s1_big_eligible)
+                    uint2 hi, lo;
+                    split_pair(o[4 * mt] * ysc[4 * mt], o[4 * mt + 1] * ysc[4 * mt + 1], hi.x, lo.x);
+                    split_pair(o[4 * mt + 2] * ysc[4 * mt + 2], o[4 * mt + 3] * ysc[4 * mt + 3], hi.y, lo.y);
+                    unsigned char* rec = reinterpret_cast<unsigned char*>(a.ys) + sform_unit(p.yd, b, (m0 >> 4) + mt, py, px, g >> 1) * 16 + (g & 1) * 8;
+                    *reinterpret_cast<uint2*>(rec) = hi;
+                    *reinterpret_cast<uint2*>(rec + 32) = lo;
+                }
             }
         }
     }
@@ -377,7 +403,7 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
     // ~458 us for either v2 instance.  (The dot epilogue first cost 561 us: one conditional load per value serialised
     // 64 memory latencies; the loads of a row are now issued together.)
     const int min_k = 64;                // 64 -> 64 channels @512²: 589 -> 491 us forward
-    if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && a.ys == nullptr && a.y != nullptr &&
+    if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && (a.ys == nullptr ? a.y != nullptr : (a.dotx == nullptr && a.M % 16 == 0 && a.rgb_y == nullptr)) &&
           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU || (a.act == OODGAN_ACT_PRELU && a.slope)) && a.in_scale == nullptr &&
           a.in_shift == nullptr &&
           !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))
@@ -402,6 +428,7 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     p.tiles_x = (a.Win + 31) / 32;
     p.Mp = (a.M + 63) / 64 * 64;
     p.mblocks = (a.M + 63) / 64;
+    p.yd = sform_dims(a.M, a.Hin, a.Win);
     if (a.dotx) {
         OODGAN_REQUIRE(a.dot_part != nullptr, "conv3x3: dotx without dot_part");
         OODGAN_REQUIRE(a.dot_nparts == ((a.Hin + 7) / 8) * p.tiles_x, "conv3x3 f16s S1: dot_nparts %d != %d", a.dot_nparts,
@@ -412,7 +439,8 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     OODGAN_REQUIRE(total > 0 && total < (1L << 31), "conv3x3: grid too large");
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (a 4-wave variant was slower than the
@@ -420,6 +448,7 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     OODGAN_REQUIRE(!a.dot_actgrad || a.dotx, "conv3x3 big: dot_actgrad without dotx");
     if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    else if (a.ys) hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     return check_launch("conv3x3_f16s_s1big");
 }

@@ -84,6 +84,7 @@ _SIGS = {
     'oodgan_conv3x3_f16s_nparts': (c_int, [c_int, c_int, c_int]),
     'oodgan_conv3x3_f16s_nparts2': (c_int, [c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_s2_fuse_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'oodgan_conv3x3_s1_ys_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_s2_grouped_supported': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_s1_actgrad_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_sform_bytes': (c_long, [c_int, c_int, c_int, c_int]),

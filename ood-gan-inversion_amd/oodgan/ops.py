@@ -887,6 +887,11 @@ def tiny_workspace_bytes(mode, B, K, M, Hin, Win):
     return int(_lib.lib().oodgan_conv3x3_tiny_workspace(mode, B, K, M, Hin, Win)) if USE_TINY else 0
 
 
+def s1_ys_supported(B, K, M, H, W):
+    """mode S1 with an S-form input writes ``ys`` from the 8-wave kernel (``want_y=False``: nothing but the S-form is produced)."""
+    return bool(_lib.lib().oodgan_conv3x3_s1_ys_supported(B, K, M, H, W))
+
+
 def s2_grouped_supported(B, K, M, groups, Hin, Win):
     """mode S2 with ``groups`` > 1 takes a phase-split S-form input (K channels per group, M = groups * Mg outputs)."""
     return bool(_lib.lib().oodgan_conv3x3_s2_grouped_supported(B, K, M, groups, Hin, Win))

@@ -555,6 +555,47 @@ def test_conv3x3_s2_grouped_sform(dev, B, G, K, Mg, H, W, tunable):
     assert (y - y2).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('B,K,M,H,W,both', [(2, 64, 64, 16, 32, True), (1, 128, 96, 20, 40, False), (2, 64, 80, 9, 33, True), (1, 64, 128, 32, 64, False)])
+def test_conv3x3_s1_big_kernel_sform_output(dev, B, K, M, H, W, both, tunable):
+    """Round 4: the 8-wave stride-1 kernel writes the NEXT conv's S-form input from its registers (oodgan_conv_args.ys; y optional) —
+    AlignNet's conv -> PReLU -> conv (SAMM/helpers.py:96-109 through e4e helpers.py:426-448) without the fp32 tensor in between.
+    Bit-identical to converting the kernel's own fp32 output; the chained second conv against torch."""
+    import torch.nn.functional as F
+    from oodgan import _lib, ops
+    tunable('s1_big_min_items', 0)
+    assert ops.s1_ys_supported(B, K, M, H, W)
+    x = synth.normal('ys.x', (B, K, H, W), 1)
+    w1 = synth.normal('ys.w1', (M, K, 3, 3), 2, 1.0 / math.sqrt(K * 9))
+    w2 = synth.normal('ys.w2', (M, M, 3, 3), 3, 1.0 / math.sqrt(M * 9))
+    slope = synth.normal('ys.sl', (M,), 4, 0.05, 0.1)
+    bias = synth.normal('ys.b', (M,), 5)
+    e = 9
+    ysc = torch.full((B, M), 2.0 ** e)
+    ysc[:, ::3] *= 2.0                                        # per-channel scales are honoured (the second conv un-scales by hand below)
+    mul2 = torch.tensor([2.0 ** -e, 2.0 ** e])
+    xs = ops.to_sform(x.to(dev))
+    p1, p2 = ops.pack_conv3x3(w1.to(dev), precision='f16s'), ops.pack_conv3x3(w2.to(dev), precision='f16s')
+    kw = dict(bias=bias.to(dev), act=ops.ACT_PRELU, slope=slope.to(dev))
+    y = ops.conv3x3(xs, p1, M, ops.CONV_S1, **kw)                                  # plain instance
+    ref1 = F.prelu(F.conv2d(x, w1, bias, padding=1), slope)
+    close(y, ref1, 2e-5)
+    want = ops.to_sform(y, ysc.to(dev))
+    ys = ops.SForm(B, M, H, W, dev)
+    _lib.dispatch_reset()
+    out = ops.conv3x3(xs, p1, M, ops.CONV_S1, ys=ys, ys_scale=ysc.to(dev), want_y=both, **kw)
+    assert _lib.dispatch_count('s1big') == 1
+    assert torch.equal(ys.data, want.data)
+    if both:
+        assert torch.equal(out, y)
+    else:
+        assert out is None
+    # the chain: second conv on the S-form written by the first (uniform scale here, undone by in_mul2)
+    ysu = torch.full((B, M), 2.0 ** e)
+    ops.conv3x3(xs, p1, M, ops.CONV_S1, ys=ys, ys_scale=ysu.to(dev), want_y=False, **kw)
+    z = ops.conv3x3(ys, p2, M, ops.CONV_S1, in_mul2=mul2.to(dev))
+    close(z, F.conv2d(ref1, w2, padding=1), 2e-5)
+
+
 @pytest.mark.parametrize('B,K,M,H,W,act', [(2, 64, 128, 16, 32, 'prelu'), (1, 48, 192, 10, 40, 'lrelu'), (2, 32, 64, 24, 34, 'none')])
 def test_conv3x3_s2_big_kernel_forward_use(dev, B, K, M, H, W, act, tunable):
     """The 8-wave stride-2 kernel as a FORWARD conv (nn.Conv2d(K, M, 3, stride 2, padding 1) of the e4e encoder's
