@@ -522,6 +522,9 @@ int oodgan_instnorm_coeffs(const float* stats, const float* gamma, const float* 
 /* y = x*sc[b,c] + sh[b,c] (+ res) */
 int oodgan_affine_apply(const float* x, const float* sc, const float* sh, const float* res, float* y,
                         int B, int C, long HW, void* stream);
+/* oodgan_affine_apply followed by oodgan_instnorm_stats of its result (bit-identical statistics), in one pass: stats (B, C, 2) */
+int oodgan_affine_apply_stats(const float* x, const float* sc, const float* sh, const float* res, float* y, float* stats, int B, int C,
+                              long HW, float eps, void* stream);
 /* AlignNet input (diff_fAndg=True, src/ops/SAMM/helpers.py:97-100):
  * out[:, :C] = IN(gen) - IN(enc), out[:, C:] = IN(enc); stats from oodgan_instnorm_stats */
 int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc,
@@ -545,6 +548,10 @@ int oodgan_conv3x3_small(const float* x, const float* w, const float* in_sc, con
 int oodgan_conv3x3_fewout_ksplit(int B, int K, int H, int W);
 int oodgan_conv3x3_fewout(const float* x, const float* w, const float* in_sc, const float* in_sh, const float* slope,
                           float* part, float* y, int B, int K, int M, int H, int W, void* stream);
+/* The same conv from a (K, 9, 4) transposed copy of the weight (K % 8 == 0), optionally together with the 1x1 conv of the same bottleneck's
+ * shortcut (w11t (K, 4): (M2 <= 4, K) transposed, applied to the RAW x; y2 (B, M2, H, W), part2 like part) in one pass over x. */
+int oodgan_conv3x3_fewout2(const float* x, const float* wt, const float* w11t, const float* in_sc, const float* in_sh, const float* slope,
+                           float* part, float* part2, float* y, float* y2, int B, int K, int M, int M2, int H, int W, void* stream);
 /* AlignNet head (helpers.py:104-107): ch0,1 -> tanh*scale ; ch2 -> sigmoid */
 int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream);
 /* SPM_Warp.add / upsample_add (helpers.py:129-147) with new_PRM (:62-77):

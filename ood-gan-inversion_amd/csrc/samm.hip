@@ -87,6 +87,79 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
         y[base + i] = x[base + i] * a + b + (res ? res[base + i] : 0.f);
 }
 
+// y = x*sc + sh + res (the InstanceNorm + shortcut sum that ends a bottleneck) AND the InstanceNorm statistics of y for the
+// bottleneck that follows, in one pass: one block per (b,c) plane, the sums in the order of instnorm_stats_kernel (bit-identical
+// statistics); the second moment re-reads the thread's own y values (L2).  Saves the statistics pass over the 2C-channel tensor.
+__global__ __launch_bounds__(256) void affine_apply_stats_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                                 const float* __restrict__ sh, const float* __restrict__ res,
+                                                                 float* __restrict__ y, float* __restrict__ stats, long HW, float eps) {
+    __shared__ float red[4];
+    __shared__ float mean_s;
+    const long base = (long)blockIdx.x * HW;
+    const float a = sc[blockIdx.x], b = sh[blockIdx.x];
+    const float* xp = x + base;
+    const float* rp = res ? res + base : nullptr;
+    float* yp = y + base;
+    float s = 0.f;
+    const bool vec = (HW & 3) == 0;
+    if (vec) {
+        const long n4 = HW >> 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 v[4], r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = reinterpret_cast<const float4*>(xp)[min(i + 256 * u, n4 - 1)];
+                r[u] = rp ? reinterpret_cast<const float4*>(rp)[min(i + 256 * u, n4 - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 o;
+                o.x = v[u].x * a + b + r[u].x; o.y = v[u].y * a + b + r[u].y; o.z = v[u].z * a + b + r[u].z; o.w = v[u].w * a + b + r[u].w;
+                const bool live = i + 256 * u < n4;
+                if (live) reinterpret_cast<float4*>(yp)[i + 256 * u] = o;
+                const float t = live ? (o.x + o.y) + (o.z + o.w) : 0.f;
+                if (u == 0) s0 += t; else if (u == 1) s1 += t; else if (u == 2) s2 += t; else s3 += t;
+            }
+        }
+        s = (s0 + s1) + (s2 + s3);
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) {
+            const float o = xp[i] * a + b + (rp ? rp[i] : 0.f);
+            yp[i] = o;
+            s += o;
+        }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) mean_s = s / (float)HW;
+    __syncthreads();
+    const float mean = mean_s;
+    float q = 0.f;
+    if (vec) {
+        const long n4 = HW >> 2;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(yp)[min(i + 256 * u, n4 - 1)];     // this thread's own stores
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float c0 = v[u].x - mean, c1 = v[u].y - mean, c2 = v[u].z - mean, c3 = v[u].w - mean;
+                const float t = i + 256 * u < n4 ? (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3) : 0.f;
+                if (u == 0) q0 += t; else if (u == 1) q1 += t; else if (u == 2) q2 += t; else q3 += t;
+            }
+        }
+        q = (q0 + q1) + (q2 + q3);
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) { const float c0 = yp[i] - mean; q += c0 * c0; }
+    }
+    q = block_sum_256(q, red);
+    if (threadIdx.x == 0) {
+        stats[2 * (long)blockIdx.x] = mean;
+        stats[2 * (long)blockIdx.x + 1] = rsqrtf(q / (float)HW + eps);
+    }
+}
+
 // grid (chunks, B*C): out[b, c] = IN(gen)-IN(enc), out[b, C+c] = IN(enc)
 __global__ __launch_bounds__(256) void align_input_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
                                                           const float* __restrict__ sg, const float* __restrict__ se,
@@ -267,6 +340,80 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const float* __rest
     const int py = r0 + ty, px = c0 + tx;
     if (py < H && px < W)
         for (int m = 0; m < M; ++m) part[(((long)b * KS + ks) * M + m) * HW + (long)py * W + px] = acc[m];
+}
+
+// Second form (round 4), K % 8 == 0: the element -> (channel, row, column) decomposition of the tile load is done ONCE per thread (it
+// cost more instructions per stage than the 288 multiply-adds), the weights are read through the scalar cache from a (K, 9, 4)
+// transposed copy (uniform address: s_load_dwordx4 instead of an LDS broadcast read per tap), and — X11 — the 1x1 shortcut conv of
+// the same bottleneck (bottleneck_IR.shortcut_layer[0], 2C -> 3 on the RAW input, e4e helpers.py:431-437) is accumulated from the
+// same pass: one read of the 2C-channel tensor for both convs.
+template <bool X11>
+__global__ __launch_bounds__(256) void conv3x3_fewout2_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                              const float* __restrict__ w11t, const float* __restrict__ in_sc,
+                                                              const float* __restrict__ in_sh, float* __restrict__ part,
+                                                              float* __restrict__ part2, int K, int M, int M2, int H, int W, int kslice,
+                                                              int tiles_x) {
+    constexpr int NE = FO_KC * (FO_TH + 2) * (FO_TW + 2), NI = (NE + 255) / 256;       // 2720 elements, 11 per thread
+    __shared__ float tile[FO_KC * (FO_TH + 2) * FO_P];
+    const int b = blockIdx.z, ks = blockIdx.y, KS = gridDim.y;
+    const int r0 = (blockIdx.x / tiles_x) * FO_TH, c0 = (blockIdx.x % tiles_x) * FO_TW;
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const long HW = (long)H * W;
+    const int k_begin = ks * kslice, k_end = min(K, k_begin + kslice);
+    int goff[NI], loff[NI], cch[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / ((FO_TH + 2) * (FO_TW + 2)), rem = e % ((FO_TH + 2) * (FO_TW + 2));
+        const int r = rem / (FO_TW + 2), q = rem % (FO_TW + 2);
+        const int iy = r0 + r - 1, ix = c0 + q - 1;
+        const bool ok = e < NE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        goff[i] = ok ? (int)((long)c * HW + (long)iy * W + ix) : -1;        // FO_KC planes: fits an int (HW <= 2^27)
+        loff[i] = e < NE ? (c * (FO_TH + 2) + r) * FO_P + q : -1;
+        cch[i] = c < FO_KC ? c : FO_KC - 1;
+    }
+    const int py = r0 + ty, px = c0 + tx;
+    const bool pok = py < H && px < W;
+    const long poff = (long)min(py, H - 1) * W + min(px, W - 1);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (long)b * K * HW;
+    for (int k0 = k_begin; k0 < k_end; k0 += FO_KC) {
+        const float* xk = xb + (long)k0 * HW;
+        float v[NI], sc_[NI], sh_[NI], raw[FO_KC];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            v[i] = goff[i] >= 0 ? xk[goff[i]] : 0.f;
+            sc_[i] = in_sc ? in_sc[(long)b * K + k0 + cch[i]] : 1.f;
+            sh_[i] = in_sh ? in_sh[(long)b * K + k0 + cch[i]] : 0.f;
+        }
+        if (X11) {
+#pragma unroll
+            for (int c = 0; c < FO_KC; ++c) raw[c] = xk[(long)c * HW + poff];
+        }
+        __syncthreads();                 // the previous stage's reads of the tile are done
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (loff[i] >= 0) tile[loff[i]] = goff[i] >= 0 ? v[i] * sc_[i] + sh_[i] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < FO_KC; ++c) {
+            const float* wk = wt + (long)(k0 + c) * 36;         // uniform: scalar loads
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float tv = tile[(c * (FO_TH + 2) + ty + t / 3) * FO_P + tx + t % 3];
+                acc[0] += wk[4 * t] * tv; acc[1] += wk[4 * t + 1] * tv; acc[2] += wk[4 * t + 2] * tv; acc[3] += wk[4 * t + 3] * tv;
+            }
+            if (X11) {
+                const float* w1 = w11t + (long)(k0 + c) * 4;
+                acc2[0] += w1[0] * raw[c]; acc2[1] += w1[1] * raw[c]; acc2[2] += w1[2] * raw[c]; acc2[3] += w1[3] * raw[c];
+            }
+        }
+    }
+    if (pok) {
+        for (int m = 0; m < M; ++m) part[(((long)b * KS + ks) * M + m) * HW + (long)py * W + px] = acc[m];
+        if (X11)
+            for (int m = 0; m < M2; ++m) part2[(((long)b * KS + ks) * M2 + m) * HW + (long)py * W + px] = acc2[m];
+    }
 }
 
 __global__ __launch_bounds__(256) void conv3x3_fewout_finish_kernel(const float* __restrict__ part, const float* __restrict__ slope,
@@ -632,6 +779,39 @@ extern "C" int oodgan_conv3x3_fewout(const float* x, const float* w, const float
     hipLaunchKernelGGL(conv3x3_fewout_finish_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), part, slope, y, KS,
                        M, HW, total);
     return check_launch("conv3x3_fewout");
+}
+
+extern "C" int oodgan_affine_apply_stats(const float* x, const float* sc, const float* sh, const float* res, float* y, float* stats, int B,
+                                         int C, long HW, float eps, void* stream) {
+    OODGAN_REQUIRE(x && sc && sh && y && stats && B > 0 && C > 0 && HW > 0, "affine_apply_stats: bad args");
+    hipLaunchKernelGGL(affine_apply_stats_kernel, dim3(B * C), dim3(256), 0, as_stream(stream), x, sc, sh, res, y, stats, HW, eps);
+    return check_launch("affine_apply_stats");
+}
+
+// wt: (K, 9, 4) transposed copy of the (M <= 4, K, 3, 3) weight (zero-filled), w11t: (K, 4) of the (M2 <= 4, K) 1x1 weight or NULL;
+// part / part2: (B, ksplit, M | M2, H, W); y2 (B, M2, H, W) <- conv1x1(x) (raw input, no activation)
+extern "C" int oodgan_conv3x3_fewout2(const float* x, const float* wt, const float* w11t, const float* in_sc, const float* in_sh,
+                                      const float* slope, float* part, float* part2, float* y, float* y2, int B, int K, int M, int M2,
+                                      int H, int W, void* stream) {
+    OODGAN_REQUIRE(x && wt && part && y && B > 0 && K > 0 && K % FO_KC == 0 && M > 0 && M <= 4 && H > 0 && W > 0 && (long)H * W <= (1L << 27),
+                   "conv3x3_fewout2: bad args (K %% 8 == 0, M <= 4)");
+    OODGAN_REQUIRE(!w11t || (part2 && y2 && M2 > 0 && M2 <= 4), "conv3x3_fewout2: the 1x1 branch needs part2, y2 and M2 <= 4");
+    const int KS = oodgan_conv3x3_fewout_ksplit(B, K, H, W);
+    const int kslice = ((K + KS - 1) / KS + FO_KC - 1) / FO_KC * FO_KC;
+    const int tiles_x = (W + FO_TW - 1) / FO_TW, tiles_y = (H + FO_TH - 1) / FO_TH;
+    OODGAN_REQUIRE(B <= 65535 && KS <= 65535 && (long)(KS - 1) * kslice < K, "conv3x3_fewout2: split");
+    const dim3 grid((unsigned)(tiles_x * tiles_y), KS, B);
+    if (w11t) hipLaunchKernelGGL((conv3x3_fewout2_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
+                                 K, M, M2, H, W, kslice, tiles_x);
+    else hipLaunchKernelGGL((conv3x3_fewout2_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
+                            K, M, M2, H, W, kslice, tiles_x);
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(conv3x3_fewout_finish_kernel, dim3(stream_grid((long)B * M * HW, 256)), dim3(256), 0, as_stream(stream), part, slope, y,
+                       KS, M, HW, (long)B * M * HW);
+    if (w11t)
+        hipLaunchKernelGGL(conv3x3_fewout_finish_kernel, dim3(stream_grid((long)B * M2 * HW, 256)), dim3(256), 0, as_stream(stream), part2,
+                           (const float*)nullptr, y2, KS, M2, HW, (long)B * M2 * HW);
+    return check_launch("conv3x3_fewout2");
 }
 
 extern "C" int oodgan_align_head(const float* x, float* y, int B, long HW, float scale, void* stream) {

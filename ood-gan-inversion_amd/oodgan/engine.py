@@ -10,6 +10,8 @@ latents, and the W+ Adam inversion loop.
 Layer order / latent indexing follow reference src/ops/StyleGAN/model.py:548-576."""
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -97,6 +99,7 @@ class GeneratorEngine:
         # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
         # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
         self.fuse_up = True
+        self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
         if (Lup is not None and self.precision == 'f16s' and self.sform and with_backward and Lup.cout % 32 == 0 and Lup.cin % 16 == 0
                 and Lup.cout <= 32 and size >= 64):
@@ -303,6 +306,15 @@ class GeneratorEngine:
                            and self.bwd_state.get(Ln.name) is not None and self.bwd_state.get(L.name) is not None
                            and ops.xf_supported(B, Ln.cin, Ln.cout, 2 * Hi, 2 * Hi))
                 one_pass = ff_tail and self.fuse_up and L.wpk_vb is not None and ops.upconv_vblur_supported(B, L.cin, L.cout, Hi, Hi)
+                # the plain forward (model(x), exact ranges) takes the same two kernels: the up-conv kernel records max|y * style| of the
+                # F-form activation it writes, the range scale of the last conv is set from it on the device — no (2H+1)² intermediate,
+                # no blur pass, no measurement pass and no S-form copy of the 1024² tensor
+                plain_tail = (self.sform and not carry and not save and not one_pass and self.plain_one_pass and self.fuse_up and self.fuse_x
+                              and self.fused_rgb and Ln is not None and Ln is self.layers_styled_last and L.wpk_vb is not None
+                              and Ln.name in self.conv_next_rgb and 16 < Ln.cin <= 32 and 16 < Ln.cout <= 32
+                              and not (cond_layers is not None and L.lat in cond_layers)
+                              and not (features_in is not None and Ln.lat < len(features_in) and features_in[Ln.lat] is not None)
+                              and ops.upconv_vblur_supported(B, L.cin, L.cout, Hi, Hi) and ops.xf_supported(B, Ln.cin, Ln.cout, 2 * Hi, 2 * Hi))
                 z = None
                 if self.sform:
                     if pending is not None:
@@ -313,6 +325,12 @@ class GeneratorEngine:
                         # ... and the (2H+1)² transposed-conv result is not written either: conv + blur + noise + bias + activation in ONE kernel
                         out = ops.upconv_vblur_fform(xs, L.wpk_vb, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w, act=True,
                                                      ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                    elif plain_tail:
+                        out = ops.upconv_vblur_fform(xs, L.wpk_vb, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w, act=True,
+                                                     ys_scale=_Cols(s_all, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                        rng.update_exact(Ln.sidx)
+                        rng.plan(s_all, d_all, Ln.row, Ln.cin, Ln.drow, Ln.cout)
+                        one_pass = True
                     else:
                         z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)
                     del xs
@@ -351,7 +369,7 @@ class GeneratorEngine:
         if save:
             self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B)
         if return_features:
-            return skip, out
+            return skip, (out.to_nchw() if isinstance(out, ops.FForm) else out)
         return skip
 
     def _demod(self, L, s_all, d_all):

@@ -334,8 +334,11 @@ class Generator(nn.Module):
                 if conditions[k] is not None and len(conditions[k]) > 1 and conditions[k][1] is not None:
                     noise[i] = conditions[k][1]
         noises = self._draw_noises(B, noise, randomize_noise)
-        image, feat = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=True, post_hook=post,
-                                            features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
+        # the last activation is only materialised in NCHW when the caller asks for it (the engine may keep it in F-form)
+        want_feat = bool(return_features) and not return_latents
+        res = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=want_feat, post_hook=post,
+                                    features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
+        image, feat = res if want_feat else (res, None)
         if return_latents:
             return image, latent
         if return_features:

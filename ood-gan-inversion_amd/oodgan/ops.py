@@ -465,6 +465,10 @@ class FwdRange:
               'absmax_scaled')
         check(_lib.lib().oodgan_fwd_range_update(_p(self.vm[l]), _p(self.q[l]), None, B, _stream()), 'fwd_range_update')
 
+    def update_exact(self, l):
+        """exact mode, when the producer of layer l's input recorded max|x*s| into vm[l] itself (oodgan_upconv_vblur_fform)."""
+        check(_lib.lib().oodgan_fwd_range_update(_p(self.vm[l]), _p(self.q[l]), None, self.B, _stream()), 'fwd_range_update')
+
     def finish(self):
         """carry mode, after the last layer: verify the scales that were used, publish the next ones, clear the maxima."""
         check(_lib.lib().oodgan_fwd_range_update(_p(self.vm), _p(self.q), _p(self.flag), self.L * self.B, _stream()), 'fwd_range_update')

@@ -18,17 +18,20 @@ from .ops import _dev, _opt, _p, _stream
 from .synth import make_kernel
 
 P = c_void_p
+FUSE_STATS = int(os.environ.get('OODGAN_SAMM_FUSE_STATS', '1'))     # statistics of a bottleneck's output computed by the pass that writes it
 FUSE_CONV_CHAIN = int(os.environ.get('OODGAN_SAMM_FUSE_CHAIN', '1'))     # AlignNet conv -> PReLU -> conv without the fp32 tensor in between
 _lib.bind_extra({
     'oodgan_instnorm_stats': (c_int, [P, P, c_int, c_int, c_long, c_float, P]),
     'oodgan_instnorm_coeffs': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'oodgan_affine_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_affine_apply_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_se_gate': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     'oodgan_conv3x3_fewout_ksplit': (c_int, [c_int, c_int, c_int, c_int]),
     'oodgan_conv3x3_fewout': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_conv3x3_fewout2': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_align_head': (c_int, [P, P, c_int, c_long, c_float, P]),
     'oodgan_field_compose': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'oodgan_warp_blend': (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -65,8 +68,21 @@ def affine_apply(x, sc, sh, res=None):
     return y
 
 
-def instance_norm(x, gamma=None, beta=None, eps=1e-5, res=None):
+def affine_apply_stats(x, sc, sh, res=None, eps=1e-5):
+    """(affine_apply(x, sc, sh, res), instnorm_stats of it) in one pass over the tensors."""
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    st = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_affine_apply_stats(_p(x), _p(sc), _p(sh), _p(_opt(res, 'res')), _p(y), _p(st), B, C, x.numel() // (B * C), eps,
+                                               _stream()), 'affine_apply_stats')
+    return y, st
+
+
+def instance_norm(x, gamma=None, beta=None, eps=1e-5, res=None, want_stats=False):
     sc, sh = instnorm_coeffs(instnorm_stats(x, eps), gamma, beta)
+    if want_stats:
+        return affine_apply_stats(x, sc, sh, res, eps)
     return affine_apply(x, sc, sh, res)
 
 
@@ -121,6 +137,37 @@ def conv3x3_fewout(x, weight, in_sc=None, in_sh=None, slope=None):
     check(L.oodgan_conv3x3_fewout(_p(x), _p(w), _p(in_sc), _p(in_sh), _p(_opt(slope, 'slope')), _p(part), _p(y), B, K, M, H, W,
                                   _stream()), 'conv3x3_fewout')
     return y
+
+
+def fewout_weights(w, w11=None):
+    """(K, 9, 4) / (K, 4) transposed, zero-filled copies of a (M <= 4, K, 3, 3) weight and a (M2 <= 4, K[,1,1]) 1x1 weight."""
+    w = _dev(w)
+    M, K = w.shape[0], w.shape[1]
+    wt = torch.zeros(K, 9, 4, device=w.device, dtype=torch.float32)
+    wt[:, :, :M] = w.reshape(M, K, 9).permute(1, 2, 0)
+    w11t = None
+    if w11 is not None:
+        w11 = _dev(w11).reshape(w11.shape[0], K)
+        w11t = torch.zeros(K, 4, device=w.device, dtype=torch.float32)
+        w11t[:, :w11.shape[0]] = w11.t()
+    return wt, w11t
+
+
+def conv3x3_fewout2(x, wt, M, in_sc=None, in_sh=None, slope=None, w11t=None, M2=0):
+    """conv3x3_fewout from prepared weights (``fewout_weights``); with ``w11t`` also the 1x1 conv of the raw x: -> (y, y2 | None)."""
+    x = _dev(x)
+    B, K, H, W = x.shape
+    L = _lib.lib()
+    ks = L.oodgan_conv3x3_fewout_ksplit(B, K, H, W)
+    part = torch.empty(B, ks, M, H, W, device=x.device, dtype=torch.float32)
+    y = torch.empty(B, M, H, W, device=x.device, dtype=torch.float32)
+    part2 = y2 = None
+    if w11t is not None:
+        part2 = torch.empty(B, ks, M2, H, W, device=x.device, dtype=torch.float32)
+        y2 = torch.empty(B, M2, H, W, device=x.device, dtype=torch.float32)
+    check(L.oodgan_conv3x3_fewout2(_p(x), _p(wt), _p(w11t), _p(in_sc), _p(in_sh), _p(_opt(slope, 'slope')), _p(part), _p(part2), _p(y), _p(y2),
+                                   B, K, M, M2, H, W, _stream()), 'conv3x3_fewout2')
+    return y, y2
 
 
 def align_head(x, scale):
@@ -243,12 +290,20 @@ class bottleneck_IR(nn.Module):
     def _prepared(self):
         w1, w2 = self.res_layer[1].weight, self.res_layer[3].weight
         key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version)
+        if self.in_channel != self.depth:
+            w0 = self.shortcut_layer[0].weight
+            key = key + (w0.data_ptr(), w0._version)
         if key != self._key:
             if not self.norm:
                 self._key, self._prep = key, {'w1': ops.pack_conv3x3(w1.detach()), 'w2': ops.pack_conv3x3(w2.detach())}
                 return self._prep
             if self.depth <= 4 and self.in_channel > 8:
-                self._key, self._prep = key, {}          # conv3x3_fewout / conv3x3_small take the raw weights
+                # conv3x3_fewout / conv3x3_small take the raw weights; the round-4 form a transposed copy (+ the 1x1 shortcut's)
+                prep = {}
+                if self.in_channel % 8 == 0:
+                    w11 = self.shortcut_layer[0].weight.detach() if self.in_channel != self.depth else None
+                    prep['wt'], prep['w11t'] = fewout_weights(w1.detach(), w11)
+                self._key, self._prep = key, prep
                 return self._prep
             prep = {'w1': ops.pack_conv3x3(w1.detach())}
             if self.depth > 8:
@@ -279,7 +334,9 @@ class bottleneck_IR(nn.Module):
             ysc = ent['ysc'][B] = torch.full((B, self.depth), 2.0 ** ent['e'], device=ent['mul2'].device, dtype=torch.float32)
         return ent['mul2'], ysc
 
-    def forward(self, x):
+    def forward(self, x, stats=None, want_stats=False):
+        """``stats``: InstanceNorm statistics of x when the producer already has them (``want_stats`` of the bottleneck in front):
+        the two passes over the 2C-channel tensor that only compute statistics disappear from an AlignNet cycle."""
         prep = self._prepared()
         rl = self.res_layer
         if not self.norm:
@@ -289,8 +346,10 @@ class bottleneck_IR(nn.Module):
             shortcut = x if self.in_channel == self.depth else conv1x1(x, self.shortcut_layer[0].weight)
             B = x.shape[0]
             one = torch.ones(B, self.depth, device=r.device, dtype=torch.float32)
-            return affine_apply(r, one, torch.zeros_like(one), res=shortcut)
-        sc, sh = instnorm_coeffs(instnorm_stats(x), rl[0].weight, rl[0].bias)
+            y = affine_apply(r, one, torch.zeros_like(one), res=shortcut)
+            return (y, instnorm_stats(y)) if want_stats else y
+        sc, sh = instnorm_coeffs(instnorm_stats(x) if stats is None else stats, rl[0].weight, rl[0].bias)
+        s1 = None
         if self.in_channel >= 64 and self.depth >= 64:
             # the AlignNet convs (2C -> 2C channels, 7x the generator's FLOPs per image): through the S-form and
             # the 8-wave kernel of the generator's own >= 64-channel layers; InstanceNorm's affine folded into the conversion
@@ -318,7 +377,11 @@ class bottleneck_IR(nn.Module):
             del xs, rs
         elif self.depth <= 4 and self.in_channel > 8:
             # AlignNet's head: 2C -> 3 -> 3 channels.  Streaming work, exact fp32, K split over the chip
-            r = conv3x3_fewout(x, rl[1].weight, sc, sh, slope=rl[2].weight)
+            if 'wt' in prep:
+                # one pass over x for the head conv and the 1x1 shortcut conv
+                r, s1 = conv3x3_fewout2(x, prep['wt'], self.depth, sc, sh, slope=rl[2].weight, w11t=prep['w11t'], M2=self.depth)
+            else:
+                r = conv3x3_fewout(x, rl[1].weight, sc, sh, slope=rl[2].weight)
             r = conv3x3_small(r, rl[3].weight)
         else:
             r = ops.conv3x3(x, prep['w1'], self.depth, CONV_S1, in_scale=sc, in_shift=sh, act=ACT_PRELU, slope=rl[2].weight)
@@ -329,9 +392,9 @@ class bottleneck_IR(nn.Module):
         if self.in_channel == self.depth:
             shortcut = x
         else:
-            s = conv1x1(x, self.shortcut_layer[0].weight)
+            s = s1 if s1 is not None else conv1x1(x, self.shortcut_layer[0].weight)
             shortcut = instance_norm(s, self.shortcut_layer[1].weight, self.shortcut_layer[1].bias)
-        return instance_norm(r, rl[4].weight, rl[4].bias, res=shortcut)
+        return instance_norm(r, rl[4].weight, rl[4].bias, res=shortcut, want_stats=want_stats)
 
 
 def scaleNshiftBlock(in_chn, out_chn, norm_type=False, bias=False):
@@ -352,7 +415,11 @@ class AlignNet(nn.Module):
         st_s = instnorm_stats(source)
         st_t = st_target if st_target is not None else instnorm_stats(target)
         a = align_input(source, target, st_s, st_t)
-        a = self.body[1](self.body[0](a))
+        if FUSE_STATS:
+            a, st_a = self.body[0](a, want_stats=True)      # the statistics the second bottleneck's norm needs come with the first one's output
+            a = self.body[1](a, stats=st_a)
+        else:
+            a = self.body[1](self.body[0](a))
         return align_head(a, self.scale)
 
 

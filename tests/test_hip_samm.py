@@ -68,6 +68,44 @@ def test_conv3x3_fewout_vs_aten(dev):
         assert torch.equal(y, samm.conv3x3_fewout(x.to(dev), w.to(dev), sc.to(dev), sh.to(dev), slope=sl.to(dev)))    # deterministic
 
 
+def test_conv3x3_fewout2_with_shortcut_conv_vs_aten(dev):
+    """Round 4: the AlignNet head conv from the transposed weight copy, together with the 1x1 shortcut conv of the same bottleneck
+    (bottleneck_IR(2C, 3): res_layer[1] on the normalised input, shortcut_layer[0] on the raw one, e4e helpers.py:426-448) in one pass."""
+    from oodgan import samm
+    for (B, K, H, W, M, M2) in ((2, 200, 20, 45, 3, 3), (1, 1024, 32, 32, 3, 3), (3, 16, 9, 7, 4, 2), (1, 256, 64, 64, 1, 0), (8, 256, 40, 33, 3, 3)):
+        x = synth.normal('f2.x', (B, K, H, W), 1, 1.3, 0.1)
+        w = synth.normal('f2.w', (M, K, 3, 3), 2, 0.05)
+        w11 = synth.normal('f2.w11', (M2, K, 1, 1), 6, 0.05) if M2 else None
+        sc = synth.normal('f2.sc', (B, K), 3, 0.2, 1.0)
+        sh = synth.normal('f2.sh', (B, K), 4, 0.3)
+        sl = synth.normal('f2.sl', (M,), 5, 0.05, 0.25)
+        ref = F.prelu(torch.cat([F.conv2d(x[b:b + 1] * sc[b].view(1, K, 1, 1) + sh[b].view(1, K, 1, 1), w, padding=1) for b in range(B)]), sl)
+        wt, w11t = samm.fewout_weights(w.to(dev), None if w11 is None else w11.to(dev))
+        y, y2 = samm.conv3x3_fewout2(x.to(dev), wt, M, sc.to(dev), sh.to(dev), slope=sl.to(dev), w11t=w11t, M2=M2)
+        close(y, ref, 2e-5)
+        if M2:
+            close(y2, F.conv2d(x, w11), 2e-5)
+        else:
+            assert y2 is None
+        ya, yb = samm.conv3x3_fewout2(x.to(dev), wt, M, sc.to(dev), sh.to(dev), slope=sl.to(dev), w11t=w11t, M2=M2)
+        assert torch.equal(y, ya) and (y2 is None or torch.equal(y2, yb))          # deterministic
+        close(samm.conv3x3_fewout2(x.to(dev), wt, M)[0], F.conv2d(x, w, padding=1), 2e-5)
+
+
+def test_affine_apply_stats_equals_two_passes(dev):
+    """y = x*sc + sh + res and the InstanceNorm statistics of y from one kernel: bit-identical to affine_apply + instnorm_stats."""
+    from oodgan import samm
+    for (B, C, H, W, res) in ((2, 24, 16, 16, True), (1, 7, 9, 13, True), (3, 16, 64, 64, False), (1, 4, 256, 256, True)):
+        x = synth.normal('as.x', (B, C, H, W), 1, 1.7, 0.4).to(dev)
+        r = synth.normal('as.r', (B, C, H, W), 2).to(dev) if res else None
+        sc = synth.normal('as.sc', (B, C), 3, 0.2, 1.0).to(dev)
+        sh = synth.normal('as.sh', (B, C), 4, 0.3).to(dev)
+        y0 = samm.affine_apply(x, sc, sh, r)
+        st0 = samm.instnorm_stats(y0)
+        y1, st1 = samm.affine_apply_stats(x, sc, sh, r)
+        assert torch.equal(y0, y1) and torch.equal(st0, st1)
+
+
 def test_warp_blend_channel_chunks(dev):
     """grid_sample + lerp with channel counts that are not a multiple of the kernel's channel chunk, B > 1."""
     from oodgan import samm
