@@ -493,6 +493,8 @@ int oodgan_act_bwd_fused_max(const float* g_feat, const float* out, const float*
 /* out2 = {2^-e, 2^e} with e chosen so that max_i |part[i]| * 2^e lies in [512,1024) (e = 0 for an all-zero or
  * non-finite input): the power-of-two scale that keeps a tensor inside the f16 range of the split-f16 kernels. */
 int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream);
+/* the same, and `part` is zeroed afterwards: a persistent slot array needs no fill launch between measurements */
+int oodgan_absmax_scale_clear(float* part, long n, float* out2, void* stream);
 
 /* ------------------------------------------------------------------ A9 loss / optimiser ---- */
 

@@ -152,10 +152,14 @@ __global__ __launch_bounds__(256) void act_bwd_fused_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ part, long n, float* __restrict__ out2) {
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void absmax_scale_kernel(float* __restrict__ part, long n, float* __restrict__ out2) {
     __shared__ float red[4];
     float m = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(part[i]));
+    for (long i = threadIdx.x; i < n; i += 256) {
+        m = fmaxf(m, fabsf(part[i]));
+        if (CLEAR) part[i] = 0.f;           // the slots are ready for the next measurement: no fill launch per use
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -364,8 +368,14 @@ extern "C" int oodgan_act_bwd_fused(const float* g_feat, const float* out, const
 
 extern "C" int oodgan_absmax_scale(const float* part, long n, float* out2, void* stream) {
     OODGAN_REQUIRE(part && out2 && n > 0, "absmax_scale: bad args");
-    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, as_stream(stream), part, n, out2);
+    hipLaunchKernelGGL(absmax_scale_kernel<false>, dim3(1), dim3(256), 0, as_stream(stream), const_cast<float*>(part), n, out2);
     return check_launch("absmax_scale");
+}
+
+extern "C" int oodgan_absmax_scale_clear(float* part, long n, float* out2, void* stream) {
+    OODGAN_REQUIRE(part && out2 && n > 0, "absmax_scale_clear: bad args");
+    hipLaunchKernelGGL(absmax_scale_kernel<true>, dim3(1), dim3(256), 0, as_stream(stream), part, n, out2);
+    return check_launch("absmax_scale_clear");
 }
 
 extern "C" int oodgan_reduce_parts(const float* part, float* out, long rows, int nparts, int accumulate, void* stream) {

@@ -135,6 +135,7 @@ _SIGS = {
     'oodgan_feature_modulation': (c_int, [P, P, P, P, c_long, c_int, P]),
     'oodgan_act_bwd_fused_max': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_absmax_scale': (c_int, [P, c_long, P, P]),
+    'oodgan_absmax_scale_clear': (c_int, [P, c_long, P, P]),
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_nparts': (c_int, [c_long]),
     'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),

@@ -348,6 +348,8 @@ def drop_stream_scratch(stream_handle):
     for pool in (_SFORM_POOL, _WS_POOL):
         for key in [k for k in pool if k[-1] == stream_handle]:
             del pool[key]
+    for key in [k for k in _VMAX_POOL if k[1] == stream_handle]:
+        del _VMAX_POOL[key]
 
 
 def sform_scratch(B, C, H, W, device, tag=0):
@@ -420,12 +422,20 @@ def absmax_mul2(x):
     e = 0 for an all-zero or non-finite tensor."""
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
-    vm = zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)     # float bit patterns, atomic max
+    # float bit patterns, atomic max; ONE persistent slot array per (device, stream, B), zeroed at creation and again by the kernel that
+    # reads it (stream order makes the reuse safe; created during warm-up, so never inside a graph capture)
+    key = (str(x.device), torch.cuda.current_stream().cuda_stream, B)
+    vm = _VMAX_POOL.get(key)
+    if vm is None:
+        vm = _VMAX_POOL[key] = torch.zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)
     mul2 = torch.empty(2, device=x.device, dtype=torch.float32)
     L = _lib.lib()
     check(L.oodgan_absmax_scaled(_p(x), None, 0, _p(vm), B, C, x.numel() // (B * C), _stream()), 'absmax_scaled')
-    check(L.oodgan_absmax_scale(_p(vm), vm.numel(), _p(mul2), _stream()), 'absmax_scale')
+    check(L.oodgan_absmax_scale_clear(_p(vm), vm.numel(), _p(mul2), _stream()), 'absmax_scale_clear')
     return mul2
+
+
+_VMAX_POOL = {}
 
 
 class FwdRange:
