@@ -377,9 +377,11 @@ __global__ __launch_bounds__(256) void conv3x3_fewout2_kernel(const float* __res
     const long poff = (long)min(py, H - 1) * W + min(px, W - 1);
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (long)b * K * HW;
-    for (int k0 = k_begin; k0 < k_end; k0 += FO_KC) {
+    // software pipeline: the loads of stage t+1 are in flight while stage t is computed (one stage at a time this kernel was a chain
+    // of K/8 exposed memory latencies per workgroup: 280 us per launch at B = 8 for 35 us of LDS / FMA work)
+    float v[NI], sc_[NI], sh_[NI], raw[FO_KC];
+    auto request = [&](int k0) {
         const float* xk = xb + (long)k0 * HW;
-        float v[NI], sc_[NI], sh_[NI], raw[FO_KC];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             v[i] = goff[i] >= 0 ? xk[goff[i]] : 0.f;
@@ -390,11 +392,20 @@ __global__ __launch_bounds__(256) void conv3x3_fewout2_kernel(const float* __res
 #pragma unroll
             for (int c = 0; c < FO_KC; ++c) raw[c] = xk[(long)c * HW + poff];
         }
+    };
+    if (k_begin < k_end) request(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += FO_KC) {
         __syncthreads();                 // the previous stage's reads of the tile are done
 #pragma unroll
         for (int i = 0; i < NI; ++i)
             if (loff[i] >= 0) tile[loff[i]] = goff[i] >= 0 ? v[i] * sc_[i] + sh_[i] : 0.f;
+        float rawc[FO_KC];
+        if (X11) {
+#pragma unroll
+            for (int c = 0; c < FO_KC; ++c) rawc[c] = raw[c];
+        }
         __syncthreads();
+        if (k0 + FO_KC < k_end) request(k0 + FO_KC);
 #pragma unroll
         for (int c = 0; c < FO_KC; ++c) {
             const float* wk = wt + (long)(k0 + c) * 36;         // uniform: scalar loads
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout2_kernel(const float* __res
             }
             if (X11) {
                 const float* w1 = w11t + (long)(k0 + c) * 4;
-                acc2[0] += w1[0] * raw[c]; acc2[1] += w1[1] * raw[c]; acc2[2] += w1[2] * raw[c]; acc2[3] += w1[3] * raw[c];
+                acc2[0] += w1[0] * rawc[c]; acc2[1] += w1[1] * rawc[c]; acc2[2] += w1[2] * rawc[c]; acc2[3] += w1[3] * rawc[c];
             }
         }
     }
