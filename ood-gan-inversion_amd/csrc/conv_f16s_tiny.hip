@@ -254,7 +254,10 @@ bool tiny_shape(const oodgan_conv_args& a, int& H) {
     else return false;
     const int Wd = a.mode == OODGAN_CONV_S1 ? a.Win : (a.Win - 1) / 2;
     // 1x1 / 2x2: only the stride-2 chains of the style heads end there (no noise, no dot: tiny_eligible)
-    return a.x_sform && H == Wd && (H == 4 || H == 8 || (a.mode == OODGAN_CONV_S2 && (H == 1 || H == 2))) && a.K % 16 == 0 && a.K >= 64 &&
+    // 16x16 / 32x32 stride-1 maps with at most 1024 positions in all: the encoder trunk at batch 1-4, where the tile kernels have 8-32
+    // workgroups walking their K chunks one after the other (the caller opts in by passing a workspace)
+    const bool mid = a.mode == OODGAN_CONV_S1 && (H == 16 || H == 32) && a.B * H * H <= 1024;
+    return a.x_sform && H == Wd && (H == 4 || H == 8 || mid || (a.mode == OODGAN_CONV_S2 && (H == 1 || H == 2))) && a.K % 16 == 0 && a.K >= 64 &&
            a.M % 32 == 0 && a.B * H * H <= 16384;
 }
 

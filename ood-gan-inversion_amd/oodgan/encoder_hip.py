@@ -65,6 +65,8 @@ class _Packed:
         return self.val
 
 
+TRUNK_TINY_MAX = int(os.environ.get('OODGAN_ENC_TRUNK_TINY_MAX', '32'))     # trunk convs on <= 1024 positions: skinny-GEMM kernel (batch 1-4)
+SMALL_S2_SFORM = int(os.environ.get('OODGAN_ENC_SMALL_S2_SFORM', '1'))
 HEADS_TINY = int(os.environ.get('OODGAN_HEADS_TINY', '1'))
 HEADS_TINY_MAX_OUT = int(os.environ.get('OODGAN_HEADS_TINY_MAX_OUT', '8'))
 HEADS_SFORM_MIN_IN = int(os.environ.get('OODGAN_HEADS_SFORM_MIN_IN', '16'))      # grouped head steps with input maps of at least this size go through the S-form (A/B: tools/forward_only.py)
@@ -80,7 +82,10 @@ def _conv3x3(x, pk, M, stride=1, **kw):
     tiny = HEADS_TINY and min(H, W) // 2 <= HEADS_TINY_MAX_OUT and ops.tiny_workspace_bytes(CONV_S2, B, K // G, M, H + 1, W + 1) > 0
     big = ops.s2_fuse_supported(B, K, M, H + 1, W + 1) if G == 1 else \
         (min(H, W) >= HEADS_SFORM_MIN_IN and ops.s2_grouped_supported(B, K // G, M, G, H + 1, W + 1))
-    if 'in_scale' not in kw and (tiny or big):
+    # a trunk conv too small for the 8-wave kernel still takes the S-form route: the 4-wave S-form kernel (what the W+ loop runs on its
+    # low-resolution layers) against the fp32-input kernel's exposed global-load latency per K chunk (118 us per conv at B = 1)
+    small = SMALL_S2_SFORM and G == 1 and K % 16 == 0 and M >= 64
+    if 'in_scale' not in kw and (tiny or big or small):
         # through the phase-split S-form (measured power-of-two range scale; bias + slope in the kernel's epilogue):
         #  * enough work for the 8-wave stride-2 kernel — the stacked first convs of the style heads (512 -> 11 x 512 channels at
         #    64² -> 32²) and the grouped steps that follow while the maps fill a useful part of its 8 x 32 tile.  The fp32-input kernel
@@ -140,7 +145,8 @@ class _HipTrunk:
             # workgroups each walking its K chunks one exposed global-load latency at a time (140 us per conv at any batch size)
             H, W = x.shape[2], x.shape[3]
             xs = ops.to_sform(x, sc1, shift=sh1, out=ops.sform_scratch(B, cin, H, W, x.device, tag=1))
-            r = ops.conv3x3(xs, self._packed(f'{idx}.w1', rl[1].weight), depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight.detach())
+            r = ops.conv3x3(xs, self._packed(f'{idx}.w1', rl[1].weight), depth, CONV_S1, act=ACT_PRELU, slope=rl[2].weight.detach(),
+                            tiny_max=TRUNK_TINY_MAX)
         else:
             r = _conv3x3(x, self._packed(f'{idx}.w1', rl[1].weight), depth, 1, in_scale=sc1, in_shift=sh1,
                          act=ACT_PRELU, slope=rl[2].weight.detach())
@@ -148,7 +154,8 @@ class _HipTrunk:
             # un-normalised PReLU(conv) output: measured power-of-two range scale for the f16 pair, undone in the conv (exact)
             mul2 = ops.absmax_mul2(r)
             rs = ops.to_sform(r, mul2=mul2, out=ops.sform_scratch(B, depth, r.shape[2], r.shape[3], x.device, tag=2))
-            r = ops.conv3x3(rs, self._packed(f'{idx}.w2', rl[3].weight), depth, CONV_S1, out_scale=sc2, bias=sh2, in_mul2=mul2)
+            r = ops.conv3x3(rs, self._packed(f'{idx}.w2', rl[3].weight), depth, CONV_S1, out_scale=sc2, bias=sh2, in_mul2=mul2,
+                            tiny_max=TRUNK_TINY_MAX)
         else:
             r = _conv3x3(r, self._packed(f'{idx}.w2', rl[3].weight), depth, stride, out_scale=sc2, bias=sh2)
         if isinstance(u.shortcut_layer, torch.nn.MaxPool2d):

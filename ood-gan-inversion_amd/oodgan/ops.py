@@ -790,11 +790,13 @@ def upconv_vblur_fform(xs, wvb, out_scale=None, bias=None, noise=None, noise_wei
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
             in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,
-            groups=1, y_fform=False, xf_act=None):
+            groups=1, y_fform=False, xf_act=None, tiny_max=8):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
-    packed weight G*Mg output channels of K inputs (mode S2; fp32 input, or phase-split S-form where ``s2_grouped_supported``)."""
+    packed weight G*Mg output channels of K inputs (mode S2; fp32 input, or phase-split S-form where ``s2_grouped_supported``).
+    ``tiny_max``: largest output size offered to the skinny-GEMM kernel (8: the generator's 4x4 / 8x8 layers; the encoder trunk passes 32,
+    which that kernel takes for maps of at most 1024 positions in all)."""
     sform_in = isinstance(x, (SForm, SFormPhases))
     fform_in = isinstance(x, FForm)      # split-f16 strip kernel with in-kernel conversion (include/oodgan.h, x_fform)
     if fform_in:
@@ -829,7 +831,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.x_sform = 1 if sform_in else 0
     a.x_fform = (2 if xf_act is not None else 1) if fform_in else 0
     ws = None
-    if sform_in and USE_TINY and wpk.precision == 'f16s' and mode in (CONV_S1, CONV_S2) and min(oh, ow) <= 8:
+    if sform_in and USE_TINY and wpk.precision == 'f16s' and mode in (CONV_S1, CONV_S2) and min(oh, ow) <= tiny_max:
         nb = _lib.lib().oodgan_conv3x3_tiny_workspace(mode, B, K, M, H, W)
         if nb > 0:
             ws = conv_workspace(nb, x.data.device)

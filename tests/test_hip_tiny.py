@@ -119,3 +119,30 @@ def test_stride2_grouped_forward_down_to_1x1(B, G, K, Mg, Ho):
         y2 = ops.conv3x3(xp, wpk, G * Mg, ops.CONV_S2, in_hw=(H + 1, H + 1), in_pitch=pitch, **kw)      # fp32-input grouped kernel
         assert _rel(y, y2) < 2e-5
     assert torch.equal(ops.conv3x3(gp, wpk, G * Mg, ops.CONV_S2, in_mul2=mul2, **kw), y)
+
+
+@pytest.mark.parametrize('B,C,M,H', [(1, 256, 256, 32), (1, 512, 512, 16), (4, 128, 64, 16), (2, 64, 96, 16)])
+def test_stride1_mid_size_maps_of_the_encoder_trunk(B, C, M, H):
+    """Round 4: 16x16 / 32x32 maps with at most 1024 positions (the IR-SE50 trunk of the e4e encoder at batch 1-4, helpers.py:479-501)
+    on the skinny-GEMM kernel — opt-in through ``tiny_max`` — with PReLU slopes or the folded BatchNorm (out_scale, bias) in the finishing pass."""
+    import torch.nn.functional as F
+    from oodgan import _lib, ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 100 + H + C)
+    x = torch.randn(B, C, H, H, generator=g)
+    sc, sh = 1 + 0.3 * torch.randn(B, C, generator=g), 0.2 * torch.randn(B, C, generator=g)
+    w = torch.randn(M, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    slope = 0.05 + 0.2 * torch.rand(M, generator=g)
+    d, bias = 1 + 0.3 * torch.randn(B, M, generator=g), torch.randn(M, generator=g)
+    xn = x * sc[:, :, None, None] + sh[:, :, None, None]
+    xs = ops.to_sform(x.to(dev), sc.to(dev), shift=sh.to(dev))
+    wf = ops.pack_conv3x3(w.to(dev), precision='f16s')
+    _lib.dispatch_reset()
+    y = ops.conv3x3(xs, wf, M, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev), tiny_max=32)
+    z = ops.conv3x3(xs, wf, M, ops.CONV_S1, out_scale=d.to(dev), bias=bias.to(dev), tiny_max=32)
+    assert _lib.dispatch_count('tiny') == 2
+    raw = F.conv2d(xn, w, padding=1)
+    assert _rel(y.cpu(), F.prelu(raw, slope)) < 2e-5
+    assert _rel(z.cpu(), raw * d[:, :, None, None] + bias[None, :, None, None]) < 2e-5
+    y0 = ops.conv3x3(xs, wf, M, ops.CONV_S1, act=ops.ACT_PRELU, slope=slope.to(dev))            # the tile kernels (default tiny_max)
+    assert _lib.dispatch_count('tiny') == 2 and _rel(y, y0) < 5e-6
