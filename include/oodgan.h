@@ -45,6 +45,7 @@ int oodgan_device_count(void);
  *   "blur_strip"       OODGAN_BLUR_STRIP       1     0: the tile kernel instead of the strip walk in oodgan_blur_act_fform / _sform_sep
  *   "upvb_waves"       OODGAN_UPVB_WAVES       12    form of oodgan_upconv_vblur_fform: 12 = one persistent 12-wave workgroup per CU, 6 / 4 = tile
  *                                                    kernels with two / three workgroups per CU (csrc/conv_f16s_upvb.hip)
+ *   "fewout_quad"      OODGAN_FEWOUT_QUAD      1     0: oodgan_conv3x3_fewout2 keeps its one-pixel-per-thread form (the A/B of csrc/samm.hip's third form)
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);

@@ -26,6 +26,7 @@ Tunable g_tun[OODGAN_TUN_COUNT] = {
     {"blurt_strip", "OODGAN_BLURT_STRIP", 1, {0}, {0}},
     {"blur_strip", "OODGAN_BLUR_STRIP", 1, {0}, {0}},
     {"upvb_waves", "OODGAN_UPVB_WAVES", 12, {0}, {0}},
+    {"fewout_quad", "OODGAN_FEWOUT_QUAD", 1, {0}, {0}},
 };
 }  // namespace
 long tunable(int id) {

@@ -427,6 +427,132 @@ __global__ __launch_bounds__(256) void conv3x3_fewout2_kernel(const float* __res
     }
 }
 
+// Third form (round 4), M == 3, K % 8 == 0, W % 4 == 0: the second form moved one dword per lane and instruction everywhere — 41 loads, 72
+// LDS reads and 320 multiply-adds per thread and stage, all three near a CU's rate limits at once (1.0-1.2 TB/s of input).  Here a
+// thread owns FOUR horizontally adjacent pixels and a wave owns TWO of the stage's eight channels:
+//   * tile load: the wave fetches its own two channels (340 elements each, six 64-lane trips) — the channel of a trip is uniform, so
+//     InstanceNorm's scale / shift are scalar loads, not 22 vector loads per thread;
+//   * a 3 x 6 window per channel is three ds_read_b128 + three ds_read_b64 for 36 taps x 3 outputs (12 LDS reads per stage, not 72);
+//   * the 1x1 conv's raw inputs are one float4 per channel;
+//   * the four waves' partial sums (24 per thread) are added through LDS at the end.
+template <bool X11>
+__global__ __launch_bounds__(256) void conv3x3_fewout3_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                              const float* __restrict__ w11t, const float* __restrict__ in_sc,
+                                                              const float* __restrict__ in_sh, float* __restrict__ part,
+                                                              float* __restrict__ part2, int K, int H, int W, int kslice, int tiles_x) {
+    constexpr int TR = FO_TH + 2, TC = FO_TW + 2, NT = 6;            // 10 x 34 elements per channel, six trips of 64 lanes
+    __shared__ __attribute__((aligned(16))) float tile[FO_KC * TR * FO_P];
+    __shared__ float red[4 * 24 * 64];
+    const int b = blockIdx.z, ks = blockIdx.y, KS = gridDim.y;
+    const int r0 = (blockIdx.x / tiles_x) * FO_TH, c0 = (blockIdx.x % tiles_x) * FO_TW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qy = lane >> 3, qx = lane & 7;
+    const long HW = (long)H * W;
+    const int k_begin = ks * kslice, k_end = min(K, k_begin + kslice);
+    int goff[NT], loff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int e = j * 64 + lane;
+        const int r = e / TC, q = e % TC;
+        const int iy = r0 + r - 1, ix = c0 + q - 1;
+        const bool in = e < TR * TC;
+        goff[j] = (in && iy >= 0 && iy < H && ix >= 0 && ix < W) ? iy * W + ix : -1;
+        loff[j] = in ? r * FO_P + q : -1;
+    }
+    const int py = r0 + qy, px = c0 + 4 * qx;
+    const bool pok = py < H && px < W;               // W % 4 == 0: the whole quad is in or out
+    const long poff = (long)min(py, H - 1) * W + min(px, W - 4);
+    float acc[4][3], acc2[4][3];
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[p_][m] = acc2[p_][m] = 0.f;
+    const float* xb = x + (long)b * K * HW;
+    float v[2][NT];
+    float4 raw[2];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* xk = xb + (long)(k0 + 2 * wave + c) * HW;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) v[c][j] = goff[j] >= 0 ? xk[goff[j]] : 0.f;
+            if (X11) raw[c] = *reinterpret_cast<const float4*>(xk + poff);
+        }
+    };
+    if (k_begin < k_end) request(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += FO_KC) {
+        __syncthreads();                 // the previous stage's reads of the tile are done
+        float4 rawc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = k0 + 2 * wave + c;                       // uniform
+            const float sc = in_sc ? in_sc[(long)b * K + k] : 1.f, sh = in_sh ? in_sh[(long)b * K + k] : 0.f;
+            float* tl = tile + (2 * wave + c) * (TR * FO_P);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (loff[j] >= 0) tl[loff[j]] = goff[j] >= 0 ? v[c][j] * sc + sh : 0.f;
+            rawc[c] = raw[c];
+        }
+        __syncthreads();
+        if (k0 + FO_KC < k_end) request(k0 + FO_KC);
+        // every wave walks all eight channels of the stage for ITS pixels?  No: a wave's threads cover the whole 8 x 32 tile (64 quads),
+        // and the wave adds the contribution of its two channels only; the other six come from the other waves (summed at the end)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = 2 * wave + c;
+            const float* wk = wt + (long)(k0 + ch) * 36;           // uniform: scalar loads
+            const float* tl = tile + ch * (TR * FO_P) + qy * FO_P + 4 * qx;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float4 a4 = *reinterpret_cast<const float4*>(tl + r * FO_P);
+                const float2 b2 = *reinterpret_cast<const float2*>(tl + r * FO_P + 4);
+                const float w6[6] = {a4.x, a4.y, a4.z, a4.w, b2.x, b2.y};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float w0 = wk[4 * (3 * r + kx)], w1 = wk[4 * (3 * r + kx) + 1], w2 = wk[4 * (3 * r + kx) + 2];
+#pragma unroll
+                    for (int p_ = 0; p_ < 4; ++p_) {
+                        const float tv = w6[p_ + kx];
+                        acc[p_][0] += w0 * tv; acc[p_][1] += w1 * tv; acc[p_][2] += w2 * tv;
+                    }
+                }
+            }
+            if (X11) {
+                const float* w1p = w11t + (long)(k0 + ch) * 4;
+                const float u0 = w1p[0], u1 = w1p[1], u2 = w1p[2];
+                const float rq[4] = {rawc[c].x, rawc[c].y, rawc[c].z, rawc[c].w};
+#pragma unroll
+                for (int p_ = 0; p_ < 4; ++p_) { acc2[p_][0] += u0 * rq[p_]; acc2[p_][1] += u1 * rq[p_]; acc2[p_][2] += u2 * rq[p_]; }
+            }
+        }
+    }
+    // the four waves' partial sums -> one (fixed order: wave 0 + 1 + 2 + 3)
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            red[(wave * 24 + m * 4 + p_) * 64 + lane] = acc[p_][m];
+            if (X11) red[(wave * 24 + 12 + m * 4 + p_) * 64 + lane] = acc2[p_][m];
+        }
+    __syncthreads();
+    // thread (wave = output index group, lane = quad): outputs m*4 + p for the 3x3 conv (0..11) and 12 + m*4 + p for the 1x1 conv
+    const int nout = X11 ? 6 : 3;
+    for (int o = wave; o < nout; o += 4) {                         // o = m (3x3) or 3 + m (1x1): one float4 of four pixels
+        float4 sum;
+        float* sp = reinterpret_cast<float*>(&sum);
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int idx = (o < 3 ? o * 4 : 12 + (o - 3) * 4) + p_;
+            sp[p_] = ((red[(0 * 24 + idx) * 64 + lane] + red[(1 * 24 + idx) * 64 + lane]) + red[(2 * 24 + idx) * 64 + lane]) + red[(3 * 24 + idx) * 64 + lane];
+        }
+        if (pok) {
+            float* dst = (o < 3 ? part : part2) + (((long)b * KS + ks) * 3 + (o < 3 ? o : o - 3)) * HW + (long)py * W + px;
+            *reinterpret_cast<float4*>(dst) = sum;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv3x3_fewout_finish_kernel(const float* __restrict__ part, const float* __restrict__ slope,
                                                                     float* __restrict__ y, int KS, int M, long HW, long total) {
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -812,7 +938,14 @@ extern "C" int oodgan_conv3x3_fewout2(const float* x, const float* wt, const flo
     const int tiles_x = (W + FO_TW - 1) / FO_TW, tiles_y = (H + FO_TH - 1) / FO_TH;
     OODGAN_REQUIRE(B <= 65535 && KS <= 65535 && (long)(KS - 1) * kslice < K, "conv3x3_fewout2: split");
     const dim3 grid((unsigned)(tiles_x * tiles_y), KS, B);
-    if (w11t) hipLaunchKernelGGL((conv3x3_fewout2_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
+    const bool quad = tunable(OODGAN_TUN_FEWOUT_QUAD) != 0;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(part2)) & 15) == 0;
+    if (quad && M == 3 && (!w11t || M2 == 3) && W % 4 == 0 && al16) {
+        if (w11t) hipLaunchKernelGGL((conv3x3_fewout3_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
+                                     K, H, W, kslice, tiles_x);
+        else hipLaunchKernelGGL((conv3x3_fewout3_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
+                                K, H, W, kslice, tiles_x);
+    } else if (w11t) hipLaunchKernelGGL((conv3x3_fewout2_kernel<true>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
                                  K, M, M2, H, W, kslice, tiles_x);
     else hipLaunchKernelGGL((conv3x3_fewout2_kernel<false>), grid, dim3(256), 0, as_stream(stream), x, wt, w11t, in_sc, in_sh, part, part2,
                             K, M, M2, H, W, kslice, tiles_x);

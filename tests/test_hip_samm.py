@@ -72,7 +72,7 @@ def test_conv3x3_fewout2_with_shortcut_conv_vs_aten(dev):
     """Round 4: the AlignNet head conv from the transposed weight copy, together with the 1x1 shortcut conv of the same bottleneck
     (bottleneck_IR(2C, 3): res_layer[1] on the normalised input, shortcut_layer[0] on the raw one, e4e helpers.py:426-448) in one pass."""
     from oodgan import samm
-    for (B, K, H, W, M, M2) in ((2, 200, 20, 45, 3, 3), (1, 1024, 32, 32, 3, 3), (3, 16, 9, 7, 4, 2), (1, 256, 64, 64, 1, 0), (8, 256, 40, 33, 3, 3)):
+    for (B, K, H, W, M, M2) in ((2, 200, 20, 45, 3, 3), (1, 1024, 32, 32, 3, 3), (3, 16, 9, 7, 4, 2), (1, 256, 64, 64, 1, 0), (8, 256, 40, 33, 3, 3), (2, 64, 20, 44, 3, 3), (2, 72, 13, 36, 3, 0), (1, 512, 128, 128, 3, 3)):
         x = synth.normal('f2.x', (B, K, H, W), 1, 1.3, 0.1)
         w = synth.normal('f2.w', (M, K, 3, 3), 2, 0.05)
         w11 = synth.normal('f2.w11', (M2, K, 1, 1), 6, 0.05) if M2 else None
