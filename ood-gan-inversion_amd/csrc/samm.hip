@@ -8,6 +8,17 @@ using namespace oodgan;
 
 namespace {
 
+// centred second moment of four values, every operation rounded on its own: the three kernels that produce InstanceNorm statistics
+// (alone, with the residual sum, with the aligned pair) must agree to the bit, whatever the compiler would contract in each of them
+__device__ __forceinline__ float sqsum4(float x, float y, float z, float w, float mean) {
+    const float a = __fsub_rn(x, mean), b = __fsub_rn(y, mean), c = __fsub_rn(z, mean), d = __fsub_rn(w, mean);
+    return __fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fadd_rn(__fmul_rn(c, c), __fmul_rn(d, d)));
+}
+__device__ __forceinline__ float sqacc(float q, float x, float mean) {
+    const float a = __fsub_rn(x, mean);
+    return __fadd_rn(q, __fmul_rn(a, a));
+}
+
 // ---------------------------------------------------------------- InstanceNorm statistics
 // one block per (b,c) plane; two passes (mean, then centred second moment) — the plane (<=256 KB)
 // is served from L2 on the second pass.
@@ -49,14 +60,13 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
             for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(p)[min(i + 256 * u, n4 - 1)];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
-                const float t = i + 256 * u < n4 ? (a * a + b * b) + (c * c + d * d) : 0.f;
+                const float t = i + 256 * u < n4 ? sqsum4(v[u].x, v[u].y, v[u].z, v[u].w, mean) : 0.f;
                 if (u == 0) q0 += t; else if (u == 1) q1 += t; else if (u == 2) q2 += t; else q3 += t;
             }
         }
         q = (q0 + q1) + (q2 + q3);
     } else {
-        for (long i = threadIdx.x; i < HW; i += 256) { const float a = p[i] - mean; q += a * a; }
+        for (long i = threadIdx.x; i < HW; i += 256) q = sqacc(q, p[i], mean);
     }
     q = block_sum_256(q, red);
     if (threadIdx.x == 0) {
@@ -144,14 +154,13 @@ __global__ __launch_bounds__(256) void affine_apply_stats_kernel(const float* __
             for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4*>(yp)[min(i + 256 * u, n4 - 1)];     // this thread's own stores
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float c0 = v[u].x - mean, c1 = v[u].y - mean, c2 = v[u].z - mean, c3 = v[u].w - mean;
-                const float t = i + 256 * u < n4 ? (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3) : 0.f;
+                const float t = i + 256 * u < n4 ? sqsum4(v[u].x, v[u].y, v[u].z, v[u].w, mean) : 0.f;
                 if (u == 0) q0 += t; else if (u == 1) q1 += t; else if (u == 2) q2 += t; else q3 += t;
             }
         }
         q = (q0 + q1) + (q2 + q3);
     } else {
-        for (long i = threadIdx.x; i < HW; i += 256) { const float c0 = yp[i] - mean; q += c0 * c0; }
+        for (long i = threadIdx.x; i < HW; i += 256) q = sqacc(q, yp[i], mean);
     }
     q = block_sum_256(q, red);
     if (threadIdx.x == 0) {
@@ -159,6 +168,11 @@ __global__ __launch_bounds__(256) void affine_apply_stats_kernel(const float* __
         stats[2 * (long)blockIdx.x + 1] = rsqrtf(q / (float)HW + eps);
     }
 }
+
+// IN(gen) - IN(enc) and IN(enc) of one element, every operation rounded on its own (as the reference's separate instance_norm / sub ops
+// do; a contracted multiply-subtract would differ between the two kernels below)
+__device__ __forceinline__ float align_e(float e, float me, float re) { return __fmul_rn(__fsub_rn(e, me), re); }
+__device__ __forceinline__ float align_d(float g, float mg, float rg, float en) { return __fsub_rn(__fmul_rn(__fsub_rn(g, mg), rg), en); }
 
 // grid (chunks, B*C): out[b, c] = IN(gen)-IN(enc), out[b, C+c] = IN(enc)
 __global__ __launch_bounds__(256) void align_input_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
@@ -171,9 +185,99 @@ __global__ __launch_bounds__(256) void align_input_kernel(const float* __restric
     float* o0 = out + ((long)b * 2 * C + c) * HW;
     float* o1 = out + ((long)b * 2 * C + C + c) * HW;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
-        const float a = (gp[i] - mg) * rg, e = (ep[i] - me) * re;
-        o0[i] = a - e;
+        const float e = align_e(ep[i], me, re);
+        o0[i] = align_d(gp[i], mg, rg, e);
         o1[i] = e;
+    }
+}
+
+// align_input AND the InstanceNorm statistics of its two output planes (the norm in front of AlignNet's first conv), one block per
+// (b, c): the sums in instnorm_stats_kernel's order over the values just stored (bit-identical statistics), second moment from the
+// thread's own stores.  Saves the statistics pass over the 2C-channel tensor.
+__global__ __launch_bounds__(256) void align_input_stats_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
+                                                                const float* __restrict__ sg, const float* __restrict__ se,
+                                                                float* __restrict__ out, float* __restrict__ stats, int C, long HW, float eps) {
+    __shared__ float red[4];
+    __shared__ float mean_s[2];
+    const int bc = blockIdx.x, b = bc / C, c = bc % C;
+    const float mg = sg[2 * bc], rg = sg[2 * bc + 1], me = se[2 * bc], re = se[2 * bc + 1];
+    const float* gp = gen + (long)bc * HW;
+    const float* ep = enc + (long)bc * HW;
+    float* o0 = out + ((long)b * 2 * C + c) * HW;
+    float* o1 = out + ((long)b * 2 * C + C + c) * HW;
+    float sa = 0.f, sb = 0.f;
+    const bool vec = (HW & 3) == 0;
+    if (vec) {
+        const long n4 = HW >> 2;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 g4[4], e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g4[u] = reinterpret_cast<const float4*>(gp)[min(i + 256 * u, n4 - 1)];
+                e4[u] = reinterpret_cast<const float4*>(ep)[min(i + 256 * u, n4 - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 e_, d_;
+                e_.x = align_e(e4[u].x, me, re); e_.y = align_e(e4[u].y, me, re); e_.z = align_e(e4[u].z, me, re); e_.w = align_e(e4[u].w, me, re);
+                d_.x = align_d(g4[u].x, mg, rg, e_.x); d_.y = align_d(g4[u].y, mg, rg, e_.y); d_.z = align_d(g4[u].z, mg, rg, e_.z); d_.w = align_d(g4[u].w, mg, rg, e_.w);
+                const bool live = i + 256 * u < n4;
+                if (live) {
+                    reinterpret_cast<float4*>(o0)[i + 256 * u] = d_;
+                    reinterpret_cast<float4*>(o1)[i + 256 * u] = e_;
+                }
+                const float ta = live ? (d_.x + d_.y) + (d_.z + d_.w) : 0.f, tb = live ? (e_.x + e_.y) + (e_.z + e_.w) : 0.f;
+                if (u == 0) { a0 += ta; b0 += tb; } else if (u == 1) { a1 += ta; b1 += tb; } else if (u == 2) { a2 += ta; b2 += tb; } else { a3 += ta; b3 += tb; }
+            }
+        }
+        sa = (a0 + a1) + (a2 + a3);
+        sb = (b0 + b1) + (b2 + b3);
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) {
+            const float e_ = align_e(ep[i], me, re), d_ = align_d(gp[i], mg, rg, e_);
+            o0[i] = d_; o1[i] = e_;
+            sa += d_; sb += e_;
+        }
+    }
+    sa = block_sum_256(sa, red);
+    sb = block_sum_256(sb, red);
+    if (threadIdx.x == 0) { mean_s[0] = sa / (float)HW; mean_s[1] = sb / (float)HW; }
+    __syncthreads();
+    const float ma = mean_s[0], mb = mean_s[1];
+    float qa = 0.f, qb = 0.f;
+    if (vec) {
+        const long n4 = HW >> 2;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        for (long i = threadIdx.x; i < n4; i += 1024) {
+            float4 d4[4], e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                       // this thread's own stores
+                d4[u] = reinterpret_cast<const float4*>(o0)[min(i + 256 * u, n4 - 1)];
+                e4[u] = reinterpret_cast<const float4*>(o1)[min(i + 256 * u, n4 - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = i + 256 * u < n4;
+                const float ta = live ? sqsum4(d4[u].x, d4[u].y, d4[u].z, d4[u].w, ma) : 0.f, tb = live ? sqsum4(e4[u].x, e4[u].y, e4[u].z, e4[u].w, mb) : 0.f;
+                if (u == 0) { a0 += ta; b0 += tb; } else if (u == 1) { a1 += ta; b1 += tb; } else if (u == 2) { a2 += ta; b2 += tb; } else { a3 += ta; b3 += tb; }
+            }
+        }
+        qa = (a0 + a1) + (a2 + a3);
+        qb = (b0 + b1) + (b2 + b3);
+    } else {
+        for (long i = threadIdx.x; i < HW; i += 256) {
+            qa = sqacc(qa, o0[i], ma);
+            qb = sqacc(qb, o1[i], mb);
+        }
+    }
+    qa = block_sum_256(qa, red);
+    qb = block_sum_256(qb, red);
+    if (threadIdx.x == 0) {
+        float* s0 = stats + 2 * ((long)b * 2 * C + c);
+        float* s1 = stats + 2 * ((long)b * 2 * C + C + c);
+        s0[0] = ma; s0[1] = rsqrtf(qa / (float)HW + eps);
+        s1[0] = mb; s1[1] = rsqrtf(qb / (float)HW + eps);
     }
 }
 
@@ -868,6 +972,13 @@ extern "C" int oodgan_align_input(const float* gen, const float* enc, const floa
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(align_input_kernel, dim3(gx, B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, C, HW);
     return check_launch("align_input");
+}
+
+extern "C" int oodgan_align_input_stats(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, float* stats,
+                                        int B, int C, long HW, float eps, void* stream) {
+    OODGAN_REQUIRE(gen && enc && st_gen && st_enc && out && stats && B > 0 && C > 0 && HW > 0, "align_input_stats: bad args");
+    hipLaunchKernelGGL(align_input_stats_kernel, dim3(B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, stats, C, HW, eps);
+    return check_launch("align_input_stats");
 }
 
 extern "C" int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,

@@ -26,6 +26,7 @@ _lib.bind_extra({
     'oodgan_affine_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_affine_apply_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
+    'oodgan_align_input_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_se_gate': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
@@ -92,6 +93,17 @@ def align_input(gen, enc, st_gen, st_enc):
     out = torch.empty(B, 2 * C, H, W, device=gen.device, dtype=torch.float32)
     check(_lib.lib().oodgan_align_input(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), B, C, H * W, _stream()), 'align_input')
     return out
+
+
+def align_input_stats(gen, enc, st_gen, st_enc, eps=1e-5):
+    """(align_input(...), instnorm_stats of it) in one pass."""
+    gen, enc = _dev(gen), _dev(enc)
+    B, C, H, W = gen.shape
+    out = torch.empty(B, 2 * C, H, W, device=gen.device, dtype=torch.float32)
+    st = torch.empty(B, 2 * C, 2, device=gen.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_align_input_stats(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), _p(st), B, C, H * W, eps, _stream()),
+          'align_input_stats')
+    return out, st
 
 
 def conv1x1(x, weight, bias=None):
@@ -414,11 +426,14 @@ class AlignNet(nn.Module):
     def forward(self, source, target, st_target=None, **kwargs):
         st_s = instnorm_stats(source)
         st_t = st_target if st_target is not None else instnorm_stats(target)
-        a = align_input(source, target, st_s, st_t)
         if FUSE_STATS:
-            a, st_a = self.body[0](a, want_stats=True)      # the statistics the second bottleneck's norm needs come with the first one's output
+            # every InstanceNorm's statistics come from the pass that writes its input: the concatenated, normalised pair here, the
+            # first bottleneck's output below
+            a, st_in = align_input_stats(source, target, st_s, st_t)
+            a, st_a = self.body[0](a, stats=st_in, want_stats=True)
             a = self.body[1](a, stats=st_a)
         else:
+            a = align_input(source, target, st_s, st_t)
             a = self.body[1](self.body[0](a))
         return align_head(a, self.scale)
 

@@ -106,6 +106,19 @@ def test_affine_apply_stats_equals_two_passes(dev):
         assert torch.equal(y0, y1) and torch.equal(st0, st1)
 
 
+def test_align_input_stats_equals_two_passes(dev):
+    """cat[IN(gen) - IN(enc), IN(enc)] (SAMM/helpers.py:96-104) and the statistics of the result from one kernel: bit-identical."""
+    from oodgan import samm
+    for (B, C, H, W) in ((2, 24, 16, 16), (1, 7, 9, 13), (3, 16, 64, 64), (1, 4, 256, 256)):
+        g = synth.normal('ai.g', (B, C, H, W), 1, 1.7, 0.4).to(dev)
+        e = synth.normal('ai.e', (B, C, H, W), 2, 0.6, -0.2).to(dev)
+        sg, se = samm.instnorm_stats(g), samm.instnorm_stats(e)
+        a0 = samm.align_input(g, e, sg, se)
+        st0 = samm.instnorm_stats(a0)
+        a1, st1 = samm.align_input_stats(g, e, sg, se)
+        assert torch.equal(a0, a1) and torch.equal(st0, st1)
+
+
 def test_warp_blend_channel_chunks(dev):
     """grid_sample + lerp with channel counts that are not a multiple of the kernel's channel chunk, B > 1."""
     from oodgan import samm
