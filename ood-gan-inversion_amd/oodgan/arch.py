@@ -327,6 +327,14 @@ class GraphedForward:
             for d, n in zip(ent['noise'], noise):
                 d.copy_(n)
         ent['graph'].replay()
+        # the captured forward runs on carried range scales (modules.Generator.forward) and cannot read their check flag inside the graph:
+        # read it here (one small device-to-host copy) and repeat the call eagerly with measured scales if it is set
+        gen = getattr(self.model, 'generator', None)
+        eng = gen._engine_obj if gen is not None and getattr(gen, '_engine_obj', None) is not None else None
+        if eng is not None and eng.fwd_range_violated():
+            eng.reset_fwd_state()
+            out, lats = self.model(x, noise=noise) if noise is not None else self.model(x)
+            return out, lats
         self.model.aligns = dict(ent['aligns'])
         return ent['out'], ent['lats']
 

@@ -220,7 +220,9 @@ class GeneratorEngine:
         s_use, d_use = s_all, d_all
         if self.sform:
             rng = self._range(B)
-            carry = range_mode == 'carry' and rng.valid and self.carry_range and cond_hook is None and features_in is None and post_hook is None
+            # cond_hook (the SAMM hook of the OOD forward) does not stand in the way: a hooked layer's output is converted by to_s(),
+            # which takes the carried scale and records the maximum like any fused producer
+            carry = range_mode == 'carry' and rng.valid and self.carry_range and features_in is None and post_hook is None
             if carry:
                 rng.plan(s_all, d_all)
             s_use, d_use = rng.s_sc, rng.d_sc
@@ -309,7 +311,7 @@ class GeneratorEngine:
                 # the plain forward (model(x), exact ranges) takes the same two kernels: the up-conv kernel records max|y * style| of the
                 # F-form activation it writes, the range scale of the last conv is set from it on the device — no (2H+1)² intermediate,
                 # no blur pass, no measurement pass and no S-form copy of the 1024² tensor
-                plain_tail = (self.sform and not carry and not save and not one_pass and self.plain_one_pass and self.fuse_up and self.fuse_x
+                plain_tail = (self.sform and not save and not one_pass and self.plain_one_pass and self.fuse_up and self.fuse_x
                               and self.fused_rgb and Ln is not None and Ln is self.layers_styled_last and L.wpk_vb is not None
                               and Ln.name in self.conv_next_rgb and 16 < Ln.cin <= 32 and 16 < Ln.cout <= 32
                               and not (cond_layers is not None and L.lat in cond_layers)
@@ -327,9 +329,10 @@ class GeneratorEngine:
                                                      ys_scale=_Cols(s_use, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
                     elif plain_tail:
                         out = ops.upconv_vblur_fform(xs, L.wpk_vb, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w, act=True,
-                                                     ys_scale=_Cols(s_all, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
-                        rng.update_exact(Ln.sidx)
-                        rng.plan(s_all, d_all, Ln.row, Ln.cin, Ln.drow, Ln.cout)
+                                                     ys_scale=_Cols(s_use if carry else s_all, Ln.row, Ln.cin), vmax=rng.vm[Ln.sidx])
+                        if not carry:       # exact ranges: the scale of the last conv from the maximum just recorded
+                            rng.update_exact(Ln.sidx)
+                            rng.plan(s_all, d_all, Ln.row, Ln.cin, Ln.drow, Ln.cout)
                         one_pass = True
                     else:
                         z = ops.conv3x3(xs, L.wpk, L.cout, CONV_T2, out_scale=d)

@@ -9,11 +9,15 @@ latents only)."""
 import math
 import random
 
+import os
+
 import torch
 from torch import nn
 
 from . import ops
 from .engine import GeneratorEngine
+
+CARRY_FORWARD = os.environ.get('OODGAN_CARRY_FORWARD', '1') != '0'      # model(x): carried forward range scales (A/B switch)
 from .synth import generator_channels, make_kernel
 
 __all__ = ['PixelNorm', 'EqualLinear', 'ModulatedConv2d', 'NoiseInjection', 'ConstantInput', 'StyledConv', 'ToRGB',
@@ -336,8 +340,20 @@ class Generator(nn.Module):
         noises = self._draw_noises(B, noise, randomize_noise)
         # the last activation is only materialised in NCHW when the caller asks for it (the engine may keep it in F-form)
         want_feat = bool(return_features) and not return_latents
-        res = self.engine().forward(latent, noises, cond_hook=hook, cond_layers=cl, return_features=want_feat, post_hook=post,
-                                    features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
+        eng = self.engine()
+        kw = dict(cond_hook=hook, cond_layers=cl, return_features=want_feat, post_hook=post,
+                  features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
+        # Forward range scales (split-f16 path) carried from the previous forward of this batch size — the W+ loop's scheme (engine.py,
+        # ops.FwdRange) for model(x) too: no measurement pass per conv input, the fused producers of the loop.  Scales are powers of two
+        # and exact as long as the carried scale keeps the new maximum inside [2^-8, 2^15) — if it does not, the flag is set and the pass
+        # is repeated with measured scales.  The first forward of a batch size (measured scales, unfused producers) and the following
+        # ones therefore differ by fp32 rounding (different kernels, <= 2e-5 on the image); the following ones are bit-identical among
+        # themselves.  Inside a stream capture the flag cannot be read: oodgan.arch.GraphedForward checks it after every replay.
+        mode = 'carry' if (CARRY_FORWARD and eng.sform and eng.carry_range) else 'exact'
+        res = eng.forward(latent, noises, range_mode=mode, **kw)
+        if mode == 'carry' and not torch.cuda.is_current_stream_capturing() and eng.fwd_range_violated():
+            eng.reset_fwd_state()
+            res = eng.forward(latent, noises, range_mode='exact', **kw)
         image, feat = res if want_feat else (res, None)
         if return_latents:
             return image, latent

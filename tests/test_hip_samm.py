@@ -327,8 +327,17 @@ def test_ood_forward_1024_batch8_image_k_vs_golden(dev, golden):
 
     out, lats = m(x, enc_lats=enc_lats, enc_feats=enc_feats, noise=noises)
     check(out, lats, 'forward')
+    prev = None
     for streams in (1, 3):
         out0, lats0, losses = m.invert(x, steps=0, noise=noises, streams=streams, enc_lats=enc_lats, enc_feats=enc_feats)
         assert losses.shape == (0, B) and torch.equal(lats0, lats)
         check(out0, lats0, f'invert(steps=0, streams={streams})')
-        assert torch.equal(out0, out)                        # same launches on the same stream: bit-identical
+        # round 4: the first forward of a batch size measures its range scales, the following ones carry them and run the fused
+        # producers of the W+ loop (modules.Generator.forward): same values to rounding against the first call, and — same launches on
+        # the same stream — bit-identical among themselves
+        d = (out0 - out).abs().max().item()
+        print(f'carried-scale forward vs measured-scale forward: max abs diff {d:.3e}')
+        assert d <= 2e-5
+        if prev is not None:
+            assert torch.equal(out0, prev)
+        prev = out0.clone()

@@ -87,9 +87,14 @@ def test_restyle_forward_1024_vs_golden(dev, golden, tmp_path):
         step = max(1, a.shape[-1] // 32)
         _close(a[:, :, ::step, ::step], g[f'align{k}_sub'], tol)
     _close(m.aligns[1024][:, :1, ::16, ::16], g['align1024_sub'], tol)
-    # second call reuses the cached average image; same noise for the remaining passes -> same result
+    # second call reuses the cached average image; same noise for the remaining passes -> same result.  Round 4: the generator passes of
+    # a later call run on carried range scales and the W+ loop's fused producers (modules.Generator.forward), the very first one of a
+    # batch size on measured scales: equal to fp32 rounding against the first call, bit-identical from then on
     out2, lats2 = m(x, noise_passes=passes)
-    assert torch.equal(lats2, lats)
+    lats2 = lats2.clone()
+    assert (lats2 - lats).abs().max().item() <= 1e-5
+    out3, lats3 = m(x, noise_passes=passes)
+    assert torch.equal(lats3, lats2)
 
 
 # ------------------------------------------------------------------ Feature-Style variant
