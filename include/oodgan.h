@@ -297,6 +297,10 @@ int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const floa
                                  const float* mul2, void* out, int B, int C, int H, int W, void* stream);
 int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
                            int C, int H, int W, int in_pitch, void* stream);
+/* the same for the FORWARD use of the stride-2 conv (nn.Conv2d(K, M, 3, stride 2, padding 1)): x is the unpadded (B,C,2H,2W) tensor, pitch in_pitch
+ * (0: 2W); the zero row / column on the top / left of the (2H+1) x (2W+1) image the conv reads are produced here, not by a padded copy */
+int oodgan_to_sform_phases_padtl(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                                 int C, int H, int W, int in_pitch, void* stream);
 int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
 /* ---- forward range control of the split-f16 path (csrc/fwd_range.hip).  ModulatedConv2d.forward in fp32
  * (src/ops/StyleGAN/model.py:233-274) has no range limit; an S-form record (hi+lo f16) holds |v| < 65504.  Every styled

@@ -802,7 +802,9 @@ __global__ __launch_bounds__(256 * NG) void conv_f16s_s2v2_kernel(const KArgs p,
 __global__ __launch_bounds__(256) void to_sform_phases_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                               int scale_stride, const float* __restrict__ mul2,
                                                               uint4* __restrict__ out, int B, int C, int H, int W, int Hin, int Win,
-                                                              int in_pitch, SPDims sp) {
+                                                              int in_pitch, SPDims sp, int pad) {
+    // pad = 1: x is the UNPADDED (B,C,2H,2W-ish) tensor of a conv with padding 1 — source pixel (yy-1, xx-1), row / column 0 of the
+    // padded image are zeros (the zero-pad copy the forward use of the stride-2 conv used to make with two torch kernels)
     const int Hh = H + 1, Wh = W + 1;
     const long total = (long)B * sp.KC * 4 * Hh * Wh;
     const float gm = mul2 ? mul2[1] : 1.f;
@@ -813,13 +815,13 @@ __global__ __launch_bounds__(256) void to_sform_phases_kernel(const float* __res
         const int ph = (int)((e / ((long)Wh * Hh)) % 4);
         const int kc = (int)((e / ((long)Wh * Hh * 4)) % sp.KC);
         const int b = (int)(e / ((long)Wh * Hh * 4 * sp.KC));
-        const int yy = 2 * i + (ph >> 1), xx = 2 * j + (ph & 1);
-        const bool inb = yy < Hin && xx < Win;
+        const int yy = 2 * i + (ph >> 1) - pad, xx = 2 * j + (ph & 1) - pad;
+        const bool inb = yy >= 0 && xx >= 0 && yy < Hin && xx < Win;
         half8 h0, h1, l0, l1;
         // one request for the record's 16 channels and scales (clamped pixel and channel), masked below — see to_sform_kernel
         float xv[16], scv[16];
         const float* scp = scale ? scale + (long)b * scale_stride : x;
-        const long pofs = (long)min(yy, Hin - 1) * in_pitch + min(xx, Win - 1);
+        const long pofs = (long)max(0, min(yy, Hin - 1)) * in_pitch + max(0, min(xx, Win - 1));
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
             const int cc = min(kc * 16 + jj, C - 1);
@@ -1027,16 +1029,27 @@ extern "C" long oodgan_sform_phases_bytes(int B, int C, int H, int W) {
     return (long)B * d.KC * 4 * d.plane * 16;
 }
 
-extern "C" int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
-                                      int C, int H, int W, int in_pitch, void* stream) {
+static int to_sform_phases_impl(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                                int C, int H, int W, int in_pitch, int pad, void* stream) {
     OODGAN_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "to_sform_phases: bad args");
     const SPDims d = sp_dims(C, H, W);
-    const int Hin = 2 * H + 1, Win = 2 * W + 1;
+    const int Hin = 2 * H + 1 - pad, Win = 2 * W + 1 - pad;
     if (in_pitch == 0) in_pitch = Win;
     const long total = (long)B * d.KC * 4 * (H + 1) * (W + 1);
     hipLaunchKernelGGL(to_sform_phases_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
-                       scale_stride, mul2, reinterpret_cast<uint4*>(out), B, C, H, W, Hin, Win, in_pitch, d);
+                       scale_stride, mul2, reinterpret_cast<uint4*>(out), B, C, H, W, Hin, Win, in_pitch, d, pad);
     return check_launch("to_sform_phases");
+}
+
+extern "C" int oodgan_to_sform_phases(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                                      int C, int H, int W, int in_pitch, void* stream) {
+    return to_sform_phases_impl(x, scale, scale_stride, mul2, out, B, C, H, W, in_pitch, 0, stream);
+}
+
+// x is the unpadded (B,C,2H,2W) input of nn.Conv2d(3, stride 2, padding 1): the zero row / column on the top / left come from the kernel
+extern "C" int oodgan_to_sform_phases_padtl(const float* x, const float* scale, int scale_stride, const float* mul2, void* out, int B,
+                                            int C, int H, int W, int in_pitch, void* stream) {
+    return to_sform_phases_impl(x, scale, scale_stride, mul2, out, B, C, H, W, in_pitch, 1, stream);
 }
 
 namespace oodgan {

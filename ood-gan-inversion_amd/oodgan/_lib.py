@@ -91,6 +91,7 @@ _SIGS = {
     'oodgan_sform_phases_bytes': (c_long, [c_int, c_int, c_int, c_int]),
     'oodgan_blurT_to_sform_phases': (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform_phases': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_to_sform_phases_padtl': (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_to_sform': (c_int, [P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     'oodgan_resize_bicubic_ac': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_avgpool': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),

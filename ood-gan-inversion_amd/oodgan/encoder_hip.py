@@ -76,7 +76,6 @@ def _conv3x3(x, pk, M, stride=1, **kw):
     if stride == 1:
         return ops.conv3x3(x, pk, M, CONV_S1, **kw)
     assert stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-    xp, pitch = _pad_tl(x)
     B, K, H, W = x.shape
     G = kw.get('groups', 1)
     tiny = HEADS_TINY and min(H, W) // 2 <= HEADS_TINY_MAX_OUT and ops.tiny_workspace_bytes(CONV_S2, B, K // G, M, H + 1, W + 1) > 0
@@ -94,9 +93,10 @@ def _conv3x3(x, pk, M, stride=1, **kw):
         #    K split over the chip, every weight read once per 128 positions.  The fp32-input kernel spent 0.83 ms on each of the
         #    4² / 2² / 1² steps of the 18 heads at batch 8 (170 MB of weights per step, re-streamed by every image's workgroups).
         mul2 = ops.absmax_mul2(x)
-        gp = ops.to_sform_phases(xp, H // 2, W // 2, mul2=mul2, in_pitch=pitch,
+        gp = ops.to_sform_phases(x, H // 2, W // 2, mul2=mul2, pad_tl=True,        # the zero pad on the top / left comes from the conversion
                                  out=ops.sform_phases_scratch(B, K, H // 2, W // 2, x.device))
         return ops.conv3x3(gp, pk, M, CONV_S2, in_mul2=mul2, **kw)
+    xp, pitch = _pad_tl(x)
     return ops.conv3x3(xp, pk, M, CONV_S2, in_hw=(H + 1, W + 1), in_pitch=pitch, **kw)
 
 

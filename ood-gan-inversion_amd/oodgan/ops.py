@@ -292,14 +292,16 @@ class SFormPhases:
         return (self.B, self.C, 2 * self.H + 1, 2 * self.W + 1)
 
 
-def to_sform_phases(x, H, W, scale=None, mul2=None, out=None, in_pitch=0):
-    """pitched fp32 (B,C,2H+1,pitch) -> phase-split S-form of x*scale[b,c]*mul2[1]."""
+def to_sform_phases(x, H, W, scale=None, mul2=None, out=None, in_pitch=0, pad_tl=False):
+    """pitched fp32 (B,C,2H+1,pitch) -> phase-split S-form of x*scale[b,c]*mul2[1].  ``pad_tl``: x is the unpadded (B,C,2H,2W) input
+    of a stride-2 conv with padding 1; its zero row / column on the top / left are produced by the kernel."""
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
     if out is None:
         out = SFormPhases(B, C, H, W, x.device)
-    check(_lib.lib().oodgan_to_sform_phases(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2),
-                                            _p(out), B, C, H, W, in_pitch, _stream()), 'to_sform_phases')
+    fn = _lib.lib().oodgan_to_sform_phases_padtl if pad_tl else _lib.lib().oodgan_to_sform_phases
+    check(fn(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2), _p(out), B, C, H, W, in_pitch, _stream()),
+          'to_sform_phases')
     return out
 
 

@@ -546,6 +546,8 @@ def test_conv3x3_s2_grouped_sform(dev, B, G, K, Mg, H, W, tunable):
     assert not ops.s2_grouped_supported(B, K, G * 64, G, H + 1, W + 1)            # Mg % 128
     mul2 = ops.absmax_mul2(x.to(dev))
     gp = ops.to_sform_phases(xp.to(dev), H // 2, W // 2, mul2=mul2, in_pitch=pitch)
+    gp2 = ops.to_sform_phases(x.to(dev), H // 2, W // 2, mul2=mul2, pad_tl=True)       # the zero pad made by the conversion itself
+    assert torch.equal(gp.data, gp2.data)
     _lib.dispatch_reset()
     y = ops.conv3x3(gp, wpk, G * Mg, ops.CONV_S2, bias=bias.to(dev), in_mul2=mul2, act=ops.ACT_PRELU, slope=slope.to(dev), groups=G)
     assert _lib.dispatch_count('s2big') == 1
