@@ -46,6 +46,8 @@ int oodgan_device_count(void);
  *   "upvb_waves"       OODGAN_UPVB_WAVES       12    form of oodgan_upconv_vblur_fform: 12 = one persistent 12-wave workgroup per CU, 6 / 4 = tile
  *                                                    kernels with two / three workgroups per CU (csrc/conv_f16s_upvb.hip)
  *   "fewout_quad"      OODGAN_FEWOUT_QUAD      1     0: oodgan_conv3x3_fewout2 keeps its one-pixel-per-thread form (the A/B of csrc/samm.hip's third form)
+ *   "tiny_mid_max"     OODGAN_TINY_MID_MAX     1024  most positions (B*H*W) of a 16x16 / 32x32 stride-1 map the skinny-GEMM kernel takes when the caller
+ *                                                    offers a workspace (the encoder trunk at batch 1-4; 8192 measured: +2.7 ms per batch of 8)
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);

@@ -256,7 +256,7 @@ bool tiny_shape(const oodgan_conv_args& a, int& H) {
     // 1x1 / 2x2: only the stride-2 chains of the style heads end there (no noise, no dot: tiny_eligible)
     // 16x16 / 32x32 stride-1 maps with at most 1024 positions in all: the encoder trunk at batch 1-4, where the tile kernels have 8-32
     // workgroups walking their K chunks one after the other (the caller opts in by passing a workspace)
-    const bool mid = a.mode == OODGAN_CONV_S1 && (H == 16 || H == 32) && a.B * H * H <= 1024;
+    const bool mid = a.mode == OODGAN_CONV_S1 && (H == 16 || H == 32) && a.B * H * H <= tunable(OODGAN_TUN_TINY_MID_MAX);
     return a.x_sform && H == Wd && (H == 4 || H == 8 || mid || (a.mode == OODGAN_CONV_S2 && (H == 1 || H == 2))) && a.K % 16 == 0 && a.K >= 64 &&
            a.M % 32 == 0 && a.B * H * H <= 16384;
 }
