@@ -111,6 +111,10 @@ int oodgan_style_affine_bwd(const float* gs, const float* wcat, const int* lat_s
 /* EqualLinear with fused_lrelu (mapping network layer, model.py:148-151): y = sqrt2*lrelu(scale*x@W^T + b*lr_mul) */
 int oodgan_equal_linear(const float* x, const float* w, const float* b, float* y, int B, int in_dim, int out_dim,
                         float scale, float lr_mul, int activate, void* stream);
+/* G independent EqualLinear layers side by side — x (B,G,I), w (G,O,I), bias (G,O) or NULL -> y (B,G,O); bit-identical to G calls of
+ * oodgan_equal_linear (the final linears of the GradualStyleBlock heads, psp_encoders.py:31-34, as ONE launch) */
+int oodgan_equal_linear_grouped(const float* x, const float* w, const float* b, float* y, int B, int G, int in_dim, int out_dim,
+                                float scale, float lr_mul, int activate, void* stream);
 /* PixelNorm (model.py:11-16): y = x * rsqrt(mean_k x^2 + 1e-8) */
 int oodgan_pixel_norm(const float* x, float* y, int B, int S, void* stream);
 

@@ -134,6 +134,27 @@ __global__ __launch_bounds__(256) void equal_linear_kernel(const float* __restri
     }
 }
 
+// G independent EqualLinear layers side by side (the final linears of the e4e style heads): x (B,G,I), w (G,O,I), bias (G,O) -> y (B,G,O);
+// one wave per output, the arithmetic and summation order of equal_linear_kernel (bit-identical to G separate calls)
+__global__ __launch_bounds__(256) void equal_linear_grouped_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, float* __restrict__ y, int B, int G,
+                                                                   int in_dim, int out_dim, float scale, float lr_mul, int activate) {
+    const int lane = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (long)B * G * out_dim) return;
+    const int o = (int)(idx % out_dim), g = (int)((idx / out_dim) % G), b = (int)(idx / ((long)out_dim * G));
+    const float* xp = x + ((long)b * G + g) * in_dim;
+    const float* wp = w + ((long)g * out_dim + o) * in_dim;
+    float acc = 0.f;
+    for (int k = lane; k < in_dim; k += 64) acc += xp[k] * (wp[k] * scale);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[(long)g * out_dim + o] * lr_mul : 0.f);
+        if (activate) v = (v > 0.f ? v : 0.2f * v) * kSqrt2;
+        y[idx] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void pixel_norm_kernel(const float* __restrict__ x, float* __restrict__ y, int S) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float acc = 0.f;
@@ -224,6 +245,15 @@ extern "C" int oodgan_equal_linear(const float* x, const float* w, const float* 
     hipLaunchKernelGGL(equal_linear_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), x, w, b, y, B, in_dim,
                        out_dim, scale, lr_mul, activate);
     return check_launch("equal_linear");
+}
+
+extern "C" int oodgan_equal_linear_grouped(const float* x, const float* w, const float* b, float* y, int B, int G, int in_dim, int out_dim,
+                                           float scale, float lr_mul, int activate, void* stream) {
+    OODGAN_REQUIRE(x && w && y && B > 0 && G > 0 && in_dim > 0 && out_dim > 0, "equal_linear_grouped: bad args");
+    const long n = (long)B * G * out_dim;
+    hipLaunchKernelGGL(equal_linear_grouped_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), x, w, b, y, B, G, in_dim,
+                       out_dim, scale, lr_mul, activate);
+    return check_launch("equal_linear_grouped");
 }
 
 extern "C" int oodgan_pixel_norm(const float* x, float* y, int B, int S, void* stream) {

@@ -71,6 +71,7 @@ _SIGS = {
     'oodgan_style_affine_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'oodgan_style_affine_bwd': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_equal_linear': (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_int, P]),
+    'oodgan_equal_linear_grouped': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, P]),
     'oodgan_pixel_norm': (c_int, [P, P, c_int, c_int, P]),
     'oodgan_weight_sqsum': (c_int, [P, P, c_int, c_int, c_int, P]),
     'oodgan_demod_fwd': (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P]),

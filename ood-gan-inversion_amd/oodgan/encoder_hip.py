@@ -217,6 +217,15 @@ class _HipTrunk:
             x_all = y
         B = x_all.shape[0]
         x_all = x_all.reshape(B, len(live), out_c)
+        lins = [self.styles[i].linear for i in live]
+        if len(live) > 1 and all(l.lr_mul == lins[0].lr_mul and l.weight.shape == lins[0].weight.shape and l.bias is not None for l in lins):
+            # the heads' final EqualLinear layers as ONE launch over the stacked weights (was: a slice copy + a launch per head)
+            w, b = self._memo(('head_lin', tuple(live)), [t for l in lins for t in (l.weight, l.bias)],
+                              lambda: (torch.stack([l.weight.detach().float() for l in lins]).contiguous(),
+                                       torch.stack([l.bias.detach().float() for l in lins]).contiguous()))
+            y = ops.equal_linear_grouped(x_all.contiguous(), w, b, lr_mul=lins[0].lr_mul)
+            self._stacked_deltas = (y, list(live))         # for callers that combine all heads at once (Encoder4EditingHIP.forward)
+            return {i: y[:, g] for g, i in enumerate(live)}
         res = {}
         for g, i in enumerate(live):
             blk = self.styles[i]
@@ -266,11 +275,21 @@ class Encoder4EditingHIP(_HipTrunk, Encoder4Editing):
             elif i == self.middle_ind:
                 features = _resize_bicubic_ac(p2, c1.shape[-2:], add=samm.conv1x1(c1, self.latlayer2.weight.detach(), self.latlayer2.bias.detach()))
             feat_of[i] = features
+        self._stacked_deltas = None
         deltas = self._style_heads(sorted(feat_of), feat_of)
-        w = deltas[0].repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
-        for i in sorted(feat_of):
-            if i > 0:
-                w[:, i] += deltas[i]
+        st = self._stacked_deltas
+        if st is not None and len(feat_of) == self.style_count and sorted(st[1]) == list(range(self.style_count)):
+            # w[:, 0] = delta_0, w[:, i] = delta_0 + delta_i (psp_encoders.py:198-214) from the stacked head outputs: three launches
+            # instead of one add per head
+            y, live = st
+            order = self._memo(('head_order', tuple(live)), (), lambda: torch.tensor([live.index(i) for i in range(self.style_count)], device=y.device))
+            w = y.index_select(1, order)
+            w[:, 1:] += w[:, :1].clone()
+        else:
+            w = deltas[0].repeat(self.style_count, 1, 1).permute(1, 0, 2).contiguous()
+            for i in sorted(feat_of):
+                if i > 0:
+                    w[:, i] += deltas[i]
         if kwargs.get('return_feats', False):
             return w, feats
         return w

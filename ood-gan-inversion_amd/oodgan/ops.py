@@ -198,6 +198,18 @@ def equal_linear(x, weight, bias=None, lr_mul=1.0, activation=False):
     return y
 
 
+def equal_linear_grouped(x, weight, bias=None, lr_mul=1.0, activation=False):
+    """G EqualLinear layers side by side: x (B,G,I), weight (G,O,I), bias (G,O) -> (B,G,O); bit-identical to G ``equal_linear`` calls."""
+    x = _dev(x)
+    w = _dev(weight, 'weight')
+    B, G, I = x.shape
+    O = w.shape[1]
+    y = torch.empty(B, G, O, device=x.device, dtype=torch.float32)
+    check(_lib.lib().oodgan_equal_linear_grouped(_p(x), _p(w), _p(_opt(bias, 'bias')), _p(y), B, G, I, O, (1.0 / math.sqrt(I)) * lr_mul,
+                                                 float(lr_mul), 1 if activation else 0, _stream()), 'equal_linear_grouped')
+    return y
+
+
 def linear(x, weight, bias=None):
     """nn.Linear (feature_style_encoder.py:45,67-68) through the EqualLinear kernel with scale 1."""
     x = _dev(x)
