@@ -16,8 +16,24 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_DEV_INDEX = None
+
+
+def _stream_handle():
+    """Raw handle of the current HIP stream of this process's device (one device per process, include/oodgan.h).  The host mirror issues
+    ~700 launches per model(x): at batch 1 the eager call is bound by the host, and `torch.cuda.current_stream().cuda_stream` — a Stream
+    object per launch — was a measurable part of it."""
+    global _DEV_INDEX
+    if _RAW_STREAM is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return _RAW_STREAM(_DEV_INDEX)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_handle())
 
 
 def zeros(*shape, device, dtype=torch.float32):
@@ -334,7 +350,7 @@ _SFORM_POOL = {}
 
 
 def sform_phases_scratch(B, C, H, W, device):
-    key = ('ph', B, C, H, W, str(device), torch.cuda.current_stream().cuda_stream)
+    key = ('ph', B, C, H, W, str(device), _stream_handle())
     buf = _SFORM_POOL.get(key)
     if buf is None:
         buf = _SFORM_POOL[key] = SFormPhases(B, C, H, W, device)
@@ -349,7 +365,7 @@ def conv_workspace(nbytes, device):
     """Scratch for ``oodgan_conv_args.workspace`` (the K-split partial tiles of csrc/conv_f16s_tiny.hip: written, then read by the
     finishing launch — no counters, no initialisation needed), one per HIP stream — two streams running the same layer at the
     same time must not share partial tiles."""
-    key = (nbytes, str(device), torch.cuda.current_stream().cuda_stream)
+    key = (nbytes, str(device), _stream_handle())
     buf = _WS_POOL.get(key)
     if buf is None:
         buf = _WS_POOL[key] = torch.empty(nbytes // 4, device=device, dtype=torch.int32)
@@ -369,7 +385,7 @@ def drop_stream_scratch(stream_handle):
 def sform_scratch(B, C, H, W, device, tag=0):
     """Reusable S-form buffer (zero border written once at allocation; producers only touch the interior, so a
     buffer can be recycled for any tensor of the same logical shape)."""
-    key = (B, C, H, W, str(device), tag, torch.cuda.current_stream().cuda_stream)
+    key = (B, C, H, W, str(device), tag, _stream_handle())
     buf = _SFORM_POOL.get(key)
     if buf is None:
         buf = _SFORM_POOL[key] = SForm(B, C, H, W, device)
@@ -438,7 +454,7 @@ def absmax_mul2(x):
     B, C = x.shape[0], x.shape[1]
     # float bit patterns, atomic max; ONE persistent slot array per (device, stream, B), zeroed at creation and again by the kernel that
     # reads it (stream order makes the reuse safe; created during warm-up, so never inside a graph capture)
-    key = (str(x.device), torch.cuda.current_stream().cuda_stream, B)
+    key = (str(x.device), _stream_handle(), B)
     vm = _VMAX_POOL.get(key)
     if vm is None:
         vm = _VMAX_POOL[key] = torch.zeros(B * VMAX_SLOTS, device=x.device, dtype=torch.int32)
