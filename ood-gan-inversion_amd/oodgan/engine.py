@@ -155,6 +155,7 @@ class GeneratorEngine:
         e.saved = None
         e.bwd_state, e.bwd_flag = {}, None
         e.fwd_range = None
+        e._ranges = {}
         return e
 
     def reset_fwd_state(self):
@@ -170,7 +171,15 @@ class GeneratorEngine:
 
     def _range(self, B):
         if self.fwd_range is None or self.fwd_range.B != B:
-            self.fwd_range = ops.FwdRange(self.n_styled, B, self.R, self.DR, self.row_layer, self.drow_layer, self.device)
+            # one state per batch size (an inversion alternates between the sub-batch of the W+ loop and the full batch of the OOD forward:
+            # the latter's carried scales survive the former)
+            ranges = self.__dict__.setdefault('_ranges', {})
+            r = ranges.get(B)
+            if r is None:
+                if len(ranges) >= 4:
+                    ranges.pop(next(iter(ranges)))
+                r = ranges[B] = ops.FwdRange(self.n_styled, B, self.R, self.DR, self.row_layer, self.drow_layer, self.device)
+            self.fwd_range = r
         return self.fwd_range
 
     def reset_bwd_state(self):
