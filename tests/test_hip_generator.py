@@ -418,3 +418,42 @@ def test_generator_1024_batch4_vs_reference(dev, golden, prec, monkeypatch):
     print(f'[{prec}] C2 generator forward 1024² B=4 vs reference fp32: sub-sample {e_sub:.2e}, crop {e_crop:.2e}, moments {e_mom:.2e} '
           f'(absmax {g["image_absmax"].item():.2f}; reference fp32 vs f64 {g["ref_f32_vs_f64"].item():.1e})')
     assert e_sub < 1e-3 and e_crop < 1e-3 and e_mom < 1e-5
+
+
+def test_generator_forward_carried_scales_and_fallback(dev):
+    """Round 4: ``Generator.forward`` carries the forward range scales from call to call (modules.CARRY_FORWARD).  (a) the second call
+    (carried scales, fused producers) equals the first (measured scales) to fp32 rounding and the third equals the second bit for bit;
+    (b) an input whose activations leave the carried window — noise maps 2^30 times larger — sets the check flag and the pass is repeated
+    with measured scales: same result as a generator that never carried anything."""
+    from oodgan import modules
+    from oodgan.modules import Generator
+    size, B = 256, 2
+    sd = synth.generator_state(size, seed=3)
+
+    def build():
+        G = Generator(size, 512, 8)
+        G.load_state_dict(sd, strict=True)
+        return G.to(dev).eval()
+    G = build()
+    z = synth.normal('carry.z', (B, 512), 5).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=6)]
+    big = [n * 2.0 ** 30 for n in noises]
+    img1, _ = G([z], noise=noises)
+    img1 = img1.clone()
+    eng = G.engine()
+    assert eng.fwd_range is not None and eng.fwd_range.valid
+    img2, _ = G([z], noise=noises)
+    img2 = img2.clone()
+    img3, _ = G([z], noise=noises)
+    assert maxdiff(img2, img1.cpu()) <= 2e-5 * img1.abs().max().item() and torch.equal(img3, img2)
+    out_big, _ = G([z], noise=big)                       # carried scales are 2^30 off: violation -> measured-scale repeat
+    assert not eng.fwd_range_violated() and torch.isfinite(out_big).all()
+    old = modules.CARRY_FORWARD
+    try:
+        modules.CARRY_FORWARD = False
+        ref_big, _ = build()([z], noise=big)
+    finally:
+        modules.CARRY_FORWARD = old
+    assert maxdiff(out_big, ref_big.cpu()) <= 2e-5 * ref_big.abs().max().item()
+    back, _ = G([z], noise=noises)                       # and back again (2^-30): violation the other way, or a valid carried window
+    assert maxdiff(back, img1.cpu()) <= 2e-5 * img1.abs().max().item()
