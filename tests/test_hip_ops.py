@@ -1,6 +1,7 @@
 """GPU parity: every HIP kernel (through the C ABI) against the CPU oracle on the same seeded inputs
 and against the committed golden vectors.  Tolerance: |diff| <= 1e-3 absolute in fp32 (north star),
 in practice ~1e-5; integer/index work is exact."""
+import ctypes
 import math
 
 import pytest
@@ -646,3 +647,29 @@ def test_conv3x3_t2_big_kernel(dev, B, Ci, Co, H, W, tunable):
     tunable('t2_big_min_items', 1000000000)
     z3 = ops.conv3x3(xs, wpk, Co, ops.CONV_T2, out_scale=d.to(dev))
     assert (z3[..., :2 * W + 1] - z[..., :2 * W + 1]).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_zero_fill_kernel_and_grouped_equal_linear(dev):
+    """Round 4 helpers: oodgan_zero (a fill kernel: unaligned starts / odd byte counts leave the neighbours alone) and
+    oodgan_equal_linear_grouped (G EqualLinear layers side by side, bit-identical to G oodgan_equal_linear calls — the final linears of the
+    e4e style heads, psp_encoders.py:31-34)."""
+    from oodgan import _lib, ops
+    buf = torch.full((4099,), 7, device=dev, dtype=torch.uint8)
+    for (off, n) in ((0, 4099), (1, 33), (5, 4000), (16, 16), (3, 1), (17, 0)):
+        buf.fill_(7)
+        rc = _lib.lib().oodgan_zero(ctypes.c_void_p(buf.data_ptr() + off), n, ops._stream())
+        assert rc == 0
+        ref = torch.full((4099,), 7, dtype=torch.uint8)
+        ref[off:off + n] = 0
+        assert torch.equal(buf.cpu(), ref), (off, n)
+    z = ops.zeros(3, 5, 7, device=dev)
+    assert z.shape == (3, 5, 7) and float(z.abs().max()) == 0.0
+    B, G, I, O = 3, 5, 96, 64
+    x = synth.normal('gl.x', (B, G, I), 1).to(dev)
+    w = synth.normal('gl.w', (G, O, I), 2).to(dev)
+    b = synth.normal('gl.b', (G, O), 3).to(dev)
+    for lr_mul, act in ((1.0, False), (0.01, True)):
+        y = ops.equal_linear_grouped(x, w, b, lr_mul=lr_mul, activation=act)
+        for g in range(G):
+            yg = ops.equal_linear(x[:, g].contiguous(), w[g], b[g], lr_mul=lr_mul, activation=act)
+            assert torch.equal(y[:, g], yg)
