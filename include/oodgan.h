@@ -173,9 +173,10 @@ typedef struct oodgan_conv_args {
     void* ys;                /* optional S-form output of (activated y) * ys_scale[b,m] for the next conv, or NULL */
     const float* ys_scale;   /* (B,M) stride ys_scale_stride, or NULL */
     int ys_scale_stride;
-    /* optional fused ToRGB partial (split-f16 strip kernel only: mode S1, 16 < K,M <= 32): rgb_y[b,k,p] =
-     * rgb_scale * sum_m rgb_w[k,m] * rgb_s[b,m] * act(y)[b,m,p]  (ToRGB.forward without bias / skip, model.py:363-372;
-     * finish with oodgan_rgb_finish).  rgb_y NULL = off. */
+    /* optional fused ToRGB partial: rgb_y[b,k,p] = rgb_scale * sum_m rgb_w[k,m] * rgb_s[b,m] * act(y)[b,m,p]  (ToRGB.forward without
+     * bias / skip, model.py:363-372; finish with oodgan_rgb_finish).  rgb_y NULL = off.  The split-f16 strip kernel (mode S1,
+     * 16 < K,M <= 32) writes the complete sums; the 8-wave stride-1 kernel (round 4, together with `ys`) writes one partial sum per
+     * 64-channel block: rgb_y is then (ceil(M/64), B, 3, Hout, Wout) and oodgan_rgb_finish_parts adds the blocks in order. */
     const float* rgb_w;      /* (3,M) */
     const float* rgb_s;      /* (B,*) stride rgb_s_stride */
     float* rgb_y;            /* (B,3,Hout,Wout) dense */
@@ -213,6 +214,9 @@ typedef struct oodgan_conv_args {
                                 with phase-split S-form input, K >= 64) run as a skinny GEMM over the batch with a K split
                                 (csrc/conv_f16s_tiny.hip); NULL: the tile kernels */
     long workspace_bytes;
+    unsigned* ys_vmax;       /* optional, with `ys` from the 8-wave stride-1 kernel (oodgan_conv3x3_s1_ys_supported): (B x OODGAN_VMAX_SLOTS) float bit patterns,
+                                max |activated y * ys_scale| of every sample atomically maxed into a slot — the forward range control of the conv
+                                that reads `ys` (as the `vmax` argument of the S-form producers), or NULL */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -474,6 +478,9 @@ int oodgan_torgb_fwd_sform(const float* x, const float* w, const float* s, int s
  * three colour sums came out of the conv kernel's epilogue (oodgan_conv_args.rgb_y).  y may alias partial. */
 int oodgan_rgb_finish(const float* partial, const float* bias, const float* skip, const float* kernel, float* y, int B, int H,
                       int W, void* stream);
+/* the same for `nparts` partial sums (nparts, B, 3, H, W), added in the order of their index (oodgan_conv_args.rgb_y of the 8-wave kernel) */
+int oodgan_rgb_finish_parts(const float* partial, int nparts, const float* bias, const float* skip, const float* kernel, float* y, int B,
+                            int H, int W, void* stream);
 
 /* feature_modulation(gen_feats, conditions, None, mod_type) (src/ops/StyleGAN/model.py:588-610; called from
  * Generator.forward :558-566 and StyleGAN2Generator.forward, stylegan2_arch.py:583-588, for cond_type != 'NOISE'), clss = 1:

@@ -487,8 +487,9 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
         case OODGAN_CONV_S1:
             if (tiny_eligible(a)) { count_dispatch(OODGAN_DC_TINY); return launch_tiny(a, a.wpk, unscale2, st); }
             if (a.x_sform && s1_strip_eligible(a)) { count_dispatch(OODGAN_DC_STRIP); return launch_s1_strip(a, a.wpk, unscale2, st); }
-            OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32)");
             if (a.x_sform && s1_big_eligible(a)) { count_dispatch(OODGAN_DC_S1BIG); return launch_s1_big(a, a.wpk, unscale2, st); }
+            OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32) and, as partial "
+                                               "sums together with ys, in the 8-wave kernel (oodgan_conv3x3_s1_ys_supported)");
             if (a.x_sform) { count_dispatch(OODGAN_DC_S1V2); return launch_s1v2(a, a.wpk, unscale2, st); }
             OODGAN_REQUIRE(a.ys == nullptr, "conv3x3_f16s: S-form output needs the S-form input kernel");
             count_dispatch(OODGAN_DC_S1PP);

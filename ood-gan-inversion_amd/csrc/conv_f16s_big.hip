@@ -64,7 +64,8 @@ constexpr int BG_ZERO = BG_SMEM;                           // 3.5 KB of zeros (t
 constexpr int BG_ZBYTES = 3584;
 constexpr int BG_CST = BG_SMEM + BG_ZBYTES;                // [3][64] floats: out scale, bias, PReLU slope of the workgroup's channels
 constexpr int BG_NZ = BG_CST + 3 * 64 * 4;                 // forward: the tile's 16 x 32 noise values, by LDS-DMA before the K loop (2 KB)
-constexpr int BG_SMEM16 = BG_NZ + 2048;                    // 162048
+constexpr int BG_RGBW = BG_NZ + 2048;                      // YS instance with the fused ToRGB partial: [3 colours][64 channels] rgb_scale * w_rgb * s_rgb
+constexpr int BG_SMEM16 = BG_RGBW + 3 * 64 * 4;            // 162816 of 163840
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifdef OODGAN_CLOCK_STAMP
@@ -211,12 +212,16 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     // (`m < M ? out_scale[m] : 0` per accumulator register) each one is a branch around a load followed by vmcnt(0): sixteen
     // serialised round trips per tile in front of the stores.  The ds_write waits for stage 0 like the loop's first barrier does;
     // the epilogue reads the table behind the loop's barriers.
-    float cst_o = 0.f, cst_b = 0.f, cst_s = 1.f;
+    float cst_o = 0.f, cst_b = 0.f, cst_s = 1.f, rgb_c0 = 0.f, rgb_c1 = 0.f, rgb_c2 = 0.f;
     if (tid < 64 && m0 + tid < M) {
         const int m = m0 + tid;
         cst_o = a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f;
         if (!DOT && a.bias) cst_b = a.bias[m];
         if (!DOT && a.act == OODGAN_ACT_PRELU) cst_s = a.slope[m];
+        if (YS && a.rgb_y) {                            // fused ToRGB partial of this 64-channel block (oodgan_conv_args.rgb_*)
+            const float sv = a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m];
+            rgb_c0 = sv * a.rgb_w[m]; rgb_c1 = sv * a.rgb_w[M + m]; rgb_c2 = sv * a.rgb_w[2 * M + m];
+        }
     }
     // Forward: the noise of this wave's two rows, one dword per lane (lanes 0-31 row 0, 32-63 row 1) from clamped pixels, straight into
     // LDS with the first stage.  In the epilogue `if (ok) nz = noise[...]` was a branch around a load followed by its use, once per
@@ -233,6 +238,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         float* cst = reinterpret_cast<float*>(smem + BG_CST);
         cst[tid] = cst_o;
         if (!DOT) { cst[64 + tid] = cst_b; cst[128 + tid] = cst_s; }
+        if (YS) {
+            float* rw = reinterpret_cast<float*>(smem + BG_RGBW);
+            rw[tid] = rgb_c0; rw[64 + tid] = rgb_c1; rw[128 + tid] = rgb_c2;
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): written before this wave arrives at the loop's first barrier
     }
     for (int t = 0; t < nchunk; ++t) {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         dsum[q] = 0.f;
     }
     const bool mfull = m0 + 64 <= M;
-    float ysc[16];
+    float ysc[16], ysmax = 0.f;
     if (YS) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -355,16 +364,36 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 if (m0 + 16 * mt < M) {          // M % 16 == 0 (s1_big_eligible)
+                    const float v0 = o[4 * mt] * ysc[4 * mt], v1 = o[4 * mt + 1] * ysc[4 * mt + 1], v2 = o[4 * mt + 2] * ysc[4 * mt + 2],
+                                v3 = o[4 * mt + 3] * ysc[4 * mt + 3];
+                    ysmax = fmaxf(fmaxf(ysmax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
                     uint2 hi, lo;
-                    split_pair(o[4 * mt] * ysc[4 * mt], o[4 * mt + 1] * ysc[4 * mt + 1], hi.x, lo.x);
-                    split_pair(o[4 * mt + 2] * ysc[4 * mt + 2], o[4 * mt + 3] * ysc[4 * mt + 3], hi.y, lo.y);
+                    split_pair(v0, v1, hi.x, lo.x);
+                    split_pair(v2, v3, hi.y, lo.y);
                     unsigned char* rec = reinterpret_cast<unsigned char*>(a.ys) + sform_unit(p.yd, b, (m0 >> 4) + mt, py, px, g >> 1) * 16 + (g & 1) * 8;
                     *reinterpret_cast<uint2*>(rec) = hi;
                     *reinterpret_cast<uint2*>(rec + 32) = lo;
                 }
             }
         }
+        if (YS && !DOT && a.rgb_y) {
+            // ToRGB partial of this pixel over the workgroup's 64 channels: 16 per lane, then the four K-group lanes of the pixel
+            const float* rw = reinterpret_cast<const float*>(smem + BG_RGBW);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = 16 * (q >> 2) + 4 * g + (q & 3);
+                c0 += rw[j] * o[q]; c1 += rw[64 + j] * o[q]; c2 += rw[128 + j] * o[q];
+            }
+            c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
+            c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+            if (ok && g == 0) {
+                float* rp = a.rgb_y + (((long)mblk * a.B + b) * 3) * ((long)H * W) + (long)py * W + px;
+                rp[0] = c0; rp[(long)H * W] = c1; rp[2 * (long)H * W] = c2;
+            }
+        }
     }
+    if (YS && a.ys_vmax) record_vmax(a.ys_vmax, b, ysmax);      // forward range control of the conv that reads `ys` (sform.hpp)
     if (DOT) {
         // sum over the 16 pixels of a lane row (DPP, the total in every lane of the row), then across the waves through LDS
 #pragma unroll
@@ -403,7 +432,7 @@ bool s1_big_eligible(const oodgan_conv_args& a) {
     // ~458 us for either v2 instance.  (The dot epilogue first cost 561 us: one conditional load per value serialised
     // 64 memory latencies; the loads of a row are now issued together.)
     const int min_k = 64;                // 64 -> 64 channels @512²: 589 -> 491 us forward
-    if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && (a.ys == nullptr ? a.y != nullptr : (a.dotx == nullptr && a.M % 16 == 0 && a.rgb_y == nullptr)) &&
+    if (!(a.mode == OODGAN_CONV_S1 && a.x_sform && a.K >= min_k && a.M >= 64 && (a.ys == nullptr ? (a.y != nullptr && a.rgb_y == nullptr) : (a.dotx == nullptr && a.M % 16 == 0)) &&
           (a.act == OODGAN_ACT_NONE || a.act == OODGAN_ACT_LRELU || (a.act == OODGAN_ACT_PRELU && a.slope)) && a.in_scale == nullptr &&
           a.in_shift == nullptr &&
           !(a.dotx && (a.noise || a.bias || a.act != OODGAN_ACT_NONE))))

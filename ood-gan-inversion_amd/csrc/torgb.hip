@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_sform_kernel(const float* __res
 // second half of ToRGB when the colour sums were formed in the conv kernel's epilogue: + bias + 2x FIR-upsampled skip
 __global__ __launch_bounds__(256) void rgb_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                          const float* __restrict__ skip, const float* __restrict__ kern,
-                                                         float* __restrict__ y, int B, int H, int W) {
+                                                         float* __restrict__ y, int B, int H, int W, int nparts) {
     __shared__ float kf[16];
     if (threadIdx.x < 16 && skip) kf[threadIdx.x] = kern[(3 - threadIdx.x / 4) * 4 + (3 - threadIdx.x % 4)];  // flipped
     __syncthreads();
@@ -323,9 +323,12 @@ __global__ __launch_bounds__(256) void rgb_finish_kernel(const float* __restrict
         const int b = (int)(e / HW);
         const long p = e % HW;
         const int Y = (int)(p / W), X = (int)(p % W);
-        float o0 = part[(long)b * 3 * HW + p] + (bias ? bias[0] : 0.f);
-        float o1 = part[(long)b * 3 * HW + HW + p] + (bias ? bias[1] : 0.f);
-        float o2 = part[(long)b * 3 * HW + 2 * HW + p] + (bias ? bias[2] : 0.f);
+        float o0 = part[(long)b * 3 * HW + p], o1 = part[(long)b * 3 * HW + HW + p], o2 = part[(long)b * 3 * HW + 2 * HW + p];
+        for (int q = 1; q < nparts; ++q) {          // partial sums of the conv's channel blocks, in the order of their index
+            const float* pq = part + (long)q * B * 3 * HW + (long)b * 3 * HW + p;
+            o0 += pq[0]; o1 += pq[HW]; o2 += pq[2 * HW];
+        }
+        if (bias) { o0 += bias[0]; o1 += bias[1]; o2 += bias[2]; }
         if (skip) {
             SkipTaps st;
             st.fetch(skip + (long)b * 3 * h2 * w2_, h2, w2_, Y, X, [&](int ky, int kx) { return kf[ky * 4 + kx]; });
@@ -376,6 +379,15 @@ extern "C" int oodgan_rgb_finish(const float* partial, const float* bias, const 
     OODGAN_REQUIRE(partial && y && B > 0 && H > 0 && W > 0, "rgb_finish: bad args");
     OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "rgb_finish: skip needs kernel and even H,W");
     hipLaunchKernelGGL(rgb_finish_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, as_stream(stream), partial, bias, skip,
-                       kernel, y, B, H, W);
+                       kernel, y, B, H, W, 1);
     return check_launch("rgb_finish");
+}
+
+extern "C" int oodgan_rgb_finish_parts(const float* partial, int nparts, const float* bias, const float* skip, const float* kernel, float* y,
+                                       int B, int H, int W, void* stream) {
+    OODGAN_REQUIRE(partial && y && nparts >= 1 && B > 0 && H > 0 && W > 0, "rgb_finish_parts: bad args");
+    OODGAN_REQUIRE(!skip || (kernel && (H % 2 == 0) && (W % 2 == 0)), "rgb_finish_parts: skip needs kernel and even H,W");
+    hipLaunchKernelGGL(rgb_finish_kernel, dim3(stream_grid((long)B * H * W, 256)), dim3(256), 0, as_stream(stream), partial, bias, skip,
+                       kernel, y, B, H, W, nparts);
+    return check_launch("rgb_finish_parts");
 }

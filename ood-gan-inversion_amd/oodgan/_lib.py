@@ -17,6 +17,9 @@ ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
 P = c_void_p  # device pointers travel as integers
 
 
+ABI_VERSION = 106
+
+
 class ConvArgs(Structure):
     _fields_ = [
         ('x', P), ('wpk', P), ('in_scale', P), ('in_shift', P), ('out_scale', P), ('bias', P), ('noise', P),
@@ -25,7 +28,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int), ('workspace', P), ('workspace_bytes', c_long),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int), ('workspace', P), ('workspace_bytes', c_long), ('ys_vmax', P),
     ]
 
 
@@ -131,6 +134,7 @@ _SIGS = {
     'oodgan_reduce_parts_cols': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd': (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     'oodgan_rgb_finish': (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    'oodgan_rgb_finish_parts': (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     'oodgan_torgb_fwd_sform': (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, P]),
     'oodgan_act_bwd_fused': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_act_bwd_nparts': (c_int, [c_long]),
@@ -162,6 +166,8 @@ def lib():
                 continue  # optional groups are bound lazily by bind_extra()
             fn.restype = res
             fn.argtypes = args
+        if h.oodgan_version() < ABI_VERSION:        # the argument structs of this mirror (ConvArgs: ys_vmax since 106) must match the library's
+            raise RuntimeError(f'{LIB_PATH} has ABI version {h.oodgan_version()}, this host layer needs >= {ABI_VERSION}: rebuild the library')
         _lib = h
     return _lib
 

@@ -99,6 +99,7 @@ class GeneratorEngine:
         # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
         # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
         self.fuse_up = True
+        self.fuse_conv_rgb = True    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
         self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
         if (Lup is not None and self.precision == 'f16s' and self.sform and with_backward and Lup.cout % 32 == 0 and Lup.cin % 16 == 0
@@ -301,8 +302,21 @@ class GeneratorEngine:
                                                        noise_weight=L.noise_w, act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)),
                                                        y_fform=ff or xf_in, in_scale=_Cols(s_use, L.row, L.cin) if xf_in else None)
                     else:
-                        out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
-                                          noise_weight=L.noise_w, act=ACT_LRELU)
+                        Lu = self.rgb_next_up.get(Lr.name) if (Lr is not None and carry) else None
+                        Hc, Wc = xs.shape[2], xs.shape[3]
+                        if (Lu is not None and self.fuse_conv_rgb and not xf_in and L.cout % 16 == 0 and Hc * Wc > 4096 and Wc % 4 == 0
+                                and ops.s1_ys_supported(B, L.cin, L.cout, Hc, Wc)):
+                            # round 4: the 8-wave conv hands BOTH consumers of its output their input from its registers — the ToRGB colour
+                            # sums (one partial per 64-channel block, finished by rgb_finish) and the S-form of out x style x range scale of
+                            # the next up-conv, with the maximum for its range control: the torgb_fwd_sform pass (a read of the feature
+                            # map at 128² ... 512²) disappears from the step
+                            pending = ops.sform_scratch(B, L.cout, Hc, Wc, self.device, tag=4)
+                            out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w,
+                                                           act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)), ys=pending,
+                                                           ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx])
+                        else:
+                            out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
+                                              noise_weight=L.noise_w, act=ACT_LRELU)
                     del xs
                 else:
                     out = ops.conv3x3(out, L.wpk, L.cout, CONV_S1, in_scale=s, out_scale=d, bias=L.bias, noise=nz,

@@ -820,7 +820,7 @@ def upconv_vblur_fform(xs, wvb, out_scale=None, bias=None, noise=None, noise_wei
 def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=None, bias=None, noise=None,
             noise_weight=None, act=ACT_NONE, slope=None, dotx=None, in_hw=None, in_pitch=0, out=None, out_pitch=0,
             in_mul2=None, ys=None, ys_scale=None, want_y=True, dot_into=None, rgb=None, jobs=None, fuse=None, dot_actgrad=None,
-            groups=1, y_fform=False, xf_act=None, tiny_max=8):
+            groups=1, y_fform=False, xf_act=None, tiny_max=8, vmax=None):
     """Implicit-GEMM 3x3 conv on the matrix cores.  ``x`` is an fp32 NCHW tensor or an ``SForm`` (split-f16 kernels,
     mode S1).  Returns y, or (y, dot[B,M]) when ``dotx`` is given; ``ys`` (an SForm) additionally receives
     act(y)*ys_scale in S-form for the next conv.  ``groups`` > 1: nn.Conv2d(groups=G) semantics — x has G*K channels, the
@@ -869,10 +869,14 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     a.groups = int(groups)
     a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
+    a.ys_vmax = _p(vmax)        # with ys from the 8-wave kernel: max |act(y) * ys_scale| per sample (forward range control of the reader)
     rgb_y = None
     if rgb is not None:         # (w_rgb (3,M), s_rgb Cols/(B,M)): also emit the ToRGB colour sums of the activated output
         w_rgb, s_rgb = rgb
-        rgb_y = torch.empty(B, 3, oh, ow, device=out.device, dtype=torch.float32)
+        # the strip kernel (32 channels) writes the complete sums, the 8-wave kernel one partial per 64-channel block: rgb_finish adds them
+        nrgb = 1 if M <= 32 else (M + 63) // 64
+        rgb_y = torch.empty(*((B, 3, oh, ow) if nrgb == 1 else (nrgb, B, 3, oh, ow)), device=x.data.device if sform_in or fform_in else x.device,
+                            dtype=torch.float32)
         a.rgb_w, a.rgb_s, a.rgb_y = _p(_dev(w_rgb, 'w_rgb').reshape(3, M)), _p(_dev(s_rgb, 's_rgb')), _p(rgb_y)
         a.rgb_s_stride, a.rgb_scale = s_rgb.shape[1], 1.0 / math.sqrt(M)
     a.ys_scale_stride = ys_scale.shape[1] if ys_scale is not None else 0
@@ -1051,6 +1055,11 @@ class ActBwdX:
 def rgb_finish(partial, bias=None, skip=None, kernel=None):
     """second half of ToRGB.forward (model.py:363-372) for colour sums produced by conv3x3(rgb=...): + bias + upsampled skip
     (in place)."""
+    if partial.dim() == 5:      # (nparts, B, 3, H, W): partial sums of the 8-wave kernel's 64-channel blocks, added in order into part 0
+        n, B, _, H, W = partial.shape
+        check(_lib.lib().oodgan_rgb_finish_parts(_p(partial), n, _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')), _p(_opt(kernel, 'kernel')),
+                                                 _p(partial), B, H, W, _stream()), 'rgb_finish_parts')
+        return partial[0]
     B, _, H, W = partial.shape
     check(_lib.lib().oodgan_rgb_finish(_p(partial), _p(_opt(bias, 'bias')), _p(_opt(skip, 'skip')), _p(_opt(kernel, 'kernel')),
                                        _p(partial), B, H, W, _stream()), 'rgb_finish')

@@ -592,6 +592,19 @@ def test_conv3x3_s1_big_kernel_sform_output(dev, B, K, M, H, W, both, tunable):
         assert torch.equal(out, y)
     else:
         assert out is None
+    # fused ToRGB partial sums (one per 64-channel block, ModulatedConv2d 1x1 without demodulation: model.py:363-372) and the maximum
+    # of what went into the S-form (forward range control of its reader), from the same launch
+    w_rgb = synth.normal('ys.wr', (3, M), 6)
+    s_rgb = synth.normal('ys.sr', (B, M), 7, 0.3, 1.0)
+    vm = torch.zeros(B * ops.VMAX_SLOTS, device=dev, dtype=torch.int32)
+    out2, part = ops.conv3x3(xs, p1, M, ops.CONV_S1, ys=ys, ys_scale=ysc.to(dev), rgb=(w_rgb.to(dev), s_rgb.to(dev)), vmax=vm, **kw)
+    assert torch.equal(out2, y) and torch.equal(ys.data, want.data)
+    rgb = ops.rgb_finish(part.clone())
+    ref_rgb = torch.einsum('km,bm,bmhw->bkhw', w_rgb, s_rgb, ref1) / math.sqrt(M)
+    close(rgb, ref_rgb, 2e-5)
+    got = vm.view(torch.float32).reshape(B, -1).max(dim=1).values.cpu()
+    exp = (y * ysc.to(dev)[:, :, None, None]).abs().amax(dim=(1, 2, 3)).cpu()
+    assert torch.equal(got, exp)
     # the chain: second conv on the S-form written by the first (uniform scale here, undone by in_mul2)
     ysu = torch.full((B, M), 2.0 ** e)
     ops.conv3x3(xs, p1, M, ops.CONV_S1, ys=ys, ys_scale=ysu.to(dev), want_y=False, **kw)
