@@ -79,7 +79,13 @@ class ConvProbe:
             e0.record()
             r = probe.orig(x, wpk, M, mode, **kw)
             e1.record()
-            probe.recs.append((e0, e1, 2.0 * B * K * M * 9 * H * W, 4.0 * (B * K * H * W + B * M * H * W + K * M * 9)))
+            # instance: since round 4 the forward launches in front of a ToRGB also write the ToRGB partial sums and the next up-conv's
+            # S-form (oodgan_conv_args.ys / rgb_y: the work of the torgb_fwd_sform pass, +4 bytes per output element)
+            fused = kw.get('ys') is not None
+            tag = 'input gradient + style-gradient dot' if kw.get('dotx') is not None else (
+                'forward + ToRGB sums + S-form of the next conv (fused outputs)' if fused else 'forward')
+            probe.recs.append((e0, e1, 2.0 * B * K * M * 9 * H * W,
+                               4.0 * (B * K * H * W + B * M * H * W * (2 if fused else 1) + K * M * 9), tag))
             return r
 
         self.ops.conv3x3 = conv3x3
@@ -89,12 +95,18 @@ class ConvProbe:
     def summary(self):
         if not self.recs:
             return None
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in self.recs)
-        flops = sum(f for _, _, f, _ in self.recs)
-        byts = sum(g for _, _, _, g in self.recs)
+        times = [a.elapsed_time(b) for a, b, _, _, _ in self.recs]
+        ms = sum(times)
+        flops = sum(f for _, _, f, _, _ in self.recs)
+        byts = sum(g for _, _, _, g, _ in self.recs)
         n = len(self.recs)
+        inst = {}
+        for t, (_, _, f, _, tag) in zip(times, self.recs):
+            d = inst.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += t; d[2] += f
+        instances = {k: dict(launches=v[0], avg_ms=round(v[1] / v[0], 4), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in inst.items()}
         return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n,
-                    bytes_per_launch=byts / n)
+                    bytes_per_launch=byts / n, instances=instances)
 
 
 def pmc_traffic_instances(a):
@@ -512,7 +524,11 @@ def main():
                     note=('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product, so its own ceiling is '
                           'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
                     launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
-                    alg_flops_per_launch=ps['flops_per_launch'])
+                    alg_flops_per_launch=ps['flops_per_launch'], instances=ps.get('instances'),
+                    instances_note=('achieved / frac average ALL launches of the kernel.  Since round 4 the forward launches in front of a ToRGB '
+                                    '(three of the eight per W+ step) also produce the ToRGB partial sums and the S-form input of the next up-conv in '
+                                    'their epilogue — the work of a separate HBM-bound pass (torgb_fwd_sform, 0.36 ms per step) that no longer '
+                                    'runs: the step is 0.1 ms shorter, these launches are ~25 % longer (DESIGN.md 13.9)') if f16s else None)
 
     if rank == 0:
         roof_timed = roofline_of(probe.summary(), f'timed region ({a.streams} concurrent HIP streams: launches share the GPU)')

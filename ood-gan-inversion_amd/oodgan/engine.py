@@ -99,7 +99,7 @@ class GeneratorEngine:
         # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
         # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
         self.fuse_up = True
-        self.fuse_conv_rgb = True    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
+        self.fuse_conv_rgb = os.environ.get('OODGAN_FUSE_CONV_RGB', '1') != '0'    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
         self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
         if (Lup is not None and self.precision == 'f16s' and self.sform and with_backward and Lup.cout % 32 == 0 and Lup.cin % 16 == 0
