@@ -311,9 +311,14 @@ class GeneratorEngine:
                             # the next up-conv, with the maximum for its range control: the torgb_fwd_sform pass (a read of the feature
                             # map at 128² ... 512²) disappears from the step
                             pending = ops.sform_scratch(B, L.cout, Hc, Wc, self.device, tag=4)
+                            # both readers of the activation are served from the epilogue: without a backward pass to save it for, the fp32
+                            # tensor is not written at all (the epilogue's stores are what these launches wait for, §13.9)
+                            keep = save or return_features or post_hook is not None
                             out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w,
                                                            act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)), ys=pending,
-                                                           ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx])
+                                                           ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx], want_y=keep)
+                            if not keep:
+                                out = ops.SFormSaved(pending, _Cols(s_use, Lu.row, Lu.cin))
                         else:
                             out = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz,
                                               noise_weight=L.noise_w, act=ACT_LRELU)

@@ -303,6 +303,20 @@ class FForm:
         return y
 
 
+class SFormSaved:
+    """An activation that exists ONLY as the S-form a conv's epilogue wrote for its consumer (``conv3x3(..., ys=, want_y=False)``): the
+    values are x * scale[b,c] split into an f16 pair, ``scale`` (a ``Cols`` / (B,C) tensor: style x range scale of the consumer) is kept
+    for the readers that need x itself.  ``shape`` is the logical (B, C, H, W)."""
+    __slots__ = ('sform', 'scale')
+
+    def __init__(self, sform, scale):
+        self.sform, self.scale = sform, scale
+
+    @property
+    def shape(self):
+        return self.sform.shape
+
+
 class SFormPhases:
     """Phase-split S-form of a (B, C, 2H+1, 2W+1) tensor (input of the stride-2 conv); H, W = conv output size."""
     __slots__ = ('data', 'B', 'C', 'H', 'W')
