@@ -326,6 +326,57 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     }
 }
 
+// ---- wide form (round 4) — block: 256 pixels x MT output channels, thread = one pixel; the weights of a K chunk of 32 staged in LDS as [k][channel] so that FOUR
+// channels come with one (broadcast) ds_read_b128 — rounds 1-3 kept them as [channel][k] and paid one ds_read_b32 per multiply-add with
+// 16 channels per block (x re-read M/16 times: 36-47 TFLOP/s whatever the shape).  Eight input planes in flight per trip (clamped
+// channel, masked by a select); the sums run in the order of k as before (bit-identical results).
+constexpr int C1W_KC = 32;
+template <int MT>
+__global__ __launch_bounds__(256) void conv1x1_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int K, int M,
+                                                      long HW) {
+    constexpr int WP = MT + 4;                                     // pitch: 16-byte aligned rows, writes spread over the banks
+    __shared__ __attribute__((aligned(16))) float ws[C1W_KC * WP];
+    const int b = blockIdx.z, m0 = blockIdx.y * MT;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pc = p < HW ? p : HW - 1;
+    const float* xp = x + (long)b * K * HW + pc;
+    float acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += C1W_KC) {
+        const int kn = (K - k0) < C1W_KC ? (K - k0) : C1W_KC;
+        __syncthreads();
+        for (int e = threadIdx.x; e < MT * C1W_KC; e += 256) {     // global reads along k, transposed into [k][channel]
+            const int j = e / C1W_KC, kk = e % C1W_KC;
+            ws[kk * WP + j] = (m0 + j < M && kk < kn) ? w[(long)(m0 + j) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        for (int kk0 = 0; kk0 < kn; kk0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float t = xp[(long)(k0 + min(kk0 + u, kn - 1)) * HW];
+                v[u] = kk0 + u < kn ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* wr = ws + min(kk0 + u, C1W_KC - 1) * WP;
+#pragma unroll
+                for (int j4 = 0; j4 < MT / 4; ++j4) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + 4 * j4);
+                    acc[4 * j4] += w4.x * v[u]; acc[4 * j4 + 1] += w4.y * v[u]; acc[4 * j4 + 2] += w4.z * v[u]; acc[4 * j4 + 3] += w4.w * v[u];
+                }
+            }
+        }
+    }
+    if (p < HW) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            if (m0 + j < M) y[((long)b * M + m0 + j) * HW + p] = acc[j] + (bias ? bias[m0 + j] : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------- squeeze-excitation gate of bottleneck_IR_SE
 // gate[b,c] = sigmoid(W2 relu(W1 mean_b))  (SEModule.forward, src/ops/e4e/encoders/helpers.py:60-76: AdaptiveAvgPool2d(1) -> fc1 ->
 // ReLU -> fc2 -> Sigmoid; the product with the input is the caller's oodgan_affine_apply).  One workgroup per sample.  As two
@@ -984,8 +1035,16 @@ extern "C" int oodgan_align_input_stats(const float* gen, const float* enc, cons
 extern "C" int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,
                               void* stream) {
     OODGAN_REQUIRE(x && w && y && B > 0 && K > 0 && M > 0 && HW > 0, "conv1x1: bad args");
-    dim3 grid((unsigned)((HW + 255) / 256), (M + C1_MT - 1) / C1_MT, B);
-    hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, as_stream(stream), x, w, bias, y, K, M, HW);
+    // 64 channels per block (x read M/64 times, [k][channel] weights in LDS) when that still gives the chip four blocks per CU: 91 / 196 /
+    // 155 us against 102 / 247 / 193 for the 16-channel form at 128->512 @64², 64->128 @256², 128->256 @128² (batch 8); on the small grids
+    // (32² maps, batch 1) the narrow form stays ahead (53 vs 74-88 us)
+    if (M > 16 && ((HW + 255) / 256) * ((M + 63) / 64) * B >= 1024) {
+        dim3 grid((unsigned)((HW + 255) / 256), (M + 63) / 64, B);
+        hipLaunchKernelGGL(conv1x1_wide_kernel<64>, grid, dim3(256), 0, as_stream(stream), x, w, bias, y, K, M, HW);
+    } else {
+        dim3 grid((unsigned)((HW + 255) / 256), (M + C1_MT - 1) / C1_MT, B);
+        hipLaunchKernelGGL(conv1x1_kernel, grid, dim3(256), 0, as_stream(stream), x, w, bias, y, K, M, HW);
+    }
     return check_launch("conv1x1");
 }
 

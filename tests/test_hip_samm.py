@@ -35,6 +35,11 @@ def test_instance_norm_and_small_convs(dev):
     x2 = synth.normal('c1.x2', (1, 130, 9, 9), 6)
     w2 = synth.normal('c1.w2', (35, 130, 1, 1), 7, 0.1)
     close(samm.conv1x1(x2.to(dev), w2.to(dev)), F.conv2d(x2, w2))
+    # the wide form (64 channels per block; grids of >= 1024 blocks): ragged pixel count, partial channel block, K chunk remainder
+    x3 = synth.normal('c1.x3', (2, 70, 130, 131), 10)
+    w3w = synth.normal('c1.w3', (72, 70, 1, 1), 11, 0.1)
+    b3 = synth.normal('c1.b3', (72,), 12)
+    close(samm.conv1x1(x3.to(dev), w3w.to(dev), b3.to(dev)), F.conv2d(x3, w3w, b3), 2e-6)
     w3 = synth.normal('c3.w', (3, 5, 3, 3), 8, 0.3)
     sl = synth.normal('c3.s', (3,), 9, 0.05, 0.25)
     close(samm.conv3x3_small(x.to(dev), w3.to(dev), slope=sl.to(dev)), F.prelu(F.conv2d(x, w3, padding=1), sl))
