@@ -326,10 +326,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     }
 }
 
-// ---- wide form (round 4) — block: 256 pixels x MT output channels, thread = one pixel; the weights of a K chunk of 32 staged in LDS as [k][channel] so that FOUR
-// channels come with one (broadcast) ds_read_b128 — rounds 1-3 kept them as [channel][k] and paid one ds_read_b32 per multiply-add with
-// 16 channels per block (x re-read M/16 times: 36-47 TFLOP/s whatever the shape).  Eight input planes in flight per trip (clamped
-// channel, masked by a select); the sums run in the order of k as before (bit-identical results).
+// ---- wide form (round 4) — block: 256 pixels x MT = 64 output channels, thread = one pixel; the weights of a K chunk of 32 staged in LDS
+// as [k][channel] so that FOUR channels come with one (broadcast) ds_read_b128, and x is read M/64 instead of M/16 times (the narrow
+// form above pays one ds_read_b32 per multiply-add: 36-47 TFLOP/s whatever the shape).  Taken where the grid still has >= 1024 blocks;
+// the sums run in the order of k as in the narrow form (same results).
 constexpr int C1W_KC = 32;
 template <int MT>
 __global__ __launch_bounds__(256) void conv1x1_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
