@@ -209,6 +209,12 @@ typedef struct oodgan_conv_args {
                                   nparts = oodgan_conv3x3_xf_nparts(B,Hin,Win) — also the dot_nparts of this instance; dotx (F-form,
                                   dotx_fform = 1) is mandatory, y NCHW. */
     int dotx_fform;          /* 1: dotx is in F-form (x_fform == 2 only) */
+    int dotx_sform;          /* 1 (mode S2 with `fuse` only, round 4): dotx is not an fp32 tensor but the S-form a conv's epilogue wrote for its consumer
+                                (`ys` of the 8-wave stride-1 kernel, y == NULL): the values are x * dotx_scale[b,m] as f16 pairs; the fused epilogue
+                                decodes them (hi + lo) / dotx_scale.  The saved activation of the 128² ... 512² conv layers inside the W+ loop then
+                                exists once, not twice. */
+    const float* dotx_scale; /* (B,M) stride dotx_scale_stride: the scale that went into that S-form (style x range scale of its consumer) */
+    int dotx_scale_stride;
     void* workspace;         /* optional scratch of workspace_bytes >= oodgan_conv3x3_tiny_workspace(...) bytes (the K-split partial tiles:
                                 written by the first launch, read by the finishing one — uninitialised is fine) owned by ONE stream: with it the 4x4 / 8x8 layers (mode S1 with S-form input, mode S2
                                 with phase-split S-form input, K >= 64) run as a skinny GEMM over the batch with a K split
@@ -301,6 +307,9 @@ int oodgan_to_sform(const float* x, const float* scale, int scale_stride, const 
  * parity images G[py][px][i][j] = x[2i+py][2j+px], each in S-form without border, so that the stride-2 conv
  * becomes stride-1 taps on contiguous runs.  H,W = OUTPUT size of the S2 conv. */
 long oodgan_sform_phases_bytes(int B, int C, int H, int W);
+/* The way back: fp32 NCHW y[b,c,p] = (hi + lo) / scale[b,c] of an S-form buffer (scale NULL = 1) — for an activation saved only as the
+ * S-form of its consumer (oodgan_conv_args.dotx_sform) when a step needs the plain tensor after all */
+int oodgan_from_sform(const void* xs, const float* scale, int scale_stride, float* y, int B, int C, int H, int W, void* stream);
 /* Fused producer: g (B,C,2H,2W) -> upfirdn2d(g, kernel, pad=(2,2)) (the adjoint of Blur(pad=(1,1)), src/ops/op/upfirdn2d.py:115-120)
  * * scale[b,c] * mul2[1], written phase-split.  kernel (4,4): the op correlates with the FLIPPED kernel like upfirdn2d. */
 int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const float* scale, int scale_stride,

@@ -73,7 +73,7 @@ struct S2Cfg {
     static constexpr int SMEM = OFF_WB + 3 * TAPB;         // 155648 (MH = 2) / 118784 (MH = 1)
     // FUSE: [7][MBW] floats of channel constants, staged BEFORE the K loop: outside the stage buffers (159232 bytes for MH = 2)
     static constexpr int OFF_CST = SMEM;
-    static constexpr int SMEM_FUSE = SMEM + 7 * MBW * 4;
+    static constexpr int SMEM_FUSE = SMEM + 8 * MBW * 4;      // row 7: 1 / dotx_scale (dotx_sform)
 };
 
 constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15); }
@@ -231,13 +231,32 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             }
             if (f.noise) enz = (f.noise_w ? f.noise_w[0] : 1.f) * f.noise[(long)(f.noise_batch > 1 ? b : 0) * HW + pix];
         }
+        if (a.dotx_sform) {
+            // the saved activation as the S-form its producer wrote: per 16-channel block four 8-byte pieces (hi / lo of channels
+            // 4 half .. +3 and 8 + 4 half .. +3) — the same 32 registers, decoded in the epilogue
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float* dr = a.dotx + ((long)b * M + m0 + mh * 64 + mt * 32) * HW + pix;
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
-                edv[EARLY ? mt : 0][r] = (eok && m0 + mh * 64 + mt * 32 + ch < M) ? dr[(long)ch * HW] : 0.f;
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int kc = min((m0 + mh * 64 + mt * 32) / 16 + blk, p.yd.KC - 1);
+                    const unsigned char* rec = reinterpret_cast<const unsigned char*>(a.dotx) +
+                        sform_unit(p.yd, b, kc, min(py_, H - 1), min(px, W - 1), 0) * 16 + 8 * half;
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const float2 t = *reinterpret_cast<const float2*>(rec + 16 * sl);
+                        edv[EARLY ? mt : 0][8 * blk + 2 * sl] = t.x;
+                        edv[EARLY ? mt : 0][8 * blk + 2 * sl + 1] = t.y;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* dr = a.dotx + ((long)b * M + m0 + mh * 64 + mt * 32) * HW + pix;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    edv[EARLY ? mt : 0][r] = (eok && m0 + mh * 64 + mt * 32 + ch < M) ? dr[(long)ch * HW] : 0.f;
+                }
             }
         }
     }
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     // FUSE: the seven per-channel constants of the fused epilogue, requested here from clamped channels — all in flight together and
     // under the first stage's fetch — and parked in LDS.  (`mok ? ptr[m] : 0` where it is used is a branch, a load and a vmcnt(0) per
     // constant: seven serialised round trips per workgroup, 3-4 us of the 21 us a tile of the 1024² -> 512² layer takes.)
-    float cv[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f};
     if constexpr (FUSE) {
         const oodgan_actbwd_fuse& f = p.f;
         if (tid < C::MBW) {
@@ -259,6 +278,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             }
             if (f.bias) cv[5] = f.bias[m];
             cv[6] = f.dscale[(long)b * f.dscale_stride + m];
+            if (a.dotx_sform) cv[7] = 1.f / a.dotx_scale[(long)b * a.dotx_scale_stride + m];
         }
     }
     // single barrier per stage: after it every wave has finished stage st-1 (its slot is free) and stage st has landed
@@ -276,6 +296,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             cst[4 * C::MBW + tid] = mok ? cv[4] : 0.f;
             cst[5 * C::MBW + tid] = mok ? cv[5] : 0.f;
             cst[6 * C::MBW + tid] = mok ? cv[6] * f.mul2[1] : 0.f;
+            cst[7 * C::MBW + tid] = mok ? cv[7] : 0.f;
             __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): written before this wave arrives at the loop's first barrier
         }
     }
@@ -355,6 +376,42 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             // branch per value), out-of-image pixels masked by a select.  Address = uniform base + a uniform channel offset per
             // value + ONE 32-bit lane offset per row (sixteen 64-bit lane addresses per row would cost 32 registers).
             float dv[RW][16];
+            if (a.dotx_sform) {
+                // S-form records (see the early loads above): raw[8 blk + 2 sl + {0,1}] = slot sl of block blk — hi slots 0,1, lo slots 2,3,
+                // each holding this lane's four channels as f16; value = (hi + lo) / scale
+#pragma unroll
+                for (int nt = 0; nt < RW; ++nt) {
+                    float raw[16];
+                    if constexpr (EARLY) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) raw[i] = edv[EARLY ? mt : 0][i];
+                    } else {
+                        const int py_ = r0 + rg * RW + nt;
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk) {
+                            const int kc = min((m0 + chb) / 16 + blk, p.yd.KC - 1);
+                            const unsigned char* rec = reinterpret_cast<const unsigned char*>(a.dotx) +
+                                sform_unit(p.yd, b, kc, min(py_, H - 1), min(px, W - 1), 0) * 16 + 8 * half;
+#pragma unroll
+                            for (int sl = 0; sl < 4; ++sl) {
+                                const float2 t = *reinterpret_cast<const float2*>(rec + 16 * sl);
+                                raw[8 * blk + 2 * sl] = t.x;
+                                raw[8 * blk + 2 * sl + 1] = t.y;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // register r: block r >> 3, slot (r >> 2) & 1, element r & 3 of the 8-byte piece
+                        const int blk = r >> 3, sl = (r >> 2) & 1, el = r & 3;
+                        const unsigned wh = __float_as_uint(raw[8 * blk + 2 * sl + (el >> 1)]), wl = __float_as_uint(raw[8 * blk + 2 * (2 + sl) + (el >> 1)]);
+                        const unsigned short bh = (unsigned short)((el & 1) ? (wh >> 16) : (wh & 0xFFFFu)), bl = (unsigned short)((el & 1) ? (wl >> 16) : (wl & 0xFFFFu));
+                        const float v = (float)__builtin_bit_cast(_Float16, bh) + (float)__builtin_bit_cast(_Float16, bl);
+                        const float inv = cst[7 * C::MBW + chb + (r & 3) + 8 * (r >> 2) + 4 * half];
+                        dv[nt][r] = okr[nt] ? v * inv : 0.f;
+                    }
+                }
+            } else {
             const unsigned char* ub = reinterpret_cast<const unsigned char*>(a.dotx + ((long)b * M + m0 + chb) * HW);
 #pragma unroll
             for (int nt = 0; nt < RW; ++nt) {
@@ -369,6 +426,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dv[nt][r] = okr[nt] ? dv[nt][r] : 0.f;
                 }
+            }
             }
             unsigned hi[RW][8], lo[RW][8];
 #pragma unroll

@@ -1011,6 +1011,38 @@ extern "C" int oodgan_to_sform(const float* x, const float* scale, int scale_str
 
 
 
+namespace {
+// S-form -> fp32 NCHW, divided by the scale that went into the S-form: the rarely taken way back for an activation that was saved only
+// as its consumer's S-form (oodgan_conv_args.dotx_sform) when a step falls back to the two-pass backward.  thread = one 64-byte record
+__global__ __launch_bounds__(256) void from_sform_kernel(const uint4* __restrict__ xs, const float* __restrict__ scale, int scale_stride,
+                                                         float* __restrict__ y, int B, SDims d) {
+    const long total = (long)B * d.KC * d.H * d.W;
+    const long HW = (long)d.H * d.W;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % d.W), yy = (int)((e / d.W) % d.H);
+        const int kc = (int)((e / HW) % d.KC), b = (int)(e / (HW * d.KC));
+        const half8* rec = reinterpret_cast<const half8*>(xs + sform_unit(d, b, kc, yy, x, 0));
+        const half8 h0 = rec[0], h1 = rec[1], l0 = rec[2], l1 = rec[3];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = kc * 16 + j;
+            if (c < d.C) {
+                const float v = (float)(j < 8 ? h0[j] : h1[j - 8]) + (float)(j < 8 ? l0[j] : l1[j - 8]);
+                y[((long)b * d.C + c) * HW + (long)yy * d.W + x] = v / (scale ? scale[(long)b * scale_stride + c] : 1.f);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int oodgan_from_sform(const void* xs, const float* scale, int scale_stride, float* y, int B, int C, int H, int W, void* stream) {
+    OODGAN_REQUIRE(xs && y && B > 0 && C > 0 && H > 0 && W > 0, "from_sform: bad args");
+    const SDims d = sform_dims(C, H, W);
+    hipLaunchKernelGGL(from_sform_kernel, dim3(stream_grid((long)B * d.KC * H * W, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const uint4*>(xs), scale, scale_stride, y, B, d);
+    return check_launch("from_sform");
+}
+
 extern "C" int oodgan_blurT_to_sform_phases(const float* g, const float* kernel, const float* scale, int scale_stride,
                                             const float* mul2, void* out, int B, int C, int H, int W, void* stream) {
     OODGAN_REQUIRE(g && kernel && out && B > 0 && C > 0 && H > 0 && W > 0, "blurT_to_sform_phases: bad args");

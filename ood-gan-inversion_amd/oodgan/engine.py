@@ -99,6 +99,7 @@ class GeneratorEngine:
         # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
         # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
         self.fuse_up = True
+        self.save_sform_only = os.environ.get('OODGAN_SAVE_SFORM_ONLY', '1') != '0'    # W+ loop: those layers' saved activation only as that S-form
         self.fuse_conv_rgb = os.environ.get('OODGAN_FUSE_CONV_RGB', '1') != '0'    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
         self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
@@ -313,7 +314,13 @@ class GeneratorEngine:
                             pending = ops.sform_scratch(B, L.cout, Hc, Wc, self.device, tag=4)
                             # both readers of the activation are served from the epilogue: without a backward pass to save it for, the fp32
                             # tensor is not written at all (the epilogue's stores are what these launches wait for, §13.9)
-                            keep = save or return_features or post_hook is not None
+                            # ... and inside the W+ loop the saved activation exists ONCE: the only reader of this layer's output in the
+                            # backward pass is the fused epilogue of the stride-2 conv above (style-gradient dot + this layer's
+                            # activation backward), which decodes it from the same S-form (oodgan_conv_args.dotx_sform)
+                            sform_only = (save and self.save_sform_only and self.fused_bwd and self.fuse_act_bwd
+                                          and self.bwd_state.get(L.name) is not None and self.bwd_state.get(Lu.name) is not None
+                                          and ops.s2_fuse_supported(B, Lu.cout, Lu.cin, 2 * Hc + 1, 2 * Wc + 1))
+                            keep = (save and not sform_only) or return_features or post_hook is not None
                             out, rgb_partial = ops.conv3x3(xs, L.wpk, L.cout, CONV_S1, out_scale=d, bias=L.bias, noise=nz, noise_weight=L.noise_w,
                                                            act=ACT_LRELU, rgb=(Lr.w_rgb, _Cols(s_all, Lr.row, Lr.cin)), ys=pending,
                                                            ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx], want_y=keep)
@@ -448,6 +455,8 @@ class GeneratorEngine:
                       and prev_rgb is not None and self.fuse_x)
             if isinstance(out, ops.FForm) and not (fused_ok and (g_feat is None or fused_pre is not None)):
                 out = out.to_nchw()         # the two-pass path reads NCHW
+            if isinstance(out, ops.SFormSaved) and fused_in is None:
+                out = out.to_nchw()         # saved only as its consumer's S-form, but this layer's activation backward did not run fused
             if isinstance(x_in, ops.FForm) and not xf_bwd:
                 x_in = x_in.to_nchw()
             s = _Cols(s_all, L.row, L.cin)

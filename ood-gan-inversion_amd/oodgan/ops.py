@@ -316,6 +316,14 @@ class SFormSaved:
     def shape(self):
         return self.sform.shape
 
+    def to_nchw(self):
+        """x as an fp32 NCHW tensor ((hi + lo) / scale): for the readers that do not take the S-form (the two-pass backward)."""
+        B, C, H, W = self.sform.shape
+        y = torch.empty(B, C, H, W, device=self.sform.data.device, dtype=torch.float32)
+        sc = self.scale
+        check(_lib.lib().oodgan_from_sform(_p(self.sform), _p(sc), 0 if sc is None else sc.shape[1], _p(y), B, C, H, W, _stream()), 'from_sform')
+        return y
+
 
 class SFormPhases:
     """Phase-split S-form of a (B, C, 2H+1, 2W+1) tensor (input of the stride-2 conv); H, W = conv output size."""
@@ -904,8 +912,13 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
     part = None
     if dotx is not None:
         dot_f = isinstance(dotx, FForm)
-        dx_ = dotx.data if dot_f else _dev(dotx, 'dotx')
+        dot_s = isinstance(dotx, SFormSaved)      # saved only as its consumer's S-form: the fused stride-2 epilogue decodes it (dotx_sform)
+        if dot_s and fuse is None:
+            dotx, dot_s = dotx.to_nchw(), False
+        dx_ = dotx.data if dot_f else (dotx.sform.data if dot_s else _dev(dotx, 'dotx'))
         a.dotx_fform = 1 if dot_f else 0
+        if dot_s:
+            a.dotx_sform, a.dotx_scale, a.dotx_scale_stride = 1, _p(dotx.scale), dotx.scale.shape[1]
         if fform_in:
             npart = _lib.lib().oodgan_conv3x3_xf_nparts(B, H, W)
         elif wpk.precision == 'f16s':

@@ -178,6 +178,28 @@ def test_s2_conv_with_fused_activation_backward(B, Co, Ci, H, W, rgb, tunable):
     # the border of the S-form must stay zero (only the interior is written)
     full = dst.data.float().abs().sum().item()
     assert full > 0
+    if Ci % 32 == 0:
+        # round 4: the saved activation handed over ONLY as the S-form its producer wrote for the up-conv (x * scale as f16 pairs,
+        # oodgan_conv_args.dotx_sform): the epilogue decodes (hi + lo) / scale — same results to the rounding of that round trip; and
+        # the way back to NCHW for the two-pass fallback
+        sc = t('sfs', (B, Ci), 0.4, 1.3) * 2.0 ** 7
+        sc[:, ::5] *= -1.0                                       # styles may be negative
+        saved = ops.SFormSaved(ops.to_sform(out_below, sc), sc)
+        back = saved.to_nchw()
+        assert (back - out_below).abs().max().item() <= 1e-6 * out_below.abs().max().item()
+        dst2 = ops.SForm(B, Ci, H, W, dev)
+        fz2 = ops.ActBwdFusion(dst2, noise, nw, bias, d_below, state, **kw)
+        _, dot2 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s_up, dotx=saved, in_mul2=mul_up, fuse=fz2, want_y=False)
+        a2 = dst2.data.float().view(-1, 2, 16)
+        va2 = a2[:, 0] + a2[:, 1]
+        assert (va2 - vb).abs().max().item() <= 4e-6 * vb.abs().max().item()
+        assert (dot2 - dot0).abs().max().item() <= 1e-5 * dot0.abs().max().item()
+        assert (fz2.r - r0).abs().max().item() <= 1e-5 * max(1e-30, r0.abs().max().item())
+        if rgb:
+            assert (fz2.t - t0).abs().max().item() <= 1e-5 * max(1e-30, t0.abs().max().item())
+        # without the fused epilogue the same object falls back to its NCHW copy
+        g_feat2, dot3 = ops.conv3x3(gp, wpk_t, Ci, ops.CONV_S2, out_scale=s_up, dotx=saved, in_mul2=mul_up)
+        assert (g_feat2 - g_feat).abs().max().item() <= 1e-6 * g_feat.abs().max().item() and (dot3 - dot0).abs().max().item() <= 1e-5 * dot0.abs().max().item()
 
 
 @pytest.mark.parametrize('B,C,H,W,sep', [(1, 32, 32, 32, True), (2, 16, 40, 64, True), (1, 48, 37, 66, True), (1, 24, 64, 34, False), (1, 16, 33, 128, True)])
