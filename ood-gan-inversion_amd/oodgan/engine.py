@@ -100,6 +100,7 @@ class GeneratorEngine:
         # the blur's vertical pass folded into two 3x3 weight sets — prepared here, once, for the layer in front of the last conv
         self.fuse_up = True
         self.save_sform_only = os.environ.get('OODGAN_SAVE_SFORM_ONLY', '1') != '0'    # W+ loop: those layers' saved activation only as that S-form
+        self.fuse_conv_rgb_64 = True     # ... from the 64² level on (the separate ToRGB pass started at 128²)
         self.fuse_conv_rgb = os.environ.get('OODGAN_FUSE_CONV_RGB', '1') != '0'    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
         self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
@@ -305,7 +306,7 @@ class GeneratorEngine:
                     else:
                         Lu = self.rgb_next_up.get(Lr.name) if (Lr is not None and carry) else None
                         Hc, Wc = xs.shape[2], xs.shape[3]
-                        if (Lu is not None and self.fuse_conv_rgb and not xf_in and L.cout % 16 == 0 and Hc * Wc > 4096 and Wc % 4 == 0
+                        if (Lu is not None and self.fuse_conv_rgb and not xf_in and L.cout % 16 == 0 and Hc * Wc > (4095 if self.fuse_conv_rgb_64 else 4096) and Wc % 4 == 0
                                 and ops.s1_ys_supported(B, L.cin, L.cout, Hc, Wc)):
                             # round 4: the 8-wave conv hands BOTH consumers of its output their input from its registers — the ToRGB colour
                             # sums (one partial per 64-channel block, finished by rgb_finish) and the S-form of out x style x range scale of
