@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: 1024² face inversions/sec (100 W+ Adam steps + final OOD/SAIM forward).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1 directly
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1 directly; N>1 self-launches N rank processes
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch: B=8 images per GPU (BASELINE.json configs[2]:
@@ -25,7 +25,8 @@ for p in (ROOT, os.path.join(ROOT, 'ood-gan-inversion_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
+if __name__ != '__main__':
+    import torch  # noqa: E402  (imported by tools/ as a module: no launcher decision to make; main() imports it after that decision)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (spec, MI355X_MICROARCH.md)
@@ -51,7 +52,69 @@ def parse():
     ap.add_argument('--no-single-stream', action='store_true', help='skip the extra leg that times the same job on ONE HIP stream')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
+    ap.add_argument('--force-launcher', action='store_true',
+                    help='start the rank processes from this process even for --gpus 1 (the path `python bench.py --gpus N` takes for N > 1)')
     return ap.parse_args()
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` with no launcher around it (WORLD_SIZE unset): this process — which has not imported torch
+    and has not touched a GPU — starts the N ranks as CHILD processes (never an exec) with the environment torch.distributed.run
+    would give them (RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), forwards rank 0's
+    stdout (the ONE JSON line) unchanged, waits for all of them and exits non-zero if any rank did; a rank that dies takes the
+    others down (they would wait in the rendezvous forever) and every failing rank's stderr tail is shown.
+    Analogue in the reference: BasicSR/scripts/dist_train.sh:15-16 (its only launcher; inference there is one process)."""
+    import socket
+    import subprocess
+    import tempfile
+    n = a.gpus
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    argv = [x for x in sys.argv[1:] if x != '--force-launcher']
+    procs, logs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK='0',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OODGAN_BENCH_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL's cross-process buffers need it on this driver
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        log = tempfile.TemporaryFile(mode='w+', prefix=f'bench_rank{r}_')
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=os.getcwd(),
+                                      stdout=(None if r == 0 else subprocess.DEVNULL), stderr=log))
+    rcs = [None] * n
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 10.0:
+            for r, p in enumerate(procs):                       # exact PIDs of our own children only
+                if rcs[r] is None:
+                    p.terminate()
+            failed_at = float('inf')
+            t_kill = time.monotonic() + 20.0
+        if failed_at == float('inf') and time.monotonic() > t_kill:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()
+        time.sleep(0.05)
+    bad = [r for r, rc in enumerate(rcs) if rc != 0]
+    for r, log in enumerate(logs):
+        log.seek(0)
+        txt = log.read()
+        log.close()
+        if r in bad:
+            sys.stderr.write(f'--- bench.py rank {r} exited with code {rcs[r]}; stderr tail ---\n' + txt[-3000:] + ('' if txt.endswith('\n') else '\n'))
+        elif r == 0 and txt:
+            sys.stderr.write(txt)
+    if bad:
+        sys.stderr.write(f'bench.py: {len(bad)} of {n} rank processes failed (ranks {bad})\n')
+        return 1
+    return 0
 
 
 class ConvProbe:
@@ -429,10 +492,15 @@ def forward_only(a, m, x, noises, reps=7, only_full=False):
 def main():
     a = parse()
     t_proc = time.perf_counter()
+    if 'WORLD_SIZE' not in os.environ and (a.gpus > 1 or a.force_launcher):
+        sys.exit(self_launch(a))                # before torch is imported: the parent never initialises a GPU
+    global torch
+    import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch N ranks with python -m torch.distributed.run --nproc-per-node N'
+    assert a.gpus == world, (f'--gpus {a.gpus} but WORLD_SIZE={world}: under a launcher --gpus must equal the number of ranks it starts '
+                             '(without a launcher, `python bench.py --gpus N` starts the N ranks itself)')
     # launched by torch.distributed.run (also with ONE rank): the process group is RCCL ('nccl') and the barrier / MAX
     # all_reduce / all_gather below run through it; a plain `python bench.py` has no process group
     dist_on = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
@@ -586,7 +654,7 @@ def main():
             'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
                                    f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
                        'global_batch': gB, 'image_size': size, 'wplus_steps': a.wsteps, 'parallelism': f'batch-shard x{world}',
-                       'collective_backend': (dist.get_backend() if dist_on else None), 'gathered_latents': list(all_lats.shape), 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
+                       'collective_backend': (dist.get_backend() if dist_on else None), 'launcher': ('bench.py self-launch' if os.environ.get('OODGAN_BENCH_SELF_LAUNCHED') else ('external' if dist_on else None)), 'gathered_latents': list(all_lats.shape), 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
             'roofline_timed_region': roof_timed if roof is not roof_timed else None,

@@ -53,7 +53,9 @@ int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);
 /* Dispatch counters of oodgan_conv3x3_f16s: how many calls since load (or oodgan_dispatch_reset) went to the kernel family
  * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
- * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", and "upvb" (oodgan_upconv_vblur_fform).  Host-side, one relaxed atomic increment per call; the reference has no
+ * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb" (oodgan_upconv_vblur_fform), and the sub-counters of the fused epilogues:
+ * "s1big_ys" (8-wave stride-1 launches that wrote `ys` / ToRGB partial sums), "s2big_fuse" (8-wave stride-2 launches with the fused activation
+ * backward), "s2big_dotx_sform" (... that decoded `dotx` from a saved S-form).  Host-side, one relaxed atomic increment per call; the reference has no
  * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
  * Returns -1 for an unknown name. */
 long oodgan_dispatch_count(const char* name);

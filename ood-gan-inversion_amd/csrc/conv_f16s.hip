@@ -482,12 +482,20 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
                    "conv3x3_f16s: the F-form output exists only in the strip kernel (mode S1, S-form input, 16 < K,M <= 32)");
     OODGAN_REQUIRE(!a.dot_actgrad || (a.mode == OODGAN_CONV_S1 && a.x_sform && a.dotx && (s1_strip_eligible(a) || s1_big_eligible(a))),
                    "conv3x3_f16s: dot_actgrad exists only in the strip / 8-wave kernels of mode S1 (oodgan_conv3x3_s1_actgrad_supported)");
+    // dotx as a saved S-form: decoded only by the FUSE instance of the 8-wave stride-2 kernel — any other kernel would read the f16
+    // pairs as fp32
+    OODGAN_REQUIRE(!a.dotx_sform || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.fuse && a.dotx && a.dotx_scale && a.dotx_scale_stride >= a.M &&
+                                     !tiny_eligible(a) && s2_big_eligible(a)),
+                   "conv3x3_f16s: dotx_sform needs mode S2, a phase-split S-form input, `fuse`, dotx, dotx_scale and a shape of the 8-wave kernel "
+                   "(oodgan_conv3x3_s2_fuse_supported)");
+    OODGAN_REQUIRE(a.ys_vmax == nullptr || (a.ys != nullptr && a.mode == OODGAN_CONV_S1 && a.x_sform && !tiny_eligible(a) && !s1_strip_eligible(a) && s1_big_eligible(a)),
+                   "conv3x3_f16s: ys_vmax only with ys from the 8-wave stride-1 kernel (oodgan_conv3x3_s1_ys_supported)");
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:
             if (tiny_eligible(a)) { count_dispatch(OODGAN_DC_TINY); return launch_tiny(a, a.wpk, unscale2, st); }
             if (a.x_sform && s1_strip_eligible(a)) { count_dispatch(OODGAN_DC_STRIP); return launch_s1_strip(a, a.wpk, unscale2, st); }
-            if (a.x_sform && s1_big_eligible(a)) { count_dispatch(OODGAN_DC_S1BIG); return launch_s1_big(a, a.wpk, unscale2, st); }
+            if (a.x_sform && s1_big_eligible(a)) { count_dispatch(OODGAN_DC_S1BIG); if (a.ys) count_dispatch(OODGAN_DC_S1BIG_YS); return launch_s1_big(a, a.wpk, unscale2, st); }
             OODGAN_REQUIRE(a.rgb_y == nullptr, "conv3x3_f16s: the fused ToRGB output exists only in the strip kernel (16 < K,M <= 32) and, as partial "
                                                "sums together with ys, in the 8-wave kernel (oodgan_conv3x3_s1_ys_supported)");
             if (a.x_sform) { count_dispatch(OODGAN_DC_S1V2); return launch_s1v2(a, a.wpk, unscale2, st); }
@@ -502,7 +510,7 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
         case OODGAN_CONV_S2:
             OODGAN_REQUIRE((a.Hin & 1) && (a.Win & 1) && a.Hin >= 3 && a.Win >= 3, "conv3x3_f16s S2: input must be odd-sized");
             if (tiny_eligible(a)) { count_dispatch(OODGAN_DC_TINY); return launch_tiny(a, a.wpk, unscale2, st); }
-            if (a.x_sform && s2_big_eligible(a)) { count_dispatch(OODGAN_DC_S2BIG); return launch_s2_big(a, a.wpk, unscale2, st); }
+            if (a.x_sform && s2_big_eligible(a)) { count_dispatch(OODGAN_DC_S2BIG); if (a.fuse) count_dispatch(OODGAN_DC_S2BIG_FUSE); if (a.dotx_sform) count_dispatch(OODGAN_DC_S2BIG_DOTXS); return launch_s2_big(a, a.wpk, unscale2, st); }
             if (a.x_sform) { count_dispatch(OODGAN_DC_S2V2); return launch_s2v2(a, a.wpk, unscale2, st); }
             count_dispatch(OODGAN_DC_S2GEN);
             return launch_mode<OODGAN_CONV_S2>(a, a.wpk, unscale2, st);

@@ -278,7 +278,12 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             }
             if (f.bias) cv[5] = f.bias[m];
             cv[6] = f.dscale[(long)b * f.dscale_stride + m];
-            if (a.dotx_sform) cv[7] = 1.f / a.dotx_scale[(long)b * a.dotx_scale_stride + m];
+            if (a.dotx_sform) {
+                // a zero scale (style exactly 0): the S-form holds zeros and the activation cannot be recovered from it; decode as 0
+                // instead of 0 * inf = NaN in the style-gradient sums
+                const float sc = a.dotx_scale[(long)b * a.dotx_scale_stride + m];
+                cv[7] = sc != 0.f ? 1.f / sc : 0.f;
+            }
         }
     }
     // single barrier per stage: after it every wave has finished stage st-1 (its slot is free) and stage st has landed

@@ -167,8 +167,8 @@ def lib():
                 continue  # optional groups are bound lazily by bind_extra()
             fn.restype = res
             fn.argtypes = args
-        if h.oodgan_version() < ABI_VERSION:        # the argument structs of this mirror (ConvArgs: ys_vmax since 106) must match the library's
-            raise RuntimeError(f'{LIB_PATH} has ABI version {h.oodgan_version()}, this host layer needs >= {ABI_VERSION}: rebuild the library')
+        if h.oodgan_version() != ABI_VERSION:        # the argument structs of this mirror (ConvArgs: ys_vmax since 106) must match the library's
+            raise RuntimeError(f'{LIB_PATH} has ABI version {h.oodgan_version()}, this host layer needs exactly {ABI_VERSION} (the argument structs must match): rebuild the library')
         _lib = h
     return _lib
 

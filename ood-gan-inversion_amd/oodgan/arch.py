@@ -322,7 +322,12 @@ class GraphedForward:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 out, lats = self.model(sx, noise=sn) if sn is not None else self.model(sx)
-            ent = self._cache[key] = dict(graph=graph, x=sx, noise=sn, out=out, lats=lats, aligns=dict(self.model.aligns))
+            gen = getattr(self.model, 'generator', None)
+            eng = getattr(gen, '_engine_obj', None) if gen is not None else None
+            # the range state THIS graph's launches read and write (one per batch size, engine._range): the check after a replay must look
+            # at this object, not at whatever batch size ran last
+            ent = self._cache[key] = dict(graph=graph, x=sx, noise=sn, out=out, lats=lats, aligns=dict(self.model.aligns),
+                                          rng=getattr(eng, 'fwd_range', None))
         ent['x'].copy_(x)
         if noise is not None:
             for d, n in zip(ent['noise'], noise):
@@ -332,8 +337,9 @@ class GraphedForward:
         # read it here (one small device-to-host copy) and repeat the call eagerly with measured scales if it is set
         gen = getattr(self.model, 'generator', None)
         eng = gen._engine_obj if gen is not None and getattr(gen, '_engine_obj', None) is not None else None
-        if eng is not None and eng.fwd_range_violated():
-            eng.reset_fwd_state()
+        rng = ent.get('rng')
+        if eng is not None and rng is not None and rng.violated():
+            eng.reset_fwd_state(rng.B)
             out, lats = self.model(x, noise=noise) if noise is not None else self.model(x)
             return out, lats
         self.model.aligns = dict(ent['aligns'])

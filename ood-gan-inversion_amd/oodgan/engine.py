@@ -161,12 +161,18 @@ class GeneratorEngine:
         e._ranges = {}
         return e
 
-    def reset_fwd_state(self):
-        """Forget the carried forward range scales (new images / new batch): the next forward measures them exactly."""
-        if self.fwd_range is not None:
-            self.fwd_range.valid = False
-            self.fwd_range.flag.zero_()
-            self.fwd_range.vm.zero_()       # maxima an aborted carry pass left behind must not enter the next measurement
+    def reset_fwd_state(self, B=None):
+        """Forget the carried forward range scales (new images / new batch): the next forward measures them exactly.
+        Every batch size's state is reset (``B``: only that one) — a state left `valid` with another image set's scales would
+        make the first forward at that batch size run in carry mode and the result depend on the call history."""
+        ranges = self.__dict__.get('_ranges', {})
+        todo = list(ranges.values()) if B is None else [r for r in (ranges.get(B),) if r is not None]
+        if self.fwd_range is not None and (B is None or self.fwd_range.B == B) and not any(r is self.fwd_range for r in todo):
+            todo.append(self.fwd_range)
+        for r in todo:
+            r.valid = False
+            r.flag.zero_()
+            r.vm.zero_()       # maxima an aborted carry pass left behind must not enter the next measurement
 
     def fwd_range_violated(self):
         """True if a carried forward scale left the exact window in any forward since reset_fwd_state() (host sync)."""
@@ -179,8 +185,8 @@ class GeneratorEngine:
             ranges = self.__dict__.setdefault('_ranges', {})
             r = ranges.get(B)
             if r is None:
-                if len(ranges) >= 4:
-                    ranges.pop(next(iter(ranges)))
+                # never evicted: captured hipGraphs (arch.GraphedForward, the W+ step graphs) hold raw pointers to a state's
+                # q / vm / flag / s_sc / d_sc — a state is ~100 KB per batch size
                 r = ranges[B] = ops.FwdRange(self.n_styled, B, self.R, self.DR, self.row_layer, self.drow_layer, self.device)
             self.fwd_range = r
         return self.fwd_range

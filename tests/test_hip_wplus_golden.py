@@ -55,7 +55,8 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
         # forward and the fused backward producers — must reproduce the same gradient
         _lib.dispatch_reset()
         img = eng.forward(w0, noises, save=True, range_mode='carry')
-        fform = [n for n in ('convs.14', 'convs.15') if isinstance(eng.saved['acts'][n], ops.FForm)]
+        saved_acts = dict(eng.saved['acts'])
+        fform = [n for n in ('convs.14', 'convs.15') if isinstance(saved_acts[n], ops.FForm)]
         loss, gimg = ops.mse_loss_grad(img, target, gmul)
         glat = eng.backward(gimg, gmul, carry_scale=True)
         nx, ns = _lib.dispatch_count('stripx'), _lib.dispatch_count('strip')
@@ -64,6 +65,15 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
             assert fform == ['convs.14', 'convs.15'], fform
             assert (nx, ns) == (2, 0), (nx, ns)
             assert _lib.dispatch_count('upvb') == 1          # ... and its up-conv in one pass (conv_f16s_upvb.hip)
+            # round 4's fused paths BY NAME: the conv layers of the 64² ... 512² levels (convs.7 / 9 / 11 / 13) hand ToRGB sums and the next
+            # up-conv's S-form out of the 8-wave conv's epilogue, their activation is saved only as that S-form, and the fused epilogue of
+            # the stride-2 conv above decodes it — a changed eligibility rule (bwd_state, s1_ys_supported, s2_fuse_supported) must fail here
+            # instead of silently moving this test back onto the two-pass path
+            sf = [n for n in ('convs.7', 'convs.9', 'convs.11', 'convs.13') if isinstance(saved_acts[n], ops.SFormSaved)]
+            assert sf == ['convs.7', 'convs.9', 'convs.11', 'convs.13'], sf
+            assert _lib.dispatch_count('s1big_ys') == 4, _lib.dispatch_count('s1big_ys')
+            assert _lib.dispatch_count('s2big_dotx_sform') == 4, _lib.dispatch_count('s2big_dotx_sform')
+            assert _lib.dispatch_count('s2big_fuse') >= 4
         elif prec == 'f16s':
             assert fform == [] and (nx, ns) == (0, 2), (fform, nx, ns)      # first step: S-form strip kernel, exact scales
         else:

@@ -37,6 +37,40 @@ def test_bench_under_torchrun_one_rank_uses_rccl():
     assert 'RCCL' in (r.stdout + r.stderr) or 'NCCL' in (r.stdout + r.stderr)       # the library announced itself
 
 
+@pytest.mark.gpu
+def test_bench_self_launch_one_rank_uses_rccl():
+    """`python bench.py --gpus N` with no launcher starts its N ranks itself (bench.self_launch); --force-launcher takes that path
+    with N = 1: the child initialises the 'nccl' group exactly as under torch.distributed.run, rank 0's JSON line arrives on the
+    parent's stdout unchanged."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-launcher', '--size', '256', '--batch', '2',
+           '--wsteps', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-modconv', '--no-single-stream', '--no-end-to-end',
+           '--no-forward-only', '--no-generator-fwd']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['config']['collective_backend'] == 'nccl' and rec['config']['launcher'] == 'bench.py self-launch'
+    assert rec['config']['gathered_latents'] == [2, 14, 512] and rec['value'] > 0
+
+
+def test_bench_self_launch_two_ranks_without_gpu_fails_loudly():
+    """The driver's N > 1 command shape with WORLD_SIZE unset.  On a box without a GPU both rank processes must die on the
+    'needs a ROCm GPU' assertion, the parent must exit non-zero and show BOTH stderr tails (on a GPU box with one device rank 1
+    fails on its device ordinal instead and takes rank 0 down; either way: rc != 0, no JSON line)."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '256', '--batch', '2', '--wsteps', '2',
+                        '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert 'rank processes failed' in r.stderr
+    if not torch.cuda.is_available():
+        assert r.stderr.count('AssertionError: bench.py needs a ROCm GPU') == 2
+        assert 'rank 0 exited with code' in r.stderr and 'rank 1 exited with code' in r.stderr
+
+
 def test_bench_refuses_mismatched_world_size():
     """--gpus must equal WORLD_SIZE (checked before anything touches a GPU)."""
     env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
