@@ -147,8 +147,12 @@ class ConvProbe:
             fused = kw.get('ys') is not None
             tag = 'input gradient + style-gradient dot' if kw.get('dotx') is not None else (
                 'forward + ToRGB sums + S-form of the next conv (fused outputs)' if fused else 'forward')
+            # outputs the launch writes: the fp32 tensor (unless want_y=False: inside the W+ loop the fused launches keep the activation only
+            # as the S-form, engine.save_sform_only) and the S-form of the next conv (4 bytes per element as well); + dotx for the input gradient
+            n_out = (0 if kw.get('want_y') is False else 1) + (1 if fused else 0)
+            n_in = 2 if kw.get('dotx') is not None else 1
             probe.recs.append((e0, e1, 2.0 * B * K * M * 9 * H * W,
-                               4.0 * (B * K * H * W + B * M * H * W * (2 if fused else 1) + K * M * 9), tag))
+                               4.0 * (B * K * H * W + (n_in - 1) * B * M * H * W + B * M * H * W * n_out + K * M * 9), tag))
             return r
 
         self.ops.conv3x3 = conv3x3
@@ -164,10 +168,11 @@ class ConvProbe:
         byts = sum(g for _, _, _, g, _ in self.recs)
         n = len(self.recs)
         inst = {}
-        for t, (_, _, f, _, tag) in zip(times, self.recs):
-            d = inst.setdefault(tag, [0, 0.0, 0.0])
-            d[0] += 1; d[1] += t; d[2] += f
-        instances = {k: dict(launches=v[0], avg_ms=round(v[1] / v[0], 4), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in inst.items()}
+        for t, (_, _, f, g, tag) in zip(times, self.recs):
+            d = inst.setdefault(tag, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += t; d[2] += f; d[3] += g
+        instances = {k: dict(launches=v[0], avg_ms=round(v[1] / v[0], 4), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                             alg_bytes_per_launch=round(v[3] / v[0])) for k, v in inst.items()}
         return dict(launches=n, avg_ms=ms / n, tflops=flops / (ms * 1e-3) / 1e12, flops_per_launch=flops / n,
                     bytes_per_launch=byts / n, instances=instances)
 
@@ -178,6 +183,16 @@ def pmc_traffic_instances(a):
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             return json.load(f).get(f'{a.precision}_b{a.batch}_s{a.size}', {}).get('instances')
+    except (OSError, ValueError):
+        return None
+
+
+def pmc_step_traffic(a):
+    """HBM bytes of one steady-state W+ step from the committed PMC passes (tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over `tools/wplus_only.py` at two step counts, difference / step difference); None when not on file."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            return json.load(f).get(f'wplus_step_{a.precision}_b{a.batch}_s{a.size}')
     except (OSError, ValueError):
         return None
 
@@ -194,6 +209,45 @@ def pmc_traffic(a):
         return rec.get(key, {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         return None
+
+
+def wplus_step_algorithmic(B, size, channel_multiplier=2):
+    """Algorithmic HBM bytes and flops of ONE steady-state W+ step (forward + backward to W+ + Adam) as the loop is scheduled
+    (DESIGN.md §4-5, §15): every tensor a launch must read or write counted once per launch, at 4 bytes per element (fp32, the 64-byte
+    S-form / F-form records of 16 channels, and the phase-split S-form all hold 4 bytes per element); weights, noise maps, per-channel
+    vectors and partial sums are left out (< 1 %).  flops = 2*B*K*M*9*H*W per styled conv forward and once more for its input gradient
+    (no weight gradients exist in this loop), + the ToRGB contractions; the folded-blur kernels' doubled taps are NOT counted."""
+    from oodgan.synth import generator_channels
+    ch = generator_channels(channel_multiplier)
+    e = 4.0 * B
+    by = fl = 0.0
+    res = 4
+    # 4x4: conv1 forward (in + out), its ToRGB, backward (g in, dotx, dx out)
+    by += e * ch[4] * 16 * (2 + 1 + 3)
+    fl += 2 * 2.0 * B * ch[4] * ch[4] * 9 * 16
+    cin = ch[4]
+    while res < size:
+        res *= 2
+        C, r2, q2, z2 = ch[res], res * res, (res // 2) ** 2, (res + 1) ** 2
+        last = res == size
+        # ---- forward
+        if last and C <= 32:
+            by += e * (cin * q2 + C * r2)                  # one-pass up-conv (conv_f16s_upvb): S-form in, F-form out
+        else:
+            by += e * (cin * q2 + C * z2)                  # transposed conv: S-form in, (2H+1)² result out
+            by += e * (C * z2 + 2 * C * r2)                # blur + noise + bias + act: result in, fp32 planes + next conv's S-form out
+        by += e * (C * r2 + C * r2)                        # conv: S-form (F-form) in; out = S-form of the next up-conv only (64² ... 512²), F-form (last), fp32 (low res)
+        if res < 64:
+            by += e * (C * r2 + (0 if last else C * r2))   # low resolution: separate ToRGB pass reads the map (and writes the next S-form)
+        fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
+        # ---- backward
+        by += e * 3 * C * r2                               # input gradient of the conv: gradient S-form (F-form: its own output) in, dotx in, dx out
+        by += e * (C * r2 + C * z2)                        # blur^T + phase split: pre-activation gradient in, phase-split S-form out
+        by += e * (C * z2 + 2 * cin * q2)                  # stride-2 conv + fused activation backward: phases in, saved activation in, S-form gradient out
+        fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
+        cin = C
+    by += e * 3 * size * size * 4                          # MSE: image + target in, gradient out; skip pyramid down (read once, write 1/4 + ...)
+    return by, fl
 
 
 def modconv_roofline(iters=30, warmup=3):
@@ -615,6 +669,37 @@ def main():
             probe.on = False
             roof = roofline_of(probe.summary(), f'exclusive single-stream pass of the same workload (batch {B}, {a.roofline_steps} W+ steps) '
                                                 'inside bench.py right after the timed region')
+        # ---- the STEP against both roofs (north_star: "throughput ... as fraction of the HBM roofline"): wall time of one W+ step of the
+        # timed region = (inversion - final OOD forward) / steps, the OOD forward timed alone right here (HIP events, same inputs)
+        step_roof = None
+        if not a.no_roofline_events:
+            model._ood_forward(x, all_lats[:B] if all_lats.shape[0] >= B else enc_lats, enc_feats, noise=noises)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            model._ood_forward(x, enc_lats, enc_feats, noise=noises)
+            e1.record()
+            torch.cuda.synchronize()
+            ood_ms = e0.elapsed_time(e1)
+            step_ms = (dt / a.steps * 1e3 - ood_ms) / max(a.wsteps, 1)
+            alg_b, alg_f = wplus_step_algorithmic(B, size)
+            pmc = pmc_step_traffic(a)
+            hbm_b = pmc.get('hbm_bytes_per_step') if pmc else None
+            step_roof = dict(
+                wall_ms_per_wplus_step=round(step_ms, 4), ood_forward_ms=round(ood_ms, 3), streams=a.streams,
+                algorithmic_gb_per_step=round(alg_b / 1e9, 3), algorithmic_tflop_per_step=round(alg_f / 1e12, 4),
+                hbm_gb_per_step_pmc=None if hbm_b is None else round(hbm_b / 1e9, 3),
+                traffic_over_algorithmic=None if hbm_b is None else round(hbm_b / alg_b, 3),
+                achieved_tbps_algorithmic=round(alg_b / step_ms / 1e9, 3), frac_hbm_algorithmic=round(alg_b / step_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                achieved_tbps_pmc=None if hbm_b is None else round(hbm_b / step_ms / 1e9, 3),
+                frac_hbm_pmc=None if hbm_b is None else round(hbm_b / step_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                achieved_tflops=round(alg_f / step_ms / 1e9, 1), frac_mfma_f16_peak=round(alg_f / step_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+                frac_of_3mfma_ceiling=round(3 * alg_f / step_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+                peak_hbm_gbps=HBM_PEAK_GBPS, peak_mfma_tflops=MFMA_F16_PEAK_TFLOPS,
+                pmc_source=None if not pmc else pmc.get('source'),
+                note='one W+ step (generator forward + MSE + backward to W+ + Adam, batch %d) of the timed region: wall time = (inversion - final OOD '
+                     'forward) / W+ steps; algorithmic bytes / flops: bench.wplus_step_algorithmic (every tensor a launch of the step must read or write, '
+                     'once per launch; 2*B*K*M*9*H*W per conv and direction); PMC bytes: 2*FETCH_SIZE + WRITE_SIZE of the step' % B)
         modconv = None
         if not a.no_modconv and world == 1:
             modconv = modconv_roofline()
@@ -657,6 +742,7 @@ def main():
                        'collective_backend': (dist.get_backend() if dist_on else None), 'launcher': ('bench.py self-launch' if os.environ.get('OODGAN_BENCH_SELF_LAUNCHED') else ('external' if dist_on else None)), 'gathered_latents': list(all_lats.shape), 'streams_per_gpu': a.streams, 'hipgraph_replay': bool(a.graph),
                        'final_loss_mean': float(losses[-1].mean().item()), 'first_loss_mean': float(losses[0].mean().item())},
             'roofline': roof,
+            'step_roofline': step_roof,
             'roofline_timed_region': roof_timed if roof is not roof_timed else None,
             'modconv2d': modconv,
             'single_stream': single,
