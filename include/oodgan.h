@@ -48,6 +48,9 @@ int oodgan_device_count(void);
  *   "fewout_quad"      OODGAN_FEWOUT_QUAD      1     0: oodgan_conv3x3_fewout2 keeps its one-pixel-per-thread form (the A/B of csrc/samm.hip's third form)
  *   "tiny_mid_max"     OODGAN_TINY_MID_MAX     1024  most positions (B*H*W) of a 16x16 / 32x32 stride-1 map the skinny-GEMM kernel takes when the caller
  *                                                    offers a workspace (the encoder trunk at batch 1-4; 8192 measured: +2.7 ms per batch of 8)
+ *   "stripx_waves"     OODGAN_STRIPX_WAVES     4     the FORWARD F-form strip conv of the 1024² level (oodgan_conv_args.x_fform = 1): 4 = one wave per SIMD
+ *                                                    (csrc/conv_f16s_stripx.hip, round 3); 8 = two waves per SIMD, the K loop split over a wave pair with
+ *                                                    de-phased producer / finisher roles (csrc/conv_f16s_stripx8.hip, round 5: measured equal)
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);

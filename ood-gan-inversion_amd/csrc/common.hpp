@@ -10,7 +10,7 @@ namespace oodgan {
 void set_error(const char* fmt, ...);
 
 // dispatch tunables (runtime.hip): environment default read once, then oodgan_set_tunable
-enum { OODGAN_TUN_S1_BIG_MIN_ITEMS = 0, OODGAN_TUN_S2_BIG_MIN_ITEMS, OODGAN_TUN_T2_BIG_MIN_ITEMS, OODGAN_TUN_BLURT_STRIP, OODGAN_TUN_BLUR_STRIP, OODGAN_TUN_UPVB_WAVES, OODGAN_TUN_FEWOUT_QUAD, OODGAN_TUN_TINY_MID_MAX, OODGAN_TUN_COUNT };
+enum { OODGAN_TUN_S1_BIG_MIN_ITEMS = 0, OODGAN_TUN_S2_BIG_MIN_ITEMS, OODGAN_TUN_T2_BIG_MIN_ITEMS, OODGAN_TUN_BLURT_STRIP, OODGAN_TUN_BLUR_STRIP, OODGAN_TUN_UPVB_WAVES, OODGAN_TUN_FEWOUT_QUAD, OODGAN_TUN_TINY_MID_MAX, OODGAN_TUN_STRIPX_WAVES, OODGAN_TUN_COUNT };
 long tunable(int id);
 
 // dispatch counters (runtime.hip, oodgan_dispatch_count): which kernel family a conv call was routed to — tests assert that the

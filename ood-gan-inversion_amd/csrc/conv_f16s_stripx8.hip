@@ -1,0 +1,431 @@
+// The forward 32 -> 32 channel 3x3 conv of the 1024² level inside the W+ loop (F-form in, F-form out; conv_f16s_stripx.hip, x_fform = 1,
+// reference ModulatedConv2d.forward + NoiseInjection + FusedLeakyReLU + ToRGB, src/ops/StyleGAN/model.py:233-274,283-292,343-372) with
+// TWO waves per SIMD.
+//
+// conv_f16s_stripx_kernel runs ONE wave per SIMD: the 36 weight fragments live in registers (144 of them) and a second workgroup has no
+// LDS.  Its ~650 instructions per tile and wave — matrix, conversion, epilogue, address arithmetic, LDS traffic — then issue from a single
+// instruction stream, every s_waitcnt stalls the whole SIMD, and the matrix pipe is 30-37 % busy (profiles/r4_final_kernel_counters.csv:
+// 65-69 % of the wave time issuing; 3.6 TB/s against the 5.9 TB/s a copy reaches).  Here a workgroup has eight waves on the same LDS image:
+//   * wave = (row r = wave & 3 of the 4-row tile, K half kh = wave >> 2): the pair of a row SPLITS THE K LOOP — each wave holds the 18
+//     weight fragments of its 16-channel block (72 registers: two waves fit a SIMD) and issues 27 of the tile's 54 matrix instructions;
+//   * the rest of the tile's work is divided by ROLE, each role with its own loop (a wave-uniform branch taken once):
+//       kh = 1, "producer":  every LDS-DMA of the loop (raw F-form rows, halo records, noise rows), the in-place fp32 -> split-f16
+//                            conversion of group t+1, and at the end of the tile its 16 partial sums into an LDS exchange buffer;
+//       kh = 0, "finisher":  the epilogue of tile t-1 — partner's partial sums + its own, out-scale, noise, bias, leaky ReLU, the ToRGB
+//                            colour sums, F-form stores — woven between its matrix instructions as before.
+//     The finisher's loop contains no LDS-DMA, so nothing there makes the compiler's waitcnt pass pessimistic; the producer's loop has no
+//     stores, so its counted vmcnt wait is simply "all but the newest (PD-1) batches".
+//   * one s_barrier per tile as before; the exchange buffer is double-buffered by tile parity (written at the end of iteration t, read at
+//     the start of iteration t+1, overwritten at the end of iteration t+2 — behind the barrier the reader passes only after its read).
+// The two instruction streams of a SIMD overlap each other's waits, and the matrix pipe sees the same 54 instructions per tile.
+// Arithmetic: identical products; the fp32 sums of the two channel blocks are added at the end instead of running through one chain
+// (tests/test_hip_stripx.py compares with the four-wave kernel and the S-form strip kernel at 1e-6).
+#include "stripx_common.hpp"
+
+namespace {
+
+constexpr int SX8_XROW = 4096;                 // exchange: [reg quad 4][64 lanes][16 B] per row
+constexpr int SX8_XONE = 4 * SX8_XROW;          // four rows
+constexpr int SX8_XBUF = SXL<false>::SMEM;      // behind the four-wave kernel's forward layout
+constexpr int SX8_SMEM = SX8_XBUF + 2 * SX8_XONE;
+
+template <bool RGB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_f16s_stripx8_fwd_kernel(
+    const StripX p, const uint4* __restrict__ wpk16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using L = SXL<false>;
+    constexpr int SX_NG = L::NG, NB = L::NB, PD = L::PD;
+    constexpr int SX_HALO = L::HALO, SX_SMALL = L::SMALL, SX_CST = L::CST, SX_EPC = L::EPC;
+    const oodgan_conv_args& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, kh = wave8 >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    int w = blockIdx.x;
+    {
+        const int total = gridDim.x, xcd = w & 7, idx = w >> 3, q = total >> 3, r = total & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = w % p.tiles_x;
+    const int seg = (w / p.tiles_x) % p.nseg;
+    const int b = w / (p.tiles_x * p.nseg);
+    const int t0 = seg * p.seg_tiles;
+    const int n = min(p.seg_tiles, p.tiles_y - t0);
+    const int c0 = tx * 32, R0 = 4 * t0;
+    const int H = a.Hin, W = a.Win;
+    constexpr int M = 32;
+    const long HW = (long)H * W;
+
+    // ---- this wave's half of the weights (channel block kh), homed in accumulation registers (see conv_f16s_stripx.hip)
+    half8 ah[9], al[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const half8* wb = reinterpret_cast<const half8*>(wpk16) + ((long)(kh * 9 + tp) * 4) * p.Mp;
+        ah[tp] = wb[(0 * 2 + half) * p.Mp + l31];
+        al[tp] = wb[(1 * 2 + half) * p.Mp + l31];
+    }
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        asm volatile("" : "+a"(ah[tp]));
+        asm volatile("" : "+a"(al[tp]));
+    }
+
+    // ---- per-workgroup constants in LDS: epilogue scale of channel m(r) = (r & 3) + 8 (r >> 2) + 4 half; bias and the modulated ToRGB rows
+    const float us = (p.w_unscale ? p.w_unscale[0] : 1.f) * (a.in_mul2 ? a.in_mul2[0] : 1.f);
+    if (tid < 32) {
+        const int hh = tid >> 4, r = tid & 15, m = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        reinterpret_cast<float*>(smem + SX_CST)[tid] = (a.out_scale ? a.out_scale[(long)b * a.out_scale_stride + m] : 1.f) * us;
+        float* e = reinterpret_cast<float*>(smem + SX_EPC) + (hh * 4 + (r >> 2)) * 16 + (r & 3);
+        e[0] = a.bias ? a.bias[m] : 0.f;
+        const float sv = RGB ? a.rgb_scale * a.rgb_s[(long)b * a.rgb_s_stride + m] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[4 * (k + 1)] = RGB ? sv * a.rgb_w[k * M + m] : 0.f;
+    }
+    const unsigned smem0 = lds_addr(smem);
+
+    // lane-constant part of the fragment addresses: record kx + l31 of this wave's channel block, slot (half + 2*lo) rotated by (c>>2)&3
+    unsigned lrd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            const int c = kx + l31;
+            lrd[kx][lo] = kh * (SX_C * 64) + c * 64 + (((half + 2 * lo + ((c >> 2) & 3)) & 3) << 4);
+        }
+    auto frag_issue = [&](const unsigned (&rbase)[3], int ky, half8 (&f)[6]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            lds_issue(f[kx], rbase[ky] + lrd[kx][0]);
+            lds_issue(f[3 + kx], rbase[ky] + lrd[kx][1]);
+        }
+    };
+    auto mfma_chunk = [&](int ky, const half8 (&f)[6], f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky * 3 + kx], f[kx], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ky * 3 + kx], f[3 + kx], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx], f[kx], acc1, 0, 0, 0);
+    };
+    const unsigned xrow = smem0 + SX8_XBUF + wave * SX8_XROW + lane * 16;      // + (tile & 1) * SX8_XONE + q * 1024
+
+    __builtin_amdgcn_s_waitcnt(SX_VM(0));            // weights, scales: retired here, never inside the loops
+
+    if (kh) {
+        // ================================================================== producer
+        // conversion role: channel block ckc = wave >> 1, pixel cpx = 16 (wave & 1) + (lane >> 2), channel quarter cq = lane & 3, in each of the
+        // group's four rows; halo columns 0 / 33 of row `wave`: lanes 0..15 = (side, kc, quarter) — conv_f16s_stripx.hip
+        const int ckc = wave >> 1, cpx = 16 * (wave & 1) + (lane >> 2), cq = lane & 3;
+        const bool even = (cq & 1) == 0;
+        const int slot = even ? (cq >> 1) : 2 + (cq >> 1);
+        const unsigned crec = (unsigned)(ckc * (SX_C * 64) + (1 + cpx) * 64);
+        const unsigned cwr = crec + ((((unsigned)slot + (((1 + cpx) >> 2) & 3)) & 3) << 4);
+        const unsigned goff0 = (unsigned)((((long)ckc * HW + c0 + cpx) * 16 + cq * 4) * 4);
+        const int hside = (lane >> 3) & 1, hkc = (lane >> 2) & 1, hcol = hside ? 33 : 0, hgx = c0 - 1 + hcol;
+        const bool hinv = hgx < 0 || hgx >= W;       // a halo column outside the image: a clamped (valid) record is fetched and multiplied by a zero scale
+        const unsigned hgoff = (unsigned)((((long)hkc * HW + min(max(hgx, 0), W - 1)) * 16 + cq * 4) * 4);
+        const unsigned hwr = (unsigned)(hkc * (SX_C * 64) + hcol * 64 + ((((unsigned)slot + ((hcol >> 2) & 3)) & 3) << 4));
+        const unsigned char* xfb = reinterpret_cast<const unsigned char*>(a.x) + (long)b * 2 * HW * 64;
+        const unsigned char* zp = reinterpret_cast<const unsigned char*>(p.zeros);
+        const long row_bytes = (long)W * 64;
+        const float* nzb = a.noise ? a.noise + (long)(a.noise_batch > 1 ? b : 0) * HW : nullptr;
+        const unsigned nzoff = (unsigned)((c0 + l31) * 4);
+
+        float xs[4], xsh[4];
+        {
+            const float m2 = a.in_mul2 ? a.in_mul2[1] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xs[j] = (a.in_scale ? a.in_scale[(long)b * a.in_scale_stride + ckc * 16 + cq * 4 + j] : 1.f) * m2;
+                xsh[j] = hinv ? 0.f : (a.in_scale ? a.in_scale[(long)b * a.in_scale_stride + hkc * 16 + cq * 4 + j] : 1.f) * m2;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(SX_VM(0));
+
+        // one LDS-DMA of a batch: raw rows + halo of group g (ring group gs, buffers g3), the noise row of tile td (buffer d3).  Every address
+        // is a wave-uniform base (scalar registers) + a 32-bit lane offset; rows outside the image read the page of zeros (offset 0).
+        auto issue_op = [&](int op, int g, int gs, int g3, int td, int d3) {
+            const int r0g = R0 + 4 * g + 1;
+            if (op < 4) {
+                const int r = r0g + op;
+                const bool rok = r >= 0 && r < H;
+                const unsigned char* base = rok ? xfb + (long)r * row_bytes : zp;
+                const unsigned off = rok ? goff0 : 0u;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)(smem + gs * SX_GROUP + op * SX_ROW + ckc * (SX_C * 64) + (1 + 16 * (wave & 1)) * 64), 16, 0, SX_NT_LD);
+            } else if (op == 4) {
+                const int r = r0g + wave;
+                const bool rok = r >= 0 && r < H;
+                const unsigned char* base = rok ? xfb + (long)r * row_bytes : zp;
+                const unsigned off = rok ? hgoff : 0u;
+                if (lane < 16) __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)(smem + SX_HALO + g3 * 1024 + wave * 256), 16, 0, SX_NT_LD);
+            } else {
+                const unsigned char* base = nzb ? reinterpret_cast<const unsigned char*>(nzb + (long)(R0 + 4 * td + wave) * W) : zp;
+                const unsigned off = nzb ? nzoff : 0u;
+                __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)(smem + SX_SMALL + d3 * 1024 + wave * 256), 4, 0, 0);
+            }
+        };
+        auto issue_batch = [&](int g, int gs, int g3, int td, int d3) {
+#pragma unroll
+            for (int op = 0; op < 6; ++op) issue_op(op, g, gs, g3, td, d3);
+        };
+        auto convert_unit = [&](const f32x4 rv, const float* xsc, unsigned dst, bool wr_ok) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rv[j] * xsc[j];
+            unsigned h01, l01, h23, l23;
+            split_pair(v[0], v[1], h01, l01);
+            split_pair(v[2], v[3], h23, l23);
+            // quarters (0,1) and (2,3) exchange: the even one collects the hi halves of the 8 channels, the odd one the lo halves
+            const unsigned s0 = even ? l01 : h01, s1 = even ? l23 : h23;
+            const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+            const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+            if (wr_ok) lds_write16(dst, even ? h01 : g0, even ? h23 : g1, even ? g0 : l01, even ? g1 : l23);
+        };
+        auto convert = [&](int gs, int g3) {
+            const unsigned ring = smem0 + gs * SX_GROUP;
+            f32x4 rv[5];
+            lds_read_rows(ring + crec + cq * 16, smem0 + SX_HALO + g3 * 1024 + wave * 256 + (lane & 15) * 16, rv[0], rv[1], rv[2], rv[3], rv[4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) convert_unit(rv[i], xs, ring + i * SX_ROW + cwr, true);
+            convert_unit(rv[4], xsh, ring + wave * SX_ROW + hwr, lane < 16);
+        };
+
+        // ---- prologue: groups -1 and 0 converted, then the batches "-PD" .. "-1"
+        issue_batch(-1, SX_NG - 1, NB - 1, 0, 0);
+        issue_batch(0, 0, 0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(SX_VM(0));
+        __builtin_amdgcn_s_barrier();                  // [P1] constants written, both groups landed (the four producer waves fetched them)
+        convert(SX_NG - 1, NB - 1);
+        convert(0, 0);
+        __builtin_amdgcn_s_waitcnt(SX_VML(0));
+        __builtin_amdgcn_s_barrier();                  // [P2]
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = PD; k >= 1; --k) {
+            const int g = PD + 1 - k, td = PD - 1 - k;
+            issue_batch(g, g % SX_NG, g % NB, min(max(td, 0), n - 1), (td + NB) % NB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        int rb = 4 * SX_NG - 2 + wave, gs1 = 1, m3 = 0;
+        for (int t = 0; t <= n; ++t) {
+            // everything but the newest PD - 1 batches (6 operations each; this role issues nothing else) has landed
+            __builtin_amdgcn_s_waitcnt(SX_VML((PD - 1) * 6));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int m3n = m3 == NB - 1 ? 0 : m3 + 1;
+            int gsn = gs1 + PD;
+            if (gsn >= SX_NG) gsn -= SX_NG;
+            int md = m3 - 2;
+            if (md < 0) md += NB;
+            const int tdn = min(t + PD - 1, n - 1);
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): retires the DMAs in the compiler's model (conv_f16s_stripx.hip)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned cring = smem0 + gs1 * SX_GROUP;
+            unsigned rbase[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                int row = rb + ky;
+                if (row >= 4 * SX_NG) row -= 4 * SX_NG;
+                rbase[ky] = smem0 + row * SX_ROW;
+            }
+            half8 fb[2][6];
+            f32x4 ru[5];
+            // ---- phase 1 (the partner wave of this SIMD runs its epilogue arithmetic meanwhile): the 27 matrix instructions of this wave's
+            // channel block, the fragments of chunk c+1 requested under chunk c.  The two roles of a SIMD are DE-PHASED on purpose: with both
+            // waves weaving vector work between their matrix instructions they competed for the matrix pipe in the same moments and for the
+            // vector pipe in the others (measured: the same time as one wave per SIMD).
+            frag_issue(rbase, 0, fb[0]);
+            lds_wait(fb[0]);
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (c < 2) frag_issue(rbase, c + 1, fb[(c + 1) & 1]);
+                if (!(SX_ABL & 4)) mfma_chunk(c, fb[c & 1], acc0, acc1);
+                if (c < 2) lds_wait(fb[(c + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 2 (the partner issues its matrix instructions): the batch's LDS-DMAs and the in-place conversion of group t+1 (the four
+            // quarters of a record have all read it — waited for below — before any of them writes)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds_issue(ru[u], cring + u * SX_ROW + crec + cq * 16);
+            lds_issue(ru[4], smem0 + SX_HALO + m3n * 1024 + wave * 256 + (lane & 15) * 16);
+            if (!(SX_ABL & 8)) {
+                issue_op(0, t + PD + 1, gsn, m3, tdn, md);
+                issue_op(1, t + PD + 1, gsn, m3, tdn, md);
+            }
+            lds_wait(ru[0], ru[1], ru[2], ru[3]);
+            lds_wait(ru[4]);
+            if (!(SX_ABL & 2)) {
+                convert_unit(ru[0], xs, cring + 0 * SX_ROW + cwr, true);
+                convert_unit(ru[1], xs, cring + 1 * SX_ROW + cwr, true);
+            }
+            if (!(SX_ABL & 8)) {
+                issue_op(2, t + PD + 1, gsn, m3, tdn, md);
+                issue_op(3, t + PD + 1, gsn, m3, tdn, md);
+            }
+            if (!(SX_ABL & 2)) {
+                convert_unit(ru[2], xs, cring + 2 * SX_ROW + cwr, true);
+                convert_unit(ru[3], xs, cring + 3 * SX_ROW + cwr, true);
+            }
+            if (!(SX_ABL & 8)) {
+                issue_op(4, t + PD + 1, gsn, m3, tdn, md);
+                issue_op(5, t + PD + 1, gsn, m3, tdn, md);
+            }
+            if (!(SX_ABL & 2)) convert_unit(ru[4], xsh, cring + wave * SX_ROW + hwr, lane < 16);
+            // the partial sums of this wave's channel block -> exchange buffer of the tile's parity
+            {
+                const unsigned xb = xrow + (t & 1) * SX8_XONE;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v0 = acc0[4 * q] + acc1[4 * q], v1 = acc0[4 * q + 1] + acc1[4 * q + 1];
+                    const float v2 = acc0[4 * q + 2] + acc1[4 * q + 2], v3 = acc0[4 * q + 3] + acc1[4 * q + 3];
+                    lds_write16(xb + q * 1024, __float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rb += 4;
+            if (rb >= 4 * SX_NG) rb -= 4 * SX_NG;
+            gs1 = gs1 == SX_NG - 1 ? 0 : gs1 + 1;
+            m3 = m3n;
+        }
+        __builtin_amdgcn_s_waitcnt(SX_VML(0));
+        return;
+    }
+
+    // ====================================================================== finisher
+    const float nwf = a.noise ? (a.noise_w ? a.noise_w[0] : 1.f) : 0.f;
+    const int px = c0 + l31;
+    __builtin_amdgcn_s_waitcnt(SX_VML(0));
+    __builtin_amdgcn_s_barrier();                      // [P1]
+    __builtin_amdgcn_s_barrier();                      // [P2]
+    int rb = 4 * SX_NG - 2 + wave, m3 = 0, m3l = NB - 1;
+    float vprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vprev[r] = 0.f;
+    for (int t = 0; t <= n; ++t) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // this wave's LDS reads of the previous tile are complete
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int m3n = m3 == NB - 1 ? 0 : m3 + 1;
+        // row of tile t-1 this wave stores; iteration 0 has nothing to store and writes (garbage) to tile 0's row, which iteration 1 overwrites
+        // — same wave, same addresses, in order — instead of branching around the stores
+        const int pyp = R0 + 4 * max(t - 1, 0) + wave;
+        float* const yfp = a.y + (((long)b * 2 * H + pyp) * W + px) * 16 + 4 * half;
+        unsigned rbase[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int row = rb + ky;
+            if (row >= 4 * SX_NG) row -= 4 * SX_NG;
+            rbase[ky] = smem0 + row * SX_ROW;
+        }
+        half8 fb[2][6];
+        f32x4 osc[4], prt[4], ec4[2][4];
+        float nzr = 0.f;
+        frag_issue(rbase, 0, fb[0]);                 // consumed in phase 2
+        {
+            const unsigned xb = xrow + ((t + 1) & 1) * SX8_XONE;       // parity of tile t - 1
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lds_issue(prt[k], xb + k * 1024);
+                lds_issue(osc[k], smem0 + SX_CST + half * 64 + k * 16);
+            }
+        }
+        lds_issue(nzr, smem0 + SX_SMALL + m3l * 1024 + wave * 256 + lane * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_issue(ec4[0][k], smem0 + SX_EPC + (half * 4 + 0) * 64 + k * 16);
+        lds_wait(fb[0]);
+        lds_wait(prt[0], prt[1], prt[2], prt[3]);
+        lds_wait(osc[0], osc[1], osc[2], osc[3]);
+        lds_wait(ec4[0][0], ec4[0][1], ec4[0][2], ec4[0][3]);
+        lds_wait(nzr);
+        const float nz = nwf * nzr;
+        float c0s = 0.f, c1s = 0.f, c2s = 0.f;
+        // ---- phase 1 (the partner wave issues its matrix instructions): the epilogue of tile t-1, slice by slice (channels 4 ec .. 4 ec + 3
+        // of each half), each slice's four channels stored at once
+        auto slice = [&](int ec, const f32x4 (&e4)[4]) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = ec * 4 + e;
+                float ov = (vprev[r] + prt[ec][e]) * osc[ec][e] + (nz + e4[0][e]);
+                if (a.act == OODGAN_ACT_LRELU) ov = (ov > 0.f ? ov : 0.2f * ov) * kSqrt2;
+                o[e] = ov;
+                if (RGB) {
+                    c0s += e4[1][e] * ov;
+                    c1s += e4[2][e] * ov;
+                    c2s += e4[3][e] * ov;
+                }
+            }
+            if (!(SX_ABL & 1)) *reinterpret_cast<float4*>(yfp + (long)(ec >> 1) * HW * 16 + (ec & 1) * 8) = make_float4(o[0], o[1], o[2], o[3]);
+            else if (o[0] == 12345.678f) yfp[0] = o[1] + o[2] + o[3];
+        };
+#pragma unroll
+        for (int ec = 0; ec < 4; ++ec) {
+            if (ec < 3) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_issue(ec4[(ec + 1) & 1][k], smem0 + SX_EPC + (half * 4 + (ec + 1)) * 64 + k * 16);
+            }
+            slice(ec, ec4[ec & 1]);
+            if (ec < 3) lds_wait(ec4[(ec + 1) & 1][0], ec4[(ec + 1) & 1][1], ec4[(ec + 1) & 1][2], ec4[(ec + 1) & 1][3]);
+        }
+        if (RGB) {
+            // the lane's 16 channels of the three colour sums; the other 16 channels sit in lane ^ 32
+            c0s += __shfl_xor(c0s, 32, 64);
+            c1s += __shfl_xor(c1s, 32, 64);
+            c2s += __shfl_xor(c2s, 32, 64);
+            if (half == 0 && (!(SX_ABL & 1) || c0s == 12345.678f)) {
+                float* rp = a.rgb_y + (long)b * 3 * HW + (long)pyp * W + px;
+                rp[0] = c0s;
+                rp[HW] = c1s;
+                rp[2 * HW] = c2s;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2: this wave's 27 matrix instructions
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c < 2) frag_issue(rbase, c + 1, fb[(c + 1) & 1]);
+            if (!(SX_ABL & 4)) mfma_chunk(c, fb[c & 1], acc0, acc1);
+            if (c < 2) lds_wait(fb[(c + 1) & 1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vprev[r] = acc0[r] + acc1[r];
+        __builtin_amdgcn_sched_barrier(0);
+        rb += 4;
+        if (rb >= 4 * SX_NG) rb -= 4 * SX_NG;
+        m3l = m3;
+        m3 = m3n;
+    }
+}
+
+}  // namespace
+
+namespace oodgan {
+
+bool stripx8_init() {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx8_fwd_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX8_SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx8_fwd_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SX8_SMEM), true);
+    return once;
+}
+
+int launch_s1_stripx8_fwd(const StripX& p, const void* wpk16, hipStream_t st) {
+    const long nblk = (long)p.a.B * p.tiles_x * p.nseg;
+    const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
+    const dim3 grid((unsigned)nblk), block(512);
+    stripx8_init();
+    if (p.a.rgb_y) hipLaunchKernelGGL((conv_f16s_stripx8_fwd_kernel<true>), grid, block, SX8_SMEM, st, p, w16);
+    else hipLaunchKernelGGL((conv_f16s_stripx8_fwd_kernel<false>), grid, block, SX8_SMEM, st, p, w16);
+    return check_launch("conv3x3_f16s_stripx8");
+}
+
+}  // namespace oodgan

@@ -28,6 +28,7 @@ Tunable g_tun[OODGAN_TUN_COUNT] = {
     {"upvb_waves", "OODGAN_UPVB_WAVES", 12, {0}, {0}},
     {"fewout_quad", "OODGAN_FEWOUT_QUAD", 1, {0}, {0}},
     {"tiny_mid_max", "OODGAN_TINY_MID_MAX", 1024, {0}, {0}},
+    {"stripx_waves", "OODGAN_STRIPX_WAVES", 4, {0}, {0}},
 };
 }  // namespace
 long tunable(int id) {

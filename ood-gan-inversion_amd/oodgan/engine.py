@@ -101,6 +101,7 @@ class GeneratorEngine:
         self.fuse_up = True
         self.save_sform_only = os.environ.get('OODGAN_SAVE_SFORM_ONLY', '1') != '0'    # W+ loop: those layers' saved activation only as that S-form
         self.fuse_conv_rgb_64 = True     # ... from the 64² level on (the separate ToRGB pass started at 128²)
+        self.sform_only_max_res = None   # A/B: largest resolution whose conv activation is saved only as the S-form (None: all eligible levels)
         self.fuse_conv_rgb = os.environ.get('OODGAN_FUSE_CONV_RGB', '1') != '0'    # ToRGB sums + the next up-conv's S-form from the 8-wave conv's epilogue (128² ... 512² levels, carried scales)
         self.plain_one_pass = os.environ.get('OODGAN_PLAIN_ONE_PASS', '1') != '0'     # the plain forward's last level through the one-pass up-conv + in-kernel conversion too (A/B flag)
         Lup = next((a for a, b in zip(styled[:-1], styled[1:]) if a.kind == 'up' and b is styled[-1]), None)
@@ -325,6 +326,7 @@ class GeneratorEngine:
                             # backward pass is the fused epilogue of the stride-2 conv above (style-gradient dot + this layer's
                             # activation backward), which decodes it from the same S-form (oodgan_conv_args.dotx_sform)
                             sform_only = (save and self.save_sform_only and self.fused_bwd and self.fuse_act_bwd
+                                          and (self.sform_only_max_res is None or Hc <= self.sform_only_max_res)
                                           and self.bwd_state.get(L.name) is not None and self.bwd_state.get(Lu.name) is not None
                                           and ops.s2_fuse_supported(B, Lu.cout, Lu.cin, 2 * Hc + 1, 2 * Wc + 1))
                             keep = (save and not sform_only) or return_features or post_hook is not None

@@ -24,9 +24,13 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 40, 96), (3, 8, 32), (1, 1024, 1024)])
-def test_forward_with_fform_input(B, H, W):
+@pytest.mark.parametrize('waves', [8, 4])
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 40, 96), (3, 8, 32), (1, 1024, 1024), (8, 256, 32)])
+def test_forward_with_fform_input(B, H, W, waves, tunable):
+    """waves = 8: conv_f16s_stripx8.hip (two waves per SIMD: K split over a wave pair, producer / finisher roles; the default);
+    waves = 4: the one-wave-per-SIMD kernel of round 3.  Both against the S-form strip kernel."""
     from oodgan import ops
+    tunable('stripx_waves', waves)
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(H * 7 + W)
     C = 32
