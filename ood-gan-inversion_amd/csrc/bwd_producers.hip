@@ -565,8 +565,10 @@ struct StripGeo {
 // bytes and +25 % time at QN = 16); wider strips did not pay for it (below).
 // Measured alternatives (1024² layer, us): 64-column strips x 16 channels (this kernel) 935; 128 columns x 16 channels with
 // 512 threads 981-1012; 128 columns x 8 channels (256 threads, half records per workgroup) 1092; no halo loads at all 742.
+// Register budget: the hot instance (PRE, rank-one kernel) fits 128 registers = four workgroups per CU; the others (two input tensors and / or a
+// general 4x4 kernel: the first W+ step, the exact-scale fallback) spilled 3-36 registers to scratch at 128 / 168 and get 256.
 template <int QN, bool XTRA, bool PRE>
-__global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu(PRE ? 4 : 3, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
+__global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu((PRE && !XTRA) ? 4 : 2, 4))) void act_bwd_blurT_strip_kernel(const ActArgs a, const float* __restrict__ kern, uint4* __restrict__ outp,
                                                                    int H, int W, SPDims sp, StripGeo geo) {
     constexpr int SW = 4 * QN, NT = 16 * QN, NWV = NT / 64;
     constexpr int BS_RP = SW + 4;       // LDS pitch of a g_pre row: 2 + SW + 1 columns, 16-byte aligned rows

@@ -221,3 +221,41 @@ def test_upconv_vblur_one_pass_equals_transposed_conv_then_blur(B, K, M, H, W, w
         assert float(((a - b2).abs() / a).max()) < 3e-6
     # a kernel that is not an outer product has no one-pass form
     assert ops.pack_upconv_vblur(w, scale, torch.eye(4, device=dev)) is None
+
+
+@pytest.mark.parametrize('waves', [12, 4])
+@pytest.mark.parametrize('B,K,M,H,W', [(2, 64, 32, 20, 45), (1, 16, 32, 7, 30), (1, 64, 32, 128, 128)])
+def test_upconv_vblur_one_pass_vs_oracle(B, K, M, H, W, waves, tunable):
+    """conv_f16s_upvb.hip DIRECTLY against the oracle's up-sampling StyledConv (oracle/ref_cpu.py: modulated_conv2d(upsample=True) —
+    conv_transpose2d + Blur, reference model.py:247-258,199-205 — then NoiseInjection + FusedLeakyReLU, model.py:343-350,283-292) on
+    ragged shapes: style, demodulation, folded vertical blur, horizontal pass on the accumulators, noise, bias, activation — nothing
+    of the HIP two-pass path in between."""
+    from oodgan import ops, synth, _lib
+    from oracle import ref_cpu as R
+    tunable('upvb_waves', waves)
+    dev = torch.device('cuda:0')
+    S = 64
+    P = {}
+    synth._styled_conv(P, 'q', K, M, S, 31 + H, True, 0.1)
+    g = torch.Generator().manual_seed(900 + H + W + K)
+    x = torch.randn(B, K, H, W, generator=g)
+    wlat = torch.randn(B, S, generator=g)
+    nz = torch.randn(B, 1, 2 * H, 2 * W, generator=g)
+    with torch.no_grad():
+        ref = R.styled_conv({k: v.double() for k, v in P.items()}, 'q', x.double(), wlat.double(), nz.double(), upsample=True)
+        # the same style / demodulation factors the host mirror computes (EqualLinear + rsqrt of the squared-weight sums, model.py:236-241)
+        s = R.equal_linear(wlat.double(), P['q.conv.modulation.weight'].double(), P['q.conv.modulation.bias'].double())
+        w = P['q.conv.weight'][0].double()
+        scale = 1.0 / math.sqrt(K * 9)
+        d = torch.rsqrt(((scale * w[None] * s[:, None, :, None, None]) ** 2).sum([2, 3, 4]) + 1e-8)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 64 * 4).contiguous().to(dev)
+    wvb = ops.pack_upconv_vblur(P['q.conv.weight'][0].to(dev), scale, k)
+    assert wvb is not None and ops.upconv_vblur_supported(B, K, M, H, W)
+    xs = ops.to_sform(x.to(dev), s.float().to(dev))
+    _lib.dispatch_reset()
+    y = ops.upconv_vblur_fform(xs, wvb, out_scale=d.float().to(dev), bias=P['q.activate.bias'].to(dev), noise=nz.to(dev),
+                               noise_weight=P['q.noise.weight'].to(dev), act=True)
+    assert _lib.dispatch_count('upvb') == 1
+    err = (y.to_nchw().double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err
