@@ -13,6 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'ood-gan-inversion_amd', 'csrc', 'conv_f16s_stripx.hip')
+SRC8 = os.path.join(ROOT, 'ood-gan-inversion_amd', 'csrc', 'conv_f16s_stripx8.hip')      # the eight-wave forward instance: same inline-assembly discipline
 
 
 def regs(tok):
@@ -28,7 +29,7 @@ def regs(tok):
 def check(path):
     text = open(path).read()
     bad = 0
-    for fn in re.finditer(r'^(_Z\S*stripx_kernel\S*):[^\n]*\n(.*?)s_endpgm', text, re.S | re.M):
+    for fn in re.finditer(r'^(_Z\S*stripx8?_(?:fwd_)?kernel\S*):[^\n]*\n(.*?)s_endpgm\n', text, re.S | re.M):
         name, body = fn.group(1), fn.group(2).split('\n')
         pending, in_asm, n_reads = set(), False, 0
         for ln, line in enumerate(body):
@@ -59,6 +60,13 @@ def check(path):
         if loop_bar:
             start = loop_bar[0]
             end = next(i for i in bars if i > start)
+            # a role loop of the eight-wave kernel ends at its backward branch, not at a barrier (the next barrier belongs to the other role)
+            labels = {l.split(';')[0].strip()[:-1]: i for i, l in enumerate(body) if l.split(';')[0].strip().endswith(':')}
+            for i in range(start + 1, end):
+                c = body[i].split(';')[0].strip()
+                if c.startswith('s_branch') and labels.get(c.split()[1], 1 << 30) < i:
+                    end = i + 1
+                    break
             for i in range(start + 1, end):
                 c = body[i].split(';')[0].strip()
                 if c.startswith('scratch_'):
@@ -77,7 +85,10 @@ if __name__ == '__main__':
     if len(sys.argv) > 1:
         sys.exit(1 if check(sys.argv[1]) else 0)
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, 'stripx.s')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Xclang', '-target-feature', '-Xclang',
-                               '-packed-fp32-ops', '-S', '--cuda-device-only', '-o', out, SRC], stderr=subprocess.DEVNULL)
-        sys.exit(1 if check(out) else 0)
+        bad = 0
+        for src in (SRC, SRC8):
+            out = os.path.join(d, os.path.basename(src) + '.s')
+            subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Xclang', '-target-feature', '-Xclang',
+                                   '-packed-fp32-ops', '-S', '--cuda-device-only', '-o', out, src], stderr=subprocess.DEVNULL)
+            bad += check(out)
+        sys.exit(1 if bad else 0)
