@@ -611,6 +611,14 @@ def _side_streams(device, n):
     return pool[:n]
 
 
+# Concurrent sub-batches (streams > 1): the 8-wave stride-1 kernel from 64 work items instead of 128.  A sub-batch of four images brings 64 items
+# to the 32² layers; on the 8-wave kernel they occupy 64 CUs for a short time and leave the rest of the chip to the other stream's launch, the
+# 4-wave ring kernel it replaces spreads 256 small workgroups over every CU.  Measured (bench.py, 2 streams, three boxes): 6.97-6.99 -> 7.10-7.16
+# img/s; on ONE stream (batch 8) the lower threshold moves the 16² layers and costs 1.3 % — hence only here.
+MULTI_STREAM_S1_BIG_MIN_ITEMS = int(os.environ.get('OODGAN_MULTI_STREAM_S1_BIG_MIN_ITEMS', '64'))
+_S1_BIG_DEFAULT = 128
+
+
 class WPlusInverter:
     """Build-defined W+ optimisation loop: ``steps`` x {G(w) with fixed noise,
     per-image MSE, backward to w, Adam(lr, betas, eps)} — anchors: reference Generator.forward with
@@ -630,6 +638,14 @@ class WPlusInverter:
             return w0.detach().clone().contiguous(), torch.empty(0, B, device=w0.device, dtype=torch.float32)
         if (streams == 1 and not use_graph) or return_trajectory:
             return self._invert_one(target, w0, noises, steps, return_trajectory)
+        from . import _lib
+        if _lib.lib().oodgan_get_tunable(b's1_big_min_items') == _S1_BIG_DEFAULT and MULTI_STREAM_S1_BIG_MIN_ITEMS != _S1_BIG_DEFAULT:
+            # (a caller / test that set the tunable itself keeps its value)
+            _lib.set_tunable('s1_big_min_items', MULTI_STREAM_S1_BIG_MIN_ITEMS)
+            try:
+                return self.invert(target, w0, noises, steps, return_trajectory, streams, use_graph)
+            finally:
+                _lib.set_tunable('s1_big_min_items', _S1_BIG_DEFAULT)
         cur = torch.cuda.current_stream()
         side = _side_streams(w0.device, streams)
         # the state resets enqueue zero-fills on the CALLER's stream: they must precede the wait_stream below, or nothing

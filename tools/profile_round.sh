@@ -15,6 +15,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 benc
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_sq1.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU -d $OUT/pmc_sq2 -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_sq2.err
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $OUT/pmc_grbm -o p -- python3 bench.py $SHORT > /dev/null 2> $OUT/pmc_grbm.err
+# HBM traffic of ONE steady-state W+ step (bench.py: step_roofline): the loop alone at two step counts, difference / step difference
+for n in 10 30; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/step_fetch_$n -o p -- python3 tools/wplus_only.py $n > $OUT/wplus_only_$n.txt 2> $OUT/step_fetch_$n.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/step_write_$n -o p -- python3 tools/wplus_only.py $n > /dev/null 2> $OUT/step_write_$n.err
+done
 # M2 leg (fp16 modulated conv) and the calibration copy (1 GiB fp32 clone: 16-byte loads and stores of known size)
 rocprofv3 --kernel-trace -d $OUT/m2_stats -o k -- python3 tools/m2_and_copy.py > $OUT/m2.json 2> $OUT/m2.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/m2_fetch -o p -- python3 tools/m2_and_copy.py > /dev/null 2>> $OUT/m2.err
@@ -28,6 +33,9 @@ python3 tools/rocpd_stats.py $OUT/m2_stats/k_results.db --csv $OUT/m2_kernel_sta
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write --csv $OUT/pmc_fetch_write.csv
 python3 tools/pmc_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_grbm --csv $OUT/pmc_sq.csv
 python3 tools/pmc_summary.py $OUT/m2_fetch $OUT/m2_write --csv $OUT/m2_pmc_fetch_write.csv
+for n in 10 30; do python3 tools/pmc_summary.py $OUT/step_fetch_$n $OUT/step_write_$n --csv $OUT/step_pmc_$n.csv; done
+python3 tools/step_traffic.py $OUT/step_pmc_10.csv 10 $OUT/step_pmc_30.csv 30 > $OUT/step_traffic.json
+python3 tools/kernel_table.py $OUT/kernel_stats_streams1.csv $OUT/pmc_fetch_write.csv $OUT/pmc_sq.csv --csv $OUT/kernel_counters.csv --top 30
 find $OUT -name "*.db" -delete
 find $OUT -type d -empty -delete
 ls -la $OUT
