@@ -221,6 +221,9 @@ class GeneratorEngine:
         if save and (features_in is not None or post_hook is not None):
             raise NotImplementedError('backward through an injected feature / feature modulation is not part of the path')
         B = latent.shape[0]
+        # forwards are counted: the activations saved for backward() live in pooled scratch buffers (ops.sform_scratch: keyed by shape and
+        # stream) and their S-form scales alias the range state — ANY later forward of this engine on the same stream may overwrite them
+        self._fwd_serial = getattr(self, '_fwd_serial', 0) + 1
         s_all = self.styles(latent)
         d_all = torch.empty(B, self.DR, device=self.device, dtype=torch.float32)
         if self.batched_tail:       # the demodulation factors of all styled convs in one launch
@@ -414,7 +417,7 @@ class GeneratorEngine:
             else:
                 rng.valid = True
         if save:
-            self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B)
+            self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B, serial=self._fwd_serial)
         if return_features:
             return skip, (out.to_nchw() if isinstance(out, ops.FForm) else out)
         return skip
@@ -440,6 +443,9 @@ class GeneratorEngine:
         sv = self.saved
         if sv is None:
             raise RuntimeError('backward() without forward(save=True)')
+        if sv.get('serial') != getattr(self, '_fwd_serial', None):
+            raise RuntimeError('backward(): another forward of this engine ran after forward(save=True) — the saved activations (pooled S-form / F-form '
+                               'buffers, scales of the range state) may have been overwritten; call backward() right after the forward it belongs to')
         acts, s_all, d_all, noises, B = sv['acts'], sv['s_all'], sv['d_all'], sv['noises'], sv['B']
         gs_all = ops.zeros(B, self.R, device=self.device)
         # gradient of the skip chain: gskip[res] for every ToRGB level

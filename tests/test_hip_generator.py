@@ -457,3 +457,24 @@ def test_generator_forward_carried_scales_and_fallback(dev):
     assert maxdiff(out_big, ref_big.cpu()) <= 2e-5 * ref_big.abs().max().item()
     back, _ = G([z], noise=noises)                       # and back again (2^-30): violation the other way, or a valid carried window
     assert maxdiff(back, img1.cpu()) <= 2e-5 * img1.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_backward_refuses_saved_activations_that_a_later_forward_may_have_overwritten(dev):
+    """the saved activations live in pooled scratch buffers; a forward between forward(save=True) and backward() may overwrite
+    them — the engine refuses instead of computing a gradient from the wrong tensors."""
+    from oodgan.engine import GeneratorEngine
+    from oodgan import ops
+    size, B = 32, 2
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=5).items()}, size)
+    lat = synth.make_latents(size, B, seed=14).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    img = eng.forward(lat, noises, save=True)
+    gmul = ops.loss_scale_for(3 * size * size)
+    _, gimg = ops.mse_loss_grad(img, torch.zeros_like(img), gmul)
+    g0 = eng.backward(gimg, gmul)                        # the normal order works
+    assert torch.isfinite(g0).all()
+    eng.forward(lat, noises, save=True)
+    eng.forward(lat, noises)                             # e.g. a model(x) call in between
+    with pytest.raises(RuntimeError, match='another forward'):
+        eng.backward(gimg, gmul)
