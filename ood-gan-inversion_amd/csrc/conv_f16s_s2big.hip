@@ -29,6 +29,16 @@ using namespace oodgan;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
+#ifdef OODGAN_CLOCK_STAMP
+// Diagnostic build only (make STAMP=1, tools/s2big_probe.py): shader-cycle stamps of the phases of a FUSE workgroup — [workgroup][wave 0|7][start, before the K loop,
+// after it, after the saved activations of M-tile 0 are in registers, after M-tile 0, after M-tile 1, end]
+__device__ unsigned long long* g_s2big_stamp = nullptr;
+__device__ long g_s2big_stamp_n = 0;
+#define S2_STAMP(i) do { if (FUSE && (wave == 0 || wave == 7)) stv[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int SB_ROWS = 9, SB_C = 33;
@@ -91,6 +101,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     const int l31 = lane & 31, half = lane >> 5;
     const int rg = wave % C::NRG, mh = wave / C::NRG;      // row group, channel half
 
+#ifdef OODGAN_CLOCK_STAMP
+    unsigned long long stv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    S2_STAMP(0);
     int w = xcd_remap(blockIdx.x, gridDim.x);
     const int mblk = w % p.mblocks;
     w /= p.mblocks;
@@ -305,6 +319,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): written before this wave arrives at the loop's first barrier
         }
     }
+    S2_STAMP(1);
     for (int st = 0; st < nstage; ++st) {
         const int py = st & 1;
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
@@ -337,6 +352,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
 #undef S2B_DMA
     }
     __builtin_amdgcn_s_barrier();            // LDS is reused by the dot reduction below
+    S2_STAMP(2);
 #undef S2B_IC
 #undef S2B_SB
 
@@ -433,6 +449,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                 }
             }
             }
+#ifdef OODGAN_CLOCK_STAMP
+            asm volatile("" : "+v"(dv[0][0]), "+v"(dv[0][15]));
+            if (mt == 0) S2_STAMP(3);
+#endif
             unsigned hi[RW][8], lo[RW][8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
@@ -495,6 +515,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                     }
                 }
             }
+#ifdef OODGAN_CLOCK_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            if (mt == 0) S2_STAMP(4); else S2_STAMP(5);
+#endif
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmaxv = fmaxf(vmaxv, __shfl_xor(vmaxv, o, 64));
@@ -513,6 +537,15 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
             f.part_r[o] = v1;
             if (f.part_t) f.part_t[o] = v2;
         }
+#ifdef OODGAN_CLOCK_STAMP
+        S2_STAMP(6);
+        if (lane == 0 && (wave == 0 || wave == 7) && g_s2big_stamp && (long)blockIdx.x < g_s2big_stamp_n) {
+            unsigned long long* q = g_s2big_stamp + ((long)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) q[i] = stv[i];
+            q[7] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         return;
     }
     // ---- epilogue from the accumulators (conv_f16s_big.hip's, NT = RW rows per wave)
@@ -653,6 +686,18 @@ extern "C" int oodgan_conv3x3_s2_grouped_supported(int B, int K, int M, int grou
     a.y = reinterpret_cast<float*>(1);
     return groups > 1 && oodgan::s2_big_eligible(a) ? 1 : 0;
 }
+
+#ifdef OODGAN_CLOCK_STAMP
+extern "C" int oodgan_debug_set_s2big_stamp_buffer(void* buf, long n) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(buf);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_s2big_stamp), &q, sizeof(q)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_s2big_stamp_n), &n, sizeof(n)) != hipSuccess) {
+        oodgan::set_error("debug_set_s2big_stamp_buffer: hipMemcpyToSymbol failed");
+        return OODGAN_E_LAUNCH;
+    }
+    return 0;
+}
+#endif
 
 namespace oodgan {
 
