@@ -332,7 +332,7 @@ int oodgan_conv3x3_nparts(int mode, int Hin, int Win);
  * style block s_sc = s*q, the conv epilogue the demodulation block d_sc = d/q (both exact).
  *   oodgan_absmax_scaled:    max_k vmax[b][k] = max_{c,p} |x[b,c,p]*s[b,c]| (atomic max into a zeroed array; non-finite -> inf)
  *   oodgan_fwd_range_update: n entries (layer-major [l][b], OODGAN_VMAX_SLOTS slots each); flag != NULL (carry mode): vmax was measured on values scaled
- *                            by q -> flag |= 1 if it left [2^-8, 2^15), |= 2 if non-finite; next q from vmax/q.
+ *                            by q -> flag |= 1 if it left [1, 2^15) (round 5; 2^-8 before: lo halves near the maximum were f16 subnormals there), |= 2 if non-finite; next q from vmax/q.
  *                            flag == NULL (exact mode): vmax is the true max, q is set from it.  vmax is zeroed.
  *   oodgan_fwd_range_plan:   s_sc[b,r] = s_all[b,r]*q[row_layer[r]][b] for rows [row0,row0+nrows) (row_layer < 0: copy),
  *                            d_sc[b,r] = d_all[b,r]/q[drow_layer[r]][b] for rows [drow0,drow0+ndrows). */

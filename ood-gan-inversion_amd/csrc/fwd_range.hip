@@ -59,7 +59,10 @@ __global__ void fwd_range_update_kernel(unsigned* __restrict__ vmax, float* __re
     float t = m;                            // true max |x*s|
     if (flag) {                             // carry mode: m was measured on values scaled by q[i]
         if (!isfinite(m)) atomicOr(flag, 2);
-        else if (m > 0.f && !(m >= 0.00390625f && m < 32768.f)) atomicOr(flag, 1);
+        // window of a carried scale: [1, 2^15).  Round 5: the lower bound was 2^-8 — there the lo halves of the values near the maximum
+        // are f16 subnormals (16 significant bits relative to the maximum instead of 22); from 1 on they are normal numbers.  The scale aims at
+        // [512, 1024), so a carried scale survives a 512-fold drop and a 32-fold rise of the maximum between two forwards
+        else if (m > 0.f && !(m >= 1.f && m < 32768.f)) atomicOr(flag, 1);
         t = m / q[i];
     }
     int e = 0;

@@ -345,7 +345,7 @@ class Generator(nn.Module):
                   features_in=kwargs.get('features_in', None), feature_scale=kwargs.get('feature_scale', 1.0))
         # Forward range scales (split-f16 path) carried from the previous forward of this batch size — the W+ loop's scheme (engine.py,
         # ops.FwdRange) for model(x) too: no measurement pass per conv input, the fused producers of the loop.  Scales are powers of two
-        # and exact as long as the carried scale keeps the new maximum inside [2^-8, 2^15) — if it does not, the flag is set and the pass
+        # and exact as long as the carried scale keeps the new maximum inside [1, 2^15) — if it does not, the flag is set and the pass
         # is repeated with measured scales.  The first forward of a batch size (measured scales, unfused producers) and the following
         # ones therefore differ by fp32 rounding (different kernels, <= 2e-5 on the image); the following ones are bit-identical among
         # themselves.  Inside a stream capture the flag cannot be read: oodgan.arch.GraphedForward checks it after every replay.

@@ -499,7 +499,7 @@ class FwdRange:
 
     * exact mode (default of a forward): every layer input is measured (``absmax_scaled``) before it is converted;
     * carry mode (steps >= 2 of the W+ loop): the fused producers use the scale measured on the previous step and record
-      this step's max; ``finish`` sets ``flag`` when a scaled max left [2^-8, 2^15) or was non-finite (the caller re-runs
+      this step's max; ``finish`` sets ``flag`` when a scaled max left [1, 2^15) or was non-finite (the caller re-runs
       in exact mode) and publishes the next scales."""
 
     def __init__(self, n_layers, B, R, DR, row_layer, drow_layer, device):
