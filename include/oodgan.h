@@ -559,13 +559,14 @@ int oodgan_affine_apply(const float* x, const float* sc, const float* sh, const 
 /* oodgan_affine_apply followed by oodgan_instnorm_stats of its result (bit-identical statistics), in one pass: stats (B, C, 2) */
 int oodgan_affine_apply_stats(const float* x, const float* sc, const float* sh, const float* res, float* y, float* stats, int B, int C,
                               long HW, float eps, void* stream);
-/* AlignNet input (diff_fAndg=True, src/ops/SAMM/helpers.py:97-100):
- * out[:, :C] = IN(gen) - IN(enc), out[:, C:] = IN(enc); stats from oodgan_instnorm_stats */
+/* AlignNet input (src/ops/SAMM/helpers.py:97-101): out[:, C:] = IN(enc) and
+ *   diff != 0 (diff_fAndg=True, every shipped config):  out[:, :C] = IN(gen) - IN(enc)
+ *   diff == 0 (diff_fAndg=False, round 5 / ABI 108):    out[:, :C] = IN(gen);        stats from oodgan_instnorm_stats */
 int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc,
-                       float* out, int B, int C, long HW, void* stream);
+                       float* out, int diff, int B, int C, long HW, void* stream);
 /* oodgan_align_input followed by oodgan_instnorm_stats of its (B, 2C, H, W) result (bit-identical statistics), in one pass: stats (B, 2C, 2) */
-int oodgan_align_input_stats(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, float* stats, int B,
-                             int C, long HW, float eps, void* stream);
+int oodgan_align_input_stats(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, float* stats, int diff,
+                             int B, int C, long HW, float eps, void* stream);
 /* dense 1x1 conv with optional bias: y[b,m,p] = sum_k w[m,k]*x[b,k,p] + bias[m]
  * replaces feats_conv (OOD_faceGAN_e4e_arch.py:70-75) and the AlignNet shortcut (helpers.py:431-434) */
 int oodgan_conv1x1(const float* x, const float* w, const float* bias, float* y, int B, int K, int M, long HW,

@@ -122,7 +122,7 @@ extern "C" int oodgan_zero(void* p, long bytes, void* stream) {
     return oodgan::check_launch("zero");
 }
 
-extern "C" int oodgan_version(void) { return 107; }      // 107: oodgan_conv_args gained dotx_sform / dotx_scale; 106: oodgan_conv_args gained ys_vmax (+ rgb_y partial sums / ys from the 8-wave stride-1 kernel), round-4 helpers; 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
+extern "C" int oodgan_version(void) { return 108; }      // 108: oodgan_align_input / oodgan_align_input_stats gained `diff` (AlignNet diff_fAndg=False), dispatch sub-counters, tunable stripx_waves; 107: oodgan_conv_args gained dotx_sform / dotx_scale; 106: oodgan_conv_args gained ys_vmax (+ rgb_y partial sums / ys from the 8-wave stride-1 kernel), round-4 helpers; 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;

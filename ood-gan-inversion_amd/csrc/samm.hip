@@ -177,7 +177,7 @@ __device__ __forceinline__ float align_d(float g, float mg, float rg, float en) 
 // grid (chunks, B*C): out[b, c] = IN(gen)-IN(enc), out[b, C+c] = IN(enc)
 __global__ __launch_bounds__(256) void align_input_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
                                                           const float* __restrict__ sg, const float* __restrict__ se,
-                                                          float* __restrict__ out, int C, long HW) {
+                                                          float* __restrict__ out, int C, long HW, int diff) {
     const int bc = blockIdx.y, b = bc / C, c = bc % C;
     const float mg = sg[2 * bc], rg = sg[2 * bc + 1], me = se[2 * bc], re = se[2 * bc + 1];
     const float* gp = gen + (long)bc * HW;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void align_input_kernel(const float* __restric
     float* o1 = out + ((long)b * 2 * C + C + c) * HW;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
         const float e = align_e(ep[i], me, re);
-        o0[i] = align_d(gp[i], mg, rg, e);
+        o0[i] = align_d(gp[i], mg, rg, diff ? e : 0.f);        // diff_fAndg = False (helpers.py:98-101): IN(gen) itself (x - 0 is exact)
         o1[i] = e;
     }
 }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void align_input_kernel(const float* __restric
 // thread's own stores.  Saves the statistics pass over the 2C-channel tensor.
 __global__ __launch_bounds__(256) void align_input_stats_kernel(const float* __restrict__ gen, const float* __restrict__ enc,
                                                                 const float* __restrict__ sg, const float* __restrict__ se,
-                                                                float* __restrict__ out, float* __restrict__ stats, int C, long HW, float eps) {
+                                                                float* __restrict__ out, float* __restrict__ stats, int C, long HW, float eps, int diff) {
     __shared__ float red[4];
     __shared__ float mean_s[2];
     const int bc = blockIdx.x, b = bc / C, c = bc % C;
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void align_input_stats_kernel(const float* __r
             for (int u = 0; u < 4; ++u) {
                 float4 e_, d_;
                 e_.x = align_e(e4[u].x, me, re); e_.y = align_e(e4[u].y, me, re); e_.z = align_e(e4[u].z, me, re); e_.w = align_e(e4[u].w, me, re);
-                d_.x = align_d(g4[u].x, mg, rg, e_.x); d_.y = align_d(g4[u].y, mg, rg, e_.y); d_.z = align_d(g4[u].z, mg, rg, e_.z); d_.w = align_d(g4[u].w, mg, rg, e_.w);
+                d_.x = align_d(g4[u].x, mg, rg, diff ? e_.x : 0.f); d_.y = align_d(g4[u].y, mg, rg, diff ? e_.y : 0.f);
+                d_.z = align_d(g4[u].z, mg, rg, diff ? e_.z : 0.f); d_.w = align_d(g4[u].w, mg, rg, diff ? e_.w : 0.f);
                 const bool live = i + 256 * u < n4;
                 if (live) {
                     reinterpret_cast<float4*>(o0)[i + 256 * u] = d_;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void align_input_stats_kernel(const float* __r
         sb = (b0 + b1) + (b2 + b3);
     } else {
         for (long i = threadIdx.x; i < HW; i += 256) {
-            const float e_ = align_e(ep[i], me, re), d_ = align_d(gp[i], mg, rg, e_);
+            const float e_ = align_e(ep[i], me, re), d_ = align_d(gp[i], mg, rg, diff ? e_ : 0.f);
             o0[i] = d_; o1[i] = e_;
             sa += d_; sb += e_;
         }
@@ -1015,20 +1016,20 @@ extern "C" int oodgan_affine_apply(const float* x, const float* sc, const float*
     return check_launch("affine_apply");
 }
 
-extern "C" int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, int B,
+extern "C" int oodgan_align_input(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, int diff, int B,
                                   int C, long HW, void* stream) {
     OODGAN_REQUIRE(gen && enc && st_gen && st_enc && out && B > 0 && C > 0 && HW > 0 && (long)B * C <= 65535,
                    "align_input: bad args");
     int gx = (int)((HW + 255) / 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(align_input_kernel, dim3(gx, B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, C, HW);
+    hipLaunchKernelGGL(align_input_kernel, dim3(gx, B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, C, HW, diff);
     return check_launch("align_input");
 }
 
-extern "C" int oodgan_align_input_stats(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, float* stats,
+extern "C" int oodgan_align_input_stats(const float* gen, const float* enc, const float* st_gen, const float* st_enc, float* out, float* stats, int diff,
                                         int B, int C, long HW, float eps, void* stream) {
     OODGAN_REQUIRE(gen && enc && st_gen && st_enc && out && stats && B > 0 && C > 0 && HW > 0, "align_input_stats: bad args");
-    hipLaunchKernelGGL(align_input_stats_kernel, dim3(B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, stats, C, HW, eps);
+    hipLaunchKernelGGL(align_input_stats_kernel, dim3(B * C), dim3(256), 0, as_stream(stream), gen, enc, st_gen, st_enc, out, stats, C, HW, eps, diff);
     return check_launch("align_input_stats");
 }
 

@@ -17,7 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
 P = c_void_p  # device pointers travel as integers
 
 
-ABI_VERSION = 107
+ABI_VERSION = 108
 
 
 class ConvArgs(Structure):

@@ -25,8 +25,8 @@ _lib.bind_extra({
     'oodgan_instnorm_coeffs': (c_int, [P, P, P, P, P, c_int, c_int, P]),
     'oodgan_affine_apply': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
     'oodgan_affine_apply_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
-    'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_long, P]),
-    'oodgan_align_input_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
+    'oodgan_align_input': (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_long, P]),
+    'oodgan_align_input_stats': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_long, c_float, P]),
     'oodgan_conv1x1': (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P]),
     'oodgan_conv3x3_small': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'oodgan_se_gate': (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
@@ -87,21 +87,21 @@ def instance_norm(x, gamma=None, beta=None, eps=1e-5, res=None, want_stats=False
     return affine_apply(x, sc, sh, res)
 
 
-def align_input(gen, enc, st_gen, st_enc):
+def align_input(gen, enc, st_gen, st_enc, diff=True):
     gen, enc = _dev(gen), _dev(enc)
     B, C, H, W = gen.shape
     out = torch.empty(B, 2 * C, H, W, device=gen.device, dtype=torch.float32)
-    check(_lib.lib().oodgan_align_input(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), B, C, H * W, _stream()), 'align_input')
+    check(_lib.lib().oodgan_align_input(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), 1 if diff else 0, B, C, H * W, _stream()), 'align_input')
     return out
 
 
-def align_input_stats(gen, enc, st_gen, st_enc, eps=1e-5):
+def align_input_stats(gen, enc, st_gen, st_enc, eps=1e-5, diff=True):
     """(align_input(...), instnorm_stats of it) in one pass."""
     gen, enc = _dev(gen), _dev(enc)
     B, C, H, W = gen.shape
     out = torch.empty(B, 2 * C, H, W, device=gen.device, dtype=torch.float32)
     st = torch.empty(B, 2 * C, 2, device=gen.device, dtype=torch.float32)
-    check(_lib.lib().oodgan_align_input_stats(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), _p(st), B, C, H * W, eps, _stream()),
+    check(_lib.lib().oodgan_align_input_stats(_p(gen), _p(enc), _p(st_gen), _p(st_enc), _p(out), _p(st), 1 if diff else 0, B, C, H * W, eps, _stream()),
           'align_input_stats')
     return out, st
 
@@ -419,9 +419,7 @@ class AlignNet(nn.Module):
         self.norm = nn.InstanceNorm2d(in_chn)
         self.body = scaleNshiftBlock(in_chn * 2, out_chn, 'InstanceNorm', kwargs.get('bias', False))
         self.scale = scale
-        self.diff_fAndg = kwargs.get('diff_fAndg', True)
-        if not self.diff_fAndg:
-            raise NotImplementedError('diff_fAndg=False is not used by any shipped config')
+        self.diff_fAndg = kwargs.get('diff_fAndg', True)       # False: the body sees cat([IN(source), IN(target)]) (helpers.py:98-101)
 
     def forward(self, source, target, st_target=None, **kwargs):
         st_s = instnorm_stats(source)
@@ -429,11 +427,11 @@ class AlignNet(nn.Module):
         if FUSE_STATS:
             # every InstanceNorm's statistics come from the pass that writes its input: the concatenated, normalised pair here, the
             # first bottleneck's output below
-            a, st_in = align_input_stats(source, target, st_s, st_t)
+            a, st_in = align_input_stats(source, target, st_s, st_t, diff=self.diff_fAndg)
             a, st_a = self.body[0](a, stats=st_in, want_stats=True)
             a = self.body[1](a, stats=st_a)
         else:
-            a = align_input(source, target, st_s, st_t)
+            a = align_input(source, target, st_s, st_t, diff=self.diff_fAndg)
             a = self.body[1](self.body[0](a))
         return align_head(a, self.scale)
 

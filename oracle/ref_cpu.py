@@ -199,11 +199,11 @@ def bottleneck_ir(P, prefix, x):
     return r + sc
 
 
-def align_net(P, prefix, source, target, scale):
-    """AlignNet.forward(source, target) with diff_fAndg=True — reference SAMM/helpers.py:96-109.
+def align_net(P, prefix, source, target, scale, diff_fAndg=True):
+    """AlignNet.forward(source, target) — reference SAMM/helpers.py:96-109 (``diff_fAndg``: :98-101).
     Returns (B,3,H,W) = [tanh*scale, tanh*scale, sigmoid]."""
     s, t = instance_norm(source), instance_norm(target)
-    a = torch.cat([s - t, t], dim=1)
+    a = torch.cat([s - t, t], dim=1) if diff_fAndg else torch.cat([s, t], dim=1)
     a = bottleneck_ir(P, f'{prefix}.body.0', a)
     a = bottleneck_ir(P, f'{prefix}.body.1', a)
     return torch.cat([torch.tanh(a[:, 0:1]) * scale, torch.tanh(a[:, 1:2]) * scale,
@@ -244,14 +244,14 @@ def warp_blend(target, field):
     return warped * alpha + target * (1 - alpha)
 
 
-def spm_warp(P, prefix, source, target, aligned=None, scale=0.08, cycle_align=2):
+def spm_warp(P, prefix, source, target, aligned=None, scale=0.08, cycle_align=2, diff_fAndg=True):
     """SPM_Warp.forward(source=encoder feat, target=generator feat, aligned=coarser field).
     reference SAMM/helpers.py:149-179.  The blur is ``Blur(pad=(2,1))`` with the un-scaled 4x4."""
     blur_k = make_kernel((1, 3, 3, 1))
     cur = target
     acc = None
     for k in range(cycle_align):
-        a = upfirdn2d(align_net(P, f'{prefix}.body', cur, source, scale), blur_k, pad=(2, 1))
+        a = upfirdn2d(align_net(P, f'{prefix}.body', cur, source, scale, diff_fAndg), blur_k, pad=(2, 1))
         acc = a if acc is None else spm_add(acc, a, scale)
         if k == cycle_align - 1 and aligned is not None:
             acc = spm_upsample_add(aligned, acc)

@@ -320,6 +320,27 @@ def gold_samm():
     save('samm.npz', **g)
 
 
+def gold_samm_nodiff():
+    """AlignNet / SPM_Warp with diff_fAndg=False (reference SAMM/helpers.py:98-101: the body sees cat([IN(source), IN(target)]) instead of
+    cat([IN(source) - IN(target), IN(target)])): the same weights and inputs as gold_samm."""
+    from src.ops.SAMM.helpers import SPM_Warp
+    C, H, B = 8, 16, 2
+    warp = SPM_Warp(C, scale=0.08, cycle_align=2, diff_fAndg=False).eval()
+    sd = synth.samm_state(C, 'm', seed=21)
+    sub = {k[len('m.alignment.'):]: v for k, v in sd.items() if k.startswith('m.alignment.')}
+    print('samm_nodiff load:', warp.load_state_dict(sub, strict=True))
+    src = synth.normal('samm.src', (B, C, H, H), 22)
+    tgt = synth.normal('samm.tgt', (B, C, H, H), 22)
+    prev = torch.cat([synth.normal('samm.prev.d', (B, 2, H // 2, H // 2), 22, 0.04),
+                      synth.uniform('samm.prev.a', (B, 1, H // 2, H // 2), 22)], dim=1)
+    g = {}
+    with torch.no_grad():
+        g['alignnet'] = warp.body(tgt, src)
+        y1, f1 = warp(src, tgt, None, prev)
+        g['warp_out_prev'], g['warp_field_prev'] = y1, f1
+    save('samm_nodiff.npz', **g)
+
+
 def gold_modbtn():
     """The `mod_btn` feature extractors of StyledscaleNshfitBlock (reference src/ops/SAMM/helpers.py:22-57,182-216): the reference
     modules with their own (seeded) initialisation, state dict + input + style + output.  C = 16 -> 16 and 16 -> 32 channels, 24x24."""
@@ -553,6 +574,8 @@ def main():
         gold_wplus_256()
     if 'samm' in which:
         gold_samm()
+    if 'samm_nodiff' in which:
+        gold_samm_nodiff()
     if 'ood' in which:
         gold_ood(1)
     if 'enc' in which:

@@ -182,6 +182,28 @@ def test_alignnet_and_spm_warp_vs_golden(dev, golden):
     close(f, g['warp_field_prev'], 3e-4)
 
 
+def test_alignnet_without_the_difference_input_vs_golden(dev, golden):
+    """diff_fAndg=False (reference SAMM/helpers.py:98-101; round 5): AlignNet sees cat([IN(source), IN(target)]).  Vectors of the real
+    SPM_Warp(diff_fAndg=False) on gold_samm's weights and inputs; fused-statistics and plain paths."""
+    from oodgan import samm
+    g, g0 = golden('samm_nodiff.npz'), golden('samm.npz')
+    sd = synth.samm_state(8, 'm', seed=21)
+    blk = samm.StyledscaleNshfitBlock(8, 8, 512, scale=0.08, cycle_align=2, diff_fAndg=False)
+    blk.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    blk = blk.to(dev)
+    src, tgt, prev = g0['src'].to(dev), g0['tgt'].to(dev), g0['prev'].to(dev)
+    for fuse in (True, False):
+        old = samm.FUSE_STATS
+        try:
+            samm.FUSE_STATS = fuse
+            close(blk.alignment.body(tgt, src), g['alignnet'], 2e-4)
+            y, f = blk(src, None, image=tgt, aligned=prev)
+        finally:
+            samm.FUSE_STATS = old
+        close(y, g['warp_out_prev'], 3e-4)
+        close(f, g['warp_field_prev'], 3e-4)
+
+
 def test_mod_btn_feature_extractors_vs_reference(dev, golden):
     """`mod_btn` = 'style_bottleneck_IR' / 'styleBlock' (reference src/ops/SAMM/helpers.py:22-57): the extractors alone (16 -> 16 and
     16 -> 32 channels: identity and 1x1 shortcut) and inside StyledscaleNshfitBlock in front of the alignment, state dicts loaded strictly

@@ -131,6 +131,18 @@ def test_samm(golden):
         close(R.new_prm(g['warp_field'][:, 2:], g['warp_field_prev'][:, 2:]), g['prm_same'])
 
 
+def test_samm_without_the_difference_input(golden):
+    """AlignNet / SPM_Warp with diff_fAndg=False (reference SAMM/helpers.py:98-101) against vectors of the real modules."""
+    g, g0 = golden('samm_nodiff.npz'), golden('samm.npz')
+    P = synth.samm_state(8, 'm', seed=21)
+    with torch.no_grad():
+        close(R.align_net(P, 'm.alignment.body', g0['tgt'], g0['src'], 0.08, diff_fAndg=False), g['alignnet'])
+        y, f = R.spm_warp(P, 'm.alignment', g0['src'], g0['tgt'], g0['prev'], 0.08, 2, diff_fAndg=False)
+        close(y, g['warp_out_prev'])
+        close(f, g['warp_field_prev'])
+        assert (g['alignnet'] - g0['alignnet']).abs().max() > 1e-3          # the option changes the result
+
+
 def test_ood_forward_1024(golden):
     """Full 1024² OOD forward after the encoder (≈15-20 s on 8 cores)."""
     g = golden('ood_1024.npz')
