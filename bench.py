@@ -84,6 +84,20 @@ def self_launch(a):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=os.getcwd(),
                                       stdout=(None if r == 0 else subprocess.DEVNULL), stderr=log))
     rcs = [None] * n
+    import signal
+    signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))     # a terminated parent takes the except path below instead of orphaning its ranks
+    try:
+        _wait_ranks(procs, rcs)
+    except BaseException:               # the parent is interrupted (SIGINT, SIGTERM via KeyboardInterrupt / SystemExit): its own children go with it
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        raise
+    return _report_ranks(n, rcs, logs)
+
+
+def _wait_ranks(procs, rcs):
+    n = len(procs)
     failed_at = None
     while any(rc is None for rc in rcs):
         for r, p in enumerate(procs):
@@ -102,6 +116,9 @@ def self_launch(a):
                 if rcs[r] is None:
                     p.kill()
         time.sleep(0.05)
+
+
+def _report_ranks(n, rcs, logs):
     bad = [r for r, rc in enumerate(rcs) if rc != 0]
     for r, log in enumerate(logs):
         log.seek(0)
