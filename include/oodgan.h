@@ -57,7 +57,8 @@ long oodgan_get_tunable(const char* name);
 /* Dispatch counters of oodgan_conv3x3_f16s: how many calls since load (or oodgan_dispatch_reset) went to the kernel family
  * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
  * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb" (oodgan_upconv_vblur_fform), and the sub-counters of the fused epilogues:
- * "s1big_ys" (8-wave stride-1 launches that wrote `ys` / ToRGB partial sums), "s2big_fuse" (8-wave stride-2 launches with the fused activation
+ * "s1big_ys" (8-wave stride-1 launches that wrote `ys` / ToRGB partial sums), "s1big_g2" / "s2big_g2" / "stripx_g2" (input-gradient launches
+ * that ran with x_hi_only, two matrix instructions per product), "s2big_fuse" (8-wave stride-2 launches with the fused activation
  * backward), "s2big_dotx_sform" (... that decoded `dotx` from a saved S-form).  Host-side, one relaxed atomic increment per call; the reference has no
  * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
  * Returns -1 for an unknown name. */
@@ -228,6 +229,12 @@ typedef struct oodgan_conv_args {
     unsigned* ys_vmax;       /* optional, with `ys` from the 8-wave stride-1 kernel (oodgan_conv3x3_s1_ys_supported): (B x OODGAN_VMAX_SLOTS) float bit patterns,
                                 max |activated y * ys_scale| of every sample atomically maxed into a slot — the forward range control of the conv
                                 that reads `ys` (as the `vmax` argument of the S-form producers), or NULL */
+    int x_hi_only;           /* 1 (round 6, precision 'f16s-g2'; split-f16 kernels with an S-form / F-form input AND `dotx`, i.e. the input-gradient
+                                instances — ignored elsewhere): the lo half of the INPUT operand is dropped, x_hi * (w_hi + w_lo): two matrix
+                                instructions per product instead of three.  The back-propagated gradient is then rounded to f16 (2^-11 relative,
+                                zero mean, independent per element) before each contraction while the weights keep their 22 bits; the reference
+                                has no counterpart (torch autograd runs the backward in fp32, model.py:233-274 through conv2d's backward) —
+                                tests bound dL/dW+ against the float64 reference and the 100-step loss curve against the reference Adam loop. */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient

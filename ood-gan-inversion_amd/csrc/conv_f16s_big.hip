@@ -80,7 +80,11 @@ __device__ long g_s1big_stamp_n = 0;
 // S-form input of the next conv — lane (n16, g) holds channels 4g .. 4g+3 of a 16-channel block of its pixel: 8 bytes of the hi slot
 // and 8 bytes of the lo slot of that pixel's record, 16 lanes = 16 consecutive records (SAMM's AlignNet: conv -> PReLU -> conv
 // without the fp32 tensor, its range measurement and its conversion pass in between)
-template <bool DOT, bool PRE, bool YS = false>
+// G2 (input-gradient instances, oodgan_conv_args.x_hi_only): the lo half of the S-form operand is dropped — x_hi * (w_hi + w_lo), TWO matrix
+// instructions per tap pair instead of three, and ONE for the ninth tap ([w_hi|w_lo] x [x_hi;x_hi]): 9 instead of 14 per 16 x 16 tile and
+// chunk.  The back-propagated gradient is rounded to f16 (2^-11 relative, zero-mean, independent per element and step); the weights keep
+// their 22 bits, so no systematic error enters (precision 'f16s-g2').
+template <bool DOT, bool PRE, bool YS = false, bool G2 = false>
 __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, const uint4* __restrict__ wpk16) {
     constexpr int NW = 8, NT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -150,17 +154,18 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         offBl[pp] = (unsigned)(ky * (BG_C * 64) + col * 64 + ((((g & 1) + 2 + 2 * ((col >> 2) & 1)) & 3) << 4));
     }
     const int col8 = n16 + 2;
-    const unsigned offB1 = (unsigned)(2 * (BG_C * 64) + col8 * 64 + (((g + 2 * ((col8 >> 2) & 1)) & 3) << 4));      // [x_hi ; x_lo] of tap 8: slot g
+    const unsigned offB1 = (unsigned)(2 * (BG_C * 64) + col8 * 64 + ((((G2 ? (g & 1) : g) + 2 * ((col8 >> 2) & 1)) & 3) << 4));      // [x_hi ; x_lo] of tap 8: slot g (G2: [x_hi ; x_hi])
 
     struct AF { half8 x[2], y[2]; };         // pair: w_hi, w_lo of two M-tiles; ninth tap: [w_hi|w_hi], [w_lo|w_lo]
     struct BF { half8 u[4], v[4]; };         // pair: x_hi, x_lo of the four N-tiles; ninth tap: [x_hi;x_lo], [x_hi;0]
     auto load_a = [&](AF& f, const unsigned char* lw, auto pp_c, auto mh_c) {
         constexpr int pp = decltype(pp_c)::value, mh = decltype(mh_c)::value;
-        const unsigned char* q = lw + (pp < 4 ? laneA + 2 * pp * 4096 : laneA1 + 8 * 4096);
+        // G2, ninth tap: A = [w_hi | w_lo] — K groups 0,1 read the hi rows, 2,3 the lo rows of the tap
+        const unsigned char* q = lw + (pp < 4 ? laneA + 2 * pp * 4096 : laneA1 + 8 * 4096 + (G2 ? (g >> 1) * 2048 : 0));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f.x[i] = *reinterpret_cast<const half8*>(q + (2 * mh + i) * 256);
-            f.y[i] = *reinterpret_cast<const half8*>(q + 2048 + (2 * mh + i) * 256);
+            if (!(G2 && pp == 4)) f.y[i] = *reinterpret_cast<const half8*>(q + 2048 + (2 * mh + i) * 256);
         }
     };
     auto load_b = [&](BF& f, const unsigned char* lx, const unsigned char* lz, auto pp_c, auto part_c) {       // part 0: u, 1: v
@@ -168,7 +173,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int o = (n >> 1) * (BG_C * 64) + (n & 1) * 1024;
-            if (pp < 4) {
+            if (G2) {
+                // hi halves only; ninth tap: B = [x_hi ; x_hi] (every K group reads the hi slot of its k-half)
+                if (part == 0) f.u[n] = *reinterpret_cast<const half8*>(lx + (pp < 4 ? offBh[pp < 4 ? pp : 0] : offB1) + o);
+            } else if (pp < 4) {
                 if (part == 0) f.u[n] = *reinterpret_cast<const half8*>(lx + offBh[pp < 4 ? pp : 0] + o);
                 else f.v[n] = *reinterpret_cast<const half8*>(lx + offBl[pp < 4 ? pp : 0] + o);
             } else {
@@ -179,7 +187,18 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     };
     auto mfma_half = [&](const AF& fa, const BF& fb, auto pp_c, auto mh_c) {
         constexpr int pp = decltype(pp_c)::value, mh = decltype(mh_c)::value;
-        if (pp < 4) {
+        if (G2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.x[i], fb.u[n], acc[2 * mh + i][n], 0, 0, 0);
+            if (pp < 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[2 * mh + i][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa.y[i], fb.u[n], acc[2 * mh + i][n], 0, 0, 0);
+            }
+        } else if (pp < 4) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -469,13 +488,19 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s1big_kernel<true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM16), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     // 8 waves: two per SIMD keep the MFMA pipe fed while the partner waits on LDS (a 4-wave variant was slower than the
     // v2 tile kernel: 474 / 475 / 552 us against 393 / 407 / 464 on the 64² / 128² / 256² layers)
     OODGAN_REQUIRE(!a.dot_actgrad || a.dotx, "conv3x3 big: dot_actgrad without dotx");
-    if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    const bool g2 = a.x_hi_only != 0 && a.dotx != nullptr;       // the input-gradient instances only: a forward call keeps all three products
+    if (g2) count_dispatch(OODGAN_DC_S1BIG_G2);
+    if (a.dot_actgrad && g2) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    else if (g2) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, false, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
+    else if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else if (a.dotx) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else if (a.ys) hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else hipLaunchKernelGGL((conv_f16s_s1big_kernel<false, false>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);

@@ -90,7 +90,9 @@ constexpr int vmcnt_imm(int n) { return ((n >> 4) & 3) << 14 | 0x0F70 | (n & 15)
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
-template <bool DOT, int MH, bool FUSE = false>
+// G2 (oodgan_conv_args.x_hi_only, input-gradient instances): x_hi * (w_hi + w_lo) — the lo half of the gradient operand is neither read from LDS
+// nor multiplied: two matrix instructions per tap instead of three (conv_f16s_big.hip, precision 'f16s-g2')
+template <bool DOT, int MH, bool FUSE = false, bool G2 = false>
 __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, const uint4* __restrict__ wpk16) {
     using C = S2Cfg<MH>;
     constexpr int RW = C::RW;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         for (int nt = 0; nt < RW; ++nt) {
             const unsigned char* xr = lx + ((rg * RW + nt + arow) * 2 + (kx & 1)) * (SB_C * 64);
             f.bh[nt] = *reinterpret_cast<const half8*>(xr + lrd[kx >> 1][0]);
-            f.bl[nt] = *reinterpret_cast<const half8*>(xr + lrd[kx >> 1][1]);
+            if (!G2) f.bl[nt] = *reinterpret_cast<const half8*>(xr + lrd[kx >> 1][1]);
         }
     };
     auto mfma_tap = [&](const Frag& f) {
@@ -210,10 +212,12 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < RW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+        if (!G2) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < RW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -748,10 +752,22 @@ int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM_FUSE),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM_FUSE), true);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM_FUSE),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<2>::SMEM_FUSE),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_s2big_kernel<true, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S2Cfg<1>::SMEM_FUSE), true);
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
-    if (fuse) {
+    const bool g2 = a.x_hi_only != 0 && a.dotx != nullptr;
+    if (g2) {
+        count_dispatch(OODGAN_DC_S2BIG_G2);
+        if (fuse) {
+            if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM_FUSE, st, p, w16);
+            else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM_FUSE, st, p, w16);
+        } else if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, false, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM, st, p, w16);
+        else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, false, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM, st, p, w16);
+    } else if (fuse) {
         if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM_FUSE, st, p, w16);
         else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM_FUSE, st, p, w16);
     } else if (mh2) {

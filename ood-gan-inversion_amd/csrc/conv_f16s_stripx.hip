@@ -42,7 +42,10 @@ namespace {
 // sums (forward).  PRE: y <- dx * act'(dotx) (oodgan_conv_args.dot_actgrad).  YF: y in F-form.  SEG: the strips are cut into
 // segments (fewer strips than CUs): rows fetched as another segment's halo must be kept out of the backward's sums; with one
 // segment per strip the only such rows lie outside the image and contribute zeros by themselves.
-template <bool BWD, bool RGB, bool PRE, bool YF, bool SEG = true>
+// G2 (input-gradient instances with oodgan_conv_args.x_hi_only, precision 'f16s-g2'): the converted operand keeps its hi half only —
+// g_hi * (w_hi + w_lo): six matrix instructions per chunk instead of nine, three fragment reads instead of six, no lo split and half
+// the LDS writes of the in-place conversion
+template <bool BWD, bool RGB, bool PRE, bool YF, bool SEG = true, bool G2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_f16s_stripx_kernel(
     const StripX p, const uint4* __restrict__ wpk16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -261,6 +264,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 v[j] = gp * ds[j];
             }
         }
+        if (G2) {
+            // hi halves only: the odd quarter hands its two packed pairs to the even one, which writes the record's hi slot
+            oodgan_half2v p01, p23;
+            p01[0] = (_Float16)v[0]; p01[1] = (_Float16)v[1];
+            p23[0] = (_Float16)v[2]; p23[1] = (_Float16)v[3];
+            const unsigned h01 = __builtin_bit_cast(unsigned, p01), h23 = __builtin_bit_cast(unsigned, p23);
+            const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)h01, 0xB1, 0xF, 0xF, false);
+            const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)h23, 0xB1, 0xF, 0xF, false);
+            if (wr_ok && even) lds_write16(dst, h01, h23, g0, g1);
+            return;
+        }
         unsigned h01, l01, h23, l23;
         split_pair(v[0], v[1], h01, l01);
         split_pair(v[2], v[3], h23, l23);
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 lds_issue(f[kx], base + lrd[kx][0]);
-                lds_issue(f[3 + kx], base + lrd[kx][1]);
+                if (!G2) lds_issue(f[3 + kx], base + lrd[kx][1]);
             }
         };
         auto unit_issue = [&](int u, f32x4& r, f32x4& s4) {       // u = 0..3: row u of the thread's pixel; 4: the halo record
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int kx = 0; kx < 3; ++kx) {
                 const int tp = ky * 3 + kx;
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], f[kx], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], f[3 + kx], acc1, 0, 0, 0);
+                if (!G2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tp][kc], f[3 + kx], acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ky * 3 + kx][kc], f[kx], acc1, 0, 0, 0);
@@ -653,6 +667,14 @@ bool stripx_init() {
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, true, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, true, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, false, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<true, false, true, false, false, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, SXL<true>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, false, false, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM),
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
@@ -746,7 +768,16 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
     const dim3 grid((unsigned)nblk), block(256);
     if (bwd) {
         const bool seg = p.nseg > 1;
-        if (a.dot_actgrad) {
+        if (a.x_hi_only) {
+            count_dispatch(OODGAN_DC_STRIPX_G2);
+            if (a.dot_actgrad) {
+                if (seg) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, true, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+                else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, false, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+            } else {
+                if (seg) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false, true, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+                else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false, false, true>), grid, block, SXL<true>::SMEM, st, p, w16);
+            }
+        } else if (a.dot_actgrad) {
             if (seg) hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, true>), grid, block, SXL<true>::SMEM, st, p, w16);
             else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, true, false, false>), grid, block, SXL<true>::SMEM, st, p, w16);
         } else {

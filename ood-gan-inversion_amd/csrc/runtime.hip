@@ -81,7 +81,7 @@ bool bound_device_ok(const char* what) {
 // ---- dispatch counters: one relaxed atomic increment per conv call, on the host
 namespace oodgan {
 namespace {
-const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb", "s1big_ys", "s2big_fuse", "s2big_dotx_sform"};
+const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb", "s1big_ys", "s2big_fuse", "s2big_dotx_sform", "s1big_g2", "s2big_g2", "stripx_g2"};
 std::atomic<long> g_dc[OODGAN_DC_COUNT];
 }  // namespace
 void count_dispatch(int id) { g_dc[id].fetch_add(1, std::memory_order_relaxed); }
@@ -122,7 +122,7 @@ extern "C" int oodgan_zero(void* p, long bytes, void* stream) {
     return oodgan::check_launch("zero");
 }
 
-extern "C" int oodgan_version(void) { return 108; }      // 108: oodgan_align_input / oodgan_align_input_stats gained `diff` (AlignNet diff_fAndg=False), dispatch sub-counters, tunable stripx_waves; 107: oodgan_conv_args gained dotx_sform / dotx_scale; 106: oodgan_conv_args gained ys_vmax (+ rgb_y partial sums / ys from the 8-wave stride-1 kernel), round-4 helpers; 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
+extern "C" int oodgan_version(void) { return 109; }      // 109: oodgan_conv_args gained x_hi_only (precision f16s-g2), oodgan_plan_*, LPIPS ops; 108: oodgan_align_input / oodgan_align_input_stats gained `diff` (AlignNet diff_fAndg=False), dispatch sub-counters, tunable stripx_waves; 107: oodgan_conv_args gained dotx_sform / dotx_scale; 106: oodgan_conv_args gained ys_vmax (+ rgb_y partial sums / ys from the 8-wave stride-1 kernel), round-4 helpers; 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep
 extern "C" const char* oodgan_last_error(void) { return oodgan::g_err; }
 extern "C" int oodgan_device_count(void) {
     int n = 0;

@@ -17,7 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_PRELU = 0, 1, 2
 P = c_void_p  # device pointers travel as integers
 
 
-ABI_VERSION = 108
+ABI_VERSION = 109
 
 
 class ConvArgs(Structure):
@@ -28,7 +28,7 @@ class ConvArgs(Structure):
         ('in_pitch', c_int), ('out_pitch', c_int), ('in_scale_stride', c_int), ('out_scale_stride', c_int),
         ('noise_batch', c_int), ('mode', c_int), ('act', c_int), ('dot_nparts', c_int), ('in_mul2', P),
         ('x_sform', c_int), ('ys', P), ('ys_scale', P), ('ys_scale_stride', c_int),
-        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int), ('dotx_sform', c_int), ('dotx_scale', P), ('dotx_scale_stride', c_int), ('workspace', P), ('workspace_bytes', c_long), ('ys_vmax', P),
+        ('rgb_w', P), ('rgb_s', P), ('rgb_y', P), ('rgb_s_stride', c_int), ('rgb_scale', c_float), ('fuse', P), ('dot_actgrad', c_int), ('groups', c_int), ('y_fform', c_int), ('x_fform', c_int), ('dotx_fform', c_int), ('dotx_sform', c_int), ('dotx_scale', P), ('dotx_scale_stride', c_int), ('workspace', P), ('workspace_bytes', c_long), ('ys_vmax', P), ('x_hi_only', c_int),
     ]
 
 

@@ -31,6 +31,11 @@ class GeneratorEngine:
     def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None):
         self.size, self.style_dim = size, style_dim
         self.precision = precision or ops.PRECISION
+        # 'f16s-g2' (round 6): the split-f16 arithmetic with the BACK-PROPAGATED gradient rounded to f16 before each contraction —
+        # g_hi * (w_hi + w_lo), two matrix instructions per product in the input-gradient convs; the forward is unchanged
+        self.grad_hi_only = self.precision == 'f16s-g2'
+        if self.grad_hi_only:
+            self.precision = 'f16s'
         self.sform = (self.precision == 'f16s') and ops.USE_SFORM
         self.log_size = int(math.log2(size))
         self.n_latent = self.log_size * 2 - 2
@@ -54,6 +59,8 @@ class GeneratorEngine:
             L.scale = 1.0 / math.sqrt(cin * 9)
             L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False, precision=self.precision)
             L.wpk_bwd = ops.pack_conv3x3(w, L.scale, transpose=True, flip=not up, precision=self.precision) if with_backward else None
+            if L.wpk_bwd is not None:
+                L.wpk_bwd.x_hi_only = self.grad_hi_only
             L.wsq = ops.weight_sqsum(w)
             L.wpk_vb = None
             L.bias = g(f'{name}.activate.bias')

@@ -739,10 +739,13 @@ PRECISION = 'f16s'   # default conv arithmetic: 'f16s' (split-f16, 3 MFMAs per p
 
 class PackedConv:
     """Packed 3x3 weights for one of the two MFMA conv kernels."""
-    __slots__ = ('data', 'unscale', 'precision', 'M')
+    __slots__ = ('data', 'unscale', 'precision', 'M', 'x_hi_only')
 
     def __init__(self, data, unscale, precision, M):
         self.data, self.unscale, self.precision, self.M = data, unscale, precision, M
+        # precision 'f16s-g2' (input-gradient packings): the conv drops the lo half of its INPUT operand — g_hi * (w_hi + w_lo), two matrix
+        # instructions per product (include/oodgan.h, oodgan_conv_args.x_hi_only)
+        self.x_hi_only = False
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -752,6 +755,8 @@ def pack_conv3x3(weight, scale=1.0, transpose=False, flip=False, precision=None)
     """(Co,Ci,3,3) -> K-major packed weights for the MFMA conv kernels (fp32: wpk[K][9][Mp]; split-f16:
     [K/16][9][hi|lo][2][Mp][8] f16 + power-of-two unscale)."""
     precision = precision or PRECISION
+    if precision == 'f16s-g2':       # the packing is the split-f16 one; the input-gradient packings are flagged by the engine
+        precision = 'f16s'
     w = _dev(weight, 'weight')
     Co, Ci = w.shape[0], w.shape[1]
     M, K = (Ci, Co) if transpose else (Co, Ci)
@@ -889,6 +894,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
             ws = conv_workspace(nb, x.data.device)
             a.workspace, a.workspace_bytes = _p(ws), nb
     a.groups = int(groups)
+    a.x_hi_only = 1 if (wpk.x_hi_only and dotx is not None) else 0
     a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
     a.ys_vmax = _p(vmax)        # with ys from the 8-wave kernel: max |act(y) * ys_scale| per sample (forward range control of the reader)

@@ -236,6 +236,70 @@ def gold_wplus_1024():
     save('wplus_1024.npz', **g)
 
 
+WPLUS_LONG = {
+    # name -> (size, global image indices of the bench recipe, steps, dtype tag, stored latent checkpoints)
+    'wplus_long_256': (256, (0, 1), 100, 'f32', (1, 5, 10, 20, 30, 60, 100)),
+    'wplus_long_256_f64': (256, (0, 1), 100, 'f64', (1, 5, 10, 20, 30, 60, 100)),
+    'wplus_long_1024': (1024, (WPLUS_1024_IMAGE,), 100, 'f32', (1, 5, 10, 20, 30, 60, 100)),
+    'wplus_long_1024_f64': (1024, (WPLUS_1024_IMAGE,), 40, 'f64', (1, 5, 10, 20, 30, 40)),
+    # image 0 of the bench batch (bench.py compares the per-image final loss of its timed inversion with this curve's end)
+    'wplus_long_1024_img0': (1024, (0,), 100, 'f32', (10, 30, 60, 100)),
+}
+
+
+def gold_wplus_long(name):
+    """The METRIC'S OWN HORIZON (BASELINE: "100 W+ steps"): the reference ``Generator``'s autograd + ``torch.optim.Adam``
+    (anchors model.py:483-585, src/models/OOD_faceGAN_model.py:398-400, BasicSR losses.py:58-83) for 100 steps on the
+    bench recipe (weights seed 0, target 1000+g, noise 2000+g, latents 3000+g with std 0.3) — at 256² for images (0, 1),
+    at 1024² for image 10 — in the reference's own float32 and, as the yardstick for how far two correct implementations
+    drift apart, in float64 (same reference code through ``G.double()``).  Stored: the per-image loss of every step, the
+    latents at a few steps, dL/dW+ of the first and the last step, statistics of the image G(w_final).  Partial results are
+    written after every checkpoint step so that an interrupted run still leaves a usable (shorter) fixture."""
+    from src.ops.StyleGAN.model import Generator
+    size, gidx, steps, tag, cps = WPLUS_LONG[name]
+    dt = torch.float64 if tag == 'f64' else torch.float32
+    B = len(gidx)
+    G = Generator(size, 512, 8).eval()
+    G.load_state_dict(synth.generator_state(size, seed=0), strict=True)
+    G = G.to(dt)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    cat = lambda parts: torch.cat(parts, 0)
+    target = cat([synth.make_images(size, 1, seed=1000 + g) for g in gidx]).to(dt)
+    per_n = [synth.make_noises(size, 1, seed=2000 + g) for g in gidx]
+    noises = [cat([n[i] for n in per_n]).to(dt) for i in range(len(per_n[0]))]
+    w = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx]).to(dt).clone().requires_grad_(True)
+    opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    g = {'image_indices': np.asarray(gidx, dtype=np.int64), 'steps': np.int64(steps)}
+    losses = []
+    import time
+    t0 = time.time()
+    for t in range(1, steps + 1):
+        opt.zero_grad()
+        img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=noises)
+        per = ((img - target) ** 2).mean(dim=(1, 2, 3))
+        per.sum().backward()
+        losses.append(per.detach().double().clone())
+        if t in (1, steps):
+            g[f'grad_step{t}'] = w.grad.detach().double().clone()
+        opt.step()
+        if t in cps:
+            g[f'w_step{t}'] = w.detach().double().clone()
+            g['losses'] = torch.stack(losses)
+            print(f'{name}: step {t}/{steps} loss {losses[-1].tolist()} ({time.time() - t0:.0f}s)', flush=True)
+            save(name + '.npz', **g)
+        del img, per
+    with torch.no_grad():
+        img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=noises)
+        per = ((img - target) ** 2).mean(dim=(1, 2, 3))
+    g['losses'] = torch.stack(losses)
+    g['final_loss'] = per.double()
+    g['final_image_sub'] = img[:, :, ::max(size // 64, 1), ::max(size // 64, 1)].float()
+    g['final_image_mean'] = img.double().mean(dim=(2, 3))
+    g['final_image_std'] = img.double().std(dim=(2, 3))
+    save(name + '.npz', **g)
+
+
 sys.path.insert(0, os.path.dirname(HERE))
 from make_golden_params import GEN_B4  # noqa: E402
 
@@ -572,6 +636,9 @@ def main():
         gold_generator_1024_b4()
     if 'wplus256' in which:
         gold_wplus_256()
+    for name in WPLUS_LONG:
+        if name in which:
+            gold_wplus_long(name)
     if 'samm' in which:
         gold_samm()
     if 'samm_nodiff' in which:

@@ -28,7 +28,7 @@ def _recipe(size, gidx, dev):
     return target, w0, noises
 
 
-@pytest.mark.parametrize('prec', ['f16s', 'f32'])
+@pytest.mark.parametrize('prec', ['f16s', 'f32', 'f16s-g2'])
 @pytest.mark.parametrize('batch', ['alone', 'image3of8'])
 def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
     """loss, image and dL/dW+ of one W+ step at 1024² vs the reference Generator evaluated in float64; every production
@@ -60,7 +60,13 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
         loss, gimg = ops.mse_loss_grad(img, target, gmul)
         glat = eng.backward(gimg, gmul, carry_scale=True)
         nx, ns = _lib.dispatch_count('stripx'), _lib.dispatch_count('strip')
-        if prec == 'f16s' and rep == 1:
+        g2 = {k: _lib.dispatch_count(k) for k in ('s1big_g2', 's2big_g2', 'stripx_g2')}
+        if prec == 'f16s-g2':
+            # round 6: every input-gradient conv of the 8-wave / strip families ran its two-instruction instance (the gradient operand rounded to f16)
+            assert g2['s1big_g2'] >= 3 and g2['s2big_g2'] >= 3 and g2['stripx_g2'] == (1 if rep == 1 else 0), g2
+        else:
+            assert not any(g2.values()), g2
+        if prec in ('f16s', 'f16s-g2') and rep == 1:
             # steady state of the loop: up-conv tail and last conv in F-form, both 1024² convs in conv_f16s_stripx
             assert fform == ['convs.14', 'convs.15'], fform
             assert (nx, ns) == (2, 0), (nx, ns)
@@ -76,7 +82,7 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
             assert _lib.dispatch_count('s1big_ys') == len(want), _lib.dispatch_count('s1big_ys')
             assert _lib.dispatch_count('s2big_dotx_sform') == len(want), _lib.dispatch_count('s2big_dotx_sform')
             assert _lib.dispatch_count('s2big_fuse') >= len(want)
-        elif prec == 'f16s':
+        elif prec in ('f16s', 'f16s-g2'):
             assert fform == [] and (nx, ns) == (0, 2), (fform, nx, ns)      # first step: S-form strip kernel, exact scales
         else:
             assert fform == [] and nx == 0
@@ -88,7 +94,8 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
         print(f'[{prec} {batch} rep{rep}] 1024² W+ step vs reference f64: |d image| {e_img:.2e} (absmax {g["image_absmax"].item():.2f}), '
               f'moments {e_mom:.2e}, loss rel {e_loss:.2e}, dL/dw rel {rel:.2e}')
         assert e_img < 1e-3 and e_mom < 1e-5 and e_loss < 1e-5
-        assert rel < 1e-4, rel
+        # 'f16s-g2': the gradient operand of every contraction is rounded to f16 (2^-11, zero mean): bar 3e-4
+        assert rel < (3e-4 if prec == 'f16s-g2' else 1e-4), rel
     assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
 
 

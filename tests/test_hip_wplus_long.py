@@ -1,0 +1,180 @@
+"""The metric's own horizon — "100 W+ steps" (BASELINE.json) — against the REAL reference: `Generator` autograd + `torch.optim.Adam`
+run for 100 steps on the bench recipe (tests/golden/make_golden.py: gold_wplus_long; anchors model.py:483-585,
+src/models/OOD_faceGAN_model.py:398-400, BasicSR losses.py:58-83) at 256² (images 0, 1) and at 1024² (image 10, image 0).
+
+What a long trajectory can and cannot be compared on: Adam's update is lr * m / (sqrt(v) + eps), i.e. ~lr * sign(g) in the first steps,
+so a coordinate whose gradient is ~0 takes either sign in two correct fp32 implementations and the latents drift apart coordinate-wise
+while the LOSS CURVE — an average over 10^5 - 10^6 pixels of a function of all coordinates — stays together.  The fixtures therefore
+hold the reference twice, in its own float32 and in float64 (same code through `G.double()`): their distance is the yardstick
+("band") for how far two correct implementations are apart at a given step, and the tests require this build to be no further from the
+float32 reference than a small multiple of that.  Steps 1-20: 1e-3 relative on every step's loss.
+
+Things only a long run exercises, asserted here: the carried forward / backward range scales while w moves (no violation flag, no
+re-run), Adam's bias correction at large t (the device step counter), the S-form-only saved activations over many overwrites, the
+concurrent-stream split of a batch, and the two-instruction gradient path ('f16s-g2') staying inside the same band.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oodgan import synth  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _recipe(size, gidx, dev):
+    cat = lambda parts: torch.cat(parts, 0).to(dev)
+    target = cat([synth.make_images(size, 1, seed=1000 + g) for g in gidx])
+    w0 = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx])
+    per = [synth.make_noises(size, 1, seed=2000 + g) for g in gidx]
+    noises = [cat([n[i] for n in per]) for i in range(len(per[0]))]
+    return target, w0, noises
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _counted(eng):
+    """Counts eng.forward calls: an inversion that tripped a range flag is re-run, i.e. makes 2x the calls."""
+    calls = {'n': 0}
+    orig = eng.forward
+
+    def fwd(*a, **kw):
+        calls['n'] += 1
+        return orig(*a, **kw)
+    eng.forward = fwd
+    return calls
+
+
+def _curve_report(tag, losses, ref, band=None):
+    """max relative distance of the loss curves over steps [0,20), [20,60), [60,100) (whatever exists)."""
+    out = {}
+    n = min(losses.shape[0], ref.shape[0])
+    rel = ((losses[:n] - ref[:n]).abs() / ref[:n].abs())
+    for lo, hi in ((0, 20), (20, 60), (60, 100)):
+        if lo < n:
+            out[lo, hi] = float(rel[lo:min(hi, n)].max())
+    msg = ', '.join(f'steps {lo + 1}-{min(hi, n)}: {v:.2e}' for (lo, hi), v in out.items())
+    if band is not None:
+        msg += ' | reference f32 vs its own f64: ' + ', '.join(f'{v:.2e}' for v in band.values())
+    print(f'[{tag}] loss-curve rel distance to the reference: {msg}')
+    return out
+
+
+@pytest.mark.parametrize('prec', ['f16s', 'f16s-g2', 'f32'])
+def test_100_steps_256_vs_reference_adam(dev, prec):
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    g32, g64 = _load('wplus_long_256.npz'), _load('wplus_long_256_f64.npz')
+    size, gidx, steps = 256, [int(i) for i in g32['image_indices']], int(g32['steps'])
+    assert steps == 100
+    target, w0, noises = _recipe(size, gidx, dev)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size, precision=prec)
+    calls = _counted(eng)
+    w, losses, traj = WPlusInverter(eng).invert(target, w0, noises, steps=steps, return_trajectory=True)
+    del eng.forward
+    assert calls['n'] == steps, f'range violation: the loop was re-run ({calls["n"]} forwards)'
+    assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
+    L, L32, L64 = losses.double().cpu(), g32['losses'], g64['losses']
+    band = _curve_report('reference f32 vs f64', L32, L64)
+    d32 = _curve_report(f'256² {prec} vs reference f32', L, L32, band)
+    d64 = _curve_report(f'256² {prec} vs reference f64', L, L64)
+    # steps 1-20: 1e-3 on every step; later: within 4x the reference's own f32/f64 distance (floor 1e-3)
+    assert d32[0, 20] < 1e-3 and d64[0, 20] < 1e-3
+    for key in ((20, 60), (60, 100)):
+        assert min(d32[key], d64[key]) < max(4 * band[key], 1e-3), (key, d32[key], d64[key], band[key])
+    # the end of the metric's horizon: loss after 100 steps
+    fin = abs(float(L[-1].mean()) - float(L32[-1].mean())) / float(L32[-1].mean())
+    print(f'[256² {prec}] loss at step 100: {L[-1].tolist()} vs reference {L32[-1].tolist()} (mean rel {fin:.2e})')
+    assert fin < 2e-3
+    # latents: the bulk of the coordinates follows the reference (those with a clear gradient sign), the distance of the rest is
+    # bounded by the step count times lr; reported next to the reference's own f32/f64 distance
+    for t in (10, 30, 100):
+        dw = (traj[t - 1].double().cpu() - g32[f'w_step{t}']).abs()
+        dref = (g32[f'w_step{t}'] - g64[f'w_step{t}']).abs()
+        print(f'[256² {prec}] w at step {t}: rms distance {float(dw.pow(2).mean().sqrt()):.2e} (reference f32 vs f64: {float(dref.pow(2).mean().sqrt()):.2e}), '
+              f'within 2e-3: {float((dw < 2e-3).double().mean()):.4f} (reference: {float((dref < 2e-3).double().mean()):.4f})')
+        assert float(dw.pow(2).mean().sqrt()) < max(3 * float(dref.pow(2).mean().sqrt()), 2e-3)
+    assert torch.isfinite(w).all()
+
+
+@pytest.mark.parametrize('prec', ['f16s', 'f16s-g2'])
+@pytest.mark.parametrize('fixture', ['wplus_long_1024.npz', 'wplus_long_1024_img0.npz'])
+def test_100_steps_1024_vs_reference_adam(dev, prec, fixture):
+    """The benchmarked geometry, one image alone (the reference CLI's per-file mode, run_ood_faceGAN_inversion.py:158-182), the loop
+    as bench.py runs it (device step counter, no trajectory)."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    if not os.path.exists(os.path.join(GOLDEN, fixture)):
+        pytest.skip(f'{fixture} not generated')
+    g32 = _load(fixture)
+    g64 = _load('wplus_long_1024_f64.npz') if fixture == 'wplus_long_1024.npz' and os.path.exists(os.path.join(GOLDEN, 'wplus_long_1024_f64.npz')) else None
+    size, gidx = 1024, [int(i) for i in g32['image_indices']]
+    steps = g32['losses'].shape[0]
+    assert steps == 100
+    target, w0, noises = _recipe(size, gidx, dev)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size, precision=prec)
+    calls = _counted(eng)
+    w, losses = WPlusInverter(eng).invert(target, w0, noises, steps=steps)
+    del eng.forward
+    assert calls['n'] == steps and not eng.bwd_scale_violated() and not eng.fwd_range_violated()
+    L, L32 = losses.double().cpu(), g32['losses']
+    band = _curve_report('reference f32 vs f64 (1024²)', L32, g64['losses']) if g64 is not None else None
+    d32 = _curve_report(f'1024² {prec} vs reference f32 ({fixture})', L, L32, band)
+    assert d32[0, 20] < 1e-3
+    assert d32[20, 60] < 2e-3 and d32[60, 100] < 2e-3
+    if band is not None:
+        n64 = g64['losses'].shape[0]
+        d64 = _curve_report(f'1024² {prec} vs reference f64', L[:n64], g64['losses'])
+        assert d64[0, 20] < 1e-3
+    fin = abs(float(L[-1]) - float(L32[-1])) / float(L32[-1])
+    print(f'[1024² {prec}] loss at step 100: {float(L[-1]):.6f} vs reference {float(L32[-1]):.6f} (rel {fin:.2e})')
+    assert fin < 1e-3
+    for t in (10, 30, 100):
+        dw = (w.double().cpu() - g32[f'w_step{t}']).abs() if t == 100 else None
+        if dw is not None:
+            print(f'[1024² {prec}] w at step 100: rms distance {float(dw.pow(2).mean().sqrt()):.2e}, within 2e-3: {float((dw < 2e-3).double().mean()):.4f}, '
+                  f'moved from w0 by rms {float((g32["w_step100"] - w0.double().cpu()).pow(2).mean().sqrt()):.2e}')
+            assert float(dw.pow(2).mean().sqrt()) < 0.25 * float((g32['w_step100'] - w0.double().cpu()).pow(2).mean().sqrt())
+    # G(w_100) of THIS build against the reference's G(w_100): the images the two inversions end on
+    img = eng.forward(w, noises)
+    sub = img[:, :, ::16, ::16].double().cpu()
+    e_img = float((sub - g32['final_image_sub'].double()).abs().max())
+    e_rms = float((sub - g32['final_image_sub'].double()).pow(2).mean().sqrt())
+    print(f'[1024² {prec}] G(w_100) vs the reference\'s: max |d pixel| {e_img:.2e}, rms {e_rms:.2e} (image std {float(g32["final_image_std"].mean()):.2f})')
+    assert e_rms < 0.02 * float(g32['final_image_std'].mean())
+
+
+def test_two_streams_and_one_stream_end_on_the_same_loss_b8(dev):
+    """bench.py's default (two concurrent sub-batches of four) against the one-stream loop over the whole batch of 8 at 1024², 100
+    steps: per-image final losses within 0.5 % — in fact bit-identical trajectories are not required (the 32² layers
+    run another kernel at the sub-batch's size), the loss is."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, gidx = 1024, list(range(8))
+    target, w0, noises = _recipe(size, gidx, dev)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size)
+    inv = WPlusInverter(eng)
+    w1, l1 = inv.invert(target, w0, noises, steps=100, streams=1)
+    w2, l2 = inv.invert(target, w0, noises, steps=100, streams=2)
+    rel = ((l2[-1] - l1[-1]).abs() / l1[-1]).max().item()
+    print(f'B=8 1024² 100 steps: final loss per image one stream {l1[-1].tolist()} | two streams: max rel distance {rel:.2e}; '
+          f'mean {l1[-1].mean().item():.6f} / {l2[-1].mean().item():.6f}')
+    assert rel < 5e-3
+    assert ((l2[:20] - l1[:20]).abs() / l1[:20]).max().item() < 1e-3
+    # image 0 of this batch against the reference's 100-step run of image 0 alone (per-image losses do not depend on the batch)
+    if os.path.exists(os.path.join(GOLDEN, 'wplus_long_1024_img0.npz')):
+        ref = _load('wplus_long_1024_img0.npz')['losses'][:, 0]
+        for tag, l in (('one stream', l1), ('two streams', l2)):
+            r = ((l[:, 0].double().cpu() - ref).abs() / ref)
+            print(f'image 0 in the batch of 8 ({tag}) vs the reference alone: steps 1-20 {float(r[:20].max()):.2e}, step 100 {float(r[-1]):.2e}')
+            assert float(r[:20].max()) < 1e-3 and float(r[-1]) < 1e-3
