@@ -64,10 +64,19 @@ def self_launch(a):
     stdout (the ONE JSON line) unchanged, waits for all of them and exits non-zero if any rank did; a rank that dies takes the
     others down (they would wait in the rendezvous forever) and every failing rank's stderr tail is shown.
     Analogue in the reference: BasicSR/scripts/dist_train.sh:15-16 (its only launcher; inference there is one process)."""
-    import socket
     import subprocess
     import tempfile
     n = a.gpus
+    rc = 1
+    for attempt in range(2):            # the port is picked by bind(0) and released before the ranks bind it: retry once if another process took it
+        rc, rendezvous_failed = _self_launch_once(a, n, subprocess, tempfile)
+        if rc == 0 or not rendezvous_failed:
+            break
+    return rc
+
+
+def _self_launch_once(a, n, subprocess, tempfile):
+    import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -79,7 +88,8 @@ def self_launch(a):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OODGAN_BENCH_SELF_LAUNCHED='1')
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL's cross-process buffers need it on this driver
         env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
-        log = tempfile.TemporaryFile(mode='w+', prefix=f'bench_rank{r}_')
+        # rank 0's stderr streams through (progress is visible and survives a killed parent); the other ranks' goes to a temp file shown on failure
+        log = None if r == 0 else tempfile.TemporaryFile(mode='w+', prefix=f'bench_rank{r}_')
         logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=os.getcwd(),
                                       stdout=(None if r == 0 else subprocess.DEVNULL), stderr=log))
@@ -92,6 +102,12 @@ def self_launch(a):
         for p in procs:
             if p.poll() is None:
                 p.terminate()
+        deadline = time.monotonic() + 10.0      # ... and are waited for: a rank inside an RCCL collective or a long kernel may ignore SIGTERM
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()                        # exact PID of our own child
         raise
     return _report_ranks(n, rcs, logs)
 
@@ -119,19 +135,23 @@ def _wait_ranks(procs, rcs):
 
 
 def _report_ranks(n, rcs, logs):
+    """-> (exit code, True if the failure looks like a lost race for the rendezvous port)."""
     bad = [r for r, rc in enumerate(rcs) if rc != 0]
+    port_lost = False
     for r, log in enumerate(logs):
-        log.seek(0)
-        txt = log.read()
-        log.close()
+        txt = ''
+        if log is not None:
+            log.seek(0)
+            txt = log.read()
+            log.close()
+        if r in bad and ('Address already in use' in txt or 'EADDRINUSE' in txt):
+            port_lost = True
         if r in bad:
-            sys.stderr.write(f'--- bench.py rank {r} exited with code {rcs[r]}; stderr tail ---\n' + txt[-3000:] + ('' if txt.endswith('\n') else '\n'))
-        elif r == 0 and txt:
-            sys.stderr.write(txt)
+            sys.stderr.write(f'--- bench.py rank {r} exited with code {rcs[r]}; stderr tail ---\n' + (txt[-3000:] if log is not None else '(streamed above)') + ('' if txt.endswith('\n') else '\n'))
     if bad:
         sys.stderr.write(f'bench.py: {len(bad)} of {n} rank processes failed (ranks {bad})\n')
-        return 1
-    return 0
+        return 1, port_lost
+    return 0, False
 
 
 class ConvProbe:

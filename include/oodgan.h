@@ -68,6 +68,27 @@ int oodgan_dispatch_reset(void);
  * host mirror uses it instead of torch.zeros inside the W+ loop, so that no torch kernel runs on the hot path. */
 int oodgan_zero(void* p, long bytes, void* stream);
 
+/* ------------------------------------------------------------------ launch plans (round 6) -- */
+/* A plan is the list of kernel launches — kernel, grid, block, dynamic LDS, stream, by-value arguments (the packed descriptors the entry
+ * points build from their argument structs) — that the calling thread made between oodgan_plan_record_begin and oodgan_plan_record_end
+ * through ANY entry point of this library.  Recording does not change what the calls do (every launch is also issued).  oodgan_plan_run
+ * re-issues the recorded launches `times` times, in order, on the streams they were recorded with: eager launches from C++ (not a
+ * hipGraph), with none of the host work that built them — the ~170 launches of one W+ step cost one call instead of ~170 ctypes calls and
+ * the Python around them (8-9 ms of host time per step against 10-11 ms of GPU time).
+ * The caller guarantees what a hipGraph replay would need: every device buffer the recorded calls used is still allocated at the same
+ * address and plays the same role (the host mirror records under a private allocator pool, oodgan/engine.py), and nothing a recorded call
+ * derived on the host from per-step state changes (the W+ loop keeps its step counter and loss row on the device:
+ * oodgan_adam_step_dev, oodgan_mse_fwd_bwd_row).  One plan is recorded and run by one thread at a time; different threads may record
+ * different plans concurrently.  The reference has no counterpart (PyTorch's eager dispatcher; torch.cuda.graphs would be the analogue).
+ * oodgan_plan_set_null_launch(1): process-wide, recorded AND direct launches become no-ops — host-cost probes only. */
+void* oodgan_plan_create(void);
+int oodgan_plan_destroy(void* plan);
+int oodgan_plan_record_begin(void* plan);
+long oodgan_plan_record_end(void* plan);       /* number of launches recorded, -1 on error */
+long oodgan_plan_size(const void* plan);
+int oodgan_plan_run(void* plan, int times);
+int oodgan_plan_set_null_launch(int on);
+
 /* ------------------------------------------------------------------ L1 custom ops ---------- */
 
 /* y = scale * leaky_relu(x + noise_w[0]*noise[b,0,p] + bias[c], slope)
@@ -544,6 +565,11 @@ int oodgan_absmax_scale_clear(float* part, long n, float* out2, void* stream);
 int oodgan_mse_fwd_bwd(const float* img, const float* target, float* gimg, float* part, float* loss,
                        int B, long CHW, float grad_mul, void* stream);
 int oodgan_mse_nparts(long CHW);
+/* the same with the losses written to row min(row_dev[0], nrows-1) of loss_table (nrows, B): row_dev is the W+ loop's device step
+ * counter (the value oodgan_adam_step_dev increments at the END of a step, i.e. the zero-based index of the running step), so a
+ * recorded step (oodgan_plan_run, hipGraph replay) fills the loss table row by row without a host-side pointer per step */
+int oodgan_mse_fwd_bwd_row(const float* img, const float* target, float* gimg, float* part, float* loss_table,
+                           const int* row_dev, int nrows, int B, long CHW, float grad_mul, void* stream);
 /* torch.optim.Adam step (no weight decay, no amsgrad), step index t>=1 given by the host:
  * anchors: get_optimizer (src/models/OOD_faceGAN_model.py:398-400). */
 int oodgan_adam_step(float* w, const float* g, float* m, float* v, long n, float lr, float beta1,
@@ -551,6 +577,43 @@ int oodgan_adam_step(float* w, const float* g, float* m, float* v, long n, float
 /* same with the step index on the device: increments t_dev[0] first, then uses it (hipGraph-replayable W+ step) */
 int oodgan_adam_step_dev(float* w, const float* g, float* m, float* v, long n, float lr, float beta1,
                          float beta2, float eps, int* t_dev, void* stream);
+
+/* ------------------------------------------------------------------ X1 LPIPS(alex) term ---- */
+/* The perceptual term of the inversion loss (north_star: "W+ Adam steps against LPIPS/L2"; reference call site
+ * src/losses/lpips_loss.py:13-34: lpips.LPIPS(net='alex')(pred, target, normalize=True) on images mapped from min_max to [0,1]).
+ * PARITY UNPINNED: the `lpips` package and its weights are not in the reference tree; these ops restate the published
+ * algorithm and are checked against oracle/lpips_cpu.py on seeded weights.  Host mirror: oodgan/lpips.py.
+ *
+ * Stride-1 2-D convolution, exact fp32 on the matrix cores, NCHW:  y = conv(x, w, pad) [+ bias] [ReLU] [+ add] [* (mask > 0)]
+ * (torch.nn.Conv2d of AlexNet's feature stack, and — with flipped / transposed weights and pad' = ks-1-pad — its input gradient, where
+ * `add` is the gradient arriving at the same tensor from its LPIPS tap and `mask` the ReLU output below).  x (B,K,Hin,Win);
+ * wpk [K][ks*ks][round_up(M,64)] (zero padded; tap = ky*ks+kx, correlation as torch); y/add/mask (B,M,Hin+2pad-ks+1,Win+2pad-ks+1);
+ * ks in {3,5}.  AlexNet's first conv (11x11, stride 4, pad 2) runs as ks=3, pad=0 on the 48-channel space-to-depth image of
+ * oodgan_lpips_prep. */
+int oodgan_conv2d_s1(const float* x, const float* wpk, const float* bias, const float* add, const float* mask, float* y, int B, int K,
+                     int M, int Hin, int Win, int ks, int pad, int relu, void* stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2) on (planes,H,W) -> (planes,(H-3)/2+1,(W-3)/2+1), and its backward merged with what surrounds
+ * it in LPIPS: gx = (scatter of gy to each window's first maximum + add) * (x > 0), x being a ReLU output (add NULL = 0). */
+int oodgan_maxpool3s2_fwd(const float* x, float* y, long planes, int H, int W, void* stream);
+int oodgan_maxpool3s2_bwd(const float* x, const float* gy, const float* add, float* gx, long planes, int H, int W, void* stream);
+/* image (B,3,H,W) -> conv1 operand (B,48,H/4+1,W/4+1): v = a*x + b0 (min_max -> [-1,1]: lpips_loss.py:27-29 followed by lpips'
+ * normalize=True), lpips.ScalingLayer (v - shift[c]) / scale[c], zero pad 2, 4x4 space-to-depth (channel c*16 + dy*4 + dx).
+ * shift3 / scale3 are HOST arrays of 3 floats.  H, W multiples of 4. */
+int oodgan_lpips_prep(const float* img, float* out48, int B, int H, int W, float a, float b0, const float* shift3, const float* scale3,
+                      void* stream);
+/* gimg (B,3,H,W) += coef * a / scale[c] * depth_to_space(g48): the gradient w.r.t. the image from the gradient w.r.t. the conv1 operand */
+int oodgan_lpips_img_grad(const float* g48, float* gimg, int B, int H, int W, float a, float coef, const float* scale3, void* stream);
+/* One LPIPS tap on features (B,C,HW).  mode 0: out = f0 / (sqrt(sum_c f0^2) + 1e-10)  (lpips.normalize_tensor; the target's, once).
+ * mode 1: part[b][blk] = partial spatial sums of d = sum_c w[c] (n0_c - n1_c)^2 (lin layer on the squared difference), blk <
+ * oodgan_lpips_head_nparts(HW), and out = coef * d(d)/d(f0) (unmasked; the consumer applies the ReLU mask).
+ * mode 2: mode 1 with out * (f0 > 0): the deepest tap, whose gradient nothing else joins. */
+int oodgan_lpips_head(const float* f0, const float* n1, const float* w, float* out, float* part, int B, int C, long HW, float coef,
+                      int mode, void* stream);
+int oodgan_lpips_head_nparts(long HW);
+/* lpips[b] = sum_taps (sum_blk parts[t][b][blk]) / hw[t]  (spatial_average + sum over the taps) -> row min(row_dev[0], nrows-1) of
+ * table (nrows,B) (row_dev NULL: row 0).  parts / nparts / hw: HOST arrays of ntaps <= 5 entries. */
+int oodgan_lpips_finish(const float* const* parts, const int* nparts, const long* hw, int ntaps, float* table, const int* row_dev,
+                        int nrows, int B, void* stream);
 
 /* ------------------------------------------------------------------ A7/A10 SAMM / SAIM ----- */
 

@@ -3,7 +3,30 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdarg>
+#include <functional>
+#include <utility>
 #include "../../include/oodgan.h"
+
+// ---- launch plans (include/oodgan.h, oodgan_plan_*; runtime.hip).  EVERY kernel launch of the library goes through launch_rec(): the
+// launch — kernel, grid, block, dynamic LDS, stream and the by-value kernel arguments, i.e. the packed descriptor structs the entry
+// points build — is a closure that is issued at once and, while the calling thread records a plan, also appended to it.  Replaying a
+// plan re-issues the closures in order from C++: eager launches (no hipGraph), none of the host work that built them.
+namespace oodgan {
+struct PlanRec;
+extern thread_local PlanRec* tl_plan_rec;
+extern int g_null_launch;                  // != 0: closures skip the launch itself (host-cost probes: tools/plan_probe.py)
+void plan_append(std::function<void()>&& f);
+template <class F>
+inline void launch_rec(F&& f) {
+    f();
+    if (__builtin_expect(tl_plan_rec != nullptr, 0)) plan_append(std::function<void()>(std::forward<F>(f)));
+}
+}  // namespace oodgan
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                        \
+    ::oodgan::launch_rec([=]() {                                                                                                 \
+        if (!::oodgan::g_null_launch) (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);      \
+    })
 
 namespace oodgan {
 

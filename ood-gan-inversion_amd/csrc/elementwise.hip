@@ -232,13 +232,16 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ img,
     if (threadIdx.x == 0) part[(long)b * nparts + blockIdx.x] = acc;
 }
 
+// row_dev != NULL: the losses go to row min(row_dev[0], nrows - 1) of a (nrows, B) table — the W+ loop's loss table indexed by its
+// device step counter, so that a recorded / replayed step (oodgan_plan_run, hipGraph) writes a new row each time
 __global__ __launch_bounds__(64) void mse_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, int nparts,
-                                                        float inv_n) {
+                                                        float inv_n, const int* __restrict__ row_dev, int nrows) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
     for (int j = lane; j < nparts; j += 64) s += part[(long)b * nparts + j];
     s = wave_sum(s);
-    if (lane == 0) loss[b] = s * inv_n;
+    const long row = row_dev ? (long)min(max(row_dev[0], 0), nrows - 1) * gridDim.x : 0;
+    if (lane == 0) loss[row + b] = s * inv_n;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
@@ -403,7 +406,21 @@ extern "C" int oodgan_mse_fwd_bwd(const float* img, const float* target, float* 
                        grad_mul * 2.0f / (float)CHW);
     int rc = check_launch("mse");
     if (rc != OODGAN_OK) return rc;
-    hipLaunchKernelGGL(mse_finish_kernel, dim3(B), dim3(64), 0, as_stream(stream), part, loss, nparts, 1.0f / (float)CHW);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(B), dim3(64), 0, as_stream(stream), part, loss, nparts, 1.0f / (float)CHW,
+                       (const int*)nullptr, 1);
+    return check_launch("mse_finish");
+}
+
+extern "C" int oodgan_mse_fwd_bwd_row(const float* img, const float* target, float* gimg, float* part, float* loss_table,
+                                      const int* row_dev, int nrows, int B, long CHW, float grad_mul, void* stream) {
+    OODGAN_REQUIRE(img && target && part && loss_table && row_dev && nrows > 0 && B > 0 && CHW > 0, "mse_row: bad args");
+    const int nparts = oodgan_mse_nparts(CHW);
+    hipLaunchKernelGGL(mse_kernel, dim3(nparts, B), dim3(256), 0, as_stream(stream), img, target, gimg, part, CHW, nparts,
+                       grad_mul * 2.0f / (float)CHW);
+    int rc = check_launch("mse");
+    if (rc != OODGAN_OK) return rc;
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(B), dim3(64), 0, as_stream(stream), part, loss_table, nparts, 1.0f / (float)CHW, row_dev,
+                       nrows);
     return check_launch("mse_finish");
 }
 

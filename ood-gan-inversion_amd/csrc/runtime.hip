@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace oodgan {
 static thread_local char g_err[512] = "";
@@ -120,6 +121,58 @@ extern "C" int oodgan_zero(void* p, long bytes, void* stream) {
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, oodgan::as_stream(stream),
                        reinterpret_cast<unsigned char*>(p), bytes);
     return oodgan::check_launch("zero");
+}
+
+// ---- launch plans (common.hpp: launch_rec)
+#include <vector>
+namespace oodgan {
+struct PlanRec {
+    std::vector<std::function<void()>> ops;
+    bool recording = false;
+};
+thread_local PlanRec* tl_plan_rec = nullptr;
+int g_null_launch = 0;
+void plan_append(std::function<void()>&& f) { tl_plan_rec->ops.emplace_back(std::move(f)); }
+}  // namespace oodgan
+
+extern "C" void* oodgan_plan_create(void) { return new (std::nothrow) oodgan::PlanRec(); }
+extern "C" int oodgan_plan_destroy(void* plan) {
+    oodgan::PlanRec* p = static_cast<oodgan::PlanRec*>(plan);
+    if (p && oodgan::tl_plan_rec == p) oodgan::tl_plan_rec = nullptr;
+    delete p;
+    return OODGAN_OK;
+}
+extern "C" int oodgan_plan_record_begin(void* plan) {
+    oodgan::PlanRec* p = static_cast<oodgan::PlanRec*>(plan);
+    OODGAN_REQUIRE(p != nullptr, "plan_record_begin: null plan");
+    OODGAN_REQUIRE(oodgan::tl_plan_rec == nullptr, "plan_record_begin: this thread is already recording a plan");
+    p->ops.clear();
+    p->recording = true;
+    oodgan::tl_plan_rec = p;
+    return OODGAN_OK;
+}
+extern "C" long oodgan_plan_record_end(void* plan) {
+    oodgan::PlanRec* p = static_cast<oodgan::PlanRec*>(plan);
+    if (p == nullptr || oodgan::tl_plan_rec != p) {
+        oodgan::set_error("plan_record_end: this thread is not recording that plan");
+        return -1;
+    }
+    oodgan::tl_plan_rec = nullptr;
+    p->recording = false;
+    return (long)p->ops.size();
+}
+extern "C" long oodgan_plan_size(const void* plan) { return plan ? (long)static_cast<const oodgan::PlanRec*>(plan)->ops.size() : -1; }
+extern "C" int oodgan_plan_run(void* plan, int times) {
+    oodgan::PlanRec* p = static_cast<oodgan::PlanRec*>(plan);
+    OODGAN_REQUIRE(p != nullptr && !p->recording && times >= 0, "plan_run: null plan, a plan still recording, or times < 0");
+    OODGAN_REQUIRE(oodgan::tl_plan_rec == nullptr, "plan_run: this thread is recording a plan");
+    for (int t = 0; t < times; ++t)
+        for (const std::function<void()>& f : p->ops) f();
+    return oodgan::check_launch("plan_run");
+}
+extern "C" int oodgan_plan_set_null_launch(int on) {
+    oodgan::g_null_launch = on ? 1 : 0;
+    return OODGAN_OK;
 }
 
 extern "C" int oodgan_version(void) { return 109; }      // 109: oodgan_conv_args gained x_hi_only (precision f16s-g2), oodgan_plan_*, LPIPS ops; 108: oodgan_align_input / oodgan_align_input_stats gained `diff` (AlignNet diff_fAndg=False), dispatch sub-counters, tunable stripx_waves; 107: oodgan_conv_args gained dotx_sform / dotx_scale; 106: oodgan_conv_args gained ys_vmax (+ rgb_y partial sums / ys from the 8-wave stride-1 kernel), round-4 helpers; 105: oodgan_upconv_vblur_fform, oodgan_zero; 104: oodgan_dispatch_count / oodgan_dispatch_reset; 102: oodgan_conv_args gained x_fform, dotx_fform, workspace, workspace_bytes; 103: oodgan_blur_act_sform_sep

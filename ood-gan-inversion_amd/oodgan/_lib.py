@@ -144,6 +144,22 @@ _SIGS = {
     'oodgan_absmax_scale': (c_int, [P, c_long, P, P]),
     'oodgan_absmax_scale_clear': (c_int, [P, c_long, P, P]),
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
+    'oodgan_mse_fwd_bwd_row': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
+    'oodgan_conv2d_s1': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'oodgan_maxpool3s2_fwd': (c_int, [P, P, c_long, c_int, c_int, P]),
+    'oodgan_maxpool3s2_bwd': (c_int, [P, P, P, P, c_long, c_int, c_int, P]),
+    'oodgan_lpips_prep': (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, POINTER(c_float), POINTER(c_float), P]),
+    'oodgan_lpips_img_grad': (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, POINTER(c_float), P]),
+    'oodgan_lpips_head': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_float, c_int, P]),
+    'oodgan_lpips_head_nparts': (c_int, [c_long]),
+    'oodgan_lpips_finish': (c_int, [POINTER(P), POINTER(c_int), POINTER(c_long), c_int, P, P, c_int, c_int, P]),
+    'oodgan_plan_create': (P, []),
+    'oodgan_plan_destroy': (c_int, [P]),
+    'oodgan_plan_record_begin': (c_int, [P]),
+    'oodgan_plan_record_end': (c_long, [P]),
+    'oodgan_plan_size': (c_long, [P]),
+    'oodgan_plan_run': (c_int, [P, c_int]),
+    'oodgan_plan_set_null_launch': (c_int, [c_int]),
     'oodgan_mse_nparts': (c_int, [c_long]),
     'oodgan_adam_step': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, P]),
     'oodgan_adam_step_dev': (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, P, P]),

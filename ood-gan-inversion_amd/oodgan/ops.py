@@ -1166,18 +1166,67 @@ def loss_scale_for(chw):
     return float(2 ** max(0, int(math.floor(math.log2(max(chw, 2) / 2.0)))))
 
 
-def mse_loss_grad(img, target, grad_mul=1.0):
-    """Per-image MSE and its gradient (times grad_mul): (loss[B], gimg)."""
+def mse_loss_grad(img, target, grad_mul=1.0, loss_out=None, table=None, row_dev=None):
+    """Per-image MSE and its gradient (times grad_mul): (loss[B], gimg).  ``loss_out``: a contiguous float32 (B,) view that receives the losses
+    (the W+ loop's row of its loss table: no copy kernel per step).  ``table`` (nrows, B) + ``row_dev`` (int32[1] on the device): the losses go
+    to row row_dev[0] of the table (oodgan_mse_fwd_bwd_row: a recorded step writes a new row on every replay); returns (None, gimg)."""
     a, t = _dev(img, 'img'), _dev(target, 'target')
     B = a.shape[0]
     CHW = a.numel() // B
     L = _lib.lib()
     npart = L.oodgan_mse_nparts(CHW)
     part = torch.empty(B, npart, device=a.device, dtype=torch.float32)
-    loss = torch.empty(B, device=a.device, dtype=torch.float32)
+    if table is not None:
+        assert table.dim() == 2 and table.shape[1] == B and table.dtype == torch.float32 and table.is_contiguous() and row_dev.dtype == torch.int32
+        g = torch.empty_like(a)
+        check(L.oodgan_mse_fwd_bwd_row(_p(a), _p(t), _p(g), _p(part), _p(table), _p(row_dev), table.shape[0], B, CHW, float(grad_mul), _stream()), 'mse_row')
+        return None, g
+    loss = torch.empty(B, device=a.device, dtype=torch.float32) if loss_out is None else loss_out
+    assert loss.shape == (B,) and loss.dtype == torch.float32 and loss.is_contiguous() and loss.device == a.device
     g = torch.empty_like(a)
     check(L.oodgan_mse_fwd_bwd(_p(a), _p(t), _p(g), _p(part), _p(loss), B, CHW, float(grad_mul), _stream()), 'mse')
     return loss, g
+
+
+class LaunchPlan:
+    """oodgan_plan_* (include/oodgan.h): the kernel launches this thread makes inside ``with plan.recording():`` — through any op of this
+    module — recorded once and re-issued from C++ by ``run()``; eager launches on the streams they were recorded with.  The caller keeps
+    every buffer the recorded calls touched allocated at the same address (``WPlusInverter`` records under a private allocator pool)."""
+
+    def __init__(self):
+        self._h = _lib.lib().oodgan_plan_create()
+        if not self._h:
+            raise RuntimeError('oodgan_plan_create failed')
+        self.size = 0
+
+    class _Rec:
+        def __init__(self, plan):
+            self.plan = plan
+
+        def __enter__(self):
+            check(_lib.lib().oodgan_plan_record_begin(self.plan._h), 'plan_record_begin')
+            return self.plan
+
+        def __exit__(self, *exc):
+            n = _lib.lib().oodgan_plan_record_end(self.plan._h)
+            if n < 0:
+                check(1, 'plan_record_end')
+            self.plan.size = int(n)
+            return False
+
+    def recording(self):
+        return LaunchPlan._Rec(self)
+
+    def run(self, times=1):
+        check(_lib.lib().oodgan_plan_run(self._h, int(times)), 'plan_run')
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                _lib.lib().oodgan_plan_destroy(h)
+            except Exception:
+                pass
 
 
 def adam_step(w, g, m, v, step, lr=0.01, betas=(0.9, 0.999), eps=1e-8):

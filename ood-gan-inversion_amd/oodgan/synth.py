@@ -21,7 +21,7 @@ import torch
 __all__ = [
     'encoder_state',
     'normal', 'uniform', 'make_kernel', 'generator_channels', 'generator_state', 'samm_state',
-    'ood_state', 'make_noises', 'make_latents', 'make_images', 'make_encoder_feats',
+    'ood_state', 'make_noises', 'make_latents', 'make_images', 'make_encoder_feats', 'lpips_state',
 ]
 
 
@@ -269,4 +269,17 @@ def featurestyle_state(seed=0, style_cnt=18):
             sd[k] = normal(name, shp, seed, 0.03, 0.25)                     # damp the residual branch (see encoder_state)
         else:
             sd[k] = normal(name, shp, seed, 0.1, 1.0)
+    return sd
+
+
+def lpips_state(seed=0):
+    """Seeded stand-in for the state dict of ``lpips.LPIPS(net='alex')`` (key names of lpips 0.1.x: the torchvision AlexNet feature convs
+    under ``net.slice{1..5}.{0,3,6,8,10}`` and the 1x1 ``lin{0..4}.model.1.weight`` layers, which the package keeps non-negative).  The
+    pretrained weights are absent: He-scaled normals keep the five taps O(1) so that every layer contributes to the loss."""
+    sd = OrderedDict()
+    for (sl, idx), (co, ci, k) in zip(((1, 0), (2, 3), (3, 6), (4, 8), (5, 10)), ((64, 3, 11), (192, 64, 5), (384, 192, 3), (256, 384, 3), (256, 256, 3))):
+        sd[f'net.slice{sl}.{idx}.weight'] = normal(f'lpips.w{sl}', (co, ci, k, k), seed, math.sqrt(2.0 / (ci * k * k)))
+        sd[f'net.slice{sl}.{idx}.bias'] = normal(f'lpips.b{sl}', (co,), seed, 0.1)
+    for k, c in enumerate((64, 192, 384, 256, 256)):
+        sd[f'lin{k}.model.1.weight'] = normal(f'lpips.lin{k}', (1, c, 1, 1), seed, 1.0).abs() * (4.0 / c)
     return sd

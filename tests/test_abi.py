@@ -66,4 +66,4 @@ def test_stripx_isa_keeps_its_hand_placed_waits():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_stripx_isa.py')], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count('inline LDS reads checked') == 8, r.stdout      # every instance of both kernels (4-wave x6, 8-wave forward x2) was found
+    assert r.stdout.count('inline LDS reads checked') == 12, r.stdout      # every instance of both kernels (4-wave x10 incl. the four two-instruction input-gradient instances of round 6, 8-wave forward x2) was found

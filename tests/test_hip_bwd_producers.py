@@ -115,7 +115,7 @@ def test_violated_scale_falls_back_to_exact_loop():
     target = synth.make_images(size, B, seed=9).to(dev)
     noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
     w0 = synth.make_latents(size, B, seed=14).to(dev)
-    inv = WPlusInverter(eng)
+    inv = WPlusInverter(eng, use_plan=False)      # the fault is injected through the Python-driven step (call counting)
     w_ref, l_ref = inv.invert(target, w0, noises, steps=4)
     # sabotage: after the first backward, blow one carried scale out of range
     orig, calls = eng.backward, {'n': 0}

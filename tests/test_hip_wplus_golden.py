@@ -170,7 +170,7 @@ def test_forward_range_violation_falls_back_to_exact(dev):
     target = synth.make_images(size, B, seed=9).to(dev)
     noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
     w0 = synth.make_latents(size, B, seed=14).to(dev)
-    inv = WPlusInverter(eng)
+    inv = WPlusInverter(eng, use_plan=False)      # the fault is injected through the Python-driven step (call counting)
     w_ref, l_ref = inv.invert(target, w0, noises, steps=4)
     orig, calls = eng.forward, {'n': 0, 'carry': 0}
 

@@ -46,18 +46,6 @@ def _load(name):
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
-def _counted(eng):
-    """Counts eng.forward calls: an inversion that tripped a range flag is re-run, i.e. makes 2x the calls."""
-    calls = {'n': 0}
-    orig = eng.forward
-
-    def fwd(*a, **kw):
-        calls['n'] += 1
-        return orig(*a, **kw)
-    eng.forward = fwd
-    return calls
-
-
 def _curve_report(tag, losses, ref, band=None):
     """max relative distance of the loss curves over steps [0,20), [20,60), [60,100) (whatever exists)."""
     out = {}
@@ -81,10 +69,9 @@ def test_100_steps_256_vs_reference_adam(dev, prec):
     assert steps == 100
     target, w0, noises = _recipe(size, gidx, dev)
     eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size, precision=prec)
-    calls = _counted(eng)
-    w, losses, traj = WPlusInverter(eng).invert(target, w0, noises, steps=steps, return_trajectory=True)
-    del eng.forward
-    assert calls['n'] == steps, f'range violation: the loop was re-run ({calls["n"]} forwards)'
+    inv = WPlusInverter(eng)
+    w, losses, traj = inv.invert(target, w0, noises, steps=steps, return_trajectory=True)
+    assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]}, f'range violation: {inv.last_stats}'
     assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
     L, L32, L64 = losses.double().cpu(), g32['losses'], g64['losses']
     band = _curve_report('reference f32 vs f64', L32, L64)
@@ -118,16 +105,19 @@ def test_100_steps_1024_vs_reference_adam(dev, prec, fixture):
     if not os.path.exists(os.path.join(GOLDEN, fixture)):
         pytest.skip(f'{fixture} not generated')
     g32 = _load(fixture)
+    if g32['losses'].shape[0] < 100:
+        pytest.skip(f'{fixture} holds {g32["losses"].shape[0]} steps only (generation still running)')
     g64 = _load('wplus_long_1024_f64.npz') if fixture == 'wplus_long_1024.npz' and os.path.exists(os.path.join(GOLDEN, 'wplus_long_1024_f64.npz')) else None
     size, gidx = 1024, [int(i) for i in g32['image_indices']]
     steps = g32['losses'].shape[0]
     assert steps == 100
     target, w0, noises = _recipe(size, gidx, dev)
     eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size, precision=prec)
-    calls = _counted(eng)
-    w, losses = WPlusInverter(eng).invert(target, w0, noises, steps=steps)
-    del eng.forward
-    assert calls['n'] == steps and not eng.bwd_scale_violated() and not eng.fwd_range_violated()
+    inv = WPlusInverter(eng)
+    w, losses = inv.invert(target, w0, noises, steps=steps)
+    assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]}, f'range violation: {inv.last_stats}'
+    assert inv.last_plan['steps'] == [steps - 2] and inv.last_plan['launches'][0] >= 60, inv.last_plan     # steps 3..100 replayed from the launch plan
+    assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
     L, L32 = losses.double().cpu(), g32['losses']
     band = _curve_report('reference f32 vs f64 (1024²)', L32, g64['losses']) if g64 is not None else None
     d32 = _curve_report(f'1024² {prec} vs reference f32 ({fixture})', L, L32, band)
@@ -172,9 +162,72 @@ def test_two_streams_and_one_stream_end_on_the_same_loss_b8(dev):
     assert rel < 5e-3
     assert ((l2[:20] - l1[:20]).abs() / l1[:20]).max().item() < 1e-3
     # image 0 of this batch against the reference's 100-step run of image 0 alone (per-image losses do not depend on the batch)
-    if os.path.exists(os.path.join(GOLDEN, 'wplus_long_1024_img0.npz')):
+    if os.path.exists(os.path.join(GOLDEN, 'wplus_long_1024_img0.npz')) and _load('wplus_long_1024_img0.npz')['losses'].shape[0] == 100:
         ref = _load('wplus_long_1024_img0.npz')['losses'][:, 0]
         for tag, l in (('one stream', l1), ('two streams', l2)):
             r = ((l[:, 0].double().cpu() - ref).abs() / ref)
             print(f'image 0 in the batch of 8 ({tag}) vs the reference alone: steps 1-20 {float(r[:20].max()):.2e}, step 100 {float(r[-1]):.2e}')
             assert float(r[:20].max()) < 1e-3 and float(r[-1]) < 1e-3
+
+
+@pytest.mark.parametrize('use_plan', [True, False])
+@pytest.mark.parametrize('which', ['forward', 'backward'])
+def test_range_violation_mid_run_repeats_one_window(dev, which, use_plan):
+    """A carried scale sabotaged after step 15 of 40: the flags are read every 10 steps on a side stream, the run goes
+    back to the last clean snapshot (step 10), repeats steps 11-20 with exact scales and continues in carry mode — 12 repeated steps
+    (window + check lag) instead of all 40, same result as the undisturbed run.  With launch plans the plan of the flagged run is dropped
+    and a new one recorded after the exact window."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size, B, steps = 32, 2, 40
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=5).items()}, size)
+    target = synth.make_images(size, B, seed=9).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
+    w0 = synth.make_latents(size, B, seed=14).to(dev)
+    inv = WPlusInverter(eng, use_plan=use_plan)
+    w_ref, l_ref = inv.invert(target, w0, noises, steps=steps)
+    assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]}
+    assert inv.last_plan['steps'] == [steps - 2 if use_plan else 0]
+    done = {'n': 0}
+
+    def sabotage(run):
+        if run.steps_run == 15 and not done['n']:
+            done['n'] = 1
+            assert eng.carry_range and eng.fused_bwd
+            if which == 'forward':
+                eng.fwd_range.q[3].mul_(2.0 ** 12)
+            else:
+                next(iter(eng.bwd_state.values())).mul_(torch.tensor([2.0 ** 30, 2.0 ** -30], device=dev))
+    inv.on_step = sabotage
+    w, l = inv.invert(target, w0, noises, steps=steps)
+    inv.on_step = None
+    print(f'{which} scale sabotaged after step 15 of {steps} (plans {use_plan}): {inv.last_stats}, plan {inv.last_plan}')
+    assert inv.last_stats['rollbacks'] == [1]
+    assert inv.last_stats['steps_run'][0] == steps + inv.check_every + inv.check_lag
+    assert eng.carry_range and eng.fused_bwd
+    assert torch.isfinite(w).all()
+    assert (l - l_ref).abs().max().item() <= 1e-5 * l_ref.abs().max().item()
+    dw = (w - w_ref).abs()          # ten steps with exact instead of carried scales in the middle of 40 Adam steps: rounding-level differences, amplified
+    assert (dw < 1e-3).float().mean().item() > 0.99 and dw.max().item() < 5e-3, (dw.max().item(), (dw < 1e-3).float().mean().item())
+    # two concurrent sub-batches, undisturbed: no rollback on either stream
+    w2, l2 = inv.invert(target, w0, noises, steps=steps, streams=2)
+    assert inv.last_stats == {'steps_run': [steps, steps], 'rollbacks': [0, 0]}
+    assert (l2 - l_ref).abs().max().item() <= 1e-4 * l_ref.abs().max().item()
+
+
+@pytest.mark.parametrize('size,B,streams', [(64, 2, 1), (256, 4, 2), (1024, 8, 2), (1024, 1, 1)])
+def test_launch_plan_is_bit_identical_to_the_python_driven_loop(dev, size, B, streams):
+    """steps 3..N re-issued from the recorded launch plan (oodgan_plan_run: ~170 launches per call) against the same
+    loop driven launch by launch from Python — same kernels, same arguments, same order: bit-identical latents and losses."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    steps = 12
+    target, w0, noises = _recipe(size, list(range(B)), dev)
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size)
+    inv_p, inv_e = WPlusInverter(eng, use_plan=True), WPlusInverter(eng, use_plan=False)
+    w_e, l_e = inv_e.invert(target, w0, noises, steps=steps, streams=streams)
+    w_p, l_p = inv_p.invert(target, w0, noises, steps=steps, streams=streams)
+    w_p2, l_p2 = inv_p.invert(target, w0, noises, steps=steps, streams=streams)       # a second inversion records its own plans
+    print(f'{size}² B={B} streams={streams}: plan {inv_p.last_plan}, eager {inv_e.last_plan}')
+    assert inv_p.last_plan['steps'] == [steps - 2] * streams and all(n > 60 for n in inv_p.last_plan['launches'])
+    assert inv_e.last_plan['steps'] == [0] * streams
+    assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
+    assert torch.equal(l_p2, l_e) and torch.equal(w_p2, w_e)

@@ -59,16 +59,33 @@ def test_bench_self_launch_two_ranks_without_gpu_fails_loudly():
     """The driver's N > 1 command shape with WORLD_SIZE unset.  On a box without a GPU both rank processes must die on the
     'needs a ROCm GPU' assertion, the parent must exit non-zero and show BOTH stderr tails (on a GPU box with one device rank 1
     fails on its device ordinal instead and takes rank 0 down; either way: rc != 0, no JSON line)."""
-    import torch
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    # deterministic on any box (ADVICE r5): the children see NO device, whatever the host has — with >= 2 visible GPUs the same command
+    # is a healthy two-rank run (test_bench_self_launch_two_ranks_on_two_gpus below)
+    env['HIP_VISIBLE_DEVICES'] = env['ROCR_VISIBLE_DEVICES'] = env['CUDA_VISIBLE_DEVICES'] = ''
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '256', '--batch', '2', '--wsteps', '2',
                         '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert 'rank processes failed' in r.stderr
-    if not torch.cuda.is_available():
-        assert r.stderr.count('AssertionError: bench.py needs a ROCm GPU') == 2
-        assert 'rank 0 exited with code' in r.stderr and 'rank 1 exited with code' in r.stderr
+    assert r.stderr.count('AssertionError: bench.py needs a ROCm GPU') == 2
+    assert 'rank 0 exited with code' in r.stderr and 'rank 1 exited with code' in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_two_gpus():
+    """The positive two-rank case (BASELINE configs[3] in miniature): two rank processes, one GPU each, RCCL all-gather of the finished
+    latents.  Skipped on the 1-GPU boxes of this pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '256', '--batch', '2', '--wsteps', '2', '--steps', '1',
+           '--warmup', '0', '--no-cpu-baseline', '--no-modconv', '--no-single-stream', '--no-end-to-end', '--no-forward-only', '--no-generator-fwd']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert rec['n_gpus'] == 2 and rec['config']['collective_backend'] == 'nccl' and rec['config']['gathered_latents'] == [4, 14, 512]
 
 
 def test_bench_refuses_mismatched_world_size():

@@ -18,12 +18,14 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 size = 1024
 dev = torch.device('cuda:0')
-eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size)
+prec = os.environ.get('OODGAN_PRECISION', 'f16s-g2')      # bench.py's default arithmetic (round 6)
+streams = int(os.environ.get('OODGAN_STREAMS', '1'))
+eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size, precision=prec)
 target = torch.cat([synth.make_images(size, 1, seed=1000 + i) for i in range(B)]).to(dev)
 noises = [torch.cat([synth.make_noises(size, 1, seed=2000 + i)[k] for i in range(B)]).to(dev) for k in range(17)]
 w0 = torch.cat([synth.make_latents(size, 1, seed=3000 + i, std=0.3) for i in range(B)]).to(dev)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-w, l = WPlusInverter(eng).invert(target, w0, noises, steps=steps)
+w, l = WPlusInverter(eng).invert(target, w0, noises, steps=steps, streams=streams)
 torch.cuda.synchronize()
-print(f'{steps} W+ steps, batch {B}: {(time.perf_counter() - t0) * 1e3:.1f} ms, final loss {l[-1].mean().item():.6f}')
+print(f'{steps} W+ steps ({prec}, {streams} stream(s)), batch {B}: {(time.perf_counter() - t0) * 1e3:.1f} ms, final loss {l[-1].mean().item():.6f}')
