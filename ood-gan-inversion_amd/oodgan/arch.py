@@ -255,10 +255,11 @@ class ood_faceGAN_e4e(nn.Module):
         return out
 
     # ---------------------------------------------------------------- build-defined: W+ refinement
-    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, use_graph=False, **kwargs):
+    def invert(self, x, steps=100, lr=0.01, noise=None, streams=1, use_graph=False, lpips_weight=0.0, lpips_state=None, **kwargs):
         """Optimisation-based inversion: w0 = encoder latents (+avg+delta), ``steps``
         Adam steps on per-image MSE with fixed noise, then ONE full OOD forward with the refined
-        latents (masks + blend).  Returns (out, lats, losses[steps,B]).
+        latents (masks + blend).  Returns (out, lats, losses[steps,B]).  ``lpips_weight`` > 0 adds that multiple of LPIPS(alex) per image to the
+        loss (opt-in; ``losses`` is then the total, ``self.last_loss_terms`` holds the two tables).
         ``streams`` (opt-in; ``bench.py`` uses 2, the CLI's ``inversion.streams`` sets it): the W+ loop advances the batch as
         that many independent sub-batches on concurrent HIP streams (images are independent; the HBM-bound layout
         kernels of one sub-batch run beside the matrix kernels of the other: +4 % at batch 8).  The
@@ -273,8 +274,20 @@ class ood_faceGAN_e4e(nn.Module):
         B = x.shape[0]
         if noise is None:
             noise = [n.expand(B, -1, -1, -1).contiguous() for n in self.generator.make_noise()]
-        inv = WPlusInverter(self.generator.engine(), lr=lr)
+        lp = None
+        if lpips_weight:
+            # loss = MSE + lpips_weight * LPIPS(alex) (reference loss class: src/losses/lpips_loss.py:13-34, min_max = the generator's (-1, 1)).
+            # ``lpips_state``: the lpips package's state dict; None = the seeded stand-in (weights absent here: parity unpinned)
+            from .lpips import LPIPSAlex
+            from .synth import lpips_state as _seeded
+            key = id(lpips_state)
+            if getattr(self, '_lpips_key', None) != key:
+                st = lpips_state if lpips_state is not None else _seeded(0)
+                self._lpips_net, self._lpips_key = LPIPSAlex({k: v.to(x.device) for k, v in st.items()}, min_max=(-1.0, 1.0)), key
+            lp = self._lpips_net
+        inv = WPlusInverter(self.generator.engine(), lr=lr, lpips=lp, lpips_weight=lpips_weight)
         w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams, use_graph=use_graph)
+        self.last_loss_terms = inv.last_terms
         kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats', 'lats', 'noise')}
         out, lats = self._ood_forward(x, w, enc_feats, noise=noise, **kw)
         return out, lats, losses

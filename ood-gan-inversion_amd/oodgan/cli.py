@@ -82,6 +82,11 @@ def run(opts, wplus_steps=None, log=None):
     steps = int(wplus_steps if wplus_steps is not None else inv.get('wplus_steps', 0))
     lr = float(inv.get('lr', 0.01))
     streams = int(inv.get('streams', 1))
+    lpips_weight = float(inv.get('lpips_weight', 0.0))       # opt-in perceptual term of the W+ loss (oodgan/lpips.py)
+    lpips_state = torch.load(inv['lpips_path'], map_location='cpu') if inv.get('lpips_path') else None
+    if lpips_weight and lpips_state is None:
+        log.warning('inversion.lpips_weight without inversion.lpips_path: the LPIPS term runs on SEEDED AlexNet / lin weights (the lpips package\'s '
+                    'pretrained weights are not part of this build)')
     graphed = None
     if inv.get('graph', False) and steps == 0:
         from .arch import GraphedForward
@@ -99,7 +104,7 @@ def run(opts, wplus_steps=None, log=None):
             with torch.no_grad():
                 t0 = time.time()
                 if steps > 0:
-                    out = model.invert(x, steps=steps, lr=lr, streams=streams)[0]
+                    out = model.invert(x, steps=steps, lr=lr, streams=streams, lpips_weight=lpips_weight, lpips_state=lpips_state)[0]
                 else:
                     out = (graphed(x) if graphed is not None else model(x))[0]
                 torch.cuda.synchronize()

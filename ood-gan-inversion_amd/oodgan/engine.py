@@ -668,6 +668,10 @@ class _WRun:
         self.t = 0
         self.dev_t = torch.zeros(1, dtype=torch.int32, device=self.w.device) if dev_counter else None
         self.lbuf = torch.empty(steps, self.w.shape[0], device=self.w.device, dtype=torch.float32)
+        # optional LPIPS(alex) term (oodgan/lpips.py): the target's normalised taps once, a second loss table
+        self.lp = inv.lpips if (inv.lpips is not None and inv.lpips_weight != 0.0) else None
+        self.lp_target = self.lp.target_taps(target) if self.lp is not None else None
+        self.lp_table = torch.zeros(steps, self.w.shape[0], device=self.w.device, dtype=torch.float32) if self.lp is not None else None
         self.traj = [None] * steps if keep_traj else None
         self.mode0 = (eng.fused_bwd, eng.carry_range)            # what the caller asked for (tests run the exact loop on purpose)
         self.guard = (eng.fused_bwd or eng.carry_range) and inv.check_every > 0
@@ -690,10 +694,14 @@ class _WRun:
         if self.dev_t is not None:
             # loss row and Adam's step index from the device counter: the recorded step is the same launch list for every t
             _, gimg = ops.mse_loss_grad(img, self.target, self.gmul, table=self.lbuf, row_dev=self.dev_t)
+            if self.lp is not None:     # gimg += gmul * lambda * d(sum_b lpips_b)/d(img); values to row t of the second table
+                self.lp.loss_and_grad(img, gimg, inv.lpips_weight * self.gmul, table=self.lp_table, row_dev=self.dev_t, target_taps=self.lp_target)
             g = eng.backward(gimg, self.gmul, carry_scale=True)
             ops.adam_step_dev(self.w, g, self.m, self.v, self.dev_t, inv.lr, inv.betas, inv.eps)
         else:
             _, gimg = ops.mse_loss_grad(img, self.target, self.gmul, loss_out=self.lbuf[self.t])
+            if self.lp is not None:
+                self.lp_table[self.t].copy_(self.lp.loss_and_grad(img, gimg, inv.lpips_weight * self.gmul, target_taps=self.lp_target))
             g = eng.backward(gimg, self.gmul, carry_scale=True)
             ops.adam_step(self.w, g, self.m, self.v, self.t + 1, inv.lr, inv.betas, inv.eps)
 
@@ -815,8 +823,13 @@ class WPlusInverter:
     ``check_every`` / ``check_lag``: the range guard of ``_WRun`` (0 = flags read only by the caller).  ``last_stats`` after a call:
     {'steps_run': forward/backward pairs enqueued per (sub-)batch, 'rollbacks': windows repeated with exact scales}."""
 
-    def __init__(self, engine, lr=0.01, betas=(0.9, 0.999), eps=1e-8, check_every=10, check_lag=2, use_plan=None):
+    def __init__(self, engine, lr=0.01, betas=(0.9, 0.999), eps=1e-8, check_every=10, check_lag=2, use_plan=None, lpips=None, lpips_weight=0.0):
         self.engine, self.lr, self.betas, self.eps = engine, lr, betas, eps
+        # loss = per-image MSE + lpips_weight * LPIPS(alex) (north_star: "W+ Adam steps against LPIPS/L2"); ``lpips``: an oodgan.lpips.LPIPSAlex
+        # (min_max = the generator's output range).  Off by default: the `lpips` weights are third-party and absent here (parity unpinned).
+        # ``invert`` then returns the TOTAL loss per step and image; ``last_terms`` = {'mse', 'lpips'} tables.
+        self.lpips, self.lpips_weight = lpips, float(lpips_weight)
+        self.last_terms = None
         # launch plans (oodgan_plan_*): on unless OODGAN_USE_PLAN=0; the single-stream loop uses the device step counter with them
         self.use_plan = (os.environ.get('OODGAN_USE_PLAN', '1') != '0') if use_plan is None else bool(use_plan)
         self.check_every, self.check_lag = int(check_every), max(0, int(check_lag))
@@ -901,21 +914,31 @@ class WPlusInverter:
         self.last_plan = {'steps': [r.plan_steps for r in runs], 'launches': [r.plan_size for r in runs]}
         if streams == 1:
             r = runs[0]
-            return (r.w, r.lbuf, r.traj) if return_trajectory else (r.w, r.lbuf)
+            losses = self._total(r.lbuf, r.lp_table)
+            return (r.w, losses, r.traj) if return_trajectory else (r.w, losses)
         cur = torch.cuda.current_stream()
         for st in side:
             cur.wait_stream(st)
         w = torch.cat([r.w for r in runs], 0)
         losses = torch.cat([r.lbuf for r in runs], 1)
+        lp = torch.cat([r.lp_table for r in runs], 1) if runs[0].lp_table is not None else None
         for r in runs:                      # tensors produced on side streams are consumed on the caller's stream
             r.w.record_stream(cur)
             r.lbuf.record_stream(cur)
-        return w, losses
+            if r.lp_table is not None:
+                r.lp_table.record_stream(cur)
+        return w, self._total(losses, lp)
+
+    def _total(self, mse, lp):
+        self.last_terms = {'mse': mse, 'lpips': lp}
+        return mse if lp is None else mse + self.lpips_weight * lp
 
     def _invert_graph(self, target, w0, noises, steps, streams):
         """hipGraph replay of one captured W+ step per stream (measured 3 % slower than eager launches on this host; kept as an
         option).  A replayed step cannot change its arithmetic mid-run: the range flags are read at the end and a flagged inversion is
         repeated eagerly (with the per-window guard)."""
+        if self.lpips is not None and self.lpips_weight != 0.0:
+            raise NotImplementedError('use_graph with the LPIPS term: use the launch plans (default) instead')
         B = w0.shape[0]
         cur = torch.cuda.current_stream()
         side = _side_streams(w0.device, streams)

@@ -117,26 +117,31 @@ class LPIPSAlex:
         part = None
         if mode != 0:
             part = torch.empty(B, _lib.lib().oodgan_lpips_head_nparts(H * W), device=f.device, dtype=torch.float32)
-        check(_lib.lib().oodgan_lpips_head(_p(f), _p(n1), _p(lin), _p(out), _p(part), B, C, H * W, float(coef), mode, _stream()), 'lpips_head')
+        # the tap's value is the SPATIAL MEAN of d (lpips.spatial_average): its gradient carries 1 / HW
+        check(_lib.lib().oodgan_lpips_head(_p(f), _p(n1), _p(lin), _p(out), _p(part), B, C, H * W, float(coef) / (H * W), mode, _stream()), 'lpips_head')
         return out, part
 
-    def set_target(self, target):
-        """Channel-normalised taps of the target image(s) (fixed during an inversion): computed once."""
+    def target_taps(self, target):
+        """Channel-normalised taps of the target image(s) (fixed during an inversion): computed once per inversion."""
         img = target.detach().float().contiguous()
-        self.target = [self._head(f, None, None, 0.0, 0)[0] for f in self.taps(img)]
-        self.target_shape = tuple(img.shape)
+        return [self._head(f, None, None, 0.0, 0)[0] for f in self.taps(img)]
+
+    def set_target(self, target):
+        self.target = self.target_taps(target)
         return self
 
-    def loss_and_grad(self, pred, gimg=None, grad_mul=1.0, table=None, row_dev=None):
+    def loss_and_grad(self, pred, gimg=None, grad_mul=1.0, table=None, row_dev=None, target_taps=None):
         """Per-image LPIPS(pred, target) (B,) — or, with ``table`` (nrows,B) + ``row_dev``, written to row row_dev[0] of the table (returns
-        None) — and, if ``gimg`` is given, gimg += grad_mul * d(sum_b lpips_b)/d(pred).  ``set_target`` first."""
-        assert self.target is not None and tuple(pred.shape) == self.target_shape
+        None) — and, if ``gimg`` is given, gimg += grad_mul * d(sum_b lpips_b)/d(pred).  The target: ``target_taps`` (from
+        ``target_taps(target)``; the W+ loop's sub-batches each keep their own) or the one of ``set_target``."""
+        tgt = self.target if target_taps is None else target_taps
+        assert tgt is not None and tgt[0].shape[0] == pred.shape[0]
         img = pred.detach().float().contiguous()
         B, _, H, W = img.shape
         f = self.taps(img)
         hg, parts = [], []
         for k in range(5):
-            g_, part = self._head(f[k], self.target[k], self.layers[k]['lin'], grad_mul, 2 if k == 4 else 1)     # the deepest tap masks itself
+            g_, part = self._head(f[k], tgt[k], self.layers[k]['lin'], grad_mul, 2 if k == 4 else 1)     # the deepest tap masks itself
             hg.append(g_)
             parts.append(part)
         L = _lib.lib()
