@@ -51,7 +51,13 @@ def parse():
     ap.add_argument('--no-generator-fwd', action='store_true', help='skip the BASELINE configs[1] leg: plain generator forward at batch 4')
     ap.add_argument('--no-single-stream', action='store_true', help='skip the extra leg that times the same job on ONE HIP stream')
     ap.add_argument('--graph', type=int, default=0, help='1: replay each W+ step from a captured hipGraph')
-    ap.add_argument('--precision', default='f16s', choices=['f16s', 'f32'], help='conv arithmetic (see DESIGN.md §3)')
+    ap.add_argument('--precision', default='f16s-g2', choices=['f16s-g2', 'f16s', 'f32'],
+                    help="conv arithmetic (DESIGN.md §2): 'f16s-g2' = split-f16, 3 matrix instructions per product in the forward and 2 in the input-gradient "
+                         "convs (default since round 6: 100-step loss curve and dL/dW+ inside the same band as 'f16s'); 'f16s' = 3 everywhere; 'f32' = exact fp32 MFMA")
+    ap.add_argument('--no-plan', action='store_true', help='drive every W+ step launch by launch from Python instead of replaying the recorded launch plan (oodgan_plan_*)')
+    ap.add_argument('--no-b1', action='store_true', help="skip the B = 1 inversion leg (the reference CLI's per-file mode)")
+    ap.add_argument('--no-lpips', action='store_true', help='skip the leg that times the inversion with the LPIPS(alex) term in the loss')
+    ap.add_argument('--no-precision-ab', action='store_true', help="skip the leg that times the same job with precision 'f16s' (3 matrix instructions everywhere)")
     ap.add_argument('--force-launcher', action='store_true',
                     help='start the rank processes from this process even for --gpus 1 (the path `python bench.py --gpus N` takes for N > 1)')
     return ap.parse_args()
@@ -163,6 +169,7 @@ class ConvProbe:
 
     def __init__(self, ops):
         self.ops, self.orig, self.recs, self.on = ops, ops.conv3x3, [], False
+        self.recs_x = []        # the in-loop 1024² ModulatedConv2d (conv_f16s_stripx forward: fp32 F-form in / out): (e0, e1, bytes, flops)
 
     def install(self):
         probe = self
@@ -172,6 +179,16 @@ class ConvProbe:
             # work items (16x32-pixel tiles x 64-channel blocks) of the dominant kernel; layers with fewer than 256 of them
             # (4x4 ... 32x32 images) are dispatched to the latency-oriented instance conv_f16s_s1v2_kernel<1, 1, 2>
             items = ((H + 15) // 16) * ((W + 31) // 32) * B * ((M + 63) // 64)
+            if (probe.on and isinstance(x, probe.ops.FForm) and kw.get('xf_act') is None and mode == probe.ops.CONV_S1
+                    and not torch.cuda.is_current_stream_capturing()):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = probe.orig(x, wpk, M, mode, **kw)
+                e1.record()
+                # s (B Ci H² + B Co H² + Co Ci 9) + s B (512 + Ci), s = 4 (+ the 3-channel ToRGB sums it also writes)
+                probe.recs_x.append((e0, e1, 4.0 * (B * K * H * W + B * M * H * W + K * M * 9) + 4.0 * B * (512 + K) + (12.0 * B * H * W if kw.get('rgb') is not None else 0.0),
+                                     2.0 * B * K * M * 9 * H * W))
+                return r
             if torch.cuda.is_current_stream_capturing() or not (probe.on and mode == probe.ops.CONV_S1 and M >= 64 and K >= 64 and
                     (wpk.precision == 'f32' or (isinstance(x, probe.ops.SForm) and items >= 256))):
                 return probe.orig(x, wpk, M, mode, **kw)
@@ -195,6 +212,16 @@ class ConvProbe:
         self.ops.conv3x3 = conv3x3
         import oodgan.engine as eng
         eng.ops.conv3x3 = conv3x3
+
+    def summary_inloop(self):
+        if not self.recs_x:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _, _ in self.recs_x]
+        t, by, fl = sum(ms) / len(ms), self.recs_x[0][2], self.recs_x[0][3]
+        return dict(workload='the fp32-I/O ModulatedConv2d 3x3 32->32 @1024x1024 INSIDE the W+ loop (last styled conv of the generator, forward: in-kernel '
+                             'conversion of the F-form input, demodulation, noise, bias, lrelu, ToRGB sums)', kernel='conv_f16s_stripx_kernel<false, true, ...>',
+                    bound='hbm', achieved=round(by / t / 1e6, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(by / t / 1e6 / HBM_PEAK_GBPS, 4), ms=round(t, 4),
+                    alg_bytes=by, tflops=round(fl / t / 1e9, 1), launches=len(ms), measured_on='exclusive single-stream pass, HIP events around each launch')
 
     def summary(self):
         if not self.recs:
@@ -607,6 +634,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=dev)
 
+    if a.no_plan:
+        os.environ['OODGAN_USE_PLAN'] = '0'
     from oodgan import ops, synth
     ops.PRECISION = a.precision
     from oodgan.arch import ood_faceGAN_e4e
@@ -658,6 +687,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     probe.on = False
+    plan_snapshot = (model.last_invert_plan, model.last_invert_stats)       # of the LAST timed inversion (later legs overwrite them)
     per_rank = None
     if dist_on:
         mine = torch.tensor([dt, float(len(cpus) if cpus else 0), t_setup, float(torch.get_num_threads())], device=dev, dtype=torch.float64)
@@ -672,7 +702,7 @@ def main():
     def roofline_of(ps, where):
         if not ps:
             return None
-        f16s = a.precision == 'f16s'
+        f16s = a.precision in ('f16s', 'f16s-g2')
         peak = MFMA_F16_PEAK_TFLOPS if f16s else MFMA_F32_PEAK_TFLOPS
         return dict(bound='mfma', achieved=round(ps['tflops'], 3), peak=peak, unit='TFLOP/s',
                     frac=round(ps['tflops'] / peak, 4), traffic=pmc_traffic(a), traffic_per_instance=pmc_traffic_instances(a),
@@ -680,8 +710,10 @@ def main():
                            ' (plain 3x3 stride-1 implicit GEMM, >=64 input channels: forward + input gradient)',
                     measured_on=where,
                     alg_bytes_per_launch=ps['bytes_per_launch'],
-                    note=('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product, so its own ceiling is '
-                          'peak/3 = 833 TFLOP/s' if f16s else 'exact fp32 MFMA'),
+                    note=(('algorithmic flops; the split-f16 scheme issues 3 MFMAs per product in the forward instances (their ceiling: peak/3 = 833 TFLOP/s)'
+                           + (" and 2 in the input-gradient instances with precision 'f16s-g2' (x_hi * (w_hi + w_lo); ceiling peak/2 = 1250 TFLOP/s; 9 instead "
+                              'of 14 matrix instructions per 16x16 tile and 16-channel chunk)' if a.precision == 'f16s-g2' else ', forward and input gradient alike'))
+                          if f16s else 'exact fp32 MFMA'),
                     launches=ps['launches'], avg_launch_ms=round(ps['avg_ms'], 4),
                     alg_flops_per_launch=ps['flops_per_launch'], instances=ps.get('instances'),
                     instances_note=('achieved / frac average ALL launches of the kernel.  Since round 4 the forward launches in front of a ToRGB '
@@ -690,8 +722,11 @@ def main():
                                     'runs: the step is 0.1 ms shorter, these launches are ~25 % longer (DESIGN.md 13.9)') if f16s else None)
 
     if rank == 0:
-        roof_timed = roofline_of(probe.summary(), f'timed region ({a.streams} concurrent HIP streams: launches share the GPU)')
+        roof_timed = roofline_of(probe.summary(), f'timed region ({a.streams} concurrent HIP streams: launches share the GPU)'
+                                 + ('' if a.no_plan else '; with launch plans only the two Python-driven steps of every inversion pass the event wrapper'))
         roof = roof_timed
+        inloop = probe.summary_inloop()
+        probe.recs_x = []
         if a.streams > 1 and not a.no_roofline_events:
             # A launch duration is a property of the kernel only while the kernel owns the GPU.  The timed region advances
             # sub-batches on concurrent streams (matrix kernels of one beside the HBM-bound producers of the other), so its
@@ -701,11 +736,13 @@ def main():
             from oodgan.engine import WPlusInverter
             probe.recs, probe.on = [], True
             lats0, _ = model.encode(x, enc_lats=enc_lats, enc_feats=enc_feats)
-            WPlusInverter(model.generator.engine()).invert(x, lats0, noises, steps=a.roofline_steps, streams=1)
+            # launch by launch from Python (use_plan=False): the events sit around every launch of the kernel
+            WPlusInverter(model.generator.engine(), use_plan=False).invert(x, lats0, noises, steps=a.roofline_steps, streams=1)
             torch.cuda.synchronize()
             probe.on = False
             roof = roofline_of(probe.summary(), f'exclusive single-stream pass of the same workload (batch {B}, {a.roofline_steps} W+ steps) '
                                                 'inside bench.py right after the timed region')
+            inloop = probe.summary_inloop()
         # ---- the STEP against both roofs (north_star: "throughput ... as fraction of the HBM roofline"): wall time of one W+ step of the
         # timed region = (inversion - final OOD forward) / steps, the OOD forward timed alone right here (HIP events, same inputs)
         step_roof = None
@@ -721,6 +758,10 @@ def main():
             step_ms = (dt / a.steps * 1e3 - ood_ms) / max(a.wsteps, 1)
             alg_b, alg_f = wplus_step_algorithmic(B, size)
             pmc = pmc_step_traffic(a)
+            # the PMC bytes belong to ONE configuration (precision, batch, stream count: the sub-batch size selects kernels at the 32² / 64² layers);
+            # they are set against this run's wall time only when it is the same one
+            if pmc and int(pmc.get('streams', 1)) != a.streams:
+                pmc = None
             hbm_b = pmc.get('hbm_bytes_per_step') if pmc else None
             step_roof = dict(
                 wall_ms_per_wplus_step=round(step_ms, 4), ood_forward_ms=round(ood_ms, 3), streams=a.streams,
@@ -731,7 +772,8 @@ def main():
                 achieved_tbps_pmc=None if hbm_b is None else round(hbm_b / step_ms / 1e9, 3),
                 frac_hbm_pmc=None if hbm_b is None else round(hbm_b / step_ms / 1e6 / HBM_PEAK_GBPS, 4),
                 achieved_tflops=round(alg_f / step_ms / 1e9, 1), frac_mfma_f16_peak=round(alg_f / step_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
-                frac_of_3mfma_ceiling=round(3 * alg_f / step_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+                frac_of_issued_mfma_ceiling=round((2.5 if a.precision == 'f16s-g2' else 3.0) * alg_f / step_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4),
+                issued_mfma_per_product=('3 forward / 2 input gradient (f16s-g2): 2.5 on average over the step' if a.precision == 'f16s-g2' else 3),
                 peak_hbm_gbps=HBM_PEAK_GBPS, peak_mfma_tflops=MFMA_F16_PEAK_TFLOPS,
                 pmc_source=None if not pmc else pmc.get('source'),
                 note='one W+ step (generator forward + MSE + backward to W+ + Adam, batch %d) of the timed region: wall time = (inversion - final OOD '
@@ -752,6 +794,63 @@ def main():
             t2 = time.perf_counter()
             single = dict(streams=1, value=round(B / (t2 - t1), 4), unit='images/s', ms_per_step=round((t2 - t1) * 1e3, 2),
                           final_loss_mean=float(ml[-1].mean().item()), note='same workload on one HIP stream')
+        def timed_invert(m_, xb, nz, el, ef, **kw):
+            m_.invert(xb, steps=a.wsteps, noise=nz, enc_lats=el, enc_feats=ef, **kw)           # warm-up (plans, pools)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, _, ml = m_.invert(xb, steps=a.wsteps, noise=nz, enc_lats=el, enc_feats=ef, **kw)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1, ml
+
+        # ---- the launch plan of the timed inversion (oodgan_plan_*): launches per recorded step, steps replayed
+        plan_info = None if plan_snapshot[0] is None else dict(
+            enabled=not a.no_plan, launches_per_step=plan_snapshot[0]['launches'], steps_replayed=plan_snapshot[0]['steps'],
+            steps_run=plan_snapshot[1]['steps_run'], rollbacks=plan_snapshot[1]['rollbacks'],
+            note='steps 3..N of every (sub-)batch are one oodgan_plan_run call each (eager launches re-issued from C++); host cost per step measured by '
+                 'tools/plan_probe.py: 0.26 ms against 1.5 ms Python-driven (profiles/r6_plan_probe.txt); rollbacks = windows repeated with exact range scales')
+        # ---- image 0 of the timed batch against the REFERENCE's 100-step run from the same start latents (tests/golden/make_golden.py:
+        # gold_wplus_long('wplus_long_1024_bench0'): reference Generator autograd + torch.optim.Adam, fp32)
+        loss_check = None
+        fx = os.path.join(ROOT, 'tests', 'golden', 'wplus_long_1024_bench0.npz')
+        if rank == 0 and size == 1024 and a.wsteps == 100 and gidx[0] == 0 and os.path.exists(fx):
+            import numpy as np
+            ref = np.load(fx)['losses'][:, 0]
+            if ref.shape[0] == 100:
+                mine = losses[:, 0].double().cpu().numpy()
+                rel = abs(mine - ref) / ref
+                loss_check = dict(image=0, final_loss=float(mine[-1]), reference_final_loss=float(ref[-1]), rel_final=float(rel[-1]),
+                                  max_rel_steps_1_20=float(rel[:20].max()), max_rel_all_steps=float(rel.max()),
+                                  reference='reference Generator autograd + torch.optim.Adam, 100 steps, fp32 (tests/golden/wplus_long_1024_bench0.npz)')
+                assert rel[:20].max() < 1e-3 and rel[-1] < 1e-3, f'W+ loss curve of image 0 left the reference band: {loss_check}'
+        b1 = None
+        if not a.no_b1 and world == 1:
+            # the reference CLI's mode: one image at a time (run_ood_faceGAN_inversion.py:158-182)
+            dt1, ml1 = timed_invert(model, x[:1], [n[:1] for n in noises], enc_lats[:1], [f[:1] for f in enc_feats], streams=1)
+            b1 = dict(batch=1, value=round(1.0 / dt1, 4), unit='images/s', ms_per_inversion=round(dt1 * 1e3, 2), ms_per_wplus_step=round(dt1 * 1e3 / max(a.wsteps, 1), 3),
+                      final_loss=float(ml1[-1].mean().item()), note=f'B = 1: {a.wsteps} W+ steps + OOD forward of ONE image on one stream')
+        lp_leg = None
+        if not a.no_lpips and world == 1:
+            dtl, mll = timed_invert(model, x, noises, enc_lats, enc_feats, streams=a.streams, lpips_weight=0.8)
+            terms = model.last_loss_terms
+            lp_leg = dict(value=round(B / dtl, 4), unit='images/s', ms_per_step=round(dtl * 1e3, 2), lpips_weight=0.8,
+                          first_total_loss_mean=float(mll[0].mean().item()), final_total_loss_mean=float(mll[-1].mean().item()),
+                          final_mse_mean=float(terms['mse'][-1].mean().item()), final_lpips_mean=float(terms['lpips'][-1].mean().item()),
+                          note='the same inversion with loss = MSE + 0.8 * LPIPS(alex) (north_star: "W+ Adam steps against LPIPS/L2"; oodgan/lpips.py, csrc/lpips.hip: exact-fp32 MFMA '
+                               'convs). SEEDED AlexNet / lin weights — the lpips package and its weights are absent (SURVEY §8c): PARITY UNPINNED, timing only; never `value`')
+        prec_ab = None
+        if not a.no_precision_ab and world == 1 and a.precision == 'f16s-g2':
+            ops.PRECISION = 'f16s'
+            try:
+                m3 = ood_faceGAN_e4e(out_size=size, style_dim=512, encoder='E4E', enable_modulation=True, warp_scale=0.08, cycle_align=2, blend_with_gen=True,
+                                     ModSize=256, build_encoder=False)
+                m3.load_state_dict(synth.ood_state(size, seed=0), strict=True)
+                m3 = m3.to(dev).eval()
+                dt3, ml3 = timed_invert(m3, x, noises, enc_lats, enc_feats, streams=a.streams)
+                prec_ab = dict(precision='f16s', value=round(B / dt3, 4), unit='images/s', ms_per_step=round(dt3 * 1e3, 2), final_loss_mean=float(ml3[-1].mean().item()),
+                               note="the same job with 3 matrix instructions per product in the input-gradient convs too (the default until round 5)")
+                del m3
+            finally:
+                ops.PRECISION = a.precision
         gen_b4 = None
         if not a.no_generator_fwd and world == 1 and size == 1024:
             gen_b4 = generator_fwd_b4(a, dev)
@@ -771,7 +870,11 @@ def main():
             'metric': '1024² face inversions/sec (100 W+ steps)', 'value': round(gB * a.steps / dt, 4), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16-split (hi+lo f16 operands, 3 MFMA/product, f32 accumulate; fp32-equivalent)' if a.precision == 'f16s' else 'f32',
+            'dtype': {'f16s': 'f16-split (hi+lo f16 operands, 3 MFMA/product, f32 accumulate; fp32-equivalent)',
+                      'f16s-g2': 'f16-split (hi+lo f16 operands, f32 accumulate): 3 MFMA/product in every forward conv (fp32-equivalent), 2 in the input-gradient convs '
+                                 '(back-propagated gradient rounded to f16 before each contraction, weights keep hi+lo); dL/dW+ vs the float64 reference 1.4e-5..3.6e-5 '
+                                 "('f16s': 1.3e-5..2.6e-5, the reference's own fp32: 2.5e-5), 100-step loss curve within 5.5e-5 of the reference's",
+                      'f32': 'f32'}[a.precision],
             'data': 'synthetic',
             'config': {'workload': f'OOD inversion loop: {a.wsteps} W+ Adam steps (fixed noise, per-image MSE) + 1 OOD '
                                    f'forward (SAMM 2 cycles x 4 levels, mask blend), {size}x{size}, batch {B} per GPU',
@@ -782,6 +885,12 @@ def main():
             'step_roofline': step_roof,
             'roofline_timed_region': roof_timed if roof is not roof_timed else None,
             'modconv2d': modconv,
+            'modconv2d_in_loop': inloop,
+            'launch_plan': plan_info,
+            'loss_check': loss_check,
+            'wplus_b1': b1,
+            'wplus_lpips': lp_leg,
+            'precision_f16s': prec_ab,
             'single_stream': single,
             'end_to_end': e2e,
             'forward_only': fwd_only,

@@ -50,7 +50,8 @@ int oodgan_device_count(void);
  *                                                    offers a workspace (the encoder trunk at batch 1-4; 8192 measured: +2.7 ms per batch of 8)
  *   "stripx_waves"     OODGAN_STRIPX_WAVES     4     the FORWARD F-form strip conv of the 1024² level (oodgan_conv_args.x_fform = 1): 4 = one wave per SIMD
  *                                                    (csrc/conv_f16s_stripx.hip, round 3); 8 = two waves per SIMD, the K loop split over a wave pair with
- *                                                    de-phased producer / finisher roles (csrc/conv_f16s_stripx8.hip, round 5: measured equal)
+ *                                                    de-phased producer / finisher roles (csrc/experimental/conv_f16s_stripx8.hip, round 5: measured equal — retired from the default
+ *                                                    build in round 6: only in a library built with `make STRIPX8=1`, OODGAN_E_ARG otherwise)
  * oodgan_set_tunable returns OODGAN_E_ARG for an unknown name; oodgan_get_tunable returns -1 for one. */
 int oodgan_set_tunable(const char* name, long value);
 long oodgan_get_tunable(const char* name);

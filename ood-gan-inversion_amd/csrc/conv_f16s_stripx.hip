@@ -680,7 +680,11 @@ bool stripx_init() {
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_stripx_kernel<false, true, false, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, SXL<false>::SMEM), true);
     (void)once;
+#ifdef OODGAN_WITH_STRIPX8
     return zero_page() != nullptr && num_cus() > 0 && stripx8_init();
+#else
+    return zero_page() != nullptr && num_cus() > 0;
+#endif
 }
 
 // strips are cut into segments only when there are fewer strips than CUs (one workgroup per CU: 152 KB of LDS); tiles of 4 rows
@@ -785,7 +789,13 @@ int launch_s1_stripx(const oodgan_conv_args& a_in, const void* wpk16, const floa
             else hipLaunchKernelGGL((conv_f16s_stripx_kernel<true, false, false, false, false>), grid, block, SXL<true>::SMEM, st, p, w16);
         }
     } else if (tunable(OODGAN_TUN_STRIPX_WAVES) == 8) {
-        return launch_s1_stripx8_fwd(p, wpk16, st);      // two waves per SIMD, K split + specialised roles (conv_f16s_stripx8.hip)
+#ifdef OODGAN_WITH_STRIPX8
+        return launch_s1_stripx8_fwd(p, wpk16, st);      // two waves per SIMD, K split + specialised roles (experimental/conv_f16s_stripx8.hip)
+#else
+        set_error("conv3x3 F-form input: stripx_waves = 8 needs a library built with `make STRIPX8=1` (csrc/experimental/conv_f16s_stripx8.hip: measured "
+                  "equal to the 4-wave kernel in round 5 and retired from the default build in round 6)");
+        return OODGAN_E_ARG;
+#endif
     } else if (a.rgb_y) hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, true, false, true>), grid, block, SXL<false>::SMEM, st, p, w16);
     else hipLaunchKernelGGL((conv_f16s_stripx_kernel<false, false, false, true>), grid, block, SXL<false>::SMEM, st, p, w16);
     return check_launch("conv3x3_f16s_stripx");

@@ -20,7 +20,7 @@
 // The two instruction streams of a SIMD overlap each other's waits, and the matrix pipe sees the same 54 instructions per tile.
 // Arithmetic: identical products; the fp32 sums of the two channel blocks are added at the end instead of running through one chain
 // (tests/test_hip_stripx.py compares with the four-wave kernel and the S-form strip kernel at 1e-6).
-#include "stripx_common.hpp"
+#include "../stripx_common.hpp"
 
 namespace {
 

@@ -287,7 +287,7 @@ class ood_faceGAN_e4e(nn.Module):
             lp = self._lpips_net
         inv = WPlusInverter(self.generator.engine(), lr=lr, lpips=lp, lpips_weight=lpips_weight)
         w, losses = inv.invert(x, lats0, noise, steps=steps, streams=streams, use_graph=use_graph)
-        self.last_loss_terms = inv.last_terms
+        self.last_loss_terms, self.last_invert_stats, self.last_invert_plan = inv.last_terms, inv.last_stats, inv.last_plan
         kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats', 'lats', 'noise')}
         out, lats = self._ood_forward(x, w, enc_feats, noise=noise, **kw)
         return out, lats, losses

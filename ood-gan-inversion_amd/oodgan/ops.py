@@ -2,6 +2,7 @@
 through the C ABI, torch tensors out.  Names/arguments mirror the reference's op layer
 (src/ops/op/upfirdn2d.py:149, src/ops/op/fused_act.py:92) where one exists."""
 import ctypes
+import os
 import math
 
 import torch
@@ -734,7 +735,10 @@ def modconv_f16(x, packed, noise=None, noise_w=None, bias=None, out=None):
 
 
 USE_SFORM = True     # S1 convs of the generator engine take their input through an S-form conversion + LDS-DMA kernel
-PRECISION = 'f16s'   # default conv arithmetic: 'f16s' (split-f16, 3 MFMAs per product) or 'f32' (exact fp32 MFMA)
+# default conv arithmetic: 'f16s-g2' (round 6: split-f16 — 3 matrix instructions per product in every forward conv, 2 in the input-gradient convs of
+# the W+ loop, where the back-propagated gradient is rounded to f16 before each contraction; identical to 'f16s' for model(x)), 'f16s' (3 everywhere)
+# or 'f32' (exact fp32 MFMA).  Evidence for the default: tests/test_hip_wplus_long.py (100-step loss curves vs the reference), test_hip_grad2.py
+PRECISION = os.environ.get('OODGAN_PRECISION', 'f16s-g2')
 
 
 class PackedConv:

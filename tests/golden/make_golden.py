@@ -244,6 +244,9 @@ WPLUS_LONG = {
     'wplus_long_1024_f64': (1024, (WPLUS_1024_IMAGE,), 40, 'f64', (1, 5, 10, 20, 30, 40)),
     # image 0 of the bench batch (bench.py compares the per-image final loss of its timed inversion with this curve's end)
     'wplus_long_1024_img0': (1024, (0,), 100, 'f32', (10, 30, 60, 100)),
+    # ... from the latents bench.py's inversion STARTS from: encoder latents + avg_latent + delta_latent of synth.ood_state(1024, seed 0)
+    # (OOD_faceGAN_e4e_arch.py:264-267) — bench.py checks image 0 of its timed batch against this curve ('loss_check' in its JSON line)
+    'wplus_long_1024_bench0': (1024, (0,), 100, 'f32', (10, 30, 60, 100)),
 }
 
 
@@ -268,7 +271,11 @@ def gold_wplus_long(name):
     target = cat([synth.make_images(size, 1, seed=1000 + g) for g in gidx]).to(dt)
     per_n = [synth.make_noises(size, 1, seed=2000 + g) for g in gidx]
     noises = [cat([n[i] for n in per_n]).to(dt) for i in range(len(per_n[0]))]
-    w = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx]).to(dt).clone().requires_grad_(True)
+    w = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx]).to(dt)
+    if name.endswith('bench0'):
+        ood = synth.ood_state(size, seed=0)
+        w = w + ood['avg_latent'].reshape(1, 1, -1).to(dt) + ood['delta_latent'].to(dt)
+    w = w.clone().requires_grad_(True)
     opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
     g = {'image_indices': np.asarray(gidx, dtype=np.int64), 'steps': np.int64(steps)}
     losses = []

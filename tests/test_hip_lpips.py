@@ -101,11 +101,17 @@ def test_lpips_value_and_image_gradient_vs_oracle(dev, size, B, min_max):
     gimg = gimg0.clone()
     per = net.loss_and_grad(pred.to(dev), gimg, grad_mul=4.0)
     e_l = _rel(per.double().cpu(), per_ref.detach())
-    gerr = ((gimg - gimg0).double().cpu() / 4.0 - pr.grad).abs()
+    gmine = (gimg - gimg0).double().cpu() / 4.0
+    gerr = (gmine - pr.grad).abs()
     e_g = float(gerr.max() / pr.grad.abs().max())
-    # a ReLU input within fp32 rounding of zero, or two max-pool candidates within rounding of each other, legitimately route the gradient
-    # differently in fp32 and in the float64 oracle: a LOCAL difference (one receptive field), so besides the max the rms and the share of
-    # pixels touched are reported, and a failing max is accepted only when those say "one kink"
+    # A ReLU input within fp32 rounding of zero, or two max-pool candidates within rounding of each other, legitimately route the gradient
+    # differently in fp32 and in float64 (one flip in conv3..5 moves a whole receptive field by ~1e-3 of the maximum).  The yardstick is the
+    # oracle against itself: its own float32 autograd vs its float64 one; this build has to be as close to ONE of the two as they are to
+    # each other (and within 1e-3 outright where no decision flips)
+    p32 = pred.clone().requires_grad_(True)
+    LO.lpips_loss(P, p32, target, min_max=min_max, reduction='none')[1].sum().backward()
+    e_self = float((p32.grad.double() - pr.grad).abs().max() / pr.grad.abs().max())
+    e_g32 = float((gmine - p32.grad.double()).abs().max() / pr.grad.abs().max())
     g_rms = float(gerr.pow(2).mean().sqrt() / pr.grad.pow(2).mean().sqrt())
     g_frac = float((gerr > 1e-4 * pr.grad.abs().max()).double().mean())
     # features on the way (the conv1-as-3x3 rewrite, pools, convs)
@@ -114,9 +120,10 @@ def test_lpips_value_and_image_gradient_vs_oracle(dev, size, B, min_max):
     shift, scale = torch.tensor(LO.SHIFT).view(1, 3, 1, 1).double(), torch.tensor(LO.SCALE).view(1, 3, 1, 1).double()
     taps_ref = LO.alexnet_taps({k: v.double() for k, v in P.items()}, (a * pred.double() + b0 - shift) / scale)
     e_t = max(_rel(t.double().cpu(), r) for t, r in zip(taps, taps_ref))
-    print(f'LPIPS {size}² B={B} min_max={min_max}: values {per.tolist()} (oracle {per_ref.tolist()}), rel {e_l:.2e}; taps {e_t:.2e}; d/dimage rel {e_g:.2e} (rms {g_rms:.2e}, share of pixels off by > 1e-4 max: {g_frac:.2e})')
+    print(f'LPIPS {size}² B={B} min_max={min_max}: values {per.tolist()} (oracle {per_ref.tolist()}), rel {e_l:.2e}; taps {e_t:.2e}; d/dimage rel {e_g:.2e} vs the f64 oracle (rms {g_rms:.2e}, share of pixels off by > 1e-4 max: {g_frac:.2e}), {e_g32:.2e} vs the f32 oracle; '
+          f'oracle f32 vs f64: {e_self:.2e}')
     assert e_t < 1e-5 and e_l < 1e-4
-    assert e_g < 1e-3 or (e_g < 2e-2 and g_rms < 2e-4 and g_frac < 2e-3), (e_g, g_rms, g_frac)
+    assert min(e_g, e_g32) < max(1e-3, 3 * e_self), (e_g, e_g32, e_self, g_rms, g_frac)
     # the module with the reference's interface (src/losses/lpips_loss.py:13-34)
     from oodgan.lpips import LPIPS_Loss
     mod = LPIPS_Loss(loss_weight=0.8, min_max=min_max, state_dict=P)

@@ -27,10 +27,21 @@ def _rel(a, b):
 @pytest.mark.parametrize('waves', [8, 4])
 @pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 40, 96), (3, 8, 32), (1, 1024, 1024), (8, 256, 32)])
 def test_forward_with_fform_input(B, H, W, waves, tunable):
-    """waves = 8: conv_f16s_stripx8.hip (two waves per SIMD: K split over a wave pair, producer / finisher roles; the default);
-    waves = 4: the one-wave-per-SIMD kernel of round 3.  Both against the S-form strip kernel."""
+    """waves = 4: the one-wave-per-SIMD kernel of round 3 (the default); waves = 8: csrc/experimental/conv_f16s_stripx8.hip (two waves per SIMD:
+    K split over a wave pair, producer / finisher roles) — measured equal in round 5 and since round 6 only in a library built with
+    `make STRIPX8=1`: the default library must refuse the tunable's value loudly.  Both against the S-form strip kernel."""
     from oodgan import ops
     tunable('stripx_waves', waves)
+    if waves == 8:
+        with open(os.path.join(R_, 'ood-gan-inversion_amd', 'oodgan', 'liboodgan_hip.so'), 'rb') as f:
+            has8 = b'conv_f16s_stripx8_fwd_kernel' in f.read()          # the kernel's symbol: only in a `make STRIPX8=1` library
+        if not has8:
+            dev = torch.device('cuda:0')
+            xf = ops.FForm(torch.zeros(1, 32, 8, 32, device=dev))
+            wf = ops.pack_conv3x3(torch.zeros(32, 32, 3, 3, device=dev), precision='f16s')
+            with pytest.raises(RuntimeError, match='STRIPX8'):
+                ops.conv3x3(xf, wf, 32, ops.CONV_S1, in_scale=torch.ones(1, 32, device=dev), out_scale=torch.ones(1, 32, device=dev))
+            return
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(H * 7 + W)
     C = 32

@@ -13,7 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'ood-gan-inversion_amd', 'csrc', 'conv_f16s_stripx.hip')
-SRC8 = os.path.join(ROOT, 'ood-gan-inversion_amd', 'csrc', 'conv_f16s_stripx8.hip')      # the eight-wave forward instance: same inline-assembly discipline
+SRC8 = os.path.join(ROOT, 'ood-gan-inversion_amd', 'csrc', 'experimental', 'conv_f16s_stripx8.hip')      # the eight-wave forward instance: same inline-assembly discipline
 
 
 def regs(tok):
