@@ -256,7 +256,9 @@ def pmc_step_traffic(a):
     WRITE_SIZE over `tools/wplus_only.py` at two step counts, difference / step difference); None when not on file."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            return json.load(f).get(f'wplus_step_{a.precision}_b{a.batch}_s{a.size}')
+            rec = json.load(f)
+            base = f'wplus_step_{a.precision}_b{a.batch}_s{a.size}'
+            return rec.get(f'{base}_streams{a.streams}') or rec.get(base)         # the pass recorded at this run's stream count, if there is one
     except (OSError, ValueError):
         return None
 
@@ -275,19 +277,23 @@ def pmc_traffic(a):
         return None
 
 
-def wplus_step_algorithmic(B, size, channel_multiplier=2):
+def wplus_step_algorithmic(B, size, channel_multiplier=2, breakdown=False):
     """Algorithmic HBM bytes and flops of ONE steady-state W+ step (forward + backward to W+ + Adam) as the loop is scheduled
-    (DESIGN.md §4-5, §15): every tensor a launch must read or write counted once per launch, at 4 bytes per element (fp32, the 64-byte
+    (DESIGN.md §4-5): every tensor a launch must read or write counted once per launch, at 4 bytes per element (fp32, the 64-byte
     S-form / F-form records of 16 channels, and the phase-split S-form all hold 4 bytes per element); weights, noise maps, per-channel
     vectors and partial sums are left out (< 1 %).  flops = 2*B*K*M*9*H*W per styled conv forward and once more for its input gradient
-    (no weight gradients exist in this loop), + the ToRGB contractions; the folded-blur kernels' doubled taps are NOT counted."""
+    (no weight gradients exist in this loop), + the ToRGB contractions; the folded-blur kernels' doubled taps are NOT counted.
+    ``breakdown``: also the bytes per role of the step (tools/step_ledger.py sets them against the PMC bytes of the kernels playing the role)."""
     from oodgan.synth import generator_channels
     ch = generator_channels(channel_multiplier)
     e = 4.0 * B
-    by = fl = 0.0
+    roles = dict.fromkeys(('up-conv (transposed / one-pass)', 'up-conv tail (blur + noise + bias + act)', 'conv forward (+ ToRGB, next S-form)',
+                           'conv input gradient (+ dot)', 'blur^T + phase split', 'stride-2 conv + fused activation backward', 'MSE + skip pyramid'), 0.0)
+    fl = 0.0
     res = 4
     # 4x4: conv1 forward (in + out), its ToRGB, backward (g in, dotx, dx out)
-    by += e * ch[4] * 16 * (2 + 1 + 3)
+    roles['conv forward (+ ToRGB, next S-form)'] += e * ch[4] * 16 * 3
+    roles['conv input gradient (+ dot)'] += e * ch[4] * 16 * 3
     fl += 2 * 2.0 * B * ch[4] * ch[4] * 9 * 16
     cin = ch[4]
     while res < size:
@@ -296,22 +302,24 @@ def wplus_step_algorithmic(B, size, channel_multiplier=2):
         last = res == size
         # ---- forward
         if last and C <= 32:
-            by += e * (cin * q2 + C * r2)                  # one-pass up-conv (conv_f16s_upvb): S-form in, F-form out
+            roles['up-conv (transposed / one-pass)'] += e * (cin * q2 + C * r2)      # one-pass up-conv (conv_f16s_upvb): S-form in, F-form out
         else:
-            by += e * (cin * q2 + C * z2)                  # transposed conv: S-form in, (2H+1)² result out
-            by += e * (C * z2 + 2 * C * r2)                # blur + noise + bias + act: result in, fp32 planes + next conv's S-form out
-        by += e * (C * r2 + C * r2)                        # conv: S-form (F-form) in; out = S-form of the next up-conv only (64² ... 512²), F-form (last), fp32 (low res)
+            roles['up-conv (transposed / one-pass)'] += e * (cin * q2 + C * z2)      # transposed conv: S-form in, (2H+1)² result out
+            roles['up-conv tail (blur + noise + bias + act)'] += e * (C * z2 + 2 * C * r2)     # result in, fp32 planes + next conv's S-form out
+        # conv: S-form (F-form) in; out = S-form of the next up-conv only (64² ... 512²), F-form (last), fp32 (low res)
+        roles['conv forward (+ ToRGB, next S-form)'] += e * (C * r2 + C * r2)
         if res < 64:
-            by += e * (C * r2 + (0 if last else C * r2))   # low resolution: separate ToRGB pass reads the map (and writes the next S-form)
+            roles['conv forward (+ ToRGB, next S-form)'] += e * (C * r2 + (0 if last else C * r2))   # low resolution: separate ToRGB pass
         fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
         # ---- backward
-        by += e * 3 * C * r2                               # input gradient of the conv: gradient S-form (F-form: its own output) in, dotx in, dx out
-        by += e * (C * r2 + C * z2)                        # blur^T + phase split: pre-activation gradient in, phase-split S-form out
-        by += e * (C * z2 + 2 * cin * q2)                  # stride-2 conv + fused activation backward: phases in, saved activation in, S-form gradient out
+        roles['conv input gradient (+ dot)'] += e * 3 * C * r2                      # gradient S-form (F-form: its own output) in, dotx in, dx out
+        roles['blur^T + phase split'] += e * (C * r2 + C * z2)                       # pre-activation gradient in, phase-split S-form out
+        roles['stride-2 conv + fused activation backward'] += e * (C * z2 + 2 * cin * q2)   # phases in, saved activation in, S-form gradient out
         fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
         cin = C
-    by += e * 3 * size * size * 4                          # MSE: image + target in, gradient out; skip pyramid down (read once, write 1/4 + ...)
-    return by, fl
+    roles['MSE + skip pyramid'] += e * 3 * size * size * 4                         # image + target in, gradient out; skip pyramid down
+    by = sum(roles.values())
+    return (by, fl, roles) if breakdown else (by, fl)
 
 
 def modconv_roofline(iters=30, warmup=3):
@@ -719,7 +727,7 @@ def main():
                     instances_note=('achieved / frac average ALL launches of the kernel.  Since round 4 the forward launches in front of a ToRGB '
                                     '(three of the eight per W+ step) also produce the ToRGB partial sums and the S-form input of the next up-conv in '
                                     'their epilogue — the work of a separate HBM-bound pass (torgb_fwd_sform, 0.36 ms per step) that no longer '
-                                    'runs: the step is 0.1 ms shorter, these launches are ~25 % longer (DESIGN.md 13.9)') if f16s else None)
+                                    'runs: the step is 0.1 ms shorter, these launches are ~25 % longer (LABNOTES.md 13.9)') if f16s else None)
 
     if rank == 0:
         roof_timed = roofline_of(probe.summary(), f'timed region ({a.streams} concurrent HIP streams: launches share the GPU)'

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
     }
     // Forward: the noise of this wave's two rows, one dword per lane (lanes 0-31 row 0, 32-63 row 1) from clamped pixels, straight into
     // LDS with the first stage.  In the epilogue `if (ok) nz = noise[...]` was a branch around a load followed by its use, once per
-    // N-tile: four serialised round trips per tile in front of the stores (round 4: 620 -> see DESIGN 13.6 for the 512² layer).
+    // N-tile: four serialised round trips per tile in front of the stores (round 4: 620 -> see LABNOTES.md 13.6 for the 512² layer).
     const bool has_nz = !DOT && a.noise != nullptr;
     if (has_nz) {
         const int ry = min(r0 + wave * NT + (lane >> 5), H - 1), rx = min(c0 + (lane & 31), W - 1);

@@ -337,7 +337,7 @@ class GeneratorEngine:
                             # map at 128² ... 512²) disappears from the step
                             pending = ops.sform_scratch(B, L.cout, Hc, Wc, self.device, tag=4)
                             # both readers of the activation are served from the epilogue: without a backward pass to save it for, the fp32
-                            # tensor is not written at all (the epilogue's stores are what these launches wait for, §13.9)
+                            # tensor is not written at all (the epilogue's stores are what these launches wait for, LABNOTES.md §13.9)
                             # ... and inside the W+ loop the saved activation exists ONCE: the only reader of this layer's output in the
                             # backward pass is the fused epilogue of the stride-2 conv above (style-gradient dot + this layer's
                             # activation backward), which decodes it from the same S-form (oodgan_conv_args.dotx_sform)
@@ -633,7 +633,7 @@ def _side_streams(device, n):
 # Concurrent sub-batches (streams > 1): the 8-wave stride-1 kernel from 64 work items instead of 128.  A sub-batch of four images brings 64 items
 # to the 32² layers; on the 8-wave kernel they occupy 64 CUs for a short time and leave the rest of the chip to the other stream's launch, the
 # 4-wave ring kernel it replaces spreads 256 small workgroups over every CU.  Measured (bench.py, 2 streams, three boxes): 6.97-6.99 -> 7.10-7.16
-# img/s; on ONE stream (batch 8) the lower threshold moves the 16² layers and costs 1.3 % — hence only here.
+# img/s; on ONE stream (batch 8) the lower threshold moves the 16² layers and costs 1.3 % — hence only here (LABNOTES.md §14.6).
 MULTI_STREAM_S1_BIG_MIN_ITEMS = int(os.environ.get('OODGAN_MULTI_STREAM_S1_BIG_MIN_ITEMS', '64'))
 _S1_BIG_DEFAULT = 128
 

@@ -1,4 +1,4 @@
-// HBM yardstick for the copy-bound kernels of the W+ step: what a plain read+write stream of the 1024² activation
+// HBM yardstick for the copy-bound kernels of the W+ step (LABNOTES.md §13): what a plain read+write stream of the 1024² activation
 // tensor — (8,32,1024,1024) fp32 = 1.07 GB in, 1.07 GB out — reaches on this part, as a function of the number of independent 16-byte
 // loads a lane keeps in flight, the store policy and the grid size.  Stand-alone (no torch):
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/copy_probe.hip -o tools/probes/build/copy_probe && tools/probes/build/copy_probe

@@ -1,4 +1,4 @@
-// Memory-pattern probe for the strip-walking producers: the same strip walk (workgroup = 16 channels x 64 columns,
+// Memory-pattern probe for the strip-walking producers (LABNOTES.md §12.8): the same strip walk (workgroup = 16 channels x 64 columns,
 // 32-row segments, three rows requested ahead, buffers rotating by name) copying a (8, 32, 1024, 1024) fp32 tensor into F-form
 // records, once from NCHW planes (256-byte pieces per channel row, 16 planes per workgroup and row: what the blur reads today) and
 // once from F-form records (4 KB per workgroup and row: what it would read if the transposed convs wrote a channel-blocked z),
