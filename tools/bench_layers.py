@@ -89,6 +89,9 @@ for res in (4, 8, 16, 32, 64, 128, 256, 512, 1024):
         fl, by = 2.0 * B * C * C * 9 * H * H, 4.0 * B * 2 * C * H * H
         report(f'S1 fwd {C}->{C} @{H}', timeit(lambda: ops.conv3x3(xs, wf, C, ops.CONV_S1, out_scale=s, bias=bias, noise=nz, noise_weight=nw, act=ops.ACT_LRELU)), fl, by)
         report(f'S1 bwd+dot {C}->{C} @{H}', timeit(lambda: ops.conv3x3(xs, wb, C, ops.CONV_S1, out_scale=s, dotx=x)), fl, by * 1.5)
+        wb2 = ops.pack_conv3x3(w, transpose=True, flip=True, precision='f16s')
+        wb2.x_hi_only = True            # precision 'f16s-g2': two matrix instructions per product
+        report(f'S1 bwd+dot G2 {C}->{C} @{H}', timeit(lambda: ops.conv3x3(xs, wb2, C, ops.CONV_S1, out_scale=s, dotx=x)), fl, by * 1.5)
         del x, xs, nz
     if res == 4:
         continue
