@@ -638,6 +638,18 @@ MULTI_STREAM_S1_BIG_MIN_ITEMS = int(os.environ.get('OODGAN_MULTI_STREAM_S1_BIG_M
 _S1_BIG_DEFAULT = 128
 
 _FLAG = {}
+_PLAN_POOLS = {}
+
+
+def _plan_pool(device):
+    """The private allocator pool a launch plan is recorded under, ONE per (device, stream) for the life of the process: the buffers a recorded step
+    touched keep their addresses while the plan lives, and the next inversion's recording reuses the same blocks (a fresh pool per inversion would
+    hand ~5 GB back to the driver and take it again every time)."""
+    key = (str(device), ops._stream_handle())
+    pool = _PLAN_POOLS.get(key)
+    if pool is None:
+        pool = _PLAN_POOLS[key] = torch.cuda.MemPool()
+    return pool
 
 
 def _flag_stream(device):
@@ -712,7 +724,7 @@ class _WRun:
             self.plan_steps += 1
         elif (self.use_plan and self.eager_left == 0 and not self.exact_until and eng.fused_bwd and eng.carry_range
               and self.steps - self.t >= 3):
-            plan, pool = ops.LaunchPlan(), torch.cuda.MemPool()
+            plan, pool = ops.LaunchPlan(), _plan_pool(self.w.device)
             with torch.cuda.use_mem_pool(pool):
                 with plan.recording():
                     self._eager_step()
