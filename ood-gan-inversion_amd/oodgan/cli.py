@@ -98,9 +98,13 @@ def run(opts, wplus_steps=None, log=None):
         save_dir = os.path.join(save_root, name)
         model.delta_latent.data += direction.cuda()
         times, metrics = [], None
-        for f in files:
-            bgr = imgio.imread(f).astype(np.float64)
-            x = imgio.image_to_input(bgr, size, device='cuda')
+        # ``inversion.batch`` files per call (default 1 = the reference's per-file loop, run_ood_faceGAN_inversion.py:158-182): images are
+        # independent on this path, and the W+ loop of one image leaves most of the GPU idle (284 ms per image alone, 131 ms in a batch of 8)
+        nb = max(1, int(inv.get('batch', 1)))
+        for c0 in range(0, len(files), nb):
+            chunk = files[c0:c0 + nb]
+            bgrs = [imgio.imread(f).astype(np.float64) for f in chunk]
+            x = torch.cat([imgio.image_to_input(bgr, size, device='cuda') for bgr in bgrs], 0)
             with torch.no_grad():
                 t0 = time.time()
                 if steps > 0:
@@ -108,14 +112,15 @@ def run(opts, wplus_steps=None, log=None):
                 else:
                     out = (graphed(x) if graphed is not None else model(x))[0]
                 torch.cuda.synchronize()
-                times.append(time.time() - t0)
-            res = imgio.tensor2img(out, rgb2bgr=True, min_max=(-1, 1))
-            imgio.imwrite(os.path.join(save_dir, 'inversion', os.path.basename(f)), res)
-            gt = bgr if bgr.shape[:2] == (size, size) else imgio.tensor2img(x, rgb2bgr=True, min_max=(-1, 1)).astype(np.float64)
-            metrics = evaluate(gt, res, metrics, opts.get('metrics'))
-            masks = imgio.extract_masks(model.aligns, size)
-            if masks is not None:
-                imgio.imwrite(os.path.join(save_dir, 'masks', os.path.basename(f)), masks)
+                times += [(time.time() - t0) / len(chunk)] * len(chunk)
+            for k, (f, bgr) in enumerate(zip(chunk, bgrs)):
+                res = imgio.tensor2img(out[k:k + 1], rgb2bgr=True, min_max=(-1, 1))
+                imgio.imwrite(os.path.join(save_dir, 'inversion', os.path.basename(f)), res)
+                gt = bgr if bgr.shape[:2] == (size, size) else imgio.tensor2img(x[k:k + 1], rgb2bgr=True, min_max=(-1, 1)).astype(np.float64)
+                metrics = evaluate(gt, res, metrics, opts.get('metrics'))
+                masks = imgio.extract_masks(model.aligns, size, index=k)
+                if masks is not None:
+                    imgio.imwrite(os.path.join(save_dir, 'masks', os.path.basename(f)), masks)
         model.delta_latent.data -= direction.cuda()
         mean = lambda v: float(np.mean(v)) if v else float('nan')
         summary[name] = dict(n=len(files), time=mean(times), psnr=mean((metrics or {}).get('psnr')),

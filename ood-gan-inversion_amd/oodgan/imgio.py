@@ -87,19 +87,19 @@ def image_to_input(bgr, size=1024, device=None):
     return x
 
 
-def extract_masks(aligns, size=1024):
+def extract_masks(aligns, size=1024, index=0):
     """aligns: dict level -> (B,3,H,W); channel 2 of every level, nearest-resized to ``size`` and concatenated along
-    the width; returns the HxW*n uint8 strip of the first batch item (None on any failure, like the reference).
-    Device tensors go through ``oodgan_resize_nearest`` (one strip buffer, written in place); host tensors through ATen."""
+    the width; returns the HxW*n uint8 strip of batch item ``index`` (the reference's CLI feeds one image: item 0; None on any
+    failure, like the reference).  Device tensors go through ``oodgan_resize_nearest`` (one strip buffer, written in place); host tensors through ATen."""
     try:
         if all(v.is_cuda for v in aligns.values()):
             from . import samm
-            return tensor2img(samm.extract_masks(aligns, size)[0], min_max=(0, 1))
+            return tensor2img(samm.extract_masks(aligns, size)[index], min_max=(0, 1))
         masks = []
         for k in sorted(aligns.keys()):
             m = aligns[k][:, 2:, ...]
             masks.append(torch.nn.functional.interpolate(m.float(), size=(size, size)))
-        return tensor2img(torch.cat(masks, dim=3)[0], min_max=(0, 1))
+        return tensor2img(torch.cat(masks, dim=3)[index], min_max=(0, 1))
     except Exception:
         return None
 

@@ -198,6 +198,25 @@ def test_cli_end_to_end(tmp_path):
             from PIL import Image
             with Image.open(tmp_path / 'results' / 'OOD_faceGAN_e4e' / name / 'masks' / n) as im:
                 assert im.size == (5 * 1024, 1024)                # levels 1..4 and the composed 1024 mask, side by side
+    # round 6: `inversion.batch` — both files in ONE call of the model.  (Pixels are not comparable with the per-file run: without `noise=` the
+    # generator draws fresh noise maps per call, as the reference does — model.py:505-508 — so only the files, their geometry and the metrics'
+    # neighbourhood are checked; that a batched inversion equals the per-image one is tests/test_hip_wplus_long.py's subject.)
+    opts['inversion'] = dict(opts.get('inversion') or {}, batch=2)
+    opts['save_dir'] = str(tmp_path / 'results_b2')
+    with open(tmp_path / 'opt_b2.yml', 'w') as f:
+        yaml.safe_dump(opts, f)
+    summary2 = cli.main(['--opt', str(tmp_path / 'opt_b2.yml'), '--wplus-steps', '2'])
+    for name in summary2:
+        assert summary2[name]['n'] == 2 and abs(summary2[name]['psnr'] - summary[name]['psnr']) < 1.0 and summary2[name]['time'] > 0
+        for n in ('00001.png', '00002.png'):
+            a = imgio.imread(str(tmp_path / 'results_b2' / 'OOD_faceGAN_e4e' / name / 'inversion' / n))
+            assert a.shape == (1024, 1024, 3)
+            with Image.open(tmp_path / 'results_b2' / 'OOD_faceGAN_e4e' / name / 'masks' / n) as im:
+                assert im.size == (5 * 1024, 1024)
+        # the two images of a batch are different inversions (their own mask strips), not copies of item 0
+        m1 = imgio.imread(str(tmp_path / 'results_b2' / 'OOD_faceGAN_e4e' / name / 'masks' / '00001.png')).astype(np.int32)
+        m2 = imgio.imread(str(tmp_path / 'results_b2' / 'OOD_faceGAN_e4e' / name / 'masks' / '00002.png')).astype(np.int32)
+        assert np.abs(m1 - m2).max() > 0
 
 
 @pytest.mark.gpu
