@@ -860,6 +860,8 @@ class WPlusInverter:
         then share the GPU with the matrix kernels of the other instead of running back to back."""
         B = w0.shape[0]
         streams = max(1, min(int(streams), B))
+        if B == 0:          # an empty shard (oodgan/parallel.py hands a rank with no images an empty batch): nothing to launch
+            steps = 0
         if steps <= 0:
             w = w0.detach().clone().contiguous()
             empty = torch.empty(0, B, device=w0.device, dtype=torch.float32)

@@ -231,3 +231,18 @@ def test_launch_plan_is_bit_identical_to_the_python_driven_loop(dev, size, B, st
     assert inv_e.last_plan['steps'] == [0] * streams
     assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
     assert torch.equal(l_p2, l_e) and torch.equal(w_p2, w_e)
+
+
+def test_empty_batch_and_zero_steps(dev):
+    """Edge cases of the loop's interface: an empty batch (a rank whose shard is empty) and steps = 0 return the start latents and an empty loss
+    table without launching anything."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    size = 32
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=5).items()}, size)
+    noises = [n.to(dev) for n in synth.make_noises(size, 2, seed=7)]
+    inv = WPlusInverter(eng)
+    w, l = inv.invert(torch.empty(0, 3, size, size, device=dev), torch.empty(0, eng.n_latent, 512, device=dev), [n[:0] for n in noises], steps=5, streams=2)
+    assert w.shape == (0, eng.n_latent, 512) and l.shape == (0, 0)
+    w0 = synth.make_latents(size, 2, seed=14).to(dev)
+    w, l, traj = inv.invert(synth.make_images(size, 2, seed=9).to(dev), w0, noises, steps=0, return_trajectory=True)
+    assert torch.equal(w, w0) and l.shape == (0, 2) and traj == []
