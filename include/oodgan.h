@@ -593,10 +593,15 @@ int oodgan_adam_step_dev(float* w, const float* g, float* m, float* v, long n, f
  * oodgan_lpips_prep. */
 int oodgan_conv2d_s1(const float* x, const float* wpk, const float* bias, const float* add, const float* mask, float* y, int B, int K,
                      int M, int Hin, int Win, int ks, int pad, int relu, void* stream);
+/* y <- (y + add) * (mask > 0) in place, n elements (16-byte aligned): the epilogue of oodgan_conv2d_s1's backward use as a pass of its own, behind an
+ * input-gradient conv that ran on oodgan_conv3x3_f16s (the 3x3 layers of the stack on the split-f16 matrix kernels, oodgan/lpips.py) */
+int oodgan_add_mask(float* y, const float* add, const float* mask, long n, void* stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2) on (planes,H,W) -> (planes,(H-3)/2+1,(W-3)/2+1), and its backward merged with what surrounds
- * it in LPIPS: gx = (scatter of gy to each window's first maximum + add) * (x > 0), x being a ReLU output (add NULL = 0). */
-int oodgan_maxpool3s2_fwd(const float* x, float* y, long planes, int H, int W, void* stream);
-int oodgan_maxpool3s2_bwd(const float* x, const float* gy, const float* add, float* gx, long planes, int H, int W, void* stream);
+ * it in LPIPS: gx = (scatter of gy to each window's first maximum + add) * (x > 0), x being a ReLU output (add NULL = 0).  idx (optional, one byte
+ * per OUTPUT element): the forward records each window's argmax (dy*3+dx, first maximum in row-major order as torch keeps it) and the backward reads it
+ * instead of re-scanning the windows. */
+int oodgan_maxpool3s2_fwd(const float* x, float* y, unsigned char* idx, long planes, int H, int W, void* stream);
+int oodgan_maxpool3s2_bwd(const float* x, const float* gy, const float* add, const unsigned char* idx, float* gx, long planes, int H, int W, void* stream);
 /* image (B,3,H,W) -> conv1 operand (B,48,H/4+1,W/4+1): v = a*x + b0 (min_max -> [-1,1]: lpips_loss.py:27-29 followed by lpips'
  * normalize=True), lpips.ScalingLayer (v - shift[c]) / scale[c], zero pad 2, 4x4 space-to-depth (channel c*16 + dy*4 + dx).
  * shift3 / scale3 are HOST arrays of 3 floats.  H, W multiples of 4. */

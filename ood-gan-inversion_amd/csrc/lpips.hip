@@ -15,6 +15,7 @@
 // staged through LDS with the next chunk's global loads in flight under the matrix loop.  Epilogue: + bias, ReLU (forward) or
 // + add, x (mask > 0) (backward: the tap's own gradient joins the back-propagated one, then the ReLU below).
 #include "conv_common.hpp"
+#include <cstdint>
 
 using namespace oodgan;
 
@@ -165,43 +166,63 @@ __global__ __launch_bounds__(256) void conv2d_s1_kernel(const Conv2dArgs p) {
     }
 }
 
-// MaxPool2d(kernel 3, stride 2), no padding (torchvision AlexNet features[2], [5])
-__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W,
-                                                             int Ho, int Wo) {
+// MaxPool2d(kernel 3, stride 2), no padding (torchvision AlexNet features[2], [5]).  idx (optional): position dy*3+dx of the window's FIRST maximum in
+// row-major order — the element torch's max_pool2d routes the gradient to
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, long planes,
+                                                             int H, int W, int Ho, int Wo) {
     const long total = planes * Ho * Wo;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int ox = (int)(e % Wo), oy = (int)((e / Wo) % Ho);
         const long pl = e / ((long)Wo * Ho);
         const float* xp = x + pl * H * W + (long)(2 * oy) * W + 2 * ox;
         float m = xp[0];
+        int arg = 0;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, xp[dy * W + dx]);
+            for (int dx = 0; dx < 3; ++dx) {
+                const float v = xp[dy * W + dx];
+                if (v > m) { m = v; arg = dy * 3 + dx; }
+            }
         y[e] = m;
+        if (idx) idx[e] = (unsigned char)arg;
     }
 }
 
-// gx = (sum over the windows whose FIRST maximum (row-major scan, as torch's max_pool2d keeps its index) is this element of gy + add)
-//      * (x > 0)  — x is a ReLU output: the mask is the ReLU backward of the layer that produced it
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                             const float* __restrict__ add, float* __restrict__ gx, long planes, int H,
-                                                             int W, int Ho, int Wo) {
-    const long total = planes * H * W;
-    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int ix = (int)(e % W), iy = (int)((e / W) % H);
-        const long pl = e / ((long)W * H);
+// gx = (sum of gy over the windows whose first maximum is this element + add) * (x > 0) — x is a ReLU output: the mask is the ReLU backward of the
+// layer that produced it.  idx != NULL: the argmax table of the forward (<= 4 byte loads per element); NULL: the windows are re-scanned (36 loads)
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ add,
+                                                             const unsigned char* __restrict__ idx, float* __restrict__ gx, long planes, int H, int W,
+                                                             int Ho, int Wo) {
+    // block = 64 columns x 4 rows of one plane (grid: column blocks, row blocks, planes): no integer division per element — with the linear
+    // grid-stride form the three divisions by 255 / 127 were a third of the kernel
+    const int ix = blockIdx.x * 64 + (threadIdx.x & 63), iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    for (long pl = blockIdx.z; pl < planes; pl += gridDim.z) {
+        if (ix >= W || iy >= H) continue;
+        const long e = (pl * H + iy) * W + ix;
         const float xv = x[e];
         float g = add ? add[e] : 0.f;
-        if (xv > 0.f) {
+        const float* gp = gy + pl * Ho * Wo;
+        if (idx) {
+            // the <= 4 windows that hold (iy, ix): rows iy>>1 and, for even iy >= 2, (iy>>1) - 1; columns alike.  Unconditional loads from clamped
+            // windows, all eight in flight together, masks at the point of use (a load inside the window loop is a dependent round trip per window)
+            const unsigned char* ip = idx + pl * Ho * Wo;
+            const int ya = min(iy >> 1, Ho - 1), yb = max((iy >> 1) - 1, 0), xa = min(ix >> 1, Wo - 1), xb = max((ix >> 1) - 1, 0);
+            const bool vya = (iy >> 1) <= Ho - 1, vyb = !(iy & 1) && iy >= 2, vxa = (ix >> 1) <= Wo - 1, vxb = !(ix & 1) && ix >= 2;
+            const int i0 = ip[(long)ya * Wo + xa], i1 = ip[(long)ya * Wo + xb], i2 = ip[(long)yb * Wo + xa], i3 = ip[(long)yb * Wo + xb];
+            const float g0 = gp[(long)ya * Wo + xa], g1 = gp[(long)ya * Wo + xb], g2 = gp[(long)yb * Wo + xa], g3 = gp[(long)yb * Wo + xb];
+            const int pya = (iy - 2 * ya) * 3, pyb = (iy - 2 * yb) * 3, pxa = ix - 2 * xa, pxb = ix - 2 * xb;
+            g += (vya && vxa && i0 == pya + pxa) ? g0 : 0.f;
+            g += (vya && vxb && i1 == pya + pxb) ? g1 : 0.f;
+            g += (vyb && vxa && i2 == pyb + pxa) ? g2 : 0.f;
+            g += (vyb && vxb && i3 == pyb + pxb) ? g3 : 0.f;
+        } else {
             const float* xp = x + pl * H * W;
-            const float* gp = gy + pl * Ho * Wo;
             const int oy0 = max((iy - 1) / 2, 0), oy1 = min(iy / 2, Ho - 1);      // windows with 2 oy <= iy <= 2 oy + 2
             const int ox0 = max((ix - 1) / 2, 0), ox1 = min(ix / 2, Wo - 1);
             for (int oy = oy0; oy <= oy1; ++oy)
                 for (int ox = ox0; ox <= ox1; ++ox) {
                     if (2 * oy > iy || 2 * ox > ix) continue;
-                    // first maximum of the window in row-major order
                     float m = -INFINITY;
                     int arg = -1;
 #pragma unroll
@@ -213,10 +234,8 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const float* __rest
                         }
                     if (arg == (iy - 2 * oy) * 3 + (ix - 2 * ox)) g += gp[(long)oy * Wo + ox];
                 }
-            gx[e] = g;
-        } else {
-            gx[e] = 0.f;
         }
+        gx[e] = xv > 0.f ? g : 0.f;
     }
 }
 
@@ -262,53 +281,84 @@ __global__ __launch_bounds__(256) void lpips_img_grad_kernel(const float* __rest
 //          out = coef * d(d)/d(f0) = coef * ( r e_c - (sum_k e_k f0_k) r^2 / s * f0_c ),  e_c = 2 w_c (n0_c - n1_c), s = |f0|, r = 1/(s + eps)
 //          (the second term is dropped where s == 0: torch's sqrt backward gives NaN there, a pixel with all C ReLU outputs at zero)
 //   mode 2: mode 1 with out additionally multiplied by (f0 > 0) — the gradient w.r.t. the pre-activation of the LAST tap
-constexpr int kHeadBlock = 256;
+// Block = 32 pixels x 8 channel groups (lane = pixel: a wave's loads of one plane are two 128-byte runs; the channel sums cross the groups through
+// LDS): 8x the workgroups of a pixel-per-thread form — the 63² taps of a 1024² image are 3969 pixels x 256-384 channels per image, 128 workgroups
+// of 256 threads on 256 CUs (322 us per tap, latency-bound) before, 1000 now.
+constexpr int kHeadPix = 32, kHeadCg = 8, kHeadBlock = kHeadPix * kHeadCg;
 __global__ __launch_bounds__(kHeadBlock) void lpips_head_kernel(const float* __restrict__ f0, const float* __restrict__ n1,
                                                                 const float* __restrict__ w, float* __restrict__ out,
                                                                 float* __restrict__ part, int C, long HW, float coef, int mode, int nblk) {
+    __shared__ float red[2][kHeadCg][kHeadPix];
     const int b = blockIdx.y;
-    const long pix = blockIdx.x * (long)kHeadBlock + threadIdx.x;
+    const int pl = threadIdx.x & (kHeadPix - 1), cg = threadIdx.x / kHeadPix;
+    const long pix = blockIdx.x * (long)kHeadPix + pl;
     const bool ok = pix < HW;
     const long p0 = ok ? pix : HW - 1;
     const float* fb = f0 + (long)b * C * HW + p0;
     float s2 = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = cg; c < C; c += kHeadCg) {
         const float v = fb[(long)c * HW];
         s2 += v * v;
     }
+    red[0][cg][pl] = s2;
+    __syncthreads();
+    s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kHeadCg; ++k) s2 += red[0][k][pl];          // the same order in every group: one value per pixel
     const float s = sqrtf(s2), r = 1.f / (s + 1e-10f);
     float* ob = out + (long)b * C * HW + p0;
-    float d = 0.f;
     if (mode == 0) {
         if (ok)
-            for (int c = 0; c < C; ++c) ob[(long)c * HW] = fb[(long)c * HW] * r;
-    } else {
-        const float* nb = n1 + (long)b * C * HW + p0;
-        float dotk = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float f = fb[(long)c * HW], df = f * r - nb[(long)c * HW], wc = w[c];
-            d += wc * df * df;
-            dotk += 2.f * wc * df * f;
-        }
-        const float q = s > 0.f ? dotk * r * r / s : 0.f;
-        if (ok)
-            for (int c = 0; c < C; ++c) {
-                const float f = fb[(long)c * HW], df = f * r - nb[(long)c * HW];
-                const float gv = coef * (2.f * w[c] * df * r - q * f);
-                ob[(long)c * HW] = (mode == 2 && !(f > 0.f)) ? 0.f : gv;      // mode 2: the deepest tap — nothing joins it, its own ReLU mask here
-            }
-        // deterministic block sum of d
-        __shared__ float red[kHeadBlock / 64];
-        float v = ok ? d : 0.f;
-        v = wave_sum(v);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t = 0.f;
-            for (int i = 0; i < kHeadBlock / 64; ++i) t += red[i];
-            part[(long)b * nblk + blockIdx.x] = t;
-        }
+            for (int c = cg; c < C; c += kHeadCg) ob[(long)c * HW] = fb[(long)c * HW] * r;
+        return;
     }
+    const float* nb = n1 + (long)b * C * HW + p0;
+    float d = 0.f, dotk = 0.f;
+    for (int c = cg; c < C; c += kHeadCg) {
+        const float f = fb[(long)c * HW], df = f * r - nb[(long)c * HW], wc = w[c];
+        d += wc * df * df;
+        dotk += 2.f * wc * df * f;
+    }
+    __syncthreads();                       // every group has read red[0]
+    red[0][cg][pl] = d;
+    red[1][cg][pl] = dotk;
+    __syncthreads();
+    d = dotk = 0.f;
+#pragma unroll
+    for (int k = 0; k < kHeadCg; ++k) { d += red[0][k][pl]; dotk += red[1][k][pl]; }
+    const float q = s > 0.f ? dotk * r * r / s : 0.f;
+    if (ok)
+        for (int c = cg; c < C; c += kHeadCg) {
+            const float f = fb[(long)c * HW], df = f * r - nb[(long)c * HW];
+            const float gv = coef * (2.f * w[c] * df * r - q * f);
+            ob[(long)c * HW] = (mode == 2 && !(f > 0.f)) ? 0.f : gv;      // mode 2: the deepest tap — nothing joins it, its own ReLU mask here
+        }
+    // deterministic block sum of d over the block's pixels (group 0 holds the per-pixel totals)
+    if (cg == 0) {
+        float v = ok ? d : 0.f;
+#pragma unroll
+        for (int o = kHeadPix / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (pl == 0) part[(long)b * nblk + blockIdx.x] = v;
+    }
+}
+
+// y = (y + add) * (mask > 0), in place: the tap's gradient joins the back-propagated one, then the ReLU below — behind an input-gradient conv that ran
+// on the split-f16 kernels of oodgan_conv3x3_f16s (their epilogue has no such term)
+__global__ __launch_bounds__(256) void add_mask_kernel(float* __restrict__ y, const float* __restrict__ add, const float* __restrict__ mask, long n4) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(y)[i];
+        const float4 a = reinterpret_cast<const float4*>(add)[i], m = reinterpret_cast<const float4*>(mask)[i];
+        v.x = m.x > 0.f ? v.x + a.x : 0.f;
+        v.y = m.y > 0.f ? v.y + a.y : 0.f;
+        v.z = m.z > 0.f ? v.z + a.z : 0.f;
+        v.w = m.w > 0.f ? v.w + a.w : 0.f;
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void add_mask_tail_kernel(float* __restrict__ y, const float* __restrict__ add, const float* __restrict__ mask, long n0, long n) {
+    const long i = n0 + blockIdx.x * 256L + threadIdx.x;
+    if (i < n) y[i] = mask[i] > 0.f ? y[i] + add[i] : 0.f;
 }
 
 struct FinishArgs {
@@ -355,17 +405,28 @@ extern "C" int oodgan_conv2d_s1(const float* x, const float* wpk, const float* b
     return check_launch("conv2d_s1");
 }
 
-extern "C" int oodgan_maxpool3s2_fwd(const float* x, float* y, long planes, int H, int W, void* stream) {
+extern "C" int oodgan_add_mask(float* y, const float* add, const float* mask, long n, void* stream) {
+    OODGAN_REQUIRE(y && add && mask && n > 0, "add_mask: bad args");
+    OODGAN_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0, "add_mask: 16-byte aligned tensors");
+    const long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(add_mask_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, as_stream(stream), y, add, mask, n4);
+    if (n4 * 4 < n) hipLaunchKernelGGL(add_mask_tail_kernel, dim3(1), dim3(256), 0, as_stream(stream), y, add, mask, n4 * 4, n);
+    return check_launch("add_mask");
+}
+
+extern "C" int oodgan_maxpool3s2_fwd(const float* x, float* y, unsigned char* idx, long planes, int H, int W, void* stream) {
     OODGAN_REQUIRE(x && y && planes > 0 && H >= 3 && W >= 3, "maxpool3s2_fwd: bad args");
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, 256)), dim3(256), 0, as_stream(stream), x, y, planes, H, W, Ho, Wo);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, 256)), dim3(256), 0, as_stream(stream), x, y, idx, planes, H, W, Ho, Wo);
     return check_launch("maxpool3s2_fwd");
 }
 
-extern "C" int oodgan_maxpool3s2_bwd(const float* x, const float* gy, const float* add, float* gx, long planes, int H, int W, void* stream) {
+extern "C" int oodgan_maxpool3s2_bwd(const float* x, const float* gy, const float* add, const unsigned char* idx, float* gx, long planes, int H, int W,
+                                     void* stream) {
     OODGAN_REQUIRE(x && gy && gx && planes > 0 && H >= 3 && W >= 3, "maxpool3s2_bwd: bad args");
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(stream_grid(planes * H * W, 256)), dim3(256), 0, as_stream(stream), x, gy, add, gx, planes, H, W, Ho, Wo);
+    const unsigned gz = (unsigned)(planes < 32768 ? planes : 32768);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, gz), dim3(256), 0, as_stream(stream), x, gy, add, idx, gx, planes, H, W, Ho, Wo);
     return check_launch("maxpool3s2_bwd");
 }
 
@@ -388,7 +449,7 @@ extern "C" int oodgan_lpips_img_grad(const float* g48, float* gimg, int B, int H
     return check_launch("lpips_img_grad");
 }
 
-extern "C" int oodgan_lpips_head_nparts(long HW) { return (int)((HW + kHeadBlock - 1) / kHeadBlock); }
+extern "C" int oodgan_lpips_head_nparts(long HW) { return (int)((HW + kHeadPix - 1) / kHeadPix); }
 
 extern "C" int oodgan_lpips_head(const float* f0, const float* n1, const float* w, float* out, float* part, int B, int C, long HW, float coef,
                                  int mode, void* stream) {

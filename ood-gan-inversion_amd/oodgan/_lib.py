@@ -146,8 +146,9 @@ _SIGS = {
     'oodgan_mse_fwd_bwd': (c_int, [P, P, P, P, P, c_int, c_long, c_float, P]),
     'oodgan_mse_fwd_bwd_row': (c_int, [P, P, P, P, P, P, c_int, c_int, c_long, c_float, P]),
     'oodgan_conv2d_s1': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    'oodgan_maxpool3s2_fwd': (c_int, [P, P, c_long, c_int, c_int, P]),
-    'oodgan_maxpool3s2_bwd': (c_int, [P, P, P, P, c_long, c_int, c_int, P]),
+    'oodgan_add_mask': (c_int, [P, P, P, c_long, P]),
+    'oodgan_maxpool3s2_fwd': (c_int, [P, P, P, c_long, c_int, c_int, P]),
+    'oodgan_maxpool3s2_bwd': (c_int, [P, P, P, P, P, c_long, c_int, c_int, P]),
     'oodgan_lpips_prep': (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, POINTER(c_float), POINTER(c_float), P]),
     'oodgan_lpips_img_grad': (c_int, [P, P, c_int, c_int, c_int, c_float, c_float, POINTER(c_float), P]),
     'oodgan_lpips_head': (c_int, [P, P, P, P, P, c_int, c_int, c_long, c_float, c_int, P]),

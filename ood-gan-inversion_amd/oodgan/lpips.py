@@ -12,12 +12,17 @@ image gradient (the MSE term's, inside the W+ loop) — forward and backward of 
 """
 import ctypes
 import math
+import os
 
 import torch
 
-from . import _lib
-from ._lib import check
+from . import _lib, ops
+from ._lib import ACT_NONE, ACT_PRELU, CONV_S1, check
 from .ops import _p, _stream
+
+# AlexNet's 3x3 layers (conv3-5: 57 % of the stack's flops) on the split-f16 matrix kernels of the generator (S-form + 8-wave stride-1 kernel: fp32-class
+# arithmetic at ~6x the exact-fp32 MFMA rate; ReLU = PReLU with zero slopes); 0: every layer on the exact-fp32 kernel of csrc/lpips.hip
+USE_F16S_3X3 = os.environ.get('OODGAN_LPIPS_F16S', '1') != '0'
 
 SHIFT = (-.030, -.088, -.188)          # lpips.ScalingLayer
 SCALE = (.458, .448, .450)
@@ -71,13 +76,27 @@ class LPIPSAlex:
                 ks, pad = 3, 0
             else:
                 ks, pad = k, (k - 1) // 2
-            self.layers.append(dict(wf=_pack(w, False), wb=_pack(w, True), bias=g(name + '.bias'), K=w.shape[1], M=co, ks=ks, pad=pad,
-                                    lin=g(f'lin{i}.model.1.weight').reshape(-1).contiguous()))
+            L = dict(wf=_pack(w, False), wb=_pack(w, True), bias=g(name + '.bias'), K=w.shape[1], M=co, ks=ks, pad=pad,
+                     lin=g(f'lin{i}.model.1.weight').reshape(-1).contiguous(), f16s=None)
+            if USE_F16S_3X3 and ks == 3 and pad == 1 and L['K'] % 16 == 0 and min(L['K'], co) >= 64:
+                L['f16s'] = (ops.pack_conv3x3(w, precision='f16s'), ops.pack_conv3x3(w, transpose=True, flip=True, precision='f16s'),
+                             torch.zeros(max(co, L['K']), device=dev))          # forward / input-gradient packings, zero PReLU slopes = ReLU
+            self.layers.append(L)
         self.target = None
 
     # ---- launches
     def _conv(self, x, L, fwd, add=None, mask=None):
         B, K, H, W = x.shape
+        if L['f16s'] is not None:
+            # S-form route: power-of-two range scale measured on the tensor (exact), conversion, 8-wave split-f16 kernel
+            mul2 = ops.absmax_mul2(x)
+            xs = ops.to_sform(x, None, mul2, out=ops.sform_scratch(B, K, H, W, x.device, tag=7))
+            if fwd:
+                return ops.conv3x3(xs, L['f16s'][0], L['M'], CONV_S1, bias=L['bias'], act=ACT_PRELU, slope=L['f16s'][2][:L['M']], in_mul2=mul2)
+            y = ops.conv3x3(xs, L['f16s'][1], L['K'], CONV_S1, act=ACT_NONE, in_mul2=mul2)
+            if add is not None:
+                check(_lib.lib().oodgan_add_mask(_p(y), _p(add), _p(mask), y.numel(), _stream()), 'add_mask')
+            return y
         ks = L['ks']
         pad = L['pad'] if fwd else ks - 1 - L['pad']
         M = L['M'] if fwd else L['K']
@@ -87,29 +106,33 @@ class LPIPSAlex:
                                           H, W, ks, pad, 1 if fwd else 0, _stream()), 'conv2d_s1')
         return y
 
-    def _pool(self, x):
+    def _pool(self, x, want_idx=False):
         B, C, H, W = x.shape
         y = torch.empty(B, C, (H - 3) // 2 + 1, (W - 3) // 2 + 1, device=x.device, dtype=torch.float32)
-        check(_lib.lib().oodgan_maxpool3s2_fwd(_p(x), _p(y), B * C, H, W, _stream()), 'maxpool_fwd')
-        return y
+        idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8) if want_idx else None       # each window's argmax, for the backward
+        check(_lib.lib().oodgan_maxpool3s2_fwd(_p(x), _p(y), _p(idx), B * C, H, W, _stream()), 'maxpool_fwd')
+        return (y, idx) if want_idx else y
 
-    def _pool_bwd(self, x, gy, add):
+    def _pool_bwd(self, x, gy, add, idx=None):
         B, C, H, W = x.shape
         gx = torch.empty_like(x)
-        check(_lib.lib().oodgan_maxpool3s2_bwd(_p(x), _p(gy), _p(add), _p(gx), B * C, H, W, _stream()), 'maxpool_bwd')
+        check(_lib.lib().oodgan_maxpool3s2_bwd(_p(x), _p(gy), _p(add), _p(idx), _p(gx), B * C, H, W, _stream()), 'maxpool_bwd')
         return gx
 
-    def taps(self, img):
-        """The five ReLU outputs of the AlexNet feature stack for img (B,3,H,W) in this object's min_max range."""
+    def taps(self, img, want_idx=False):
+        """The five ReLU outputs of the AlexNet feature stack for img (B,3,H,W) in this object's min_max range (``want_idx``: + the argmax tables
+        of the two max-pools, for the backward)."""
         B, _, H, W = img.shape
         x48 = torch.empty(B, 48, H // 4 + 1, W // 4 + 1, device=img.device, dtype=torch.float32)
         check(_lib.lib().oodgan_lpips_prep(_p(img), _p(x48), B, H, W, self.a, self.b0, self.shift, self.scale, _stream()), 'lpips_prep')
         t1 = self._conv(x48, self.layers[0], True)
-        t2 = self._conv(self._pool(t1), self.layers[1], True)
-        t3 = self._conv(self._pool(t2), self.layers[2], True)
+        p1, i1 = self._pool(t1, True)
+        t2 = self._conv(p1, self.layers[1], True)
+        p2, i2 = self._pool(t2, True)
+        t3 = self._conv(p2, self.layers[2], True)
         t4 = self._conv(t3, self.layers[3], True)
         t5 = self._conv(t4, self.layers[4], True)
-        return [t1, t2, t3, t4, t5]
+        return ([t1, t2, t3, t4, t5], (i1, i2)) if want_idx else [t1, t2, t3, t4, t5]
 
     def _head(self, f, n1, lin, coef, mode):
         B, C, H, W = f.shape
@@ -138,7 +161,7 @@ class LPIPSAlex:
         assert tgt is not None and tgt[0].shape[0] == pred.shape[0]
         img = pred.detach().float().contiguous()
         B, _, H, W = img.shape
-        f = self.taps(img)
+        f, (pidx1, pidx2) = self.taps(img, want_idx=True)
         hg, parts = [], []
         for k in range(5):
             g_, part = self._head(f[k], tgt[k], self.layers[k]['lin'], grad_mul, 2 if k == 4 else 1)     # the deepest tap masks itself
@@ -161,9 +184,9 @@ class LPIPSAlex:
             g4 = self._conv(hg[4], self.layers[4], False, add=hg[3], mask=f[3])
             g3 = self._conv(g4, self.layers[3], False, add=hg[2], mask=f[2])
             gp2 = self._conv(g3, self.layers[2], False)                        # gradient w.r.t. pool2's output
-            g2 = self._pool_bwd(f[1], gp2, hg[1])
+            g2 = self._pool_bwd(f[1], gp2, hg[1], pidx2)
             gp1 = self._conv(g2, self.layers[1], False)
-            g1 = self._pool_bwd(f[0], gp1, hg[0])
+            g1 = self._pool_bwd(f[0], gp1, hg[0], pidx1)
             g48 = self._conv(g1, self.layers[0], False)                        # 3x3 "full": (B,48,H/4+1,W/4+1)
             check(L.oodgan_lpips_img_grad(_p(g48), _p(gimg), B, H, W, self.a, 1.0, self.scale, _stream()), 'lpips_img_grad')
         return out

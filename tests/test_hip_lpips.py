@@ -73,7 +73,8 @@ def test_maxpool3s2_forward_and_backward(dev, B, C, H, W):
     y = torch.empty(B, C, Ho, Wo, device=dev)
     L = _lib.lib()
     xd = x.to(dev)
-    _lib.check(L.oodgan_maxpool3s2_fwd(_p(xd), _p(y), B * C, H, W, _stream()), 'pool')
+    idx = torch.empty(B, C, Ho, Wo, device=dev, dtype=torch.uint8)
+    _lib.check(L.oodgan_maxpool3s2_fwd(_p(xd), _p(y), _p(idx), B * C, H, W, _stream()), 'pool')
     assert torch.equal(y.cpu(), ref.detach().float())
     gy = synth.normal('mp.g', (B, C, Ho, Wo), 2)
     add = synth.normal('mp.a', (B, C, H, W), 3)
@@ -81,8 +82,10 @@ def test_maxpool3s2_forward_and_backward(dev, B, C, H, W):
     want = ((gx_ref + add.double()) * (x.double() > 0)).float()
     gx = torch.empty(B, C, H, W, device=dev)
     gd, ad = gy.to(dev), add.to(dev)
-    _lib.check(L.oodgan_maxpool3s2_bwd(_p(xd), _p(gd), _p(ad), _p(gx), B * C, H, W, _stream()), 'pool bwd')
-    assert _rel(gx.cpu().double(), want.double()) < 1e-6
+    for use_idx in (True, False):           # with the forward's argmax table, and re-scanning the windows
+        gx.fill_(7.0)
+        _lib.check(L.oodgan_maxpool3s2_bwd(_p(xd), _p(gd), _p(ad), _p(idx) if use_idx else None, _p(gx), B * C, H, W, _stream()), 'pool bwd')
+        assert _rel(gx.cpu().double(), want.double()) < 1e-6
 
 
 @pytest.mark.parametrize('size,B,min_max', [(64, 2, (-1.0, 1.0)), (128, 1, (0.0, 1.0)), (256, 2, (-1.0, 1.0))])
