@@ -59,7 +59,7 @@ long oodgan_get_tunable(const char* name);
  * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
  * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb" (oodgan_upconv_vblur_fform), and the sub-counters of the fused epilogues:
  * "s1big_ys" (8-wave stride-1 launches that wrote `ys` / ToRGB partial sums), "s1big_g2" / "s2big_g2" / "stripx_g2" (input-gradient launches
- * that ran with x_hi_only, two matrix instructions per product), "s2big_fuse" (8-wave stride-2 launches with the fused activation
+ * that ran with x_hi_only, two matrix instructions per product), "s2big_xh" (... on 32-byte hi-only input records, x_hi_only = 2), "s2big_fuse" (8-wave stride-2 launches with the fused activation
  * backward), "s2big_dotx_sform" (... that decoded `dotx` from a saved S-form).  Host-side, one relaxed atomic increment per call; the reference has no
  * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
  * Returns -1 for an unknown name. */
@@ -256,7 +256,9 @@ typedef struct oodgan_conv_args {
                                 instructions per product instead of three.  The back-propagated gradient is then rounded to f16 (2^-11 relative,
                                 zero mean, independent per element) before each contraction while the weights keep their 22 bits; the reference
                                 has no counterpart (torch autograd runs the backward in fp32, model.py:233-274 through conv2d's backward) —
-                                tests bound dL/dW+ against the float64 reference and the 100-step loss curve against the reference Adam loop. */
+                                tests bound dL/dW+ against the float64 reference and the 100-step loss curve against the reference Adam loop.
+                                2 (mode S2 with a phase-split S-form input and dotx, shapes of oodgan_conv3x3_s2_fuse_supported): as 1, and x holds the
+                                32-byte hi-only records oodgan_act_bwd_blurT_sform_phases_hi writes (half the bytes written and read). */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -443,6 +445,14 @@ int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, con
                                       const float* s_rgb, int s_rgb_stride, float rgb_scale, const float* dscale,
                                       int dscale_stride, const float* mul2, const float* kernel, void* out_phases,
                                       float* part_r, float* part_t, float* part_max, int B, int C, int H, int W, void* stream);
+/* The same without a ToRGB branch and with HI-ONLY output (round 6, precision 'f16s-g2'): 32-byte records holding the hi f16 halves of the 16
+ * channels — record r of a phase plane at byte r*32 of the plane's first half of the SAME buffer geometry (oodgan_sform_phases_bytes) — for a
+ * consumer that never reads the lo halves: oodgan_conv3x3_f16s with oodgan_conv_args.x_hi_only = 2.  Halves the bytes this producer writes and
+ * that conv reads.  Exists where oodgan_act_bwd_blurT_hi_supported(H, W) says so (the strip walk). */
+int oodgan_act_bwd_blurT_hi_supported(int H, int W);
+int oodgan_act_bwd_blurT_sform_phases_hi(const float* g_feat, const float* out, const float* noise, int noise_batch, const float* noise_w,
+                                         const float* bias, const float* dscale, int dscale_stride, const float* mul2, const float* kernel,
+                                         void* out_phases, float* part_r, float* part_max, int B, int C, int H, int W, void* stream);
 int oodgan_absmax_scale_check(const float* part, long n, float* state, int* flag, void* stream);
 
 /* ---- batched tail of the W+ backward (csrc/bwd_tail.hip): per-layer jobs that only feed the style-gradient accumulator,

@@ -558,6 +558,8 @@ struct StripGeo {
     int nstrips, nseg, seg_rows;      // seg_rows: position rows per segment (>= 16)
     int tiles_x, tiles_y;             // partial-sum slot table of the tile kernel (nstrips <= tiles_x, nseg <= tiles_y)
     int extra;                        // 1: W is a multiple of the strip's positions — the last strip also emits position j = W
+    int hi_only;                      // 1 (round 6, oodgan_act_bwd_blurT_sform_phases_hi): 32-byte records, the hi halves only — record r of a phase plane
+                                      // at byte r*32 of that plane's FIRST half; the consumer is the two-instruction stride-2 conv (x_hi_only = 2)
 };
 
 // QN = float4 column groups per channel: the strip is SW = 4*QN g columns = 2*QN positions wide, the workgroup 16*QN threads.
@@ -805,9 +807,14 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu((PRE &&
                     h8[cc] = hh;
                     l8[cc] = (_Float16)(val - (float)hh);
                 }
-                half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
-                recp[hf] = h8;
-                recp[2 + hf] = l8;
+                if (geo.hi_only) {      // a lane pair = the 32 bytes of a record: a wave writes 32 consecutive records = 1 KB contiguous
+                    half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 2));
+                    recp[hf] = h8;
+                } else {
+                    half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + j) * 4));
+                    recp[hf] = h8;
+                    recp[2 + hf] = l8;
+                }
             }
             if (XTRA && xtra && tid < 16) {          // the four records of position j = W (px = 1 lies beyond the image: zeros)
                 const int ph = tid >> 2, sl = tid & 3, py = ph >> 1, px = ph & 1;
@@ -819,8 +826,12 @@ __global__ __launch_bounds__(16 * QN) __attribute__((amdgpu_waves_per_eu((PRE &&
                     const _Float16 hh = (_Float16)val;
                     o8[cc] = (sl & 2) ? (_Float16)(val - (float)hh) : hh;
                 }
-                half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + W) * 4));
-                recp[sl] = o8;
+                if (geo.hi_only) {
+                    if (sl < 2) reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + W) * 2))[sl] = o8;
+                } else {
+                    half8* recp = reinterpret_cast<half8*>(outp + ((((long)b * sp.KC + kc) * 4 + ph) * sp.plane + ((long)i * sp.Wq + W) * 4));
+                    recp[sl] = o8;
+                }
             }
         }
     };
@@ -984,12 +995,37 @@ extern "C" int oodgan_act_bwd_blurT_pre_supported(int H, int W) { return H >= 32
 
 extern "C" int oodgan_act_bwd_blurT_nparts(int H, int W) { return ((W + 1 + 31) / 32) * ((H + 1 + 3) / 4); }
 
+static int act_bwd_blurT_impl(const float* g_feat, const float* out, const float* noise, int noise_batch, const float* noise_w, const float* bias,
+                              const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale, const float* dscale,
+                              int dscale_stride, const float* mul2, const float* kernel, void* out_phases, float* part_r, float* part_t, float* part_max,
+                              int B, int C, int H, int W, void* stream, int hi_only);
+
+// 1 when oodgan_act_bwd_blurT_sform_phases_hi exists for an up-conv input of H x W: the strip walk only (no ToRGB branch)
+extern "C" int oodgan_act_bwd_blurT_hi_supported(int H, int W) { return H >= 32 && W >= 32 && blurT_strip_enabled() ? 1 : 0; }
+
 extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, const float* noise, int noise_batch,
                                                  const float* noise_w, const float* bias, const float* g_rgb,
                                                  const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale,
                                                  const float* dscale, int dscale_stride, const float* mul2,
                                                  const float* kernel, void* out_phases, float* part_r, float* part_t,
                                                  float* part_max, int B, int C, int H, int W, void* stream) {
+    return act_bwd_blurT_impl(g_feat, out, noise, noise_batch, noise_w, bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, dscale, dscale_stride, mul2, kernel,
+                              out_phases, part_r, part_t, part_max, B, C, H, W, stream, 0);
+}
+
+extern "C" int oodgan_act_bwd_blurT_sform_phases_hi(const float* g_feat, const float* out, const float* noise, int noise_batch,
+                                                    const float* noise_w, const float* bias, const float* dscale, int dscale_stride,
+                                                    const float* mul2, const float* kernel, void* out_phases, float* part_r, float* part_max,
+                                                    int B, int C, int H, int W, void* stream) {
+    OODGAN_REQUIRE(oodgan_act_bwd_blurT_hi_supported(H, W), "act_bwd_blurT hi-only records: the strip walk only (H, W >= 32, tunable blurt_strip)");
+    return act_bwd_blurT_impl(g_feat, out, noise, noise_batch, noise_w, bias, nullptr, nullptr, nullptr, 0, 0.f, dscale, dscale_stride, mul2, kernel,
+                              out_phases, part_r, nullptr, part_max, B, C, H, W, stream, 1);
+}
+
+static int act_bwd_blurT_impl(const float* g_feat, const float* out, const float* noise, int noise_batch, const float* noise_w, const float* bias,
+                              const float* g_rgb, const float* w_rgb, const float* s_rgb, int s_rgb_stride, float rgb_scale, const float* dscale,
+                              int dscale_stride, const float* mul2, const float* kernel, void* out_phases, float* part_r, float* part_t, float* part_max,
+                              int B, int C, int H, int W, void* stream, int hi_only) {
     ActArgs a;
     int rc = fill_args(a, g_feat, out, noise, noise_batch, noise_w, bias, g_rgb, w_rgb, s_rgb, s_rgb_stride, rgb_scale, dscale,
                        dscale_stride, mul2, part_r, part_t, part_max, B, C, 2 * H, 2 * W);
@@ -1011,6 +1047,7 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
         StripGeo geo;
         // the extra-column form saves the (W+1)-th strip and costs registers in every workgroup (20 spilled): it pays on the
         // narrowest layer only (64²: 87 -> 75 us; 128² and 256²: 139 -> 146, 252 -> 275)
+        geo.hi_only = hi_only;
         geo.extra = ((W % (2 * QN)) == 0 && W <= 32) ? 1 : 0;
         geo.nstrips = geo.extra ? W / (2 * QN) : (W + 1 + 2 * QN - 1) / (2 * QN);
         geo.tiles_x = tiles_x;
@@ -1037,6 +1074,7 @@ extern "C" int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const floa
 #undef OODGAN_STRIP_LAUNCH
         return check_launch("act_bwd_blurT_sform_phases/strip");
     }
+    OODGAN_REQUIRE(!hi_only, "act_bwd_blurT hi-only records: not reachable (strip walk refused this call)");
     if (g_rgb)
         hipLaunchKernelGGL(act_bwd_blurT_sp_kernel<true>, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, kernel,
                            reinterpret_cast<uint4*>(out_phases), H, W, d, tiles_x, tiles_y);

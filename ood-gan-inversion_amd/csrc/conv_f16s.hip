@@ -490,6 +490,9 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
                    "(oodgan_conv3x3_s2_fuse_supported)");
     OODGAN_REQUIRE(a.ys_vmax == nullptr || (a.ys != nullptr && a.mode == OODGAN_CONV_S1 && a.x_sform && !tiny_eligible(a) && !s1_strip_eligible(a) && s1_big_eligible(a)),
                    "conv3x3_f16s: ys_vmax only with ys from the 8-wave stride-1 kernel (oodgan_conv3x3_s1_ys_supported)");
+    OODGAN_REQUIRE(a.x_hi_only != 2 || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.dotx && !tiny_eligible(a) && s2_big_eligible(a)),
+                   "conv3x3_f16s: x_hi_only = 2 (32-byte hi-only input records) exists only in the two-instruction 8-wave stride-2 kernel "
+                   "(mode S2, phase-split S-form input, dotx, a shape oodgan_conv3x3_s2_fuse_supported accepts)");
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:

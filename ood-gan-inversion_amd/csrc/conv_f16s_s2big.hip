@@ -117,7 +117,12 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
     const int H = p.Hout, W = p.Wout, M = a.M;
 
     // ---- per-lane DMA source offsets (bytes) of this wave's 5 x pieces, relative to the (b, chunk, py) base
+    // XH (G2 instances with oodgan_conv_args.x_hi_only == 2): x holds 32-byte hi-only records (oodgan_act_bwd_blurT_sform_phases_hi) — record r of a
+    // phase plane at byte r*32 of the plane's first half.  The LDS image is unchanged (64-byte records whose lo slots stay unwritten: this instance never
+    // reads them); the lanes of a DMA piece that would carry a lo slot are switched off: half the bytes from L2 / HBM, the same number of instructions
+    const bool xh = G2 && a.x_hi_only == 2;
     unsigned offx[5];
+    bool xok[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         int P = (wave + 8 * i) * 64 + lane;
@@ -125,7 +130,14 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         const int row = P / SB_ROWSLOTS, rem = P % SB_ROWSLOTS;
         const int px = rem / (SB_C * 4), q = rem % (SB_C * 4);
         const int c = q >> 2, s = ((q & 3) - ((c >> 2) & 3)) & 3;
-        offx[i] = (unsigned)(((long)px * p.sp.plane + ((long)(r0 + row) * p.sp.Wq + (c0 + c)) * 4 + s) * 16);
+        if (xh) {
+            // (the phase planes keep their stride: the 32-byte records fill the first half of each)
+            offx[i] = (unsigned)(((long)px * p.sp.plane + ((long)(r0 + row) * p.sp.Wq + (c0 + c)) * 2 + (s & 1)) * 16);
+            xok[i] = s < 2;
+        } else {
+            offx[i] = (unsigned)(((long)px * p.sp.plane + ((long)(r0 + row) * p.sp.Wq + (c0 + c)) * 4 + s) * 16);
+            xok[i] = true;
+        }
     }
     const long plane_bytes = p.sp.plane * 16;
     // grouped convolution (oodgan_conv_args.groups, plain epilogue only): the channel block selects its group's K input channels
@@ -147,8 +159,9 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
         if (j < 5) {
             unsigned char* dx_ = smem + (py ? C::OFF_XB : C::OFF_XA);
             const unsigned char* xsrc = xb + ((long)t * 4 + py * 2) * plane_bytes;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + offx[j]),
-                                             (lds_void*)(dx_ + (wave + 8 * j) * 1024), 16, 0, 0);
+            if (!G2 || xok[j])
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + offx[j]),
+                                                 (lds_void*)(dx_ + (wave + 8 * j) * 1024), 16, 0, 0);
             return;
         }
         const int i = j - 5;
@@ -760,8 +773,10 @@ int launch_s2_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     (void)once;
     const uint4* w16 = reinterpret_cast<const uint4*>(wpk16);
     const bool g2 = a.x_hi_only != 0 && a.dotx != nullptr;
+    OODGAN_REQUIRE(a.x_hi_only != 2 || (g2 && a.groups <= 1), "conv3x3 S2 big: hi-only input records (x_hi_only = 2) need dotx (the two-instruction instances) and no groups");
     if (g2) {
         count_dispatch(OODGAN_DC_S2BIG_G2);
+        if (a.x_hi_only == 2) count_dispatch(OODGAN_DC_S2BIG_XH);
         if (fuse) {
             if (mh2) hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 2, true, true>), dim3((unsigned)total), dim3(512), S2Cfg<2>::SMEM_FUSE, st, p, w16);
             else hipLaunchKernelGGL((conv_f16s_s2big_kernel<true, 1, true, true>), dim3((unsigned)total), dim3(512), S2Cfg<1>::SMEM_FUSE, st, p, w16);

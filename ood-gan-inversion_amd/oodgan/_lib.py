@@ -119,6 +119,8 @@ _SIGS = {
     'oodgan_act_bwd_blurT_nparts': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_pre_supported': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'oodgan_act_bwd_blurT_hi_supported': (c_int, [c_int, c_int]),
+    'oodgan_act_bwd_blurT_sform_phases_hi': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_absmax_scale_check': (c_int, [P, c_long, P, P, P]),
     'oodgan_reduce_batch': (c_int, [P, c_int, P]),
     'oodgan_demod_bwd_batch': (c_int, [P, c_int, P]),

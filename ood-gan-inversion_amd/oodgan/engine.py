@@ -101,6 +101,7 @@ class GeneratorEngine:
         self.conv_next_rgb = {a.name: b for a, b in zip(layers[:-1], layers[1:]) if a.kind == 'conv' and b.kind == 'rgb'}
         self.by_name = {L.name: L for L in layers}
         self.fuse_act_bwd = True     # activation backward of the conv layers inside the stride-2 conv's epilogue (carried scales)
+        self.hi_records = os.environ.get('OODGAN_HI_RECORDS', '1') != '0'    # f16s-g2: 32-byte hi-only gradient records between the blur^T producer and the stride-2 conv
         self.fused_rgb = True
         self.fuse_x = True           # 1024² level: F-form activations, the strip convs convert their input themselves (conv_f16s_stripx.hip)
         # the up-conv of that level in ONE pass (transposed conv + blur + noise + bias + activation -> F-form, csrc/conv_f16s_upvb.hip):
@@ -443,6 +444,13 @@ class GeneratorEngine:
                                      ctypes.c_void_p(d_all.data_ptr() + 4 * L.drow), self.DR, B, L.cin, L.cout, L.scale,
                                      ops._stream()), 'demod_fwd')
 
+    def _hi_records(self, B, L, Hd, Rg):
+        """precision 'f16s-g2': the gradient of an up-conv layer goes to its stride-2 input-gradient conv as 32-byte hi-only records when that
+        conv is the two-instruction 8-wave kernel (which never reads a lo half) and the producer is the strip walk (oodgan_act_bwd_blurT_sform_phases_hi):
+        half the bytes written by the one and read by the other."""
+        return bool(self.grad_hi_only and self.hi_records and Rg is None and ops.blurT_hi_supported(Hd, Hd)
+                    and ops.s2_fuse_supported(B, L.cout, L.cin, 2 * Hd + 1, 2 * Hd + 1))
+
     # ------------------------------------------------------------------ backward (w.r.t. latents only)
     def backward(self, gimg, grad_scale=1.0, carry_scale=False):
         """gimg (B,3,size,size), already multiplied by ``grad_scale`` -> dL/dlatent (B,n_latent,S).
@@ -514,12 +522,13 @@ class GeneratorEngine:
                     # g_feat already is g_pre: blur^T + phase split of one tensor; r = noise / bias term + s * dot of that conv
                     gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(None, g_feat, nz, L.noise_w, L.bias, d, st, gin, blur_kernel=self.k4x4_flip,
-                                                              jobs=jobs, dot_of=fused_pre)
+                                                              jobs=jobs, dot_of=fused_pre, hi_only=self._hi_records(B, L, Hd, Rg))
                     fused_pre = None
                 else:
                     gin = ops.sform_phases_scratch(B, L.cout, Hd, Hd, self.device)
                     rsum, tsum, part_m = ops.act_bwd_producer(out, g_feat, nz, L.noise_w, L.bias, d, st, gin,
-                                                              blur_kernel=self.k4x4_flip, t_into=t_into, jobs=jobs, **rgb_kw)
+                                                              blur_kernel=self.k4x4_flip, t_into=t_into, jobs=jobs,
+                                                              hi_only=self._hi_records(B, L, Hd, Rg), **rgb_kw)
                 mul2, g_pre = st, None
             else:
                 if Rg is not None:
@@ -641,11 +650,15 @@ _FLAG = {}
 _PLAN_POOLS = {}
 
 
-def _plan_pool(device):
-    """The private allocator pool a launch plan is recorded under, ONE per (device, stream) for the life of the process: the buffers a recorded step
-    touched keep their addresses while the plan lives, and the next inversion's recording reuses the same blocks (a fresh pool per inversion would
-    hand ~5 GB back to the driver and take it again every time)."""
-    key = (str(device), ops._stream_handle())
+def _plan_pool(device, batch):
+    """The private allocator pool a launch plan is recorded under, ONE per (device, stream, batch size) for the life of the process: the buffers a
+    recorded step touched keep their addresses while the plan lives, and the next inversion's recording reuses the same blocks (a fresh pool per
+    inversion hands ~5 GB back to the driver and takes it again: 35 ms per inversion of 8, measured).  Per batch size: a step of ONE image recorded
+    into blocks a batch of 8 left behind ran 2.6x slower (724 against 274 ms per inversion, scratch/b1_probe.py) — its tensors are then carved out
+    of a few multi-GB segments instead of sized segments."""
+    if os.environ.get('OODGAN_PLAN_POOL_CACHE', '1') == '0':
+        return torch.cuda.MemPool()
+    key = (str(device), ops._stream_handle(), int(batch))
     pool = _PLAN_POOLS.get(key)
     if pool is None:
         pool = _PLAN_POOLS[key] = torch.cuda.MemPool()
@@ -724,7 +737,7 @@ class _WRun:
             self.plan_steps += 1
         elif (self.use_plan and self.eager_left == 0 and not self.exact_until and eng.fused_bwd and eng.carry_range
               and self.steps - self.t >= 3):
-            plan, pool = ops.LaunchPlan(), _plan_pool(self.w.device)
+            plan, pool = ops.LaunchPlan(), _plan_pool(self.w.device, self.w.shape[0])
             with torch.cuda.use_mem_pool(pool):
                 with plan.recording():
                     self._eager_step()

@@ -328,12 +328,15 @@ class SFormSaved:
 
 class SFormPhases:
     """Phase-split S-form of a (B, C, 2H+1, 2W+1) tensor (input of the stride-2 conv); H, W = conv output size."""
-    __slots__ = ('data', 'B', 'C', 'H', 'W')
+    __slots__ = ('data', 'B', 'C', 'H', 'W', 'hi_only')
 
     def __init__(self, B, C, H, W, device):
         n = _lib.lib().oodgan_sform_phases_bytes(B, C, H, W)
         self.data = torch.zeros(n // 2, device=device, dtype=torch.float16)
         self.B, self.C, self.H, self.W = B, C, H, W
+        # True while the buffer holds the 32-byte hi-only records of oodgan_act_bwd_blurT_sform_phases_hi (set / cleared by the producers;
+        # conv3x3 then passes x_hi_only = 2)
+        self.hi_only = False
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -350,6 +353,7 @@ def to_sform_phases(x, H, W, scale=None, mul2=None, out=None, in_pitch=0, pad_tl
     B, C = x.shape[0], x.shape[1]
     if out is None:
         out = SFormPhases(B, C, H, W, x.device)
+    out.hi_only = False
     fn = _lib.lib().oodgan_to_sform_phases_padtl if pad_tl else _lib.lib().oodgan_to_sform_phases
     check(fn(_p(x), _p(_opt(scale, 'scale')), 0 if scale is None else scale.shape[1], _p(mul2), _p(out), B, C, H, W, in_pitch, _stream()),
           'to_sform_phases')
@@ -363,6 +367,7 @@ def blurT_to_sform_phases(g, kernel, scale=None, mul2=None, out=None):
     H, W = g.shape[2] // 2, g.shape[3] // 2
     if out is None:
         out = SFormPhases(B, C, H, W, g.device)
+    out.hi_only = False
     check(_lib.lib().oodgan_blurT_to_sform_phases(_p(g), _p(_dev(kernel)), _p(_opt(scale, 'scale')),
                                                   0 if scale is None else scale.shape[1], _p(mul2), _p(out), B, C, H, W,
                                                   _stream()), 'blurT_to_sform_phases')
@@ -602,8 +607,13 @@ def _reduce_parts(part, rows, npart):
     return out
 
 
+def blurT_hi_supported(H, W):
+    """``act_bwd_producer(..., blur_kernel=k, hi_only=True)`` exists for an up-conv input of H x W."""
+    return bool(_lib.lib().oodgan_act_bwd_blurT_hi_supported(H, W))
+
+
 def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, g_rgb=None, w_rgb=None, s_rgb=None,
-                     blur_kernel=None, t_into=None, jobs=None, dot_of=None):
+                     blur_kernel=None, t_into=None, jobs=None, dot_of=None, hi_only=False):
     """Fused backward producer (include/oodgan.h): the gradient of bias+noise+lrelu*sqrt2 (+ToRGB branch) of ``out``
     written straight into ``dst`` — an ``SForm`` (plain conv layer) or, with ``blur_kernel``, an ``SFormPhases``
     (up-conv layer: blur^T and phase split fused) — scaled by ``dscale[b,c] * mul2[1]``.
@@ -634,9 +644,16 @@ def act_bwd_producer(out, g_feat, noise, noise_weight, bias, dscale, mul2, dst, 
               dscale.shape[1], _p(mul2)]
     if fform:
         check(L.oodgan_act_bwd_sform_f(*common[1:], _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()), 'act_bwd_sform_f')
+    elif up and hi_only:
+        # 32-byte hi-only records for the two-instruction stride-2 conv (precision 'f16s-g2'): the caller made sure that conv takes them
+        assert g_rgb is None and part_t is None
+        check(L.oodgan_act_bwd_blurT_sform_phases_hi(*common[:6], *common[11:], _p(_dev(blur_kernel)), _p(dst), _p(part_r), _p(part_m),
+                                                     B, C, H // 2, W // 2, _stream()), 'act_bwd_blurT_sform_phases_hi')
+        dst.hi_only = True
     elif up:
         check(L.oodgan_act_bwd_blurT_sform_phases(*common, _p(_dev(blur_kernel)), _p(dst), _p(part_r), _p(part_t), _p(part_m),
                                                   B, C, H // 2, W // 2, _stream()), 'act_bwd_blurT_sform_phases')
+        dst.hi_only = False
     else:
         check(L.oodgan_act_bwd_sform(*common, _p(dst), _p(part_r), _p(part_t), _p(part_m), B, C, H, W, _stream()),
               'act_bwd_sform')
@@ -899,6 +916,9 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
             a.workspace, a.workspace_bytes = _p(ws), nb
     a.groups = int(groups)
     a.x_hi_only = 1 if (wpk.x_hi_only and dotx is not None) else 0
+    if isinstance(x, SFormPhases) and x.hi_only:
+        assert a.x_hi_only == 1, 'hi-only input records need the two-instruction input-gradient conv (precision f16s-g2, dotx)'
+        a.x_hi_only = 2
     a.y_fform = 1 if y_fform else 0
     a.ys, a.ys_scale = _p(ys), _p(_opt(ys_scale, 'ys_scale'))
     a.ys_vmax = _p(vmax)        # with ys from the 8-wave kernel: max |act(y) * ys_scale| per sample (forward range control of the reader)

@@ -218,3 +218,58 @@ def test_generator_backward_g2_vs_oracle_autograd(dev, size, B, tunable):
         assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
     print(f'size {size}: dL/dw rel err vs f64 autograd: {rels}')
     assert max(rels.values()) < 3e-4
+
+
+@pytest.mark.parametrize('pre', [False, True])
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 64, 128, 32, 32), (1, 128, 64, 40, 72), (2, 32, 64, 64, 64)])
+def test_hi_only_gradient_records_between_blurT_producer_and_s2_conv(dev, B, Co, Ci, H, W, pre, tunable):
+    """oodgan_act_bwd_blurT_sform_phases_hi writes 32-byte hi-only records, the two-instruction 8-wave stride-2 conv reads them with
+    oodgan_conv_args.x_hi_only = 2: the SAME hi halves as in the 64-byte records, so the conv's results are bit-identical to the full-record
+    path (which ignores its lo halves) — with and without the fused activation backward; a conv that needs the lo halves refuses the buffer."""
+    from oodgan import ops, _lib
+    tunable('s2_big_min_items', 0)
+    assert ops.blurT_hi_supported(H, W) and ops.s2_fuse_supported(B, Co, Ci, 2 * H + 1, 2 * W + 1)
+    t = lambda n, shp, std=1.0, mean=0.0: synth.normal('hr.' + n, shp, 50 + Ci, std, mean).to(dev)
+    k4 = torch.flip(synth.make_kernel() * 4.0, [0, 1]).contiguous().to(dev)
+    out_up = t('outup', (B, Co, 2 * H, 2 * W))                   # saved output of the up-conv layer (its activation backward is the producer's job)
+    g_feat = t('g', (B, Co, 2 * H, 2 * W), 1e-3)
+    nz, nw, bias = t('nz', (B, 1, 2 * H, 2 * W)), torch.tensor([0.1], device=dev), t('bias', (Co,), 0.1)
+    d_up = t('d', (B, Co), 0.2, 1.0).abs()
+    mul2 = torch.tensor([2.0 ** -9, 2.0 ** 9], device=dev)
+    x_in = t('xin', (B, Ci, H, W))                               # input of the up-conv (dotx of its input-gradient conv)
+    s_in = t('s', (B, Ci), 0.3, 1.0)
+    w = t('w', (Co, Ci, 3, 3), 1.0 / math.sqrt(Ci * 9))
+    w2 = _g2(ops.pack_conv3x3(w, 1.0, transpose=True, flip=False, precision='f16s'))
+    w3 = ops.pack_conv3x3(w, 1.0, transpose=True, flip=False, precision='f16s')
+    res = []
+    for hi in (False, True):
+        gin = ops.SFormPhases(B, Co, H, W, dev)
+        if pre:
+            dag = ops.DotActGrad()
+            dag.dot_part, dag.scale = torch.zeros(B, Co, 4, device=dev), d_up
+            g_pre = g_feat * torch.where(out_up > 0, 2 ** 0.5, 0.2 * 2 ** 0.5)
+            r, _, pm = ops.act_bwd_producer(None, g_pre, nz, nw, bias, d_up, mul2, gin, blur_kernel=k4, dot_of=dag, hi_only=hi)
+        else:
+            r, _, pm = ops.act_bwd_producer(out_up, g_feat, nz, nw, bias, d_up, mul2, gin, blur_kernel=k4, hi_only=hi)
+        assert gin.hi_only == hi
+        _lib.dispatch_reset()
+        dx, dot = ops.conv3x3(gin, w2, Ci, ops.CONV_S2, out_scale=s_in, dotx=x_in, in_mul2=mul2)
+        assert _lib.dispatch_count('s2big_g2') == 1 and _lib.dispatch_count('s2big_xh') == (1 if hi else 0)
+        res.append((dx, dot, r, pm, gin))
+    (dx0, dot0, r0, pm0, _), (dx1, dot1, r1, pm1, gin_hi) = res
+    assert torch.equal(dx1, dx0) and torch.equal(dot1, dot0) and torch.equal(r1, r0) and torch.equal(pm1, pm0)
+    if Ci % 32 == 0:
+        # ... and behind the fused activation backward of the conv layer below
+        out_below = t('ob', (B, Ci, H, W))
+        d_below = t('db', (B, Ci), 0.2, 1.0).abs()
+        _, _, _, state = ops.act_bwd_fused(out_below, dx0, nz[:, :, :H, :W].contiguous(), nw, t('b2', (Ci,), 0.1), want_scale=True, dscale=d_below)
+        outs = []
+        for gin in (res[0][4], gin_hi):
+            dst = ops.SForm(B, Ci, H, W, dev)
+            fz = ops.ActBwdFusion(dst, nz[:, :, :H, :W].contiguous(), nw, t('b2', (Ci,), 0.1), d_below, state)
+            _, dotf = ops.conv3x3(gin, w2, Ci, ops.CONV_S2, out_scale=s_in, dotx=out_below, in_mul2=mul2, fuse=fz, want_y=False)
+            outs.append((dst.data.clone(), dotf, fz.r))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # a conv that reads the lo halves must refuse hi-only records
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.conv3x3(gin_hi, w3, Ci, ops.CONV_S2, out_scale=s_in, dotx=x_in, in_mul2=mul2)

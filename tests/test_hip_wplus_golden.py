@@ -64,6 +64,9 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
         if prec == 'f16s-g2':
             # round 6: every input-gradient conv of the 8-wave / strip families ran its two-instruction instance (the gradient operand rounded to f16)
             assert g2['s1big_g2'] >= 3 and g2['s2big_g2'] >= 3 and g2['stripx_g2'] == (1 if rep == 1 else 0), g2
+            # ... and in the steady state the up-conv layers' gradients travel as 32-byte hi-only records (blur^T strip producer -> stride-2 conv)
+            nxh = _lib.dispatch_count('s2big_xh')
+            assert (nxh == 0) if rep == 0 else (3 <= nxh <= 5), nxh
         else:
             assert not any(g2.values()), g2
         if prec in ('f16s', 'f16s-g2') and rep == 1:
