@@ -59,7 +59,7 @@ long oodgan_get_tunable(const char* name);
  * `name` — "stripx" (conv_f16s_stripx.hip: F-form input, 1024² level of the W+ loop), "strip", "s1big", "s1v2", "s1pp", "tiny",
  * "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb" (oodgan_upconv_vblur_fform), and the sub-counters of the fused epilogues:
  * "s1big_ys" (8-wave stride-1 launches that wrote `ys` / ToRGB partial sums), "s1big_g2" / "s2big_g2" / "stripx_g2" (input-gradient launches
- * that ran with x_hi_only, two matrix instructions per product), "s2big_xh" (... on 32-byte hi-only input records, x_hi_only = 2), "s2big_fuse" (8-wave stride-2 launches with the fused activation
+ * that ran with x_hi_only, two matrix instructions per product), "s2big_xh" / "s1big_xh" (... on 32-byte hi-only input records, x_hi_only = 2), "s2big_fuse" (8-wave stride-2 launches with the fused activation
  * backward), "s2big_dotx_sform" (... that decoded `dotx` from a saved S-form).  Host-side, one relaxed atomic increment per call; the reference has no
  * counterpart (cuDNN picks its algorithm silently) — the parity tests use them to assert which kernel they pinned.
  * Returns -1 for an unknown name. */
@@ -257,8 +257,10 @@ typedef struct oodgan_conv_args {
                                 zero mean, independent per element) before each contraction while the weights keep their 22 bits; the reference
                                 has no counterpart (torch autograd runs the backward in fp32, model.py:233-274 through conv2d's backward) —
                                 tests bound dL/dW+ against the float64 reference and the 100-step loss curve against the reference Adam loop.
-                                2 (mode S2 with a phase-split S-form input and dotx, shapes of oodgan_conv3x3_s2_fuse_supported): as 1, and x holds the
-                                32-byte hi-only records oodgan_act_bwd_blurT_sform_phases_hi writes (half the bytes written and read). */
+                                2 (with dotx; mode S2 with a phase-split S-form input of a shape oodgan_conv3x3_s2_fuse_supported accepts, or mode S1 with an
+                                S-form input on the 8-wave kernel, oodgan_conv3x3_s1_actgrad_supported-like shapes): as 1, and x holds 32-byte
+                                hi-only records — what oodgan_act_bwd_blurT_sform_phases_hi / oodgan_actbwd_fuse.ys_hi_only write (half the bytes
+                                written and read). */
 } oodgan_conv_args;
 
 /* Fused epilogue of the stride-2 input-gradient conv (csrc/conv_f16s_s2big.hip).  The conv's result IS the gradient
@@ -286,6 +288,10 @@ typedef struct oodgan_actbwd_fuse {
     int s_rgb_stride, noise_batch, dscale_stride;
     float rgb_scale;
     long nmax;               /* entries of part_max: B * tiles * ceil(M/64) * 8 */
+    int ys_hi_only;          /* 1 (round 6, precision 'f16s-g2'; oodgan_conv3x3_f16s mode S2 `fuse` only): ys receives 32-byte hi-only records — record
+                                r of a (b, 16-channel block) plane at byte r*32 of that plane, the plane stride unchanged — for a consumer that never
+                                reads the lo halves: mode S1 with x_hi_only = 2 on the 8-wave kernel.  The buffer must be one that only ever holds
+                                hi-only records (its zero border lives at the hi-only addresses). */
 } oodgan_actbwd_fuse;
 
 /* Implicit-GEMM 3x3 convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -450,6 +456,8 @@ int oodgan_act_bwd_blurT_sform_phases(const float* g_feat, const float* out, con
  * consumer that never reads the lo halves: oodgan_conv3x3_f16s with oodgan_conv_args.x_hi_only = 2.  Halves the bytes this producer writes and
  * that conv reads.  Exists where oodgan_act_bwd_blurT_hi_supported(H, W) says so (the strip walk). */
 int oodgan_act_bwd_blurT_hi_supported(int H, int W);
+/* 1 when oodgan_conv3x3_f16s (mode S1, S-form input, dotx) of this shape takes x_hi_only = 2 (the 8-wave stride-1 kernel) */
+int oodgan_conv3x3_s1_xh_supported(int B, int K, int M, int H, int W);
 int oodgan_act_bwd_blurT_sform_phases_hi(const float* g_feat, const float* out, const float* noise, int noise_batch, const float* noise_w,
                                          const float* bias, const float* dscale, int dscale_stride, const float* mul2, const float* kernel,
                                          void* out_phases, float* part_r, float* part_max, int B, int C, int H, int W, void* stream);

@@ -44,7 +44,7 @@ enum { OODGAN_DC_STRIPX = 0, OODGAN_DC_STRIP, OODGAN_DC_S1BIG, OODGAN_DC_S1V2, O
        // fused activation backward; ... decoding its dotx from the saved S-form
        OODGAN_DC_S1BIG_YS, OODGAN_DC_S2BIG_FUSE, OODGAN_DC_S2BIG_DOTXS,
        // round 6: input-gradient launches with oodgan_conv_args.x_hi_only (two matrix instructions per product)
-       OODGAN_DC_S1BIG_G2, OODGAN_DC_S2BIG_G2, OODGAN_DC_STRIPX_G2, OODGAN_DC_S2BIG_XH, OODGAN_DC_COUNT };
+       OODGAN_DC_S1BIG_G2, OODGAN_DC_S2BIG_G2, OODGAN_DC_STRIPX_G2, OODGAN_DC_S2BIG_XH, OODGAN_DC_S1BIG_XH, OODGAN_DC_COUNT };
 void count_dispatch(int id);
 
 // One process per GPU: per-kernel setup (dynamic-LDS attributes, the zero page and CU count of the F-form strip

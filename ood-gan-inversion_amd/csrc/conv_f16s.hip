@@ -450,6 +450,16 @@ extern "C" int oodgan_conv3x3_s1_actgrad_supported(int B, int K, int M, int H, i
     return (s1_strip_eligible(a) || s1_big_eligible(a)) && oodgan_act_bwd_blurT_pre_supported(H / 2, W / 2) && !(H & 1) && !(W & 1) ? 1 : 0;
 }
 
+// 1 when mode S1 with an S-form input and dotx of this shape runs the 8-wave kernel, whose two-instruction instances take 32-byte hi-only input
+// records (oodgan_conv_args.x_hi_only = 2; the caller offers no skinny-GEMM workspace for maps this large)
+extern "C" int oodgan_conv3x3_s1_xh_supported(int B, int K, int M, int H, int W) {
+    oodgan_conv_args a = {};
+    a.mode = OODGAN_CONV_S1; a.x_sform = 1; a.B = B; a.K = K; a.M = M; a.Hin = H; a.Win = W;
+    a.y = reinterpret_cast<float*>(1);
+    a.dotx = reinterpret_cast<const float*>(1);
+    return (H > 8 && W > 8 && !s1_strip_eligible(a) && s1_big_eligible(a)) ? 1 : 0;
+}
+
 // 1 when mode S1 with an S-form input of this shape writes oodgan_conv_args.ys from the 8-wave kernel's registers (y may then be NULL)
 extern "C" int oodgan_conv3x3_s1_ys_supported(int B, int K, int M, int H, int W) {
     oodgan_conv_args a = {};
@@ -490,9 +500,10 @@ extern "C" int oodgan_conv3x3_f16s(const oodgan_conv_args* args, const float* un
                    "(oodgan_conv3x3_s2_fuse_supported)");
     OODGAN_REQUIRE(a.ys_vmax == nullptr || (a.ys != nullptr && a.mode == OODGAN_CONV_S1 && a.x_sform && !tiny_eligible(a) && !s1_strip_eligible(a) && s1_big_eligible(a)),
                    "conv3x3_f16s: ys_vmax only with ys from the 8-wave stride-1 kernel (oodgan_conv3x3_s1_ys_supported)");
-    OODGAN_REQUIRE(a.x_hi_only != 2 || (a.mode == OODGAN_CONV_S2 && a.x_sform && a.dotx && !tiny_eligible(a) && s2_big_eligible(a)),
-                   "conv3x3_f16s: x_hi_only = 2 (32-byte hi-only input records) exists only in the two-instruction 8-wave stride-2 kernel "
-                   "(mode S2, phase-split S-form input, dotx, a shape oodgan_conv3x3_s2_fuse_supported accepts)");
+    OODGAN_REQUIRE(a.x_hi_only != 2 || (a.x_sform && a.dotx && !tiny_eligible(a) &&
+                                        ((a.mode == OODGAN_CONV_S2 && s2_big_eligible(a)) || (a.mode == OODGAN_CONV_S1 && !s1_strip_eligible(a) && s1_big_eligible(a)))),
+                   "conv3x3_f16s: x_hi_only = 2 (32-byte hi-only input records) exists only in the two-instruction 8-wave kernels (S-form input, dotx; mode S2 on a "
+                   "shape oodgan_conv3x3_s2_fuse_supported accepts, mode S1 on a shape of the 8-wave stride-1 kernel)");
     hipStream_t st = as_stream(stream);
     switch (a.mode) {
         case OODGAN_CONV_S1:

@@ -104,6 +104,10 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
 
     constexpr int NPW = (BG_PIECES + NW - 1) / NW;          // 10
     unsigned off[NPW];
+    // XH (G2 instances with oodgan_conv_args.x_hi_only == 2): x holds 32-byte hi-only records (oodgan_actbwd_fuse.ys_hi_only) at half the in-plane offsets;
+    // the LDS image keeps its 64-byte records (this instance never reads the lo slots), the lanes of a piece that would carry a lo slot stay off
+    const bool xh = G2 && a.x_hi_only == 2;
+    unsigned xmask = 0;      // bit i: this lane takes part in piece i
     const int KC = p.xd.KC;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
@@ -114,8 +118,15 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
             const int row = P / (BG_C * 4), q = P % (BG_C * 4);
             const int c = q >> 2, sl = ((q & 3) - 2 * ((c >> 2) & 1)) & 3;
             const int rr = min(r0 + row, p.xd.Hp - 1);
-            off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + sl) * 16);
+            if (xh) {
+                off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 2 + (sl & 1)) * 16);
+                if (sl < 2) xmask |= 1u << i;
+            } else {
+                off[i] = (unsigned)((((long)rr * p.xd.Wp + (c0 + c)) * 4 + sl) * 16);
+                xmask |= 1u << i;
+            }
         } else {
+            xmask |= 1u << i;
             const int u = (pc - BG_XPIECES) * 64 + lane;
             const int row = u >> 6, j = u & 63;
             off[i] = (unsigned)((((long)row * p.Mp) + m0 + j) * 16);
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(512) void conv_f16s_s1big_kernel(const BigConv p, c
         if (pc >= BG_PIECES) return;
         unsigned char* dst = smem + buf * BG_STAGE;
         const unsigned char* src = (pc < BG_XPIECES ? xb + (long)t * xplane_bytes : wb + (long)t * wchunk_bytes) + off[i];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
+        if (!G2 || ((xmask >> i) & 1u))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void*)(dst + pc * 1024), 16, 0, 0);
     };
     for (int i = tid; i < BG_ZBYTES / 16; i += 512) reinterpret_cast<uint4*>(smem + BG_ZERO)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();         // the loop's barriers wait for vmcnt only: make the zero region visible to every wave here
@@ -497,7 +509,9 @@ int launch_s1_big(const oodgan_conv_args& a_in, const void* wpk16, const float* 
     // v2 tile kernel: 474 / 475 / 552 us against 393 / 407 / 464 on the 64² / 128² / 256² layers)
     OODGAN_REQUIRE(!a.dot_actgrad || a.dotx, "conv3x3 big: dot_actgrad without dotx");
     const bool g2 = a.x_hi_only != 0 && a.dotx != nullptr;       // the input-gradient instances only: a forward call keeps all three products
+    OODGAN_REQUIRE(a.x_hi_only != 2 || g2, "conv3x3 big: hi-only input records (x_hi_only = 2) need dotx (the two-instruction instances)");
     if (g2) count_dispatch(OODGAN_DC_S1BIG_G2);
+    if (g2 && a.x_hi_only == 2) count_dispatch(OODGAN_DC_S1BIG_XH);
     if (a.dot_actgrad && g2) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else if (g2) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, false, false, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);
     else if (a.dot_actgrad) hipLaunchKernelGGL((conv_f16s_s1big_kernel<true, true>), dim3((unsigned)total), dim3(512), BG_SMEM16, st, p, w16);

@@ -510,8 +510,19 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                         red[(rg * 3 + 2) * C::MBW + ch] = v2;
                     }
                 }
+                if (f.ys_hi_only) {       // the consumer never reads a lo half (x_hi_only = 2): no second conversion, no lo store
 #pragma unroll
-                for (int nt = 0; nt < RW; ++nt) split_pair(vv[nt][0], vv[nt][1], hi[nt][r2], lo[nt][r2]);
+                    for (int nt = 0; nt < RW; ++nt) {
+                        half2v h2;
+                        h2[0] = (_Float16)vv[nt][0];
+                        h2[1] = (_Float16)vv[nt][1];
+                        hi[nt][r2] = __builtin_bit_cast(unsigned, h2);
+                        lo[nt][r2] = 0u;
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < RW; ++nt) split_pair(vv[nt][0], vv[nt][1], hi[nt][r2], lo[nt][r2]);
+                }
             }
             // 64-byte records: lanes 0-31 hold channels {0-3, 8-11} of a 16-channel block, lanes 32-63 {4-7, 12-15};
             // one v_permlane32_swap pair completes the 16-byte slots (half 0 -> slots 0 / 2, half 1 -> slots 1 / 3)
@@ -522,9 +533,16 @@ __global__ __launch_bounds__(512) void conv_f16s_s2big_kernel(const S2Big p, con
                 for (int cb = 0; cb < 2; ++cb) {
                     auto h0 = __builtin_amdgcn_permlane32_swap(hi[nt][cb * 4 + 0], hi[nt][cb * 4 + 2], false, false);
                     auto h1 = __builtin_amdgcn_permlane32_swap(hi[nt][cb * 4 + 1], hi[nt][cb * 4 + 3], false, false);
+                    const int kc = (m0 + chb) / 16 + cb;
+                    if (f.ys_hi_only) {
+                        if (okr[nt] && kc < p.yd.KC) {      // record at half the in-plane offset: 32 lanes x 2 halves = 1 KB contiguous per wave and row
+                            uint4* rec = reinterpret_cast<uint4*>(f.ys) + (((long)b * p.yd.KC + kc) * p.yd.plane + ((long)(py_ + 1) * p.yd.Wp + (px + 1)) * 2);
+                            rec[half] = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+                        }
+                        continue;
+                    }
                     auto l0 = __builtin_amdgcn_permlane32_swap(lo[nt][cb * 4 + 0], lo[nt][cb * 4 + 2], false, false);
                     auto l1 = __builtin_amdgcn_permlane32_swap(lo[nt][cb * 4 + 1], lo[nt][cb * 4 + 3], false, false);
-                    const int kc = (m0 + chb) / 16 + cb;
                     if (okr[nt] && kc < p.yd.KC) {
                         uint4* rec = reinterpret_cast<uint4*>(f.ys) + sform_unit(p.yd, b, kc, py_, px, 0);
                         rec[half] = make_uint4(h0[0], h1[0], h0[1], h1[1]);

@@ -82,7 +82,7 @@ bool bound_device_ok(const char* what) {
 // ---- dispatch counters: one relaxed atomic increment per conv call, on the host
 namespace oodgan {
 namespace {
-const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb", "s1big_ys", "s2big_fuse", "s2big_dotx_sform", "s1big_g2", "s2big_g2", "stripx_g2", "s2big_xh"};
+const char* const g_dc_name[OODGAN_DC_COUNT] = {"stripx", "strip", "s1big", "s1v2", "s1pp", "tiny", "t2big", "t2v2", "t2gen", "s2big", "s2v2", "s2gen", "upvb", "s1big_ys", "s2big_fuse", "s2big_dotx_sform", "s1big_g2", "s2big_g2", "stripx_g2", "s2big_xh", "s1big_xh"};
 std::atomic<long> g_dc[OODGAN_DC_COUNT];
 }  // namespace
 void count_dispatch(int id) { g_dc[id].fetch_add(1, std::memory_order_relaxed); }

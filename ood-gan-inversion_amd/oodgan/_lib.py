@@ -36,7 +36,7 @@ class ActBwdFuse(Structure):
     """oodgan_actbwd_fuse (include/oodgan.h): fused activation backward of the stride-2 input-gradient conv."""
     _fields_ = [('g_rgb', P), ('w_rgb', P), ('s_rgb', P), ('noise', P), ('noise_w', P), ('bias', P), ('dscale', P), ('mul2', P), ('ys', P),
                 ('part_r', P), ('part_t', P), ('part_max', P), ('s_rgb_stride', c_int), ('noise_batch', c_int), ('dscale_stride', c_int),
-                ('rgb_scale', c_float), ('nmax', c_long)]
+                ('rgb_scale', c_float), ('nmax', c_long), ('ys_hi_only', c_int)]
 
 
 class ReduceJob(Structure):
@@ -120,6 +120,7 @@ _SIGS = {
     'oodgan_act_bwd_blurT_pre_supported': (c_int, [c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases': (c_int, [P, P, P, c_int, P, P, P, P, P, c_int, c_float, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_act_bwd_blurT_hi_supported': (c_int, [c_int, c_int]),
+    'oodgan_conv3x3_s1_xh_supported': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'oodgan_act_bwd_blurT_sform_phases_hi': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'oodgan_absmax_scale_check': (c_int, [P, c_long, P, P, P]),
     'oodgan_reduce_batch': (c_int, [P, c_int, P]),

@@ -578,9 +578,11 @@ class GeneratorEngine:
                     # the stride-2 conv's result is the gradient w.r.t. the output of the conv layer below (x_in): its
                     # epilogue continues with that layer's activation backward (+ ToRGB branch) and writes the S-form
                     Rp = self.conv_next_rgb[Lp.name]
-                    fz = ops.ActBwdFusion(ops.sform_scratch(B, Lp.cout, Hd, Hd, self.device), noises[Lp.noise_idx], Lp.noise_w, Lp.bias,
-                                          _Cols(d_all, Lp.drow, Lp.cout), stp, g_rgb=gskip[Lp.res], w_rgb=Rp.w_rgb,
-                                          s_rgb=_Cols(s_all, Rp.row, Rp.cin), t_into=_Cols(gs_all, Rp.row, Rp.cin))
+                    # f16s-g2: that S-form as 32-byte hi-only records when the conv that reads it is the two-instruction 8-wave stride-1 kernel
+                    hi = bool(self.grad_hi_only and self.hi_records and ops.s1_xh_supported(B, Lp.cout, Lp.cin, Hd, Hd))
+                    fz = ops.ActBwdFusion((ops.sform_hi_scratch if hi else ops.sform_scratch)(B, Lp.cout, Hd, Hd, self.device), noises[Lp.noise_idx],
+                                          Lp.noise_w, Lp.bias, _Cols(d_all, Lp.drow, Lp.cout), stp, g_rgb=gskip[Lp.res], w_rgb=Rp.w_rgb,
+                                          s_rgb=_Cols(s_all, Rp.row, Rp.cin), t_into=_Cols(gs_all, Rp.row, Rp.cin), hi_only=hi)
                 pre = None
                 if (L.kind == 'conv' and Lp is not None and Lp.kind == 'up' and self.fuse_act_bwd and self.bwd_state.get(L.src) is not None
                         and ops.s1_actgrad_supported(B, L.cout, L.cin, out.shape[2], out.shape[3])):
@@ -707,10 +709,14 @@ class _WRun:
         self.host = inv._pinned(len(inv._runs)) if self.guard else None
         inv._runs.append(self)
         # launch plan (round 6): the first step measures exact scales (its own launch sequence); the second — the first
-        # steady-state step — is RECORDED while it runs (oodgan_plan_*, under a private allocator pool so that every buffer it touched
-        # keeps its address), and every later step is one oodgan_plan_run call instead of ~170 ctypes calls and the Python between them
+        # steady-state step — runs from Python as well: it CREATES the persistent scratch buffers only the carried-scale path uses (pooled
+        # S-forms with a zero border, hi-only record buffers, max slots).  Created inside the recording they would be carved out of blocks
+        # that temporaries of the same step held earlier, and on every replay those temporaries' kernels would write over them — borders
+        # included (seen as NaN from the second replay on).  The third step is RECORDED while it runs (oodgan_plan_*, under a private
+        # allocator pool so that every buffer it touched keeps its address); every later step is one oodgan_plan_run call instead of ~100
+        # ctypes calls and the Python between them
         self.use_plan = bool(inv.use_plan) and dev_counter and not keep_traj and eng.sform
-        self.plan, self.pool, self.eager_left, self.plan_steps, self.plan_size = None, None, 1, 0, 0
+        self.plan, self.pool, self.eager_left, self.plan_steps, self.plan_size = None, None, 2, 0, 0
 
     # ---- one W+ step on the current stream
     def _eager_step(self):
@@ -802,7 +808,7 @@ class _WRun:
         eng.reset_bwd_state()                                    # the next step measures its scales exactly, like the first of a run
         eng.reset_fwd_state()
         self.exact_until = 0
-        self.eager_left = 1
+        self.eager_left = 2
         self.clean = (self.t, self.w.clone(), self.m.clone(), self.v.clone())
 
     def _advance(self):

@@ -266,12 +266,15 @@ def demod(s, wsq, scale):
 class SForm:
     """S-form activation buffer (csrc/sform.hpp): (B, C, H, W) logical, 64-byte {hi,lo} f16 records per pixel and
     16-channel block, zero border + tile padding.  ``data`` must stay zero outside the interior."""
-    __slots__ = ('data', 'B', 'C', 'H', 'W')
+    __slots__ = ('data', 'B', 'C', 'H', 'W', 'hi_only')
 
     def __init__(self, B, C, H, W, device):
         n = _lib.lib().oodgan_sform_bytes(B, C, H, W)
         self.data = torch.zeros(n // 2, device=device, dtype=torch.float16)
         self.B, self.C, self.H, self.W = B, C, H, W
+        # True: the buffer holds 32-byte hi-only records (oodgan_actbwd_fuse.ys_hi_only) and is DEDICATED to them — its zero border lives at the
+        # hi-only addresses; conv3x3 passes x_hi_only = 2
+        self.hi_only = False
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -916,7 +919,7 @@ def conv3x3(x, wpk, M, mode=CONV_S1, in_scale=None, in_shift=None, out_scale=Non
             a.workspace, a.workspace_bytes = _p(ws), nb
     a.groups = int(groups)
     a.x_hi_only = 1 if (wpk.x_hi_only and dotx is not None) else 0
-    if isinstance(x, SFormPhases) and x.hi_only:
+    if isinstance(x, (SForm, SFormPhases)) and x.hi_only:
         assert a.x_hi_only == 1, 'hi-only input records need the two-instruction input-gradient conv (precision f16s-g2, dotx)'
         a.x_hi_only = 2
     a.y_fform = 1 if y_fform else 0
@@ -994,6 +997,18 @@ def tiny_workspace_bytes(mode, B, K, M, Hin, Win):
     return int(_lib.lib().oodgan_conv3x3_tiny_workspace(mode, B, K, M, Hin, Win)) if USE_TINY else 0
 
 
+def s1_xh_supported(B, K, M, H, W):
+    """mode S1 with an S-form input and ``dotx`` runs the 8-wave kernel, whose two-instruction instances read 32-byte hi-only records."""
+    return bool(_lib.lib().oodgan_conv3x3_s1_xh_supported(B, K, M, H, W))
+
+
+def sform_hi_scratch(B, C, H, W, device):
+    """Reusable S-form buffer DEDICATED to 32-byte hi-only records (its zero border lives at their addresses)."""
+    buf = sform_scratch(B, C, H, W, device, tag='hi')
+    buf.hi_only = True
+    return buf
+
+
 def s1_ys_supported(B, K, M, H, W):
     """mode S1 with an S-form input writes ``ys`` from the 8-wave kernel (``want_y=False``: nothing but the S-form is produced)."""
     return bool(_lib.lib().oodgan_conv3x3_s1_ys_supported(B, K, M, H, W))
@@ -1025,7 +1040,8 @@ class ActBwdFusion:
     (oodgan_actbwd_fuse, include/oodgan.h): the same quantities ``act_bwd_producer`` returns — (r, t, part_max) and the
     S-form gradient ``dst`` — produced by ``conv3x3(..., mode=CONV_S2, fuse=this)`` for the layer whose output is ``dotx``."""
 
-    def __init__(self, dst, noise, noise_weight, bias, dscale, mul2, g_rgb=None, w_rgb=None, s_rgb=None, t_into=None):
+    def __init__(self, dst, noise, noise_weight, bias, dscale, mul2, g_rgb=None, w_rgb=None, s_rgb=None, t_into=None, hi_only=False):
+        self.hi_only = bool(hi_only)        # dst receives 32-byte hi-only records (a buffer dedicated to them: sform_scratch(tag='hi'))
         self.dst, self.noise, self.noise_weight, self.bias, self.dscale, self.mul2 = dst, _opt(noise, 'noise'), _opt(noise_weight, 'nw'), _opt(bias, 'bias'), dscale, mul2
         self.g_rgb, self.w_rgb, self.s_rgb, self.t_into = _opt(g_rgb, 'g_rgb'), w_rgb, s_rgb, t_into
         self.r = self.t = self.part_m = None
@@ -1046,6 +1062,8 @@ class ActBwdFusion:
         z.dscale, z.dscale_stride, z.mul2, z.ys = _p(self.dscale), self.dscale.shape[1], _p(self.mul2), _p(self.dst)
         z.part_r, z.part_t, z.part_max = _p(self.part_r), _p(self.part_t), _p(self.part_m)
         z.rgb_scale, z.nmax = 1.0 / math.sqrt(M), self.part_m.numel()
+        z.ys_hi_only = 1 if self.hi_only else 0
+        assert self.dst.hi_only == self.hi_only, 'a hi-only S-form scratch is dedicated to hi-only records'
         return z
 
     def finish(self, dot_part, nparts, jobs):

@@ -263,13 +263,29 @@ def test_hi_only_gradient_records_between_blurT_producer_and_s2_conv(dev, B, Co,
         out_below = t('ob', (B, Ci, H, W))
         d_below = t('db', (B, Ci), 0.2, 1.0).abs()
         _, _, _, state = ops.act_bwd_fused(out_below, dx0, nz[:, :, :H, :W].contiguous(), nw, t('b2', (Ci,), 0.1), want_scale=True, dscale=d_below)
+        # the fused epilogue's own S-form output as hi-only records too (oodgan_actbwd_fuse.ys_hi_only), read by the two-instruction 8-wave
+        # stride-1 conv (x_hi_only = 2): bit-identical to the full-record chain
+        tunable('s1_big_min_items', 1)
+        w1 = t('w1', (Ci, Ci, 3, 3), 1.0 / math.sqrt(Ci * 9))
+        w1b = _g2(ops.pack_conv3x3(w1, transpose=True, flip=True, precision='f16s'))
+        dot1x = t('d1x', (B, Ci, H, W))
+        s1v = t('s1v', (B, Ci), 0.3, 1.0)
         outs = []
-        for gin in (res[0][4], gin_hi):
+        for gin, hi in ((res[0][4], False), (gin_hi, True)):
             dst = ops.SForm(B, Ci, H, W, dev)
-            fz = ops.ActBwdFusion(dst, nz[:, :, :H, :W].contiguous(), nw, t('b2', (Ci,), 0.1), d_below, state)
+            dst.hi_only = hi
+            fz = ops.ActBwdFusion(dst, nz[:, :, :H, :W].contiguous(), nw, t('b2', (Ci,), 0.1), d_below, state, hi_only=hi)
             _, dotf = ops.conv3x3(gin, w2, Ci, ops.CONV_S2, out_scale=s_in, dotx=out_below, in_mul2=mul2, fuse=fz, want_y=False)
-            outs.append((dst.data.clone(), dotf, fz.r))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+            xh_ok = ops.s1_xh_supported(B, Ci, Ci, H, W)
+            if hi and not xh_ok:
+                continue
+            _lib.dispatch_reset()
+            dx1, dot1 = ops.conv3x3(dst, w1b, Ci, ops.CONV_S1, out_scale=s1v, dotx=dot1x, in_mul2=state)
+            assert _lib.dispatch_count('s1big_xh') == (1 if hi else 0)
+            outs.append((dx1, dot1, dotf, fz.r, fz.part_m.max()))
+        if len(outs) == 2:
+            for u, v in zip(outs[0], outs[1]):
+                assert torch.equal(u, v)
     # a conv that reads the lo halves must refuse hi-only records
     with pytest.raises((RuntimeError, AssertionError)):
         ops.conv3x3(gin_hi, w3, Ci, ops.CONV_S2, out_scale=s_in, dotx=x_in, in_mul2=mul2)

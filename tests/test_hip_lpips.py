@@ -174,5 +174,5 @@ def test_wplus_loop_with_the_lpips_term_vs_oracle(dev, streams, use_plan):
           f'within 2e-3: {float((dw < 2e-3).double().mean()):.4f}; plan {inv.last_plan}')
     assert e_tot < 1e-3 and e_lp < 1e-3
     assert float((dw < 2e-3).double().mean()) > 0.995
-    assert inv.last_plan['steps'] == ([steps - 2] * streams if use_plan else [0] * streams)
+    assert inv.last_plan['steps'] == ([steps - 3] * streams if use_plan else [0] * streams)
     assert (losses[-1] < losses[0]).all()

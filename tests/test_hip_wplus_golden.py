@@ -67,6 +67,8 @@ def test_wplus_step_1024_vs_reference_autograd(dev, golden, prec, batch):
             # ... and in the steady state the up-conv layers' gradients travel as 32-byte hi-only records (blur^T strip producer -> stride-2 conv)
             nxh = _lib.dispatch_count('s2big_xh')
             assert (nxh == 0) if rep == 0 else (3 <= nxh <= 5), nxh
+            n1xh = _lib.dispatch_count('s1big_xh')      # ... and the conv layers' (stride-2 conv's fused epilogue -> stride-1 input-gradient conv)
+            assert (n1xh == 0) if rep == 0 else (3 <= n1xh <= 5), n1xh
         else:
             assert not any(g2.values()), g2
         if prec in ('f16s', 'f16s-g2') and rep == 1:

@@ -116,7 +116,7 @@ def test_100_steps_1024_vs_reference_adam(dev, prec, fixture):
     inv = WPlusInverter(eng)
     w, losses = inv.invert(target, w0, noises, steps=steps)
     assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]}, f'range violation: {inv.last_stats}'
-    assert inv.last_plan['steps'] == [steps - 2] and inv.last_plan['launches'][0] >= 60, inv.last_plan     # steps 3..100 replayed from the launch plan
+    assert inv.last_plan['steps'] == [steps - 3] and inv.last_plan['launches'][0] >= 60, inv.last_plan     # steps 4..100 replayed from the launch plan
     assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
     L, L32 = losses.double().cpu(), g32['losses']
     band = _curve_report('reference f32 vs f64 (1024²)', L32, g64['losses']) if g64 is not None else None
@@ -186,7 +186,7 @@ def test_range_violation_mid_run_repeats_one_window(dev, which, use_plan):
     inv = WPlusInverter(eng, use_plan=use_plan)
     w_ref, l_ref = inv.invert(target, w0, noises, steps=steps)
     assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]}
-    assert inv.last_plan['steps'] == [steps - 2 if use_plan else 0]
+    assert inv.last_plan['steps'] == [steps - 3 if use_plan else 0]
     done = {'n': 0}
 
     def sabotage(run):
@@ -216,7 +216,7 @@ def test_range_violation_mid_run_repeats_one_window(dev, which, use_plan):
 
 @pytest.mark.parametrize('size,B,streams', [(64, 2, 1), (256, 4, 2), (1024, 8, 2), (1024, 1, 1)])
 def test_launch_plan_is_bit_identical_to_the_python_driven_loop(dev, size, B, streams):
-    """steps 3..N re-issued from the recorded launch plan (oodgan_plan_run: ~170 launches per call) against the same
+    """steps 4..N re-issued from the recorded launch plan (oodgan_plan_run: ~170 launches per call) against the same
     loop driven launch by launch from Python — same kernels, same arguments, same order: bit-identical latents and losses."""
     from oodgan.engine import GeneratorEngine, WPlusInverter
     steps = 12
@@ -227,7 +227,7 @@ def test_launch_plan_is_bit_identical_to_the_python_driven_loop(dev, size, B, st
     w_p, l_p = inv_p.invert(target, w0, noises, steps=steps, streams=streams)
     w_p2, l_p2 = inv_p.invert(target, w0, noises, steps=steps, streams=streams)       # a second inversion records its own plans
     print(f'{size}² B={B} streams={streams}: plan {inv_p.last_plan}, eager {inv_e.last_plan}')
-    assert inv_p.last_plan['steps'] == [steps - 2] * streams and all(n > 60 for n in inv_p.last_plan['launches'])
+    assert inv_p.last_plan['steps'] == [steps - 3] * streams and all(n > 60 for n in inv_p.last_plan['launches'])
     assert inv_e.last_plan['steps'] == [0] * streams
     assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
     assert torch.equal(l_p2, l_e) and torch.equal(w_p2, w_e)
@@ -246,3 +246,21 @@ def test_empty_batch_and_zero_steps(dev):
     w0 = synth.make_latents(size, 2, seed=14).to(dev)
     w, l, traj = inv.invert(synth.make_images(size, 2, seed=9).to(dev), w0, noises, steps=0, return_trajectory=True)
     assert torch.equal(w, w0) and l.shape == (0, 2) and traj == []
+
+
+def test_launch_plan_in_a_fresh_process_state(dev):
+    """The hazard the second Python-driven step exists for (engine._WRun): a persistent scratch buffer first created INSIDE the recorded step is carved
+    out of blocks its temporaries used earlier and gets overwritten on every replay.  A fresh engine + the hi-only record buffers (created only by
+    the carried-scale path) + plan + range guard, from the very first inversion: no rollback, same result as the Python-driven loop."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    from oodgan import ops
+    size, B, steps = 256, 4, 16
+    target, w0, noises = _recipe(size, list(range(B)), dev)
+    ops._SFORM_POOL.clear()                 # as in a fresh process: every pooled scratch buffer is created by this inversion
+    eng = GeneratorEngine({k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}, size)
+    inv = WPlusInverter(eng, use_plan=True)
+    w_p, l_p = inv.invert(target, w0, noises, steps=steps)
+    assert inv.last_stats == {'steps_run': [steps], 'rollbacks': [0]} and inv.last_plan['steps'] == [steps - 3], (inv.last_stats, inv.last_plan)
+    assert torch.isfinite(l_p).all()
+    w_e, l_e = WPlusInverter(eng, use_plan=False).invert(target, w0, noises, steps=steps)
+    assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
