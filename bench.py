@@ -277,13 +277,16 @@ def pmc_traffic(a):
         return None
 
 
-def wplus_step_algorithmic(B, size, channel_multiplier=2, breakdown=False):
+def wplus_step_algorithmic(B, size, channel_multiplier=2, breakdown=False, hi_records=False):
     """Algorithmic HBM bytes and flops of ONE steady-state W+ step (forward + backward to W+ + Adam) as the loop is scheduled
     (DESIGN.md §4-5): every tensor a launch must read or write counted once per launch, at 4 bytes per element (fp32, the 64-byte
     S-form / F-form records of 16 channels, and the phase-split S-form all hold 4 bytes per element); weights, noise maps, per-channel
     vectors and partial sums are left out (< 1 %).  flops = 2*B*K*M*9*H*W per styled conv forward and once more for its input gradient
     (no weight gradients exist in this loop), + the ToRGB contractions; the folded-blur kernels' doubled taps are NOT counted.
-    ``breakdown``: also the bytes per role of the step (tools/step_ledger.py sets them against the PMC bytes of the kernels playing the role)."""
+    ``breakdown``: also the bytes per role of the step (tools/step_ledger.py sets them against the PMC bytes of the kernels playing the role).
+    ``hi_records`` (precision 'f16s-g2'): the gradient tensors between the blur^T strip producer, the stride-2 conv, its fused epilogue and the stride-1
+    input-gradient conv are 32-byte hi-only records — 2 bytes per element instead of 4 — from the 64² level up (below it and at the 1024² level's
+    F-form conv nothing changes)."""
     from oodgan.synth import generator_channels
     ch = generator_channels(channel_multiplier)
     e = 4.0 * B
@@ -312,9 +315,12 @@ def wplus_step_algorithmic(B, size, channel_multiplier=2, breakdown=False):
             roles['conv forward (+ ToRGB, next S-form)'] += e * (C * r2 + (0 if last else C * r2))   # low resolution: separate ToRGB pass
         fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
         # ---- backward
-        roles['conv input gradient (+ dot)'] += e * 3 * C * r2                      # gradient S-form (F-form: its own output) in, dotx in, dx out
-        roles['blur^T + phase split'] += e * (C * r2 + C * z2)                       # pre-activation gradient in, phase-split S-form out
-        roles['stride-2 conv + fused activation backward'] += e * (C * z2 + 2 * cin * q2)   # phases in, saved activation in, S-form gradient out
+        hg = 0.5 if (hi_records and res >= 64) else 1.0                             # gradient records of this level's up-conv
+        hc = 0.5 if (hi_records and 64 <= res < size) else 1.0                      # ... of this level's conv layer (S-form input of its input gradient)
+        hp = 0.5 if (hi_records and 128 <= res) else 1.0                            # ... written by this level's stride-2 conv for the conv layer BELOW (64² and up)
+        roles['conv input gradient (+ dot)'] += e * (2 + hc) * C * r2               # gradient S-form (F-form: its own output) in, dotx in, dx out
+        roles['blur^T + phase split'] += e * (C * r2 + hg * C * z2)                  # pre-activation gradient in, phase-split S-form out
+        roles['stride-2 conv + fused activation backward'] += e * (hg * C * z2 + (1 + hp) * cin * q2)   # phases in, saved activation in, S-form gradient out
         fl += 2.0 * B * 9 * (cin * C * q2 + C * C * r2) + 2.0 * B * 3 * C * r2
         cin = C
     roles['MSE + skip pyramid'] += e * 3 * size * size * 4                         # image + target in, gradient out; skip pyramid down
@@ -764,7 +770,7 @@ def main():
             torch.cuda.synchronize()
             ood_ms = e0.elapsed_time(e1)
             step_ms = (dt / a.steps * 1e3 - ood_ms) / max(a.wsteps, 1)
-            alg_b, alg_f = wplus_step_algorithmic(B, size)
+            alg_b, alg_f = wplus_step_algorithmic(B, size, hi_records=(a.precision == 'f16s-g2'))
             pmc = pmc_step_traffic(a)
             # the PMC bytes belong to ONE configuration (precision, batch, stream count: the sub-batch size selects kernels at the 32² / 64² layers);
             # they are set against this run's wall time only when it is the same one

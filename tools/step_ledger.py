@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Byte ledger of one steady-state W+ step: HBM bytes by ROLE — algorithmic (bench.wplus_step_algorithmic: every tensor a launch must
 read or write, once) against measured (PMC 2*FETCH_SIZE + WRITE_SIZE of the kernels playing the role, tools/step_traffic.py), sorted by the excess.
-    python tools/step_ledger.py profiles/r6_final_step_traffic_streams1.json [B] [size]"""
+    python tools/step_ledger.py profiles/r6_final_step_traffic_streams1.json [B] [size] [--full-records]
+(--full-records: the algorithmic column for 64-byte gradient records, precision 'f16s' / the state before the hi-only records of round 6)"""
 import json
 import os
 import sys
@@ -22,9 +23,11 @@ ROLE_OF = (('upvb', 'up-conv (transposed / one-pass)'), ('t2big', 'up-conv (tran
 def main():
     import bench
     t = json.load(open(sys.argv[1]))
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    size = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-    alg, _, roles = bench.wplus_step_algorithmic(B, size, breakdown=True)
+    pos = [v for v in sys.argv[2:] if not v.startswith('--')]
+    B = int(pos[0]) if len(pos) > 0 else 8
+    size = int(pos[1]) if len(pos) > 1 else 1024
+    hi = '--full-records' not in sys.argv
+    alg, _, roles = bench.wplus_step_algorithmic(B, size, breakdown=True, hi_records=hi)
     meas = dict.fromkeys(roles, 0.0)
     named = 0.0
     for k in t['top_kernels']:
