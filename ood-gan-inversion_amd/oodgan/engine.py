@@ -656,7 +656,7 @@ def _plan_pool(device, batch):
     """The private allocator pool a launch plan is recorded under, ONE per (device, stream, batch size) for the life of the process: the buffers a
     recorded step touched keep their addresses while the plan lives, and the next inversion's recording reuses the same blocks (a fresh pool per
     inversion hands ~5 GB back to the driver and takes it again: 35 ms per inversion of 8, measured).  Per batch size: a step of ONE image recorded
-    into blocks a batch of 8 left behind ran 2.6x slower (724 against 274 ms per inversion, scratch/b1_probe.py) — its tensors are then carved out
+    into blocks a batch of 8 left behind ran 2.6x slower (724 against 274 ms per inversion, tools/plan_pool_probe.py) — its tensors are then carved out
     of a few multi-GB segments instead of sized segments."""
     if os.environ.get('OODGAN_PLAN_POOL_CACHE', '1') == '0':
         return torch.cuda.MemPool()
