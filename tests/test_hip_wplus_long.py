@@ -264,3 +264,28 @@ def test_launch_plan_in_a_fresh_process_state(dev):
     assert torch.isfinite(l_p).all()
     w_e, l_e = WPlusInverter(eng, use_plan=False).invert(target, w0, noises, steps=steps)
     assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
+
+
+@pytest.mark.parametrize('size,B,streams', [(256, 1, 1), (256, 3, 2), (256, 5, 3), (512, 2, 1), (512, 5, 2), (1024, 3, 2)])
+def test_ragged_batches_plan_and_hi_records_vs_three_instruction_loop(dev, size, B, streams):
+    """Batch sizes and stream counts off the benchmarked 8 / 2 (ragged sub-batches take other kernels per sub-batch: the 8-wave kernels and with them
+    the two-instruction instances and the hi-only records start at 128 — 64 with concurrent streams — work items): the default loop (f16s-g2, launch plans,
+    range guard) is bit-identical to its Python-driven self and within the gradient-rounding band of the three-instruction loop ('f16s')."""
+    from oodgan.engine import GeneratorEngine, WPlusInverter
+    steps = 10
+    target, w0, noises = _recipe(size, list(range(B)), dev)
+    state = {k: v.to(dev) for k, v in synth.generator_state(size, seed=0).items()}
+    eng = GeneratorEngine(state, size)
+    assert eng.grad_hi_only
+    inv = WPlusInverter(eng)
+    w_p, l_p = inv.invert(target, w0, noises, steps=steps, streams=streams)
+    ns = min(streams, B)
+    assert inv.last_stats == {'steps_run': [steps] * ns, 'rollbacks': [0] * ns} and inv.last_plan['steps'] == [steps - 3] * ns, (inv.last_stats, inv.last_plan)
+    w_e, l_e = WPlusInverter(eng, use_plan=False).invert(target, w0, noises, steps=steps, streams=streams)
+    assert torch.equal(l_p, l_e) and torch.equal(w_p, w_e)
+    eng3 = GeneratorEngine(state, size, precision='f16s')
+    w_3, l_3 = WPlusInverter(eng3).invert(target, w0, noises, steps=steps, streams=streams)
+    rel = ((l_p - l_3).abs() / l_3).max().item()
+    dw = (w_p - w_3).abs()
+    print(f'{size}² B={B} streams={streams}: f16s-g2 vs f16s over {steps} steps: loss rel {rel:.2e}, |dw| max {dw.max().item():.2e}, within 2e-3: {(dw < 2e-3).float().mean().item():.5f}')
+    assert rel < 1e-3 and (dw < 2e-3).float().mean().item() > 0.995
