@@ -28,7 +28,7 @@ class _Layer:
 
 
 class GeneratorEngine:
-    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None):
+    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None, narrow=1):
         self.size, self.style_dim = size, style_dim
         self.precision = precision or ops.PRECISION
         # 'f16s-g2' (round 6): the split-f16 arithmetic with the BACK-PROPAGATED gradient rounded to f16 before each contraction —
@@ -40,7 +40,7 @@ class GeneratorEngine:
         self.log_size = int(math.log2(size))
         self.n_latent = self.log_size * 2 - 2
         self.num_layers = (self.log_size - 2) * 2 + 1
-        ch = generator_channels(channel_multiplier)
+        ch = generator_channels(channel_multiplier, narrow)
         g = lambda k: state[prefix + k].detach().float().contiguous()
         dev = g('input.input').device
         if dev.type != 'cuda':

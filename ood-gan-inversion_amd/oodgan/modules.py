@@ -216,14 +216,19 @@ class Generator(nn.Module):
     """``Generator(size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1,3,3,1], lr_mlp=0.01)``
     reference model.py:375-585; state-dict keys identical."""
 
-    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01, narrow=1):
         super().__init__()
         if list(blur_kernel) != [1, 3, 3, 1]:
             raise NotImplementedError('only the [1,3,3,1] resample kernel of the shipped configs is implemented')
-        self.size, self.style_dim, self.channel_multiplier = size, style_dim, channel_multiplier
+        self.size, self.style_dim, self.channel_multiplier, self.narrow = size, style_dim, channel_multiplier, narrow
         self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
                                                    for _ in range(n_mlp)])
-        self.channels = generator_channels(channel_multiplier)
+        # ``narrow`` (not a parameter of the reference's model.Generator: the keyword serves StyleGAN2Generator, stylegan2_arch.py:422,435-443) scales
+        # every channel count; the matrix kernels take 16-channel blocks
+        self.channels = generator_channels(channel_multiplier, narrow)
+        used = [self.channels[2 ** i] for i in range(2, int(math.log(size, 2)) + 1)]
+        if any(c % 16 or c < 16 for c in used):
+            raise NotImplementedError(f'channel counts {used} (narrow={narrow}, channel_multiplier={channel_multiplier}): every layer needs a multiple of 16 channels')
         self.input = ConstantInput(self.channels[4])
         self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
         self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
@@ -253,7 +258,7 @@ class Generator(nn.Module):
     def engine(self):
         key = self._weights_key()
         if self._engine_obj is None or key != self._engine_key:
-            self._engine_obj = GeneratorEngine(self.state_dict(), self.size, self.style_dim, self.channel_multiplier)
+            self._engine_obj = GeneratorEngine(self.state_dict(), self.size, self.style_dim, self.channel_multiplier, narrow=self.narrow)
             self._engine_key = key
         return self._engine_obj
 
@@ -382,9 +387,8 @@ class StyleGAN2Generator(nn.Module):
     def __init__(self, out_size, num_style_feat=512, num_mlp=8, channel_multiplier=2, resample_kernel=(1, 3, 3, 1),
                  lr_mlp=0.01, narrow=1):
         super().__init__()
-        if narrow != 1:
-            raise NotImplementedError('narrow != 1 is not used by any shipped config')
-        self._inner = [Generator(out_size, num_style_feat, num_mlp, channel_multiplier, list(resample_kernel), lr_mlp)]
+        # narrow (stylegan2_arch.py:422,435-443): every channel count x narrow — built where all of them stay multiples of 16 (round 6)
+        self._inner = [Generator(out_size, num_style_feat, num_mlp, channel_multiplier, list(resample_kernel), lr_mlp, narrow=narrow)]
         inner = self._inner[0]
         self.num_style_feat, self.out_size = num_style_feat, out_size
         self.log_size, self.num_layers, self.num_latent = inner.log_size, inner.num_layers, inner.n_latent

@@ -77,7 +77,7 @@ def _to_rgb(sd, prefix, cin, style_dim, seed, upsample):
 
 
 def generator_state(size, style_dim=512, n_mlp=8, channel_multiplier=2, seed=0, lr_mlp=0.01,
-                    noise_weight=0.1, prefix=''):
+                    noise_weight=0.1, prefix='', narrow=1):
     """Full rosinality-layout state dict for ``Generator(size, style_dim, n_mlp, cm)``.
 
     Init distributions follow the reference constructors (randn conv / modulation weights,
@@ -85,7 +85,7 @@ def generator_state(size, style_dim=512, n_mlp=8, channel_multiplier=2, seed=0, 
     biases and noise strengths are made non-zero so that every term is exercised and the
     OOD callback's division by ``NoiseInjection.weight`` is finite.
     """
-    ch = generator_channels(channel_multiplier)
+    ch = generator_channels(channel_multiplier, narrow)
     log_size = int(math.log2(size))
     sd = OrderedDict()
     for i in range(1, n_mlp + 1):

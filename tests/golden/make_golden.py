@@ -169,6 +169,26 @@ def gold_generator(size=32):
     return G, sd, lat, noises
 
 
+def gold_generator_narrow(size=64, narrow=0.5):
+    """``StyleGAN2Generator(out_size, narrow=0.5)`` of the REFERENCE (src/ops/StyleGAN/stylegan2_arch.py:399-605; channel counts x narrow, :422,435-443):
+    forward from W+ latents with explicit noise.  Weights: the rosinality-layout recipe state at the narrowed channel counts, remapped to the BasicSR
+    key layout by the test's own map (checked here against the reference module's key set)."""
+    from src.ops.StyleGAN.stylegan2_arch import StyleGAN2Generator
+    from oodgan.modules import StyleGAN2Generator as Mine
+    G = StyleGAN2Generator(size, narrow=narrow).eval()
+    ros = synth.generator_state(size, seed=5, narrow=narrow)
+    mine = Mine(size, narrow=narrow)
+    bsd = {mine._ros_to_basicsr(k): v for k, v in ros.items() if not k.endswith('.kernel')}
+    missing = G.load_state_dict(bsd, strict=True)
+    print('narrow generator load:', missing)
+    B = 2
+    lat = synth.make_latents(size, B, seed=6)
+    noises = synth.make_noises(size, B, seed=7)
+    with torch.no_grad():
+        img, _ = G(lat, input_is_latent=True, noise=noises)          # with input_is_latent the reference takes the (B, n_latent, S) tensor itself
+    save(f'generator_narrow_s{size}.npz', image=img, narrow=np.float64(narrow), channels=np.asarray([G.channels[str(2 ** i)] for i in range(2, int(np.log2(size)) + 1)]))
+
+
 def gold_wplus(size=32, steps=5):
     """W+ Adam trajectory through the REFERENCE Generator autograd (SURVEY §8 A9 anchors)."""
     from src.ops.StyleGAN.model import Generator
@@ -635,6 +655,8 @@ def main():
         gold_ops()
     if 'gen' in which:
         gold_generator(32)
+    if 'narrow' in which:
+        gold_generator_narrow(64, 0.5)
     if 'wplus' in which:
         gold_wplus(32, 5)
     if 'wplus1024' in which:

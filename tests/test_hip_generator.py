@@ -54,6 +54,27 @@ def test_stylegan2generator_basicsr_keys(dev, golden):
     assert set(G.state_dict().keys()) == set(bsd.keys())
 
 
+def test_stylegan2generator_narrow_vs_reference(dev, golden):
+    """``StyleGAN2Generator(out_size=64, narrow=0.5)`` (stylegan2_arch.py:422,435-443: every channel count halved — 256 channels throughout at 64²)
+    against the reference module's output (tests/golden/make_golden.py: gold_generator_narrow); a narrow that leaves a layer with a channel count
+    that is not a multiple of 16 is refused loudly."""
+    from oodgan.modules import StyleGAN2Generator
+    g = golden('generator_narrow_s64.npz')
+    G = StyleGAN2Generator(64, narrow=0.5)
+    ros = synth.generator_state(64, seed=5, narrow=0.5)
+    assert [G._inner[0].channels[2 ** i] for i in range(2, 7)] == [int(c) for c in g['channels']]
+    G.load_state_dict({G._ros_to_basicsr(k): v for k, v in ros.items() if not k.endswith('.kernel')}, strict=True)
+    G = G.to(dev)
+    lat = synth.make_latents(64, 2, seed=6).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(64, 2, seed=7)]
+    img, _ = G(lat, input_is_latent=True, noise=noises)
+    e = maxdiff(img, g['image'])
+    print(f'StyleGAN2Generator(64, narrow=0.5) vs reference: max |d| {e:.2e} on |image| <= {g["image"].abs().max().item():.2f}')
+    assert e < 1e-3
+    with pytest.raises(NotImplementedError):
+        StyleGAN2Generator(1024, narrow=0.25)           # 8 channels at 1024²
+
+
 @pytest.mark.parametrize('prec', ['f16s', 'f32'])
 @pytest.mark.parametrize('size,B', [(16, 2), (64, 1)])
 def test_generator_backward_vs_oracle_autograd(dev, size, B, prec):
