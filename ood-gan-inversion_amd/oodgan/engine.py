@@ -9,6 +9,7 @@ latents, and the W+ Adam inversion loop.
     of a whole forward is one MFMA contraction and its backward one kernel.
 Layer order / latent indexing follow reference src/ops/StyleGAN/model.py:548-576."""
 import math
+import re
 
 import os
 
@@ -28,7 +29,8 @@ class _Layer:
 
 
 class GeneratorEngine:
-    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None, narrow=1):
+    def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None, narrow=1,
+                 blur_kernel=(1, 3, 3, 1), upsample_kernel=(1, 3, 3, 1)):
         self.size, self.style_dim = size, style_dim
         self.precision = precision or ops.PRECISION
         # 'f16s-g2' (round 6): the split-f16 arithmetic with the BACK-PROPAGATED gradient rounded to f16 before each contraction —
@@ -47,9 +49,26 @@ class GeneratorEngine:
             raise RuntimeError('GeneratorEngine needs its parameters on a ROCm device (no CPU fallback)')
         self.device = dev
         self.const_input = g('input.input')
-        self.k4x4 = (make_kernel() * 4.0).to(dev)          # Blur(upsample_factor=2) / Upsample kernel
+        # The kernels of Blur(upsample_factor=2) in the up-convs (model.py:72-81,199-205) and of Upsample in ToRGB's skip path (model.py:30-48,
+        # 353-372).  Both are registered buffers: what the state holds is what the reference runs (a loaded checkpoint overrides the constructor's
+        # taps — and model.py:455 builds ToRGB WITHOUT the constructor's ``blur_kernel``, so the two families may differ); the keyword taps serve
+        # states without these keys (BasicSR layout: stylegan2_arch.py:61,115 keeps them as plain attributes)
+        def family(pattern, taps, what):
+            pat = re.compile('^' + re.escape(prefix) + pattern + r'\.kernel$')
+            held = [v.detach().float().cpu() for k, v in state.items() if pat.match(k)]
+            k4 = held[0] if held else make_kernel(tuple(taps)) * 4.0
+            if tuple(k4.shape) != (4, 4):
+                raise NotImplementedError(f'{what} kernel of shape {tuple(k4.shape)}: the fused producers are built for four taps (every shipped config: [1,3,3,1])')
+            if any(h.shape != k4.shape or not torch.equal(h, k4) for h in held):
+                raise NotImplementedError(f'the {what} kernels of the state differ between layers')
+            return k4.contiguous()
+
+        k4 = family(r'convs\.\d+\.conv\.blur', blur_kernel, 'Blur')
+        self.k4x4 = k4.to(dev)
         self.k4x4_flip = torch.flip(self.k4x4, [0, 1]).contiguous()
-        self.k4x4_rank1 = bool(torch.linalg.matrix_rank(make_kernel().double()) == 1)
+        self.k4x4_rank1 = bool(torch.linalg.matrix_rank(k4.double()) == 1)
+        self.k_up = family(r'to_rgbs\.\d+\.upsample', upsample_kernel, 'Upsample').to(dev)
+        self.k_up_flip = torch.flip(self.k_up, [0, 1]).contiguous()
         layers = []
 
         def styled(name, cin, cout, res, lat, up, nidx):
@@ -281,7 +300,7 @@ class GeneratorEngine:
         for L in self.layers:
             s = _Cols(s_all, L.row, L.cin)
             if L.kind == 'rgb' and rgb_partial is not None:
-                skip = ops.rgb_finish(rgb_partial, L.bias, skip, self.k4x4 if skip is not None else None)
+                skip = ops.rgb_finish(rgb_partial, L.bias, skip, self.k_up if skip is not None else None)
                 rgb_partial = None
                 continue
             if L.kind == 'rgb':
@@ -290,10 +309,10 @@ class GeneratorEngine:
                         and out.shape[3] % 4 == 0):
                     # one pass over the feature map: RGB contribution AND the next up-conv's S-form input (x its style)
                     pending = ops.sform_scratch(B, L.cin, out.shape[2], out.shape[3], self.device)
-                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None, ys=pending,
+                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k_up if skip is not None else None, ys=pending,
                                      ys_scale=_Cols(s_use, Lu.row, Lu.cin), vmax=rng.vm[Lu.sidx])
                 else:
-                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k4x4 if skip is not None else None)
+                    skip = ops.torgb(out, L.w_rgb, s, L.bias, skip, self.k_up if skip is not None else None)
                 continue
             d = _Cols(d_use, L.drow, L.cout)
             nz = noises[L.noise_idx]
@@ -473,7 +492,7 @@ class GeneratorEngine:
         gskip = {self.size: gimg.contiguous()}
         r = self.size
         while r > 4:
-            gskip[r // 2] = ops.upfirdn2d(gskip[r], self.k4x4_flip, up=1, down=2, pad=(1, 1))
+            gskip[r // 2] = ops.upfirdn2d(gskip[r], self.k_up_flip, up=1, down=2, pad=(1, 1))
             r //= 2
         g_feat = None
         prev_rgb = None

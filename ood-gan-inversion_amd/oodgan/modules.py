@@ -216,10 +216,10 @@ class Generator(nn.Module):
     """``Generator(size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1,3,3,1], lr_mlp=0.01)``
     reference model.py:375-585; state-dict keys identical."""
 
-    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01, narrow=1):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01, narrow=1, rgb_blur_kernel=None):
         super().__init__()
-        if list(blur_kernel) != [1, 3, 3, 1]:
-            raise NotImplementedError('only the [1,3,3,1] resample kernel of the shipped configs is implemented')
+        if len(blur_kernel) != 4:
+            raise NotImplementedError(f'blur_kernel {list(blur_kernel)}: the fused producers are built for four taps (every shipped config: [1,3,3,1])')
         self.size, self.style_dim, self.channel_multiplier, self.narrow = size, style_dim, channel_multiplier, narrow
         self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
                                                    for _ in range(n_mlp)])
@@ -243,7 +243,8 @@ class Generator(nn.Module):
             cout = self.channels[2 ** i]
             self.convs.append(StyledConv(cin, cout, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
             self.convs.append(StyledConv(cout, cout, 3, style_dim, blur_kernel=blur_kernel))
-            self.to_rgbs.append(ToRGB(cout, style_dim))
+            # model.py:455 builds ToRGB without ``blur_kernel`` (its Upsample keeps [1,3,3,1]); stylegan2_arch.py:494 passes resample_kernel: ``rgb_blur_kernel``
+            self.to_rgbs.append(ToRGB(cout, style_dim) if rgb_blur_kernel is None else ToRGB(cout, style_dim, blur_kernel=list(rgb_blur_kernel)))
             cin = cout
         self.n_latent = self.log_size * 2 - 2
         self._engine_obj, self._engine_key = None, None
@@ -388,7 +389,8 @@ class StyleGAN2Generator(nn.Module):
                  lr_mlp=0.01, narrow=1):
         super().__init__()
         # narrow (stylegan2_arch.py:422,435-443): every channel count x narrow — built where all of them stay multiples of 16 (round 6)
-        self._inner = [Generator(out_size, num_style_feat, num_mlp, channel_multiplier, list(resample_kernel), lr_mlp, narrow=narrow)]
+        self._inner = [Generator(out_size, num_style_feat, num_mlp, channel_multiplier, list(resample_kernel), lr_mlp, narrow=narrow,
+                                 rgb_blur_kernel=list(resample_kernel))]
         inner = self._inner[0]
         self.num_style_feat, self.out_size = num_style_feat, out_size
         self.log_size, self.num_layers, self.num_latent = inner.log_size, inner.num_layers, inner.n_latent

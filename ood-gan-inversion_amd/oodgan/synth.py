@@ -77,8 +77,8 @@ def _to_rgb(sd, prefix, cin, style_dim, seed, upsample):
 
 
 def generator_state(size, style_dim=512, n_mlp=8, channel_multiplier=2, seed=0, lr_mlp=0.01,
-                    noise_weight=0.1, prefix='', narrow=1):
-    """Full rosinality-layout state dict for ``Generator(size, style_dim, n_mlp, cm)``.
+                    noise_weight=0.1, prefix='', narrow=1, blur_kernel=(1, 3, 3, 1), upsample_kernel=(1, 3, 3, 1)):
+    """Full rosinality-layout state dict for ``Generator(size, style_dim, n_mlp, cm, blur_kernel)``.
 
     Init distributions follow the reference constructors (randn conv / modulation weights,
     ``randn/lr_mul`` mapping weights, modulation bias 1: model.py:129-158,219-223) except that
@@ -107,6 +107,13 @@ def generator_state(size, style_dim=512, n_mlp=8, channel_multiplier=2, seed=0, 
     for li in range(num_layers):
         r = 2 ** ((li + 5) // 2)
         sd[f'noises.noise_{li}'] = normal(f'noises.noise_{li}', (1, 1, r, r), seed)
+    # the registered buffers of Blur (from the constructor's ``blur_kernel``) and of ToRGB's Upsample (model.py:455: always [1,3,3,1] as
+    # constructed; a checkpoint may hold anything) — model.py:30-48,72-81
+    for k_ in sd:
+        if k_.endswith('.blur.kernel') and tuple(blur_kernel) != (1, 3, 3, 1):
+            sd[k_] = make_kernel(blur_kernel) * 4.0
+        if k_.endswith('.upsample.kernel') and tuple(upsample_kernel) != (1, 3, 3, 1):
+            sd[k_] = make_kernel(upsample_kernel) * 4.0
     if prefix:
         sd = OrderedDict((prefix + k_, v) for k_, v in sd.items())
     return sd

@@ -84,7 +84,7 @@ def mapping_network(P, z, n_mlp=8, lr_mlp=0.01, prefix=''):
 
 # --------------------------------------------------------------------------- A2/A3 modulated conv
 def modulated_conv2d(x, w_lat, weight, mod_weight, mod_bias, demodulate=True, upsample=False,
-                     blur_taps=(1, 3, 3, 1)):
+                     blur_taps=(1, 3, 3, 1), blur_kernel=None):
     """reference model.py:233-274 (plain and upsample branches; downsample is off-path).
 
     x (B,Ci,H,W); w_lat (B,style_dim); weight (1,Co,Ci,k,k).  Literal 1e-8 at :240."""
@@ -100,9 +100,12 @@ def modulated_conv2d(x, w_lat, weight, mod_weight, mod_bias, demodulate=True, up
         y = F.conv_transpose2d(x.reshape(1, B * Ci, H, W), wt, padding=0, stride=2, groups=B)
         y = y.reshape(B, Co, y.shape[2], y.shape[3])
         # Blur(pad=(pad0,pad1), upsample_factor=2): model.py:199-205,72-88
-        p = (len(blur_taps) - 2) - (k - 1)
+        # ``blur_kernel``: the registered buffer ``conv.blur.kernel`` (model.py:72-81) as the checkpoint holds it — a loaded state dict
+        # overrides what the constructor's ``blur_kernel`` taps built; the pads follow the tap count either way
+        kb = make_kernel(blur_taps) * 4.0 if blur_kernel is None else blur_kernel
+        p = (kb.shape[0] - 2) - (k - 1)
         pad0, pad1 = (p + 1) // 2 + 2 - 1, p // 2 + 1
-        return upfirdn2d(y, make_kernel(blur_taps) * 4.0, pad=(pad0, pad1))
+        return upfirdn2d(y, kb, pad=(pad0, pad1))
     y = F.conv2d(x.reshape(1, B * Ci, H, W), wgt.reshape(B * Co, Ci, k, k), padding=k // 2, groups=B)
     return y.reshape(B, Co, y.shape[2], y.shape[3])
 
@@ -113,7 +116,8 @@ def styled_conv(P, prefix, x, w_lat, noise, upsample=False, hook=None):
     ``hook(raw_conv_out, w_lat, noise, noise_weight)`` (if given) plays the role of the
     reference callback at model.py:288-290: it returns the tensor that replaces ``noise``."""
     y = modulated_conv2d(x, w_lat, P[f'{prefix}.conv.weight'], P[f'{prefix}.conv.modulation.weight'],
-                         P[f'{prefix}.conv.modulation.bias'], True, upsample)
+                         P[f'{prefix}.conv.modulation.bias'], True, upsample,
+                         blur_kernel=P.get(f'{prefix}.conv.blur.kernel') if upsample else None)
     nw = P[f'{prefix}.noise.weight']
     if hook is not None:
         noise = hook(y, w_lat, noise, nw)
@@ -127,8 +131,11 @@ def to_rgb(P, prefix, x, w_lat, skip=None, blur_taps=(1, 3, 3, 1)):
                          P[f'{prefix}.conv.modulation.bias'], demodulate=False)
     y = y + P[f'{prefix}.bias']
     if skip is not None:
-        p = len(blur_taps) - 2
-        y = y + upfirdn2d(skip, make_kernel(blur_taps) * 4.0, up=2, pad=((p + 1) // 2 + 1, p // 2))
+        ku = P.get(f'{prefix}.upsample.kernel')          # Upsample's registered buffer (model.py:30-48), as loaded
+        if ku is None:
+            ku = make_kernel(blur_taps) * 4.0
+        p = ku.shape[0] - 2
+        y = y + upfirdn2d(skip, ku, up=2, pad=((p + 1) // 2 + 1, p // 2))
     return y
 
 

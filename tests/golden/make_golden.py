@@ -256,6 +256,77 @@ def gold_wplus_1024():
     save('wplus_1024.npz', **g)
 
 
+BLUR_TAPS = (1, 4, 2, 1)        # an ASYMMETRIC four-tap filter: a flipped or transposed kernel anywhere in the chain shows
+UP_TAPS = (2, 1, 3, 1)          # ... and another one for ToRGB's Upsample where the fixture says so
+
+
+def gold_wplus_blur(size, gidx, steps, up_taps=(1, 3, 3, 1)):
+    """``Generator(size, 512, 8, blur_kernel=[1,4,2,1])`` of the reference (model.py:376-384: the taps of every Blur / Upsample): one forward
+    and ``steps`` Adam steps through the reference's autograd in float64 (and the first step in its own float32) on the bench recipe's inputs.
+    The filter is asymmetric on purpose — with [1,3,3,1] a flipped, transposed or mirrored kernel in a fused producer / its adjoint is invisible.
+    ``up_taps``: the kernel of ToRGB's Upsample.  As CONSTRUCTED it stays [1,3,3,1] whatever ``blur_kernel`` says (model.py:455 builds ToRGB
+    without it) — the 64² fixture; it is a registered buffer, so a checkpoint can hold another one (strict load) — the 256² / 1024² fixtures."""
+    from src.ops.StyleGAN.model import Generator
+    sd = synth.generator_state(size, seed=0, blur_kernel=BLUR_TAPS, upsample_kernel=up_taps)
+    cat = lambda parts: torch.cat(parts, 0)
+    target = cat([synth.make_images(size, 1, seed=1000 + g) for g in gidx])
+    per_n = [synth.make_noises(size, 1, seed=2000 + g) for g in gidx]
+    noises = [cat([n[i] for n in per_n]) for i in range(len(per_n[0]))]
+    lat = cat([synth.make_latents(size, 1, seed=3000 + g, std=0.3) for g in gidx])
+    g = {'taps': np.asarray(BLUR_TAPS, dtype=np.int64), 'up_taps': np.asarray(up_taps, dtype=np.int64), 'image_indices': np.asarray(gidx, dtype=np.int64)}
+    for tag, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        G = Generator(size, 512, 8, blur_kernel=list(BLUR_TAPS)).eval()
+        if tuple(up_taps) == (1, 3, 3, 1):      # the constructor alone already built these buffers
+            assert all(torch.equal(G.state_dict()[k], sd[k]) for k in sd if k.endswith('.kernel'))
+        G.load_state_dict(sd, strict=True)
+        G = G.to(dt)
+        for p in G.parameters():
+            p.requires_grad_(False)
+        w = lat.to(dt).clone().requires_grad_(True)
+        opt = torch.optim.Adam([w], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+        losses, traj = [], []
+        for t in range(steps if tag == 'f64' else 1):
+            opt.zero_grad()
+            img, _ = G(w, input_is_tensor=True, input_is_latent=True, noise=[n.to(dt) for n in noises])
+            per = ((img - target.to(dt)) ** 2).mean(dim=(1, 2, 3))
+            per.sum().backward()
+            losses.append(per.detach().clone())
+            if t == 0:
+                g[f'grad_{tag}'] = w.grad.detach().clone()
+                if tag == 'f64':
+                    im = img.detach()
+                    st = max(size // 64, 1)
+                    g['image_sub'] = im[:, :, ::st, ::st].float()
+                    g['image_mean'] = im.mean(dim=(2, 3))
+                    g['image_std'] = im.std(dim=(2, 3))
+                    g['image_absmax'] = im.abs().amax()
+            opt.step()
+            traj.append(w.detach().clone())
+        if tag == 'f64':
+            g['losses'] = torch.stack(losses)
+            g['traj'] = torch.stack(traj)
+        del G, img, per, w
+    rel = (g['grad_f32'].double() - g['grad_f64']).abs().max() / g['grad_f64'].abs().max()
+    print(f'wplus_blur_{size}: losses {g["losses"][:, 0].tolist()}; reference fp32 vs fp64 gradient: rel {rel.item():.2e}')
+    save(f'wplus_blur_{size}.npz', **g)
+
+
+def gold_generator_resample(size=64):
+    """``StyleGAN2Generator(out_size, resample_kernel=(1,4,2,1))`` of the reference (stylegan2_arch.py:420,455-494: the taps reach every smoothing
+    layer AND ToRGB's up-sampling; its kernels are plain attributes, not buffers): forward from W+ latents with explicit noise."""
+    from src.ops.StyleGAN.stylegan2_arch import StyleGAN2Generator
+    from oodgan.modules import StyleGAN2Generator as Mine
+    G = StyleGAN2Generator(size, resample_kernel=BLUR_TAPS).eval()
+    ros = synth.generator_state(size, seed=5)
+    mine = Mine(size)
+    G.load_state_dict({mine._ros_to_basicsr(k): v for k, v in ros.items() if not k.endswith('.kernel')}, strict=True)
+    lat = synth.make_latents(size, 2, seed=6)
+    noises = synth.make_noises(size, 2, seed=7)
+    with torch.no_grad():
+        img, _ = G(lat, input_is_latent=True, noise=noises)
+    save(f'generator_resample_s{size}.npz', image=img, taps=np.asarray(BLUR_TAPS, dtype=np.int64))
+
+
 WPLUS_LONG = {
     # name -> (size, global image indices of the bench recipe, steps, dtype tag, stored latent checkpoints)
     'wplus_long_256': (256, (0, 1), 100, 'f32', (1, 5, 10, 20, 30, 60, 100)),
@@ -665,6 +736,14 @@ def main():
         gold_generator_1024_b4()
     if 'wplus256' in which:
         gold_wplus_256()
+    if 'wplus_blur_64' in which:
+        gold_wplus_blur(64, (0, 1), 4)
+    if 'wplus_blur_256' in which:
+        gold_wplus_blur(256, (0, 1), 3, UP_TAPS)
+    if 'wplus_blur_1024' in which:
+        gold_wplus_blur(1024, (WPLUS_1024_IMAGE,), 2, UP_TAPS)
+    if 'resample' in which:
+        gold_generator_resample(64)
     for name in WPLUS_LONG:
         if name in which:
             gold_wplus_long(name)

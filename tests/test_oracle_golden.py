@@ -200,3 +200,33 @@ def test_generator_1024_b4_oracle_vs_reference(golden):
     close(img[:, :, ::16, ::16], g['image_sub'][k:k + 1], 5e-5)
     close(img[:, :, 448:512, 512:576], g['image_crop'][k:k + 1], 5e-5)
     assert (img.double().mean(dim=(2, 3)) - g['image_mean'][k:k + 1]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('size', [64, 256])
+def test_wplus_asymmetric_blur_kernel_oracle_vs_reference(golden, size):
+    """``Generator(blur_kernel=[1,4,2,1])`` (model.py:376-384): the oracle takes Blur / Upsample kernels from the state dict, as the reference's
+    registered buffers do; the asymmetric taps pin every flip of the chain.  64²: ToRGB's Upsample as constructed ([1,3,3,1], model.py:455);
+    256²: a second asymmetric kernel there (checkpoint buffers).  Image, loss curve and dL/dW+ vs the reference in float64."""
+    g = golden(f'wplus_blur_{size}.npz')
+    gidx = [int(i) for i in g['image_indices']]
+    P = synth.generator_state(size, seed=0, blur_kernel=tuple(int(t) for t in g['taps']), upsample_kernel=tuple(int(t) for t in g['up_taps']))
+    cat = lambda parts: torch.cat(parts, 0)
+    target = cat([synth.make_images(size, 1, seed=1000 + i) for i in gidx])
+    per = [synth.make_noises(size, 1, seed=2000 + i) for i in gidx]
+    noises = [cat([n[k] for n in per]) for k in range(len(per[0]))]
+    w0 = cat([synth.make_latents(size, 1, seed=3000 + i, std=0.3) for i in gidx])
+    w = w0.clone().requires_grad_(True)
+    img = R.generator_forward(P, w, noises, size)
+    R.wplus_loss(img, target).backward()
+    st = max(size // 64, 1)
+    assert (img.detach()[:, :, ::st, ::st] - g['image_sub']).abs().max().item() < 1e-4
+    rel = (w.grad.double() - g['grad_f64']).abs().max().item() / g['grad_f64'].abs().max().item()
+    assert rel < 1e-4, rel
+    steps = g['losses'].shape[0]
+    _, losses, traj = R.wplus_invert(P, target, w0, noises, size, steps=steps, return_trajectory=True)
+    close(losses.double(), g['losses'], 1e-4)
+    assert ((torch.stack(traj).double() - g['traj']).abs() < 2e-3).float().mean().item() > 0.999
+    # the default-kernel state must NOT reproduce it (the fixture really depends on the taps)
+    with torch.no_grad():
+        img0 = R.generator_forward(synth.generator_state(size, seed=0), w0, noises, size)
+    assert (img0[:, :, ::st, ::st] - g['image_sub']).abs().max().item() > 1e-2
