@@ -28,6 +28,54 @@ class _Layer:
                  'bias', 'noise_w', 'scale', 'noise_idx', 'src', 'sidx', 'wpk_vb')
 
 
+def _pad_channels_to_16(state, prefix, log_size, ch):
+    """The matrix kernels take 16-channel blocks.  A generator with other channel counts (``StyleGAN2Generator(narrow=...)``, stylegan2_arch.py:422,
+    435-443: 8 channels at 1024² for narrow = 0.25) runs as the SAME function on zero-padded tensors: padded input channels get zero conv / ToRGB
+    weights and a zero modulation row and bias (style 0), padded output channels zero weights and bias — they only ever hold lrelu(noise), which
+    every reader multiplies by zero, and no gradient reaches the latents through them.  ToRGB weights of a padded layer carry sqrt(padded / real):
+    the ops compute 1/sqrt(C) from the count they see.  Returns (state with the padded tensors, {res: padded count})."""
+    up16 = lambda c: (c + 15) // 16 * 16
+    chp = {r: up16(c) for r, c in ch.items()}
+    out = dict(state)
+
+    def pad(key, sizes):            # sizes: {dim: new size}
+        t = state[prefix + key]
+        shape = list(t.shape)
+        for d, n in sizes.items():
+            shape[d] = n
+        if shape == list(t.shape):
+            return
+        new = torch.zeros(shape, dtype=t.dtype, device=t.device)
+        new[tuple(slice(0, n) for n in t.shape)] = t
+        out[prefix + key] = new
+
+    def styled(name, cin, cout):
+        pad(f'{name}.conv.weight', {1: up16(cout), 2: up16(cin)})
+        pad(f'{name}.conv.modulation.weight', {0: up16(cin)})
+        pad(f'{name}.conv.modulation.bias', {0: up16(cin)})
+        pad(f'{name}.activate.bias', {0: up16(cout)})
+
+    def rgb(name, cin):
+        pad(f'{name}.conv.weight', {2: up16(cin)})
+        # every ToRGB op derives its fan-in scale 1/sqrt(C) from the channel count it is handed (the padded one): fold the ratio into the weights
+        if up16(cin) != cin:
+            out[prefix + f'{name}.conv.weight'] = out[prefix + f'{name}.conv.weight'] * math.sqrt(up16(cin) / cin)
+        pad(f'{name}.conv.modulation.weight', {0: up16(cin)})
+        pad(f'{name}.conv.modulation.bias', {0: up16(cin)})
+
+    pad('input.input', {1: up16(ch[4])})
+    styled('conv1', ch[4], ch[4])
+    rgb('to_rgb1', ch[4])
+    cin = ch[4]
+    for j in range(log_size - 2):
+        cout = ch[2 ** (j + 3)]
+        styled(f'convs.{2 * j}', cin, cout)
+        styled(f'convs.{2 * j + 1}', cout, cout)
+        rgb(f'to_rgbs.{j}', cout)
+        cin = cout
+    return out, chp
+
+
 class GeneratorEngine:
     def __init__(self, state, size, style_dim=512, channel_multiplier=2, prefix='', with_backward=True, precision=None, narrow=1,
                  blur_kernel=(1, 3, 3, 1), upsample_kernel=(1, 3, 3, 1)):
@@ -43,6 +91,15 @@ class GeneratorEngine:
         self.n_latent = self.log_size * 2 - 2
         self.num_layers = (self.log_size - 2) * 2 + 1
         ch = generator_channels(channel_multiplier, narrow)
+        used = [ch[2 ** i] for i in range(2, self.log_size + 1)]
+        if any(c < 1 for c in used):
+            raise ValueError(f'channel counts {used} (narrow={narrow}, channel_multiplier={channel_multiplier})')
+        self.padded = any(c % 16 for c in used)
+        self.real_channels = dict(ch)
+        if self.padded:
+            state, chp = _pad_channels_to_16(state, prefix, self.log_size, ch)
+        else:
+            chp = ch
         g = lambda k: state[prefix + k].detach().float().contiguous()
         dev = g('input.input').device
         if dev.type != 'cuda':
@@ -71,9 +128,11 @@ class GeneratorEngine:
         self.k_up_flip = torch.flip(self.k_up, [0, 1]).contiguous()
         layers = []
 
-        def styled(name, cin, cout, res, lat, up, nidx):
+        up16 = lambda c: (c + 15) // 16 * 16
+
+        def styled(name, cin, cout, res, lat, up, nidx):        # cin / cout: the REAL counts (fan-in scale); the layer runs on the padded ones
             L = _Layer()
-            L.name, L.kind, L.cin, L.cout, L.res, L.lat, L.noise_idx = name, ('up' if up else 'conv'), cin, cout, res, lat, nidx
+            L.name, L.kind, L.cin, L.cout, L.res, L.lat, L.noise_idx = name, ('up' if up else 'conv'), up16(cin), up16(cout), res, lat, nidx
             w = g(f'{name}.conv.weight')[0]                 # (Co,Ci,3,3)
             L.scale = 1.0 / math.sqrt(cin * 9)
             L.wpk = ops.pack_conv3x3(w, L.scale, transpose=False, flip=False, precision=self.precision)
@@ -89,10 +148,10 @@ class GeneratorEngine:
 
         def rgb(name, cin, res, lat):
             L = _Layer()
-            L.name, L.kind, L.cin, L.cout, L.res, L.lat = name, 'rgb', cin, 3, res, lat
-            L.w_rgb = g(f'{name}.conv.weight').reshape(3, cin).contiguous()
+            L.name, L.kind, L.cin, L.cout, L.res, L.lat = name, 'rgb', up16(cin), 3, res, lat
+            L.w_rgb = g(f'{name}.conv.weight').reshape(3, up16(cin)).contiguous()
             L.bias = g(f'{name}.bias').reshape(3).contiguous()
-            L.scale = 1.0 / math.sqrt(cin)
+            L.scale = 1.0 / math.sqrt(up16(cin))    # with the weights of a padded layer x sqrt(padded / real) (_pad_channels_to_16)
             layers.append(L)
             return L
 
@@ -245,6 +304,8 @@ class GeneratorEngine:
         (feature_modulation for cond_type 'SFT' / 'ADD' / 'FUSE', model.py:558-566).
         range_mode (split-f16 only, ops.FwdRange): 'exact' measures max|x*s| of every conv input before converting it;
         'carry' (the W+ loop) uses the scales of the previous forward with the fused producers and verifies them."""
+        if self.padded and (cond_hook is not None or features_in is not None or post_hook is not None):
+            raise NotImplementedError('conditioning hooks / feature injection on a generator whose channel counts are zero-padded to multiples of 16')
         if save and (features_in is not None or post_hook is not None):
             raise NotImplementedError('backward through an injected feature / feature modulation is not part of the path')
         B = latent.shape[0]
@@ -452,7 +513,8 @@ class GeneratorEngine:
         if save:
             self.saved = dict(acts=acts, s_all=s_all, d_all=d_all, noises=noises, B=B, serial=self._fwd_serial)
         if return_features:
-            return skip, (out.to_nchw() if isinstance(out, ops.FForm) else out)
+            feat = out.to_nchw() if isinstance(out, ops.FForm) else out
+            return skip, (feat[:, :self.real_channels[self.size]].contiguous() if self.padded else feat)
         return skip
 
     def _demod(self, L, s_all, d_all):

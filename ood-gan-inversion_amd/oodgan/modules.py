@@ -224,11 +224,11 @@ class Generator(nn.Module):
         self.style = nn.Sequential(PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
                                                    for _ in range(n_mlp)])
         # ``narrow`` (not a parameter of the reference's model.Generator: the keyword serves StyleGAN2Generator, stylegan2_arch.py:422,435-443) scales
-        # every channel count; the matrix kernels take 16-channel blocks
+        # every channel count; the matrix kernels take 16-channel blocks — GeneratorEngine zero-pads other counts (engine._pad_channels_to_16)
         self.channels = generator_channels(channel_multiplier, narrow)
         used = [self.channels[2 ** i] for i in range(2, int(math.log(size, 2)) + 1)]
-        if any(c % 16 or c < 16 for c in used):
-            raise NotImplementedError(f'channel counts {used} (narrow={narrow}, channel_multiplier={channel_multiplier}): every layer needs a multiple of 16 channels')
+        if any(c < 1 for c in used):
+            raise ValueError(f'channel counts {used} (narrow={narrow}, channel_multiplier={channel_multiplier})')
         self.input = ConstantInput(self.channels[4])
         self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
         self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)

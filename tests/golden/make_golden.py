@@ -186,7 +186,9 @@ def gold_generator_narrow(size=64, narrow=0.5):
     noises = synth.make_noises(size, B, seed=7)
     with torch.no_grad():
         img, _ = G(lat, input_is_latent=True, noise=noises)          # with input_is_latent the reference takes the (B, n_latent, S) tensor itself
-    save(f'generator_narrow_s{size}.npz', image=img, narrow=np.float64(narrow), channels=np.asarray([G.channels[str(2 ** i)] for i in range(2, int(np.log2(size)) + 1)]))
+    st = max(size // 128, 1)        # 64²: the whole image; larger sizes: a sub-sample and moments
+    save(f'generator_narrow_s{size}.npz', image=img[:, :, ::st, ::st], image_mean=img.double().mean(dim=(2, 3)), image_std=img.double().std(dim=(2, 3)),
+         narrow=np.float64(narrow), channels=np.asarray([G.channels[str(2 ** i)] for i in range(2, int(np.log2(size)) + 1)]))
 
 
 def gold_wplus(size=32, steps=5):
@@ -728,6 +730,9 @@ def main():
         gold_generator(32)
     if 'narrow' in which:
         gold_generator_narrow(64, 0.5)
+    if 'narrow_pad' in which:           # channel counts that are not multiples of 16 (the engine zero-pads them): 24 at 256², 8 at 1024²
+        gold_generator_narrow(256, 0.1875)
+        gold_generator_narrow(1024, 0.25)
     if 'wplus' in which:
         gold_wplus(32, 5)
     if 'wplus1024' in which:

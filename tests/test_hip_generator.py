@@ -54,25 +54,60 @@ def test_stylegan2generator_basicsr_keys(dev, golden):
     assert set(G.state_dict().keys()) == set(bsd.keys())
 
 
-def test_stylegan2generator_narrow_vs_reference(dev, golden):
-    """``StyleGAN2Generator(out_size=64, narrow=0.5)`` (stylegan2_arch.py:422,435-443: every channel count halved — 256 channels throughout at 64²)
-    against the reference module's output (tests/golden/make_golden.py: gold_generator_narrow); a narrow that leaves a layer with a channel count
-    that is not a multiple of 16 is refused loudly."""
+@pytest.mark.parametrize('size,narrow', [(64, 0.5), (256, 0.1875), (1024, 0.25)])
+def test_stylegan2generator_narrow_vs_reference(dev, golden, size, narrow):
+    """``StyleGAN2Generator(out_size, narrow=...)`` (stylegan2_arch.py:422,435-443: every channel count x narrow) against the reference module's
+    output (tests/golden/make_golden.py: gold_generator_narrow).  64² / 0.5: 256 channels throughout.  256² / 0.1875: 96 ... 48, 24 channels and
+    1024² / 0.25: 128 ... 16, 8 channels — counts that are not multiples of the matrix kernels' 16-channel block: the engine runs the same function on
+    zero-padded tensors (engine._pad_channels_to_16); the W+ gradient of such a generator is checked against the oracle's float64 autograd."""
     from oodgan.modules import StyleGAN2Generator
-    g = golden('generator_narrow_s64.npz')
-    G = StyleGAN2Generator(64, narrow=0.5)
-    ros = synth.generator_state(64, seed=5, narrow=0.5)
-    assert [G._inner[0].channels[2 ** i] for i in range(2, 7)] == [int(c) for c in g['channels']]
+    from oodgan.engine import GeneratorEngine
+    from oodgan import ops
+    g = golden(f'generator_narrow_s{size}.npz')
+    G = StyleGAN2Generator(size, narrow=narrow)
+    ros = synth.generator_state(size, seed=5, narrow=narrow)
+    log = size.bit_length() - 1
+    assert [G._inner[0].channels[2 ** i] for i in range(2, log + 1)] == [int(c) for c in g['channels']]
     G.load_state_dict({G._ros_to_basicsr(k): v for k, v in ros.items() if not k.endswith('.kernel')}, strict=True)
     G = G.to(dev)
-    lat = synth.make_latents(64, 2, seed=6).to(dev)
-    noises = [n.to(dev) for n in synth.make_noises(64, 2, seed=7)]
+    B = 2
+    lat = synth.make_latents(size, B, seed=6).to(dev)
+    noises = [n.to(dev) for n in synth.make_noises(size, B, seed=7)]
     img, _ = G(lat, input_is_latent=True, noise=noises)
-    e = maxdiff(img, g['image'])
-    print(f'StyleGAN2Generator(64, narrow=0.5) vs reference: max |d| {e:.2e} on |image| <= {g["image"].abs().max().item():.2f}')
-    assert e < 1e-3
+    st = max(size // 128, 1)
+    e = maxdiff(img[:, :, ::st, ::st], g['image'])
+    e_m = max(maxdiff(img.double().mean(dim=(2, 3)), g['image_mean']), maxdiff(img.double().std(dim=(2, 3)), g['image_std']))
+    padded = G._inner[0].engine().padded
+    print(f'StyleGAN2Generator({size}, narrow={narrow}) vs reference: max |d| {e:.2e} on |image| <= {g["image"].abs().max().item():.2f}, moments {e_m:.2e}, zero-padded: {padded}')
+    assert e < 1e-3 and e_m < 1e-5
+    assert padded == any(int(c) % 16 for c in g['channels'])
+    # return_features hands out the real channels only
+    _, feat = G._inner[0](lat, input_is_tensor=True, input_is_latent=True, noise=noises, return_features=True)
+    assert feat.shape[1] == int(g['channels'][-1])
+    if not padded:
+        return
+    # the W+ gradient through the padded layers (exact step, then the carried-scale step with the fused producers) vs the oracle in float64
+    P = ros
+    Bg = 1
+    w = synth.make_latents(size, Bg, seed=14).double().requires_grad_(True)
+    nz = synth.make_noises(size, Bg, seed=7)
+    target = synth.make_images(size, Bg, seed=9)
+    img_ref = R.generator_forward({k: v.double() for k, v in P.items()}, w, [n.double() for n in nz], size)
+    R.wplus_loss(img_ref, target.double()).backward()
+    eng = GeneratorEngine({k: v.to(dev) for k, v in P.items()}, size, narrow=narrow)
+    gmul = ops.loss_scale_for(3 * size * size)
+    eng.reset_bwd_state()
+    eng.reset_fwd_state()
+    for rep in range(2):
+        im = eng.forward(w.detach().float().to(dev), [n.to(dev) for n in nz], save=True, range_mode='carry')
+        loss, gimg = ops.mse_loss_grad(im, target.to(dev), gmul)
+        glat = eng.backward(gimg, gmul, carry_scale=True)
+        rel = (glat.cpu().double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+        print(f'  rep{rep}: image {maxdiff(im, img_ref.detach().float()):.2e}, dL/dW+ rel {rel:.2e}')
+        assert maxdiff(im, img_ref.detach().float()) < 1e-3 and rel < 3e-4
+    assert not eng.bwd_scale_violated() and not eng.fwd_range_violated()
     with pytest.raises(NotImplementedError):
-        StyleGAN2Generator(1024, narrow=0.25)           # 8 channels at 1024²
+        eng.forward(w.detach().float().to(dev), [n.to(dev) for n in nz], cond_hook=lambda *a: None, cond_layers=[5])
 
 
 @pytest.mark.parametrize('prec', ['f16s', 'f32'])
