@@ -97,9 +97,7 @@ class GeneratorEngine:
         self.padded = any(c % 16 for c in used)
         self.real_channels = dict(ch)
         if self.padded:
-            state, chp = _pad_channels_to_16(state, prefix, self.log_size, ch)
-        else:
-            chp = ch
+            state, _ = _pad_channels_to_16(state, prefix, self.log_size, ch)
         g = lambda k: state[prefix + k].detach().float().contiguous()
         dev = g('input.input').device
         if dev.type != 'cuda':
