@@ -616,8 +616,27 @@ def forward_only(a, m, x, noises, reps=7, only_full=False):
         out[tag]['graph_replay_images_per_s'] = round(b / tgm, 3)
         gf.reset()
         del gf
+        # opt-in: forward range scales carried from call to call (OODGAN_CARRY_FORWARD=1 — results then depend on the previous call at
+        # fp32-rounding level, which is why it is not the default)
+        from oodgan import modules as _mod
+        old = _mod.CARRY_FORWARD
+        try:
+            _mod.CARRY_FORWARD = True
+            for _ in range(3):
+                m(xb, noise=nb)
+            torch.cuda.synchronize()
+            tc = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                m(xb, noise=nb)
+                torch.cuda.synchronize()
+                tc.append(time.perf_counter() - t0)
+            out[tag]['carried_scales_latency_ms'] = round(statistics.median(tc) * 1e3, 3)
+        finally:
+            _mod.CARRY_FORWARD = old
     out['note'] = ('model(x): e4e encoder (256x256) + OOD forward (generator + SAMM 2 cycles x 4 levels + mask blend) at '
-                   f'{a.size}x{a.size}, host wall time incl. synchronize, median of {reps}; the reference times exactly this call')
+                   f'{a.size}x{a.size}, host wall time incl. synchronize, median of {reps}; the reference times exactly this call.  Default = every call measures its '
+                   'range scales (a pure function of its inputs); carried_scales_latency_ms = the opt-in OODGAN_CARRY_FORWARD=1')
     return out
 
 

@@ -477,7 +477,8 @@ def test_generator_1024_batch4_vs_reference(dev, golden, prec, monkeypatch):
 
 
 def test_generator_forward_carried_scales_and_fallback(dev):
-    """Round 4: ``Generator.forward`` carries the forward range scales from call to call (modules.CARRY_FORWARD).  (a) the second call
+    """``Generator.forward`` with modules.CARRY_FORWARD (opt-in since round 6) carries the forward range scales from call to call.  (0) by DEFAULT the
+    forward is a pure function of its inputs: a call after other inputs equals a fresh generator's call bit for bit.  (a) with the switch on the second call
     (carried scales, fused producers) equals the first (measured scales) to fp32 rounding and the third equals the second bit for bit;
     (b) an input whose activations leave the carried window — noise maps 2^30 times larger — sets the check flag and the pass is repeated
     with measured scales: same result as a generator that never carried anything."""
@@ -490,29 +491,40 @@ def test_generator_forward_carried_scales_and_fallback(dev):
         G = Generator(size, 512, 8)
         G.load_state_dict(sd, strict=True)
         return G.to(dev).eval()
-    G = build()
     z = synth.normal('carry.z', (B, 512), 5).to(dev)
     noises = [n.to(dev) for n in synth.make_noises(size, B, seed=6)]
     big = [n * 2.0 ** 30 for n in noises]
-    img1, _ = G([z], noise=noises)
-    img1 = img1.clone()
-    eng = G.engine()
-    assert eng.fwd_range is not None and eng.fwd_range.valid
-    img2, _ = G([z], noise=noises)
-    img2 = img2.clone()
-    img3, _ = G([z], noise=noises)
-    assert maxdiff(img2, img1.cpu()) <= 2e-5 * img1.abs().max().item() and torch.equal(img3, img2)
-    out_big, _ = G([z], noise=big)                       # carried scales are 2^30 off: violation -> measured-scale repeat
-    assert not eng.fwd_range_violated() and torch.isfinite(out_big).all()
+    assert modules.CARRY_FORWARD is False                # the shipped default
+    G0 = build()
+    cold, _ = G0([z], noise=noises)
+    cold = cold.clone()
+    G0([z * 3.0], noise=big)                             # something else in between ...
+    again, _ = G0([z], noise=noises)
+    fresh, _ = build()([z], noise=noises)
+    assert torch.equal(again, cold) and torch.equal(fresh, cold)      # ... leaves no trace
     old = modules.CARRY_FORWARD
     try:
+        modules.CARRY_FORWARD = True
+        G = build()
+        img1, _ = G([z], noise=noises)
+        img1 = img1.clone()
+        assert torch.equal(img1, cold)                   # the first call of a carrying generator measures: same as the default
+        eng = G.engine()
+        assert eng.fwd_range is not None and eng.fwd_range.valid
+        img2, _ = G([z], noise=noises)
+        img2 = img2.clone()
+        img3, _ = G([z], noise=noises)
+        assert maxdiff(img2, img1.cpu()) <= 2e-5 * img1.abs().max().item() and torch.equal(img3, img2)
+        out_big, _ = G([z], noise=big)                       # carried scales are 2^30 off: violation -> measured-scale repeat
+        assert not eng.fwd_range_violated() and torch.isfinite(out_big).all()
         modules.CARRY_FORWARD = False
         ref_big, _ = build()([z], noise=big)
+        modules.CARRY_FORWARD = True
+        assert maxdiff(out_big, ref_big.cpu()) <= 2e-5 * ref_big.abs().max().item()
+        back, _ = G([z], noise=noises)                       # and back again (2^-30): violation the other way, or a valid carried window
+        assert maxdiff(back, img1.cpu()) <= 2e-5 * img1.abs().max().item()
     finally:
         modules.CARRY_FORWARD = old
-    assert maxdiff(out_big, ref_big.cpu()) <= 2e-5 * ref_big.abs().max().item()
-    back, _ = G([z], noise=noises)                       # and back again (2^-30): violation the other way, or a valid carried window
-    assert maxdiff(back, img1.cpu()) <= 2e-5 * img1.abs().max().item()
 
 
 @pytest.mark.gpu
