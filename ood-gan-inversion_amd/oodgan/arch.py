@@ -8,6 +8,7 @@ The e4e encoder (the step *before* the path) is pluggable: ``
 callable ``encoder(x256, return_feats=True) -> (lats (B,18,512), feats[>=4])``; alternatively the
 encoder outputs can be passed to ``forward`` as ``enc_lats=`` / ``enc_feats=``."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -290,6 +291,12 @@ class ood_faceGAN_e4e(nn.Module):
         self.last_loss_terms, self.last_invert_stats, self.last_invert_plan = inv.last_terms, inv.last_stats, inv.last_plan
         kw = {k: v for k, v in kwargs.items() if k not in ('noise_passes', 'truncation', 'enc_lats', 'enc_feats', 'lats', 'noise')}
         out, lats = self._ood_forward(x, w, enc_feats, noise=noise, **kw)
+        # An inversion returns finished results.  Without this the host runs ahead into the next inversion's set-up while the device still works
+        # on this one: blocks this inversion's side streams freed are then not yet reusable, the caching allocator goes to the driver for new ones
+        # and every inversion pays ~20 ms (measured, bench.py back-to-back inversions on one box: 1054-1061 ms without, 1036-1047 ms with it —
+        # profiles/r6_invert_sync_ab.txt; until round 6 a host read of the
+        # carried-scale flag in Generator.forward happened to provide this synchronisation)
+        torch.cuda.current_stream().synchronize()
         return out, lats, losses
 
 
